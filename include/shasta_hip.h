@@ -1,0 +1,163 @@
+/*
+ * shasta_hip.h -- C ABI of the MI355X (gfx950) ShaSTA affinity hot path.
+ *
+ * The reference (tsadja/ShaSTA) has no native plugin on this path: its boundary is the Python
+ * `nn.Module.forward` of det3d/models/tracker/shasta.py and the ATen ops below it.  This header
+ * is the C boundary a maintainer binds instead (ctypes / pybind / cgo alike): plain pointers and
+ * sizes, no torch types, every call asynchronous on the caller's `hipStream_t`, no allocation
+ * inside, no globals, `int` status (0 = ok, <0 = SHASTA_E_*), never exit()/abort().
+ * All pointers are DEVICE pointers unless a parameter name starts with `h_`.
+ * All arithmetic is fp32 (the reference runs apex O0 = fp32, tools/nusc_shasta/train.py:149).
+ *
+ * Each entry point cites the reference code it replaces (paths relative to the reference root).
+ */
+#ifndef SHASTA_HIP_H
+#define SHASTA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* shasta_stream_t; /* a hipStream_t; NULL = the null stream */
+
+#define SHASTA_OK 0
+#define SHASTA_E_ARG (-1)       /* bad size / null pointer / unsupported shape */
+#define SHASTA_E_WORKSPACE (-2) /* workspace too small */
+#define SHASTA_E_LAUNCH (-3)    /* hipGetLastError() != hipSuccess after a launch */
+#define SHASTA_E_ALIGN (-4)     /* pointer or leading dimension not aligned as documented */
+
+/* Library/ABI version (bumped on any signature change) and a human readable build string. */
+int shasta_abi_version(void);
+const char* shasta_build_info(void);
+/* Last hip error string seen by a failed call on this thread (never NULL). */
+const char* shasta_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  point -> voxel scatter (+ per-voxel mean)
+ * replaces det3d/ops/point_cloud/point_cloud_ops.py:112-184 (`points_to_voxel`, kernel :7-55,
+ * reverse_index=True as called from det3d/core/input/voxel_generator.py:19-30) and
+ * det3d/models/readers/voxel_encoder.py:18-28 (`VoxelFeatureExtractorV3.forward`).
+ * Output order and contents are bit-identical to the serial reference loop: voxels are numbered
+ * in first-touch order of the input points, new voxels past `max_voxels` are dropped, each voxel
+ * keeps its first `max_points` points in input order.
+ *
+ *  points      (P, ndim) fp32, ndim >= 3, xyz first
+ *  range6      h_: x0,y0,z0,x1,y1,z1 ; voxel3 h_: vx,vy,vz   (fp32, as numpy float32 in the ref)
+ *  voxels      (max_voxels, max_points, ndim) fp32   -- zero padded
+ *  coors       (max_voxels, 3) int32 z,y,x
+ *  num_points  (max_voxels,) int32
+ *  mean        (max_voxels, ndim) fp32 or NULL        -- sum over slots / count
+ *  num_voxels  (1,) int32 device scalar (V); rows >= V of the outputs are left zeroed
+ *  cell_map    (gz*gy*gx,) int32, must hold 0x7fffffff everywhere on entry (see
+ *              shasta_voxelize_cell_map_bytes / _init); restored to that state on exit, so one
+ *              map serves every call on the stream (the reference allocates 331 MB per call).
+ *  workspace   shasta_voxelize_workspace_bytes(P, max_voxels, max_points) bytes
+ * ------------------------------------------------------------------------------------------ */
+size_t shasta_voxelize_cell_map_bytes(const float* h_range6, const float* h_voxel3);
+int shasta_voxelize_cell_map_init(int32_t* cell_map, size_t bytes, shasta_stream_t stream);
+size_t shasta_voxelize_workspace_bytes(int num_points, int max_voxels, int max_points);
+int shasta_voxelize_mean_f32(const float* points, int num_points, int ndim, const float* h_range6,
+                             const float* h_voxel3, int max_points, int max_voxels, float* voxels,
+                             int32_t* coors, int32_t* num_points_per_voxel, float* mean,
+                             int32_t* num_voxels, int32_t* cell_map, void* workspace,
+                             size_t workspace_bytes, shasta_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  BEV bilinear gather at box centre / edge mid-points
+ * replaces Shasta.get_box_center (det3d/models/tracker/shasta.py:121-161),
+ * center_to_corner_box2d (det3d/core/bbox/box_torch_ops.py:184-203),
+ * BEVFeatureExtractor.forward (det3d/models/second_stage/bird_eye_view.py:18-41) and
+ * bilinear_interpolate_torch (det3d/core/utils/center_utils.py:92-121).
+ *
+ *  bev     (B,H,W,C) fp32 NHWC
+ *  boxes   (B,N,>=7) fp32 rows [x,y,z,w,l,h,yaw,...], `box_stride` floats per row,
+ *          `box_batch_stride` floats per batch item
+ *  out     feature table: row n of batch b at out + b*out_batch_stride + n*out_row_stride,
+ *          num_point*C floats [pt0 C | pt1 C | ...]; num_point in {1,4,5}
+ * ------------------------------------------------------------------------------------------ */
+int shasta_bev_gather_f32(const float* bev, int B, int H, int W, int C, const float* boxes, int N,
+                          int box_stride, int box_batch_stride, int num_point, float pc_x0,
+                          float pc_y0, float vs_x, float vs_y, float out_stride, float* out,
+                          int out_row_stride, int out_batch_stride, shasta_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weights of the affinity network, raw nn.Linear layout (out_features, in_features) row major,
+ * exactly the tensors of the reference state_dict (det3d/models/tracker/shasta.py:49-106).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct shasta_linear {
+    const float* weight; /* (out, in) */
+    const float* bias;   /* (out,) */
+} shasta_linear;
+
+typedef struct shasta_weights {
+    int max_obj;   /* N */
+    int num_feats; /* nf: 1..7 */
+    int feat_dim;  /* F = share_conv_channel * num_point; supported: 64, 256, 320 */
+    shasta_linear aug_shape[4][2]; /* aug_shape.{i}.{0,2}: (N*F/64, N*F), (F, N*F/64) */
+    shasta_linear aug_dets[4][2];  /* aug_dets.{i}.{0,2}:  (7N/32, 7N), (7, 7N/32)     */
+    shasta_linear fuse_shape[4];   /* fuse_shape.{0,2,4,6}: 2F->F/8->F/16->F/32->1      */
+    shasta_linear fuse_det[3];     /* fuse_det.{0,2,4}:     2nf->32->8->1               */
+    shasta_linear res_coeff[3];    /* res_coeff.{0,2,4}:    2F+2nf->32+F/8->8+F/32->3   */
+    shasta_linear aff[6];          /* aff.{0,2,4,6,8,10}:   N+2->128->64->32->64->128->N+2 */
+} shasta_weights;
+
+/* Packed (kernel-ready) copy of the small pair/aff weights: MFMA fragments of the pair MLPs,
+ * the factorised first layers, zero padded aff matrices.  The 4 GB aug_shape matrices are used
+ * in place and never copied.  Re-pack whenever the weights change. */
+size_t shasta_packed_bytes(int max_obj, int num_feats, int feat_dim);
+int shasta_pack_weights_f32(const shasta_weights* w, void* packed, size_t packed_bytes,
+                            shasta_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3-K6  affinity forward after the gather: Shasta.forward, det3d/models/tracker/shasta.py:240-325
+ *   anchors (aug_shape :241-247, aug_dets :260-267), back-projection (:270, IN PLACE on
+ *   det_boxes), anchor concat (:273-274), hand-designed residuals (:277-283), fuse_shape
+ *   (:286-290), fuse_det (:293-307), res_coeff (:310-316), combine (:319), aff + softmaxes
+ *   (:323-325).
+ *
+ *  feat, prev_feat  (B, N+2, F) fp32 tables; rows [0,N) filled by shasta_bev_gather_f32 (out_row_stride=F,
+ *                   out_batch_stride=(N+2)*F); rows N, N+1 are written here (anchor shape embeddings:
+ *                   feat gets dead_trk_geom, fn_geom; prev_feat gets newborn_geom, fp_geom)
+ *  det_boxes        (B,N,box_stride>=10) fp32 [x,y,z,w,l,h,yaw,vx,vy,dt,...]; x,y are back-projected in place
+ *  prev_det_boxes   (B,N,box_stride>=7)
+ *  det_tab, prev_tab (B, N+2, 8) fp32 out: the 7-vectors after back-projection with the anchor boxes
+ *                   appended (prev_tab rows N,N+1 = newborn, fp ; det_tab rows N,N+1 = dead_trk, fn)
+ *  matched1         (B, N, N+2) fp32 out  = softmax over dim 2 of matched[:, :-2, :]
+ *  matched2         (B, N+2, N) fp32 out  = softmax over dim 1 of matched[:, :, :-2]
+ *  residual_out     (B, N+2, N+2) fp32 or NULL: the aff input (for parity tests)
+ *  matched_out      (B, N+2, N+2) fp32 or NULL: the aff output before the softmaxes
+ * ------------------------------------------------------------------------------------------ */
+size_t shasta_forward_workspace_bytes(int B, int max_obj, int num_feats, int feat_dim);
+int shasta_affinity_forward_f32(const shasta_weights* w, const void* packed, int B, float* feat,
+                                float* prev_feat, float* det_boxes, const float* prev_det_boxes,
+                                int box_stride, float* det_tab, float* prev_tab, float* matched1,
+                                float* matched2, float* residual_out, float* matched_out,
+                                void* workspace, size_t workspace_bytes, shasta_stream_t stream);
+
+/* Stage entry points (the forward above is exactly these in sequence; exposed for per-stage parity
+ * tests and for callers that own the schedule).  Layouts as documented above. */
+int shasta_anchor_shape_f32(const shasta_weights* w, int B, float* feat, float* prev_feat, void* workspace,
+                            size_t workspace_bytes, shasta_stream_t stream);
+int shasta_anchor_boxes_f32(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes,
+                            int box_stride, float* det_tab, float* prev_tab, void* workspace,
+                            size_t workspace_bytes, shasta_stream_t stream);
+int shasta_pair_residual_f32(const shasta_weights* w, const void* packed, int B, const float* feat,
+                             const float* prev_feat, const float* det_tab, const float* prev_tab,
+                             float* residual, int ld_residual, void* workspace, size_t workspace_bytes,
+                             shasta_stream_t stream);
+int shasta_aff_softmax_f32(const shasta_weights* w, const void* packed, int B, const float* residual,
+                           int ld_residual, float* matched1, float* matched2, float* matched_out,
+                           void* workspace, size_t workspace_bytes, shasta_stream_t stream);
+
+/* Generic fp32 MFMA GEMM used by the stages above: C[m][n] = act(sum_k A[m][k]*W[n][k] + bias[n]).
+ * act: 0 none, 1 relu, 2 abs.  lda/ldw multiples of 4 and 16-byte aligned bases. */
+int shasta_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C,
+                       int ldc, int M, int N, int K, int act, shasta_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHASTA_HIP_H */

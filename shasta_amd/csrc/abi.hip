@@ -1,0 +1,17 @@
+// ABI bookkeeping: version, build string, thread-local last error.
+#include "common.hpp"
+#include <string.h>
+
+namespace shasta {
+static thread_local char g_err[256] = "";
+void set_error(const char* what, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+}
+void set_error_msg(const char* what) { snprintf(g_err, sizeof(g_err), "%s", what); }
+}  // namespace shasta
+
+extern "C" int shasta_abi_version(void) { return 1; }
+extern "C" const char* shasta_build_info(void) {
+    return "shasta_hip gfx950 fp32 (hipcc " __VERSION__ ")";
+}
+extern "C" const char* shasta_last_error(void) { return shasta::g_err; }

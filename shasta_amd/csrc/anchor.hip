@@ -1,0 +1,307 @@
+// K3: anchor MLPs.
+//  * aug_shape[0..3] (det3d/models/tracker/shasta.py:49-57, applied :241-244):
+//      abs(Linear(N*F -> N*F/64) -> ReLU -> Linear(-> F)) on the flattened feature table.
+//      [0]=newborn_geom, [1]=fp_geom from the CURRENT features, [2]=dead_trk_geom, [3]=fn_geom from the PREVIOUS.
+//      Results are written straight into rows N, N+1 of the (B, N+2, F) tables (the cat of :246-247):
+//      prev_feat gets newborn, fp ; feat gets dead_trk, fn.
+//  * aug_dets[0..3] (shasta.py:69-76, applied :260-267): Linear(7N -> 7N//32) -> ReLU -> Linear(-> 7), dims abs'd,
+//      evaluated on the boxes BEFORE back-projection; then back-projection (:270, in place) and the cat (:273-274).
+//
+// The first aug_shape layer is the HBM term of the whole path: 4 x (N*F/64) x (N*F) fp32 = 4.1 GB at N=500,F=256.
+// It is a weight-streaming skinny GEMM: every weight is read exactly once per call (non-temporal loads, so the
+// activation vectors stay in L2), R rows x BT batch items accumulate per lane in registers, lanes walk K with
+// 16-byte loads (1 KiB per wave-instruction, fully coalesced), K is split across waves so that >= 4k waves stream
+// concurrently, and the split-K partials are summed in a fixed order afterwards (no float atomics -> bitwise
+// reproducible).
+#include "common.hpp"
+
+namespace shasta {
+
+struct AnchorL1Args {
+    const float* W[4];  // aug_shape.i.0.weight  (H, K)
+    const float* x[2];  // [0] feat table (mlps 0,1)  [1] prev_feat table (mlps 2,3)
+    float* part;        // (KS, B, 4H)
+    int H, K, B, KS, Kc, x_batch_stride, groups_per_mlp;
+};
+
+template <int BT, int R>
+__global__ __launch_bounds__(256) void anchor_l1_kernel(AnchorL1Args a) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int G = 4 * a.groups_per_mlp;
+    if (item >= G * a.KS) return;
+    const int ks = item / G, g = item % G;
+    const int mlp = g / a.groups_per_mlp, r0 = (g % a.groups_per_mlp) * R;
+    const int b0 = blockIdx.y * BT;
+    const int kbeg = ks * a.Kc, kend = min(a.K, kbeg + a.Kc);
+
+    const float* wrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wrow[r] = a.W[mlp] + (size_t)min(r0 + r, a.H - 1) * a.K;
+    const float* xb[BT];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) xb[b] = a.x[mlp >> 1] + (size_t)min(b0 + b, a.B - 1) * a.x_batch_stride;
+
+    float acc[R][BT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int b = 0; b < BT; ++b) acc[r][b] = 0.0f;
+
+    for (int k = kbeg + 4 * lane; k < kend; k += 256) {
+        f32x4 xv[BT], wv[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wrow[r] + k));
+#pragma unroll
+        for (int b = 0; b < BT; ++b) xv[b] = *reinterpret_cast<const f32x4*>(xb[b] + k);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int b = 0; b < BT; ++b) {
+                float s = acc[r][b];
+                s = fmaf(wv[r][0], xv[b][0], s);
+                s = fmaf(wv[r][1], xv[b][1], s);
+                s = fmaf(wv[r][2], xv[b][2], s);
+                s = fmaf(wv[r][3], xv[b][3], s);
+                acc[r][b] = s;
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            const float s = wave_sum(acc[r][b]);
+            if (lane == 0 && r0 + r < a.H && b0 + b < a.B)
+                a.part[((size_t)ks * a.B + (b0 + b)) * (4 * a.H) + mlp * a.H + r0 + r] = s;
+        }
+}
+
+// hidden[b][r] = relu(bias1[r] + sum_ks part[ks][b][r]),  r over the 4H concatenated hidden units
+__global__ void anchor_hidden_kernel(const float* __restrict__ part, const float* b0, const float* b1,
+                                     const float* b2, const float* b3, float* __restrict__ hidden, int H, int B,
+                                     int KS) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = B * 4 * H;
+    if (i >= total) return;
+    const int r = i % (4 * H);
+    const int mlp = r / H, j = r % H;
+    const float* bias = mlp == 0 ? b0 : mlp == 1 ? b1 : mlp == 2 ? b2 : b3;
+    float s = part[i];
+    for (int ks = 1; ks < KS; ++ks) s += part[(size_t)ks * total + i];
+    hidden[i] = fmaxf(s + bias[j], 0.0f);
+}
+
+struct AnchorL2Args {
+    const float* W[4];  // aug_shape.i.2.weight (F, H)
+    const float* bias[4];
+    const float* hidden;  // (B, 4H)
+    float* feat;          // (B, N+2, F)
+    float* prev_feat;
+    int H, F, N, B;
+};
+
+// one wave per (b, mlp, j): out = abs(b2[j] + W2[j,:] . hidden[b, mlp, :])
+__global__ __launch_bounds__(256) void anchor_l2_kernel(AnchorL2Args a) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= a.B * 4 * a.F) return;
+    const int j = item % a.F, mlp = (item / a.F) & 3, b = item / (4 * a.F);
+    const float* w = a.W[mlp] + (size_t)j * a.H;
+    const float* h = a.hidden + (size_t)b * 4 * a.H + mlp * a.H;
+    float s = 0.0f;
+    for (int i = lane; i < a.H; i += 64) s = fmaf(w[i], h[i], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+        const float v = fabsf(s + a.bias[mlp][j]);
+        // mlp 0,1 (newborn, fp) -> prev_feat rows N, N+1 ; mlp 2,3 (dead_trk, fn) -> feat rows N, N+1
+        float* tab = (mlp < 2) ? a.prev_feat : a.feat;
+        tab[((size_t)b * (a.N + 2) + a.N + (mlp & 1)) * a.F + j] = v;
+    }
+}
+
+struct BoxL1Args {
+    const float* W[4];  // aug_dets.i.0.weight (HD, 7N)
+    const float* bias[4];
+    const float* det;   // (B, N, box_stride), pre back-projection
+    const float* prev;
+    float* hid;  // (B, 4, HD)
+    int HD, N, B, box_stride;
+};
+
+// one wave per (b, mlp, u): hid = relu(b1[u] + W1[u,:] . boxes7_flat)
+__global__ __launch_bounds__(256) void box_l1_kernel(BoxL1Args a) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= a.B * 4 * a.HD) return;
+    const int u = item % a.HD, mlp = (item / a.HD) & 3, b = item / (4 * a.HD);
+    const float* w = a.W[mlp] + (size_t)u * 7 * a.N;
+    const float* x = ((mlp < 2) ? a.det : a.prev) + (size_t)b * a.N * a.box_stride;
+    float s = 0.0f;
+    for (int k = lane; k < 7 * a.N; k += 64) {
+        const int n = k / 7, c = k - 7 * n;
+        s = fmaf(w[k], x[(size_t)n * a.box_stride + c], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) a.hid[item] = fmaxf(s + a.bias[mlp][u], 0.0f);
+}
+
+struct BoxL2Args {
+    const float* W[4];  // aug_dets.i.2.weight (7, HD)
+    const float* bias[4];
+    const float* hid;
+    float* det;  // back-projected in place
+    const float* prev;
+    float* det_tab;  // (B, N+2, 8)
+    float* prev_tab;
+    int HD, N, B, box_stride;
+};
+
+// one workgroup per batch item: the 4x7 anchor outputs, then back-projection (shasta.py:270) and the
+// (N+2, 8) box tables (shasta.py:273-274; column 7 is padding and written as 0).
+__global__ __launch_bounds__(256) void box_l2_tables_kernel(BoxL2Args a) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < 32) {
+        float v = 0.0f;
+        const int mlp = tid >> 3, c = tid & 7;
+        if (c < 7) {
+            const float* w = a.W[mlp] + (size_t)c * a.HD;
+            const float* h = a.hid + ((size_t)b * 4 + mlp) * a.HD;
+            float s = 0.0f;
+            for (int i = 0; i < a.HD; ++i) s = fmaf(w[i], h[i], s);
+            v = s + a.bias[mlp][c];
+            if (c >= 3 && c < 6) v = fabsf(v);
+        }
+        // mlp 0,1 (newborn, fp) extend the PREVIOUS boxes; 2,3 (dead_trk, fn) extend the CURRENT ones
+        float* tab = (mlp < 2) ? a.prev_tab : a.det_tab;
+        tab[((size_t)b * (a.N + 2) + a.N + (mlp & 1)) * 8 + c] = v;
+    }
+    for (int n = tid; n < a.N; n += blockDim.x) {
+        float* d = a.det + ((size_t)b * a.N + n) * a.box_stride;
+        const float* p = a.prev + ((size_t)b * a.N + n) * a.box_stride;
+        const float dt = d[9];
+        const float x = d[0] - d[7] * dt, y = d[1] - d[8] * dt;  // separately rounded mul, sub
+        d[0] = x;
+        d[1] = y;
+        float* dr = a.det_tab + ((size_t)b * (a.N + 2) + n) * 8;
+        float* pr = a.prev_tab + ((size_t)b * (a.N + 2) + n) * 8;
+        dr[0] = x;
+        dr[1] = y;
+#pragma unroll
+        for (int c = 2; c < 7; ++c) dr[c] = d[c];
+        dr[7] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) pr[c] = p[c];
+        pr[7] = 0.0f;
+    }
+}
+
+size_t anchor_shape_workspace_bytes(int B, int N, int F) {
+    const int H = N * F / 64;
+    // worst-case KS is bounded by 64
+    return align_up((size_t)64 * B * 4 * H * sizeof(float), 256) + align_up((size_t)B * 4 * H * sizeof(float), 256);
+}
+
+template <int BT, int R>
+static void launch_l1(const AnchorL1Args& a, hipStream_t st) {
+    const int G = 4 * a.groups_per_mlp;
+    dim3 grid(cdiv(G * a.KS, 4), cdiv(a.B, BT));
+    hipLaunchKernelGGL((anchor_l1_kernel<BT, R>), grid, dim3(256), 0, st, a);
+}
+
+int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes,
+                 hipStream_t st) {
+    const int N = w->max_obj, F = w->feat_dim;
+    const int K = N * F, H = K / 64;
+    if (ws_bytes < anchor_shape_workspace_bytes(B, N, F)) {
+        set_error_msg("anchor_shape: workspace too small");
+        return SHASTA_E_WORKSPACE;
+    }
+    if (B == 0) return SHASTA_OK;
+    constexpr int R = 8;
+    AnchorL1Args a;
+    for (int i = 0; i < 4; ++i) a.W[i] = w->aug_shape[i][0].weight;
+    a.x[0] = feat;
+    a.x[1] = prev_feat;
+    a.H = H;
+    a.K = K;
+    a.B = B;
+    a.x_batch_stride = (N + 2) * F;
+    a.groups_per_mlp = cdiv(H, R);
+    const int G = 4 * a.groups_per_mlp;
+    // enough waves to fill 256 CUs x 16 streaming waves, K chunks of >= 1024 floats, multiples of 256
+    int ks = max(1, min(min(64, cdiv(4096, G)), cdiv(K, 1024)));
+    a.Kc = cdiv(cdiv(K, ks), 256) * 256;
+    a.KS = cdiv(K, a.Kc);
+    float* part = static_cast<float*>(ws);
+    float* hidden = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)64 * B * 4 * H * sizeof(float), 256));
+    a.part = part;
+    if (B == 1) launch_l1<1, R>(a, st);
+    else if (B == 2) launch_l1<2, R>(a, st);
+    else if (B <= 4) launch_l1<4, R>(a, st);
+    else launch_l1<8, R>(a, st);
+    int rc = check_launch("anchor_l1");
+    if (rc) return rc;
+    const int total = B * 4 * H;
+    hipLaunchKernelGGL(anchor_hidden_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, part,
+                       w->aug_shape[0][0].bias, w->aug_shape[1][0].bias, w->aug_shape[2][0].bias,
+                       w->aug_shape[3][0].bias, hidden, H, B, a.KS);
+    rc = check_launch("anchor_hidden");
+    if (rc) return rc;
+    AnchorL2Args l2;
+    for (int i = 0; i < 4; ++i) {
+        l2.W[i] = w->aug_shape[i][1].weight;
+        l2.bias[i] = w->aug_shape[i][1].bias;
+    }
+    l2.hidden = hidden;
+    l2.feat = feat;
+    l2.prev_feat = prev_feat;
+    l2.H = H;
+    l2.F = F;
+    l2.N = N;
+    l2.B = B;
+    hipLaunchKernelGGL(anchor_l2_kernel, dim3(cdiv(B * 4 * F, 4)), dim3(256), 0, st, l2);
+    return check_launch("anchor_l2");
+}
+
+size_t anchor_boxes_workspace_bytes(int B, int N) { return align_up((size_t)B * 4 * max(1, 7 * N / 32) * sizeof(float), 256); }
+
+int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes, int box_stride,
+                 float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st) {
+    const int N = w->max_obj, HD = 7 * N / 32;
+    if (B == 0) return SHASTA_OK;
+    if (HD > 0) {
+        BoxL1Args a;
+        for (int i = 0; i < 4; ++i) {
+            a.W[i] = w->aug_dets[i][0].weight;
+            a.bias[i] = w->aug_dets[i][0].bias;
+        }
+        a.det = det_boxes;
+        a.prev = prev_det_boxes;
+        a.hid = hid_ws;
+        a.HD = HD;
+        a.N = N;
+        a.B = B;
+        a.box_stride = box_stride;
+        hipLaunchKernelGGL(box_l1_kernel, dim3(cdiv(B * 4 * HD, 4)), dim3(256), 0, st, a);
+        int rc = check_launch("box_l1");
+        if (rc) return rc;
+    }
+    BoxL2Args b2;
+    for (int i = 0; i < 4; ++i) {
+        b2.W[i] = w->aug_dets[i][1].weight;
+        b2.bias[i] = w->aug_dets[i][1].bias;
+    }
+    b2.hid = hid_ws;
+    b2.det = det_boxes;
+    b2.prev = prev_det_boxes;
+    b2.det_tab = det_tab;
+    b2.prev_tab = prev_tab;
+    b2.HD = HD;
+    b2.N = N;
+    b2.B = B;
+    b2.box_stride = box_stride;
+    hipLaunchKernelGGL(box_l2_tables_kernel, dim3(B), dim3(256), 0, st, b2);
+    return check_launch("box_l2_tables");
+}
+
+}  // namespace shasta

@@ -1,0 +1,118 @@
+// K2: BEV bilinear gather at box centre / edge mid-points.
+// Restates (in one kernel) Shasta.get_box_center (det3d/models/tracker/shasta.py:121-161),
+// center_to_corner_box2d (det3d/core/bbox/box_torch_ops.py:184-203), BEVFeatureExtractor.forward
+// (det3d/models/second_stage/bird_eye_view.py:18-41) and bilinear_interpolate_torch
+// (det3d/core/utils/center_utils.py:92-121).
+//
+// Layout: one wavefront per (batch, object, point); lane c owns channels c, c+64, ...  so each of
+// the four corner fetches is one coalesced C*4-byte row of the NHWC map (256 B at C=64).  The
+// output row [pt0 C | pt1 C | ...] is written directly in the packed (N, num_point*C) order the
+// reference builds with a cat of sections (bird_eye_view.py:35-37).
+// HBM-bound: 4*C*4 B read + C*4 B written per point.
+#include "common.hpp"
+
+namespace shasta {
+
+// Arithmetic notes (parity): every product/sum below is a separately rounded fp32 op
+// (__fmul_rn/__fadd_rn/__fsub_rn, never contracted) because the reference evaluates them as
+// separate ATen ops; the metric->pixel map keeps the reference's two successive divisions
+// (bird_eye_view.py:19-20) -- a fused reciprocal changes floor() for ~1e-6 of coordinates.
+__global__ __launch_bounds__(256) void bev_gather_kernel(
+    const float* __restrict__ bev, int H, int W, int C, const float* __restrict__ boxes, int N,
+    int box_stride, int box_batch_stride, int num_point, float pc_x0, float pc_y0, float vs_x,
+    float vs_y, float out_stride_px, float* __restrict__ out, int out_row_stride,
+    int out_batch_stride, int total_points) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= total_points) return;
+    const int pt = wave % num_point;
+    const int n = (wave / num_point) % N;
+    const int b = wave / (num_point * N);
+
+    const float* box = boxes + (size_t)b * box_batch_stride + (size_t)n * box_stride;
+    const float cx = box[0], cy = box[1];
+    float px = cx, py = cy;
+    // point type: num_point==5 -> [centre, front, back, left, right]; 4 -> no centre; 1 -> centre
+    const int edge = (num_point == 5) ? pt - 1 : (num_point == 4 ? pt : -1);
+    if (edge >= 0) {
+        const float w = box[3], l = box[4], yaw = box[6];
+        const float s = sinf(yaw), c = cosf(yaw);
+        // unit corners (clockwise from the minimum point): (-.5,-.5) (-.5,.5) (.5,.5) (.5,-.5)
+        // edge mid-points: front=(c0+c1)/2, back=(c2+c3)/2, left=(c0+c3)/2, right=(c1+c2)/2
+        const int ia = (edge == 0) ? 0 : (edge == 1) ? 2 : (edge == 2) ? 0 : 1;
+        const int ib = (edge == 0) ? 1 : (edge == 1) ? 3 : (edge == 2) ? 3 : 2;
+        float qx[2], qy[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int ci = k ? ib : ia;
+            const float ux = (ci < 2) ? -0.5f : 0.5f;
+            const float uy = (ci == 1 || ci == 2) ? 0.5f : -0.5f;
+            const float dx = __fmul_rn(w, ux), dy = __fmul_rn(l, uy);
+            // rotation_2d: x' = x*cos + y*sin ; y' = -x*sin + y*cos   (box_torch_ops.py:145-158)
+            const float rx = __fadd_rn(__fmul_rn(dx, c), __fmul_rn(dy, s));
+            const float ry = __fadd_rn(__fmul_rn(-dx, s), __fmul_rn(dy, c));
+            qx[k] = __fadd_rn(rx, cx);
+            qy[k] = __fadd_rn(ry, cy);
+        }
+        px = __fdiv_rn(__fadd_rn(qx[0], qx[1]), 2.0f);
+        py = __fdiv_rn(__fadd_rn(qy[0], qy[1]), 2.0f);
+    }
+    const float x = __fdiv_rn(__fdiv_rn(__fsub_rn(px, pc_x0), vs_x), out_stride_px);
+    const float y = __fdiv_rn(__fdiv_rn(__fsub_rn(py, pc_y0), vs_y), out_stride_px);
+    // floor -> int with clamping done in float first so that wild coordinates (inf/NaN/1e30)
+    // cannot overflow the conversion; the reference clamps the int64 indices.
+    const float fx = floorf(x), fy = floorf(y);
+    auto clampi = [](float f, int hi) -> int {
+        if (!(f > -2.0f)) return 0 - 1;  // also NaN -> behaves like far-left (weights become NaN anyway)
+        if (f > (float)(hi + 1)) return hi + 1;
+        return (int)f;
+    };
+    int x0 = clampi(fx, W), y0 = clampi(fy, H);
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 = min(max(x0, 0), W - 1);
+    x1 = min(max(x1, 0), W - 1);
+    y0 = min(max(y0, 0), H - 1);
+    y1 = min(max(y1, 0), H - 1);
+    const float fx0 = (float)x0, fx1 = (float)x1, fy0 = (float)y0, fy1 = (float)y1;
+    const float wa = __fmul_rn(__fsub_rn(fx1, x), __fsub_rn(fy1, y));
+    const float wb = __fmul_rn(__fsub_rn(fx1, x), __fsub_rn(y, fy0));
+    const float wc = __fmul_rn(__fsub_rn(x, fx0), __fsub_rn(fy1, y));
+    const float wd = __fmul_rn(__fsub_rn(x, fx0), __fsub_rn(y, fy0));
+
+    const float* im = bev + (size_t)b * H * W * C;
+    const float* Ia = im + ((size_t)y0 * W + x0) * C;
+    const float* Ib = im + ((size_t)y1 * W + x0) * C;
+    const float* Ic = im + ((size_t)y0 * W + x1) * C;
+    const float* Id = im + ((size_t)y1 * W + x1) * C;
+    float* o = out + (size_t)b * out_batch_stride + (size_t)n * out_row_stride + (size_t)pt * C;
+    for (int ch = lane; ch < C; ch += 64) {
+        float v = __fmul_rn(Ia[ch], wa);
+        v = __fadd_rn(v, __fmul_rn(Ib[ch], wb));
+        v = __fadd_rn(v, __fmul_rn(Ic[ch], wc));
+        v = __fadd_rn(v, __fmul_rn(Id[ch], wd));
+        o[ch] = v;
+    }
+}
+
+}  // namespace shasta
+
+extern "C" int shasta_bev_gather_f32(const float* bev, int B, int H, int W, int C, const float* boxes,
+                                     int N, int box_stride, int box_batch_stride, int num_point,
+                                     float pc_x0, float pc_y0, float vs_x, float vs_y, float out_stride,
+                                     float* out, int out_row_stride, int out_batch_stride,
+                                     shasta_stream_t stream) {
+    using namespace shasta;
+    SHASTA_REQUIRE(bev && boxes && out, "bev_gather: null pointer");
+    SHASTA_REQUIRE(B >= 0 && N >= 0 && H > 0 && W > 0 && C > 0, "bev_gather: bad size");
+    SHASTA_REQUIRE(num_point == 1 || num_point == 4 || num_point == 5, "bev_gather: num_point must be 1, 4 or 5");
+    SHASTA_REQUIRE(box_stride >= (num_point == 1 ? 2 : 7) && out_row_stride >= num_point * C, "bev_gather: bad stride");
+    const long total = (long)B * N * num_point;
+    if (total == 0) return SHASTA_OK;
+    SHASTA_REQUIRE(total < (1L << 30), "bev_gather: too many points");
+    const int waves_per_block = 4;
+    const int blocks = cdiv((int)total, waves_per_block);
+    hipLaunchKernelGGL(bev_gather_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, as_stream(stream), bev,
+                       H, W, C, boxes, N, box_stride, box_batch_stride, num_point, pc_x0, pc_y0, vs_x, vs_y,
+                       out_stride, out, out_row_stride, out_batch_stride, (int)total);
+    return check_launch("bev_gather");
+}

@@ -1,0 +1,47 @@
+// Shared helpers for the gfx950 kernels of the ShaSTA affinity path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/shasta_hip.h"
+
+namespace shasta {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+void set_error(const char* what, hipError_t e);
+void set_error_msg(const char* what);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(what, e);
+        return SHASTA_E_LAUNCH;
+    }
+    return SHASTA_OK;
+}
+
+inline hipStream_t as_stream(shasta_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+#define SHASTA_REQUIRE(cond, msg)            \
+    do {                                     \
+        if (!(cond)) {                       \
+            shasta::set_error_msg(msg);      \
+            return SHASTA_E_ARG;             \
+        }                                    \
+    } while (0)
+
+// wave-wide sum, result in every lane (fixed butterfly order -> deterministic)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+}  // namespace shasta

@@ -1,0 +1,171 @@
+// C-ABI entry points of the affinity forward: argument checks, workspace carving, stage sequencing.
+#include "common.hpp"
+#include "pair_layout.hpp"
+
+namespace shasta {
+size_t anchor_shape_workspace_bytes(int B, int N, int F);
+size_t anchor_boxes_workspace_bytes(int B, int N);
+size_t pair_workspace_bytes(int B, int N, int F);
+size_t aff_workspace_bytes(int B, int N);
+int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes, hipStream_t st);
+int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes, int box_stride,
+                 float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st);
+int pair_residual(const shasta_weights* w, const float* packed, int B, const float* feat, const float* prev_feat,
+                  const float* det_tab, const float* prev_tab, float* residual, int ld, void* ws, size_t ws_bytes,
+                  hipStream_t st);
+int aff_softmax(const shasta_weights* w, const float* packed, int B, const float* residual, int ld, float* m1,
+                float* m2, float* matched_out, void* ws, size_t ws_bytes, hipStream_t st);
+int pack_weights(const shasta_weights* w, float* packed, hipStream_t st);
+
+static int check_weights(const shasta_weights* w) {
+    SHASTA_REQUIRE(w, "null weights");
+    SHASTA_REQUIRE(w->max_obj >= 1 && w->max_obj <= 4094, "max_obj out of range");
+    SHASTA_REQUIRE(w->num_feats >= 1 && w->num_feats <= 7, "num_feats must be 1..7");
+    SHASTA_REQUIRE(w->feat_dim == 64 || w->feat_dim == 256 || w->feat_dim == 320, "feat_dim must be 64, 256 or 320");
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j) {
+            SHASTA_REQUIRE(w->aug_shape[i][j].weight && w->aug_shape[i][j].bias, "aug_shape weights missing");
+            SHASTA_REQUIRE(w->aug_dets[i][j].weight && w->aug_dets[i][j].bias, "aug_dets weights missing");
+        }
+    for (int i = 0; i < 4; ++i) SHASTA_REQUIRE(w->fuse_shape[i].weight && w->fuse_shape[i].bias, "fuse_shape weights missing");
+    for (int i = 0; i < 3; ++i) {
+        SHASTA_REQUIRE(w->fuse_det[i].weight && w->fuse_det[i].bias, "fuse_det weights missing");
+        SHASTA_REQUIRE(w->res_coeff[i].weight && w->res_coeff[i].bias, "res_coeff weights missing");
+    }
+    for (int i = 0; i < 6; ++i) SHASTA_REQUIRE(w->aff[i].weight && w->aff[i].bias, "aff weights missing");
+    for (int i = 0; i < 4; ++i)
+        SHASTA_REQUIRE((uintptr_t)w->aug_shape[i][0].weight % 16 == 0, "aug_shape.*.0.weight must be 16-byte aligned");
+    return SHASTA_OK;
+}
+
+struct FwdWs {
+    size_t anchor, boxes, pair, aff, residual, total;
+    FwdWs(int B, int N, int F) {
+        const int T = N + 2, Dp = (T + 3) / 4 * 4;
+        anchor = anchor_shape_workspace_bytes(B, N, F);
+        boxes = anchor_boxes_workspace_bytes(B, N);
+        pair = pair_workspace_bytes(B, N, F);
+        aff = aff_workspace_bytes(B, N);
+        residual = align_up((size_t)B * T * Dp * sizeof(float), 256);
+        // anchor / pair / aff scratch is live one stage at a time -> shared region
+        size_t stage = anchor > pair ? anchor : pair;
+        stage = stage > aff ? stage : aff;
+        stage = stage > boxes ? stage : boxes;
+        total = stage + residual;
+    }
+};
+
+}  // namespace shasta
+
+using namespace shasta;
+
+extern "C" size_t shasta_packed_bytes(int max_obj, int num_feats, int feat_dim) {
+    if (feat_dim != 64 && feat_dim != 256 && feat_dim != 320) return 0;
+    return PackedLayout(max_obj, num_feats, feat_dim).total * sizeof(float);
+}
+
+extern "C" int shasta_pack_weights_f32(const shasta_weights* w, void* packed, size_t packed_bytes,
+                                       shasta_stream_t stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    SHASTA_REQUIRE(packed && (uintptr_t)packed % 16 == 0, "pack: packed buffer null or not 16-byte aligned");
+    if (packed_bytes < shasta_packed_bytes(w->max_obj, w->num_feats, w->feat_dim)) {
+        set_error_msg("pack: packed buffer too small");
+        return SHASTA_E_WORKSPACE;
+    }
+    return pack_weights(w, static_cast<float*>(packed), as_stream(stream));
+}
+
+extern "C" size_t shasta_forward_workspace_bytes(int B, int max_obj, int num_feats, int feat_dim) {
+    (void)num_feats;
+    return FwdWs(B, max_obj, feat_dim).total;
+}
+
+extern "C" int shasta_anchor_shape_f32(const shasta_weights* w, int B, float* feat, float* prev_feat, void* workspace,
+                                       size_t workspace_bytes, shasta_stream_t stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    SHASTA_REQUIRE(B >= 0 && feat && prev_feat && workspace, "anchor_shape: bad argument");
+    SHASTA_REQUIRE(((uintptr_t)feat | (uintptr_t)prev_feat) % 16 == 0, "anchor_shape: tables must be 16-byte aligned");
+    return anchor_shape(w, B, feat, prev_feat, workspace, workspace_bytes, as_stream(stream));
+}
+
+extern "C" int shasta_anchor_boxes_f32(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes,
+                                       int box_stride, float* det_tab, float* prev_tab, void* workspace,
+                                       size_t workspace_bytes, shasta_stream_t stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    SHASTA_REQUIRE(B >= 0 && det_boxes && prev_det_boxes && det_tab && prev_tab && workspace, "anchor_boxes: bad argument");
+    SHASTA_REQUIRE(box_stride >= 10, "anchor_boxes: box rows need [x,y,z,w,l,h,yaw,vx,vy,dt]");
+    if (workspace_bytes < anchor_boxes_workspace_bytes(B, w->max_obj)) {
+        set_error_msg("anchor_boxes: workspace too small");
+        return SHASTA_E_WORKSPACE;
+    }
+    return anchor_boxes(w, B, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, static_cast<float*>(workspace),
+                        as_stream(stream));
+}
+
+extern "C" int shasta_pair_residual_f32(const shasta_weights* w, const void* packed, int B, const float* feat,
+                                        const float* prev_feat, const float* det_tab, const float* prev_tab,
+                                        float* residual, int ld_residual, void* workspace, size_t workspace_bytes,
+                                        shasta_stream_t stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    SHASTA_REQUIRE(B >= 0 && packed && feat && prev_feat && det_tab && prev_tab && residual && workspace,
+                   "pair_residual: bad argument");
+    SHASTA_REQUIRE(ld_residual >= w->max_obj + 2, "pair_residual: ld_residual < N+2");
+    SHASTA_REQUIRE(((uintptr_t)feat | (uintptr_t)prev_feat | (uintptr_t)packed) % 16 == 0, "pair_residual: alignment");
+    return pair_residual(w, static_cast<const float*>(packed), B, feat, prev_feat, det_tab, prev_tab, residual,
+                         ld_residual, workspace, workspace_bytes, as_stream(stream));
+}
+
+extern "C" int shasta_aff_softmax_f32(const shasta_weights* w, const void* packed, int B, const float* residual,
+                                      int ld_residual, float* matched1, float* matched2, float* matched_out,
+                                      void* workspace, size_t workspace_bytes, shasta_stream_t stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    SHASTA_REQUIRE(B >= 0 && packed && residual && matched1 && matched2 && workspace, "aff_softmax: bad argument");
+    SHASTA_REQUIRE(ld_residual >= w->max_obj + 2, "aff_softmax: ld_residual < N+2");
+    return aff_softmax(w, static_cast<const float*>(packed), B, residual, ld_residual, matched1, matched2, matched_out,
+                       workspace, workspace_bytes, as_stream(stream));
+}
+
+extern "C" int shasta_affinity_forward_f32(const shasta_weights* w, const void* packed, int B, float* feat,
+                                           float* prev_feat, float* det_boxes, const float* prev_det_boxes,
+                                           int box_stride, float* det_tab, float* prev_tab, float* matched1,
+                                           float* matched2, float* residual_out, float* matched_out, void* workspace,
+                                           size_t workspace_bytes, shasta_stream_t stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    SHASTA_REQUIRE(B >= 0 && packed && feat && prev_feat && det_boxes && prev_det_boxes && det_tab && prev_tab &&
+                       matched1 && matched2 && workspace,
+                   "forward: null pointer");
+    SHASTA_REQUIRE(box_stride >= 10, "forward: box rows need [x,y,z,w,l,h,yaw,vx,vy,dt]");
+    SHASTA_REQUIRE(((uintptr_t)feat | (uintptr_t)prev_feat | (uintptr_t)packed | (uintptr_t)workspace) % 16 == 0,
+                   "forward: feat/prev_feat/packed/workspace must be 16-byte aligned");
+    const int N = w->max_obj, F = w->feat_dim, T = N + 2, Dp = (T + 3) / 4 * 4;
+    const FwdWs L(B, N, F);
+    if (workspace_bytes < L.total) {
+        set_error_msg("forward: workspace too small");
+        return SHASTA_E_WORKSPACE;
+    }
+    if (B == 0) return SHASTA_OK;
+    hipStream_t st = as_stream(stream);
+    float* residual = static_cast<float*>(workspace);
+    void* stage = static_cast<char*>(workspace) + L.residual;
+    const size_t stage_bytes = L.total - L.residual;
+    const float* pk = static_cast<const float*>(packed);
+    if ((rc = anchor_shape(w, B, feat, prev_feat, stage, stage_bytes, st))) return rc;
+    if ((rc = anchor_boxes(w, B, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, static_cast<float*>(stage), st)))
+        return rc;
+    if ((rc = pair_residual(w, pk, B, feat, prev_feat, det_tab, prev_tab, residual, Dp, stage, stage_bytes, st))) return rc;
+    if (residual_out) {
+        hipError_t e = hipMemcpy2DAsync(residual_out, (size_t)T * sizeof(float), residual, (size_t)Dp * sizeof(float),
+                                        (size_t)T * sizeof(float), (size_t)B * T, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) {
+            set_error("forward: copy residual", e);
+            return SHASTA_E_LAUNCH;
+        }
+    }
+    return aff_softmax(w, pk, B, residual, Dp, matched1, matched2, matched_out, stage, stage_bytes, st);
+}

@@ -1,0 +1,94 @@
+"""ctypes binding of the C ABI in include/shasta_hip.h (libshasta_hip.so, built in-tree by shasta_amd.build).
+
+PyTorch is only plumbing here: it owns device memory and the current HIP stream; every compute call goes
+through the C ABI with raw device pointers.  There is NO fallback: if the library is missing or a call fails,
+`ShastaHipError` is raised.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libshasta_hip.so")
+_lib = None
+
+
+class ShastaHipError(RuntimeError):
+    pass
+
+
+class Linear(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p)]
+
+
+class Weights(C.Structure):
+    _fields_ = [("max_obj", C.c_int), ("num_feats", C.c_int), ("feat_dim", C.c_int),
+                ("aug_shape", (Linear * 2) * 4), ("aug_dets", (Linear * 2) * 4),
+                ("fuse_shape", Linear * 4), ("fuse_det", Linear * 3), ("res_coeff", Linear * 3),
+                ("aff", Linear * 6)]
+
+
+# every symbol include/shasta_hip.h declares: name -> (restype, argtypes)
+_P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_WP = C.POINTER(Weights)
+SYMBOLS = {
+    "shasta_abi_version": (_I, []),
+    "shasta_build_info": (C.c_char_p, []),
+    "shasta_last_error": (C.c_char_p, []),
+    "shasta_voxelize_cell_map_bytes": (_Z, [_P, _P]),
+    "shasta_voxelize_cell_map_init": (_I, [_P, _Z, _P]),
+    "shasta_voxelize_workspace_bytes": (_Z, [_I, _I, _I]),
+    "shasta_voxelize_mean_f32": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "shasta_bev_gather_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P, _I, _I, _P]),
+    "shasta_packed_bytes": (_Z, [_I, _I, _I]),
+    "shasta_pack_weights_f32": (_I, [_WP, _P, _Z, _P]),
+    "shasta_forward_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "shasta_affinity_forward_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "shasta_anchor_shape_f32": (_I, [_WP, _I, _P, _P, _P, _Z, _P]),
+    "shasta_anchor_boxes_f32": (_I, [_WP, _I, _P, _P, _I, _P, _P, _P, _Z, _P]),
+    "shasta_pair_residual_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
+    "shasta_aff_softmax_f32": (_I, [_WP, _P, _I, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    "shasta_gemm_nt_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+}
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load libshasta_hip.so and bind every declared symbol.  Raises ShastaHipError when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ShastaHipError("HIP extension missing: %s (run `python -m shasta_amd.build`); "
+                             "there is no CPU fallback" % _LIB_PATH)
+    lib = C.CDLL(_LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise ShastaHipError("%s failed (%d): %s" % (what, rc, load().shasta_last_error().decode()))
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ShastaHipError("expected a device tensor (the HIP path has no CPU fallback)")
+    if t.dtype != torch.float32 and t.dtype != torch.int32 and t.dtype != torch.uint8:
+        raise ShastaHipError("unexpected dtype %s" % t.dtype)
+    if not t.is_contiguous():
+        raise ShastaHipError("expected a contiguous tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,283 @@
+"""`Shasta`: the affinity network with the reference's model API, computed by hand-written HIP kernels.
+
+Mirror of det3d/models/tracker/shasta.py:9-327 (`Shasta(BaseTrack)`):
+  * same constructor keywords (:11-25), same sub-module creation ORDER (so a seeded default init gives the same
+    weights and `children()` indices 1,2 are backbone, neck as tools/nusc_shasta/train.py:184-191 expects),
+    same `state_dict` key names and shapes (:42-106);
+  * `forward(example, train_mode=True) -> (matched1 (B,N,N+2), matched2 (B,N+2,N), example)` with the reference's
+    side effects: `example["det_boxes"][:, :, :2]` back-projected in place (:216,270), `example["bev_feature"]`
+    set to the NHWC map after shared_conv (:224), `self.newborn/fp/dead_trk/fn` anchor boxes (:260-267).
+The nn.Linear modules here only HOLD the parameters; every compute step of rows 4-16 of SURVEY.md 8(a) runs through
+the C ABI (include/shasta_hip.h).  There is no PyTorch/CPU fallback: without the built library, or with CPU
+tensors, forward raises.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import builder, hip
+from .registry import TRACK
+
+
+class BaseTrack(nn.Module):
+    """det3d/models/tracker/base.py:11-72 (the properties Shasta uses)."""
+
+    def __init__(self):
+        super().__init__()
+        self.fp16_enabled = False
+
+    @property
+    def with_reader(self):
+        return hasattr(self, "reader") and self.reader is not None
+
+    @property
+    def with_neck(self):
+        return hasattr(self, "neck") and self.neck is not None
+
+
+@TRACK.register_module
+class Shasta(BaseTrack):
+    def __init__(self, reader, backbone, neck, bev_extractor, train_cfg=None, test_cfg=None, pretrained=None,
+                 max_obj=100, num_feats=7, in_channels=512, share_conv_channel=64, num_point=5):
+        super().__init__()
+        self.reader = builder.build_reader(reader)
+        self.backbone = builder.build_backbone(backbone)
+        self.neck = builder.build_neck(neck)
+        self.bev_extractor = builder.build_second_stage_module(bev_extractor)
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+        self.init_weights(pretrained=pretrained)
+
+        self.num_feats = num_feats
+        self.max_obj = max_obj
+        self.num_point = num_point
+
+        self.shared_conv = nn.Sequential(
+            nn.Conv2d(in_channels, share_conv_channel, kernel_size=3, padding=1, bias=True),
+            nn.BatchNorm2d(share_conv_channel),
+            nn.ReLU(inplace=True),
+        )
+        self.aug_shape = nn.ModuleList()
+        self.aug_shape_input = max_obj * share_conv_channel * num_point
+        self.aug_shape_output = share_conv_channel * num_point
+        for _ in range(4):
+            self.aug_shape.append(nn.Sequential(
+                nn.Linear(self.aug_shape_input, self.aug_shape_input // 64),
+                nn.ReLU(inplace=True),
+                nn.Linear(self.aug_shape_input // 64, self.aug_shape_output),
+            ))
+        F = self.aug_shape_output
+        self.fuse_shape = nn.Sequential(
+            nn.Linear(2 * F, F // 8), nn.ReLU(inplace=True),
+            nn.Linear(F // 8, F // 16), nn.ReLU(inplace=True),
+            nn.Linear(F // 16, F // 32), nn.ReLU(inplace=True),
+            nn.Linear(F // 32, 1),
+        )
+        self.aug_input = max_obj * 7
+        self.aug_dets = nn.ModuleList()
+        for _ in range(4):
+            self.aug_dets.append(nn.Sequential(
+                nn.Linear(self.aug_input, self.aug_input // 32),
+                nn.ReLU(inplace=True),
+                nn.Linear(self.aug_input // 32, 7),
+            ))
+        self.fuse_det = nn.Sequential(
+            nn.Linear(self.num_feats * 2, 32), nn.ReLU(inplace=True),
+            nn.Linear(32, 8), nn.ReLU(inplace=True),
+            nn.Linear(8, 1),
+        )
+        self.res_coeff = nn.Sequential(
+            nn.Linear(self.num_feats * 2 + F * 2, 32 + F // 8), nn.ReLU(inplace=True),
+            nn.Linear(32 + F // 8, 8 + F // 32), nn.ReLU(inplace=True),
+            nn.Linear(8 + F // 32, 3),
+        )
+        self.aff = nn.Sequential(
+            nn.Linear(max_obj + 2, 128), nn.ReLU(inplace=True),
+            nn.Linear(128, 64), nn.ReLU(inplace=True),
+            nn.Linear(64, 32), nn.ReLU(inplace=True),
+            nn.Linear(32, 64), nn.ReLU(inplace=True),
+            nn.Linear(64, 128), nn.ReLU(inplace=True),
+            nn.Linear(128, max_obj + 2),
+        )
+        self.softmax1 = nn.Softmax(dim=2)
+        self.softmax2 = nn.Softmax(dim=1)
+
+        # HIP-side state (not parameters, not in state_dict)
+        self._packed = None
+        self._packed_key = None
+        self._wstruct = None
+        self._bufs = {}
+        self.keep_intermediates = False  # tests: also return residual / matched via self.last_intermediates
+        self.last_intermediates = None
+
+    # ---- reference API -------------------------------------------------------------------------------------
+    def init_weights(self, pretrained=None):
+        """shasta.py:111-119 swallows every error; here a missing/broken checkpoint is reported loudly but, like the
+        reference, does not abort construction."""
+        if pretrained is None:
+            return
+        try:
+            checkpoint = torch.load(pretrained, map_location="cpu")
+            sd = checkpoint.get("state_dict", checkpoint) if isinstance(checkpoint, dict) else checkpoint
+            load_state_dict_permissive(self, sd)
+            print("init weight from {}".format(pretrained))
+        except Exception as e:  # noqa: BLE001
+            print("no pretrained model at {} ({})".format(pretrained, e))
+
+    def extract_feat(self, data):
+        """shasta.py:164-210.  With a backbone/neck registered by the user the call sequence is the reference's.
+        Without them (this package does not ship the spconv backbone or the RPN) the neck outputs are read from
+        `data['bev_map']`, `data['prev_bev_map']` (B, in_channels, H, W)."""
+        if self.backbone is None:
+            if "bev_map" not in data or "prev_bev_map" not in data:
+                raise KeyError("Shasta.extract_feat: no backbone configured and example has no 'bev_map'/'prev_bev_map' "
+                               "(neck outputs) nor 'bev_feature'/'prev_bev_feature'")
+            return data["bev_map"], None, data["prev_bev_map"], None
+        if "voxels" not in data or "prev_voxels" not in data:
+            raise KeyError("Shasta.extract_feat: only the hard-voxel branch is supported (the reference's dynamic "
+                           "branch never defines prev_input_features, shasta.py:165-176,201-203)")
+        input_features = self.reader(data["voxels"], data["num_points"])
+        prev_input_features = self.reader(data["prev_voxels"], data["prev_num_points"])
+        x, vf = self.backbone(input_features, data["coordinates"], len(data["points"]), data["shape"][0])
+        px, pvf = self.backbone(prev_input_features, data["prev_coordinates"], len(data["prev_points"]),
+                                data["prev_shape"][0])
+        if self.with_neck:
+            x = self.neck(x)
+            px = self.neck(px)
+        return x, vf, px, pvf
+
+    # ---- HIP plumbing --------------------------------------------------------------------------------------
+    def _small_params(self):
+        mods = [self.fuse_shape[0], self.fuse_shape[2], self.fuse_shape[4], self.fuse_shape[6], self.fuse_det[0],
+                self.fuse_det[2], self.fuse_det[4], self.res_coeff[0], self.res_coeff[2], self.res_coeff[4],
+                self.aff[0]]
+        return [p for m in mods for p in (m.weight, m.bias)]
+
+    def _weights(self):
+        """shasta_weights struct over the live parameter storage (no copies)."""
+        def lin(m):
+            for p in (m.weight, m.bias):
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise hip.ShastaHipError("Shasta parameters must be contiguous fp32 device tensors "
+                                             "(call .cuda() first; there is no CPU path)")
+            return hip.Linear(m.weight.data_ptr(), m.bias.data_ptr())
+
+        w = hip.Weights()
+        w.max_obj, w.num_feats, w.feat_dim = self.max_obj, self.num_feats, self.aug_shape_output
+        for i in range(4):
+            w.aug_shape[i][0], w.aug_shape[i][1] = lin(self.aug_shape[i][0]), lin(self.aug_shape[i][2])
+            w.aug_dets[i][0], w.aug_dets[i][1] = lin(self.aug_dets[i][0]), lin(self.aug_dets[i][2])
+        for j, k in enumerate((0, 2, 4, 6)):
+            w.fuse_shape[j] = lin(self.fuse_shape[k])
+        for j, k in enumerate((0, 2, 4)):
+            w.fuse_det[j] = lin(self.fuse_det[k])
+            w.res_coeff[j] = lin(self.res_coeff[k])
+        for j, k in enumerate((0, 2, 4, 6, 8, 10)):
+            w.aff[j] = lin(self.aff[k])
+        return w
+
+    def _ensure_packed(self, w, device):
+        key = tuple((p.data_ptr(), p._version) for p in self._small_params())
+        if self._packed is not None and self._packed_key == key and self._packed.device == device:
+            return
+        lib = hip.load()
+        nbytes = lib.shasta_packed_bytes(self.max_obj, self.num_feats, self.aug_shape_output)
+        if nbytes == 0:
+            raise hip.ShastaHipError("unsupported feature width F=%d (supported: 64, 256, 320)" % self.aug_shape_output)
+        self._packed = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        hip.check(lib.shasta_pack_weights_f32(C.byref(w), hip.ptr(self._packed), nbytes, hip.stream_ptr()),
+                  "shasta_pack_weights_f32")
+        self._packed_key = key
+
+    def _buffers(self, B, device):
+        k = (B, str(device))
+        if k not in self._bufs:
+            lib = hip.load()
+            N, F = self.max_obj, self.aug_shape_output
+            ws = lib.shasta_forward_workspace_bytes(B, N, self.num_feats, F)
+            self._bufs[k] = dict(
+                feat=torch.empty(B, N + 2, F, device=device), prev_feat=torch.empty(B, N + 2, F, device=device),
+                det_tab=torch.empty(B, N + 2, 8, device=device), prev_tab=torch.empty(B, N + 2, 8, device=device),
+                ws=torch.empty((ws + 3) // 4, dtype=torch.float32, device=device), ws_bytes=ws)
+        return self._bufs[k]
+
+    def affinity_from_bev(self, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes):
+        """Rows 4-16 of SURVEY.md 8(a) (shasta.py:231-325) on device.  bev maps (B,H,W,C) fp32 NHWC, boxes (B,N,>=10)
+        fp32 contiguous; det_boxes[:, :, :2] is back-projected in place."""
+        lib = hip.load()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._small_params()):
+            raise hip.ShastaHipError("the HIP affinity path is forward-only in this build: call under torch.no_grad()")
+        B, N = det_boxes.shape[0], det_boxes.shape[1]
+        if N != self.max_obj or prev_det_boxes.shape[1] != N:
+            raise ValueError("det_boxes must be padded to max_obj=%d rows (got %d)" % (self.max_obj, N))
+        dev = det_boxes.device
+        w = self._weights()
+        self._ensure_packed(w, dev)
+        bufs = self._buffers(B, dev)
+        self.bev_extractor.gather_boxes(bev_nhwc, det_boxes, self.num_point, bufs["feat"])
+        self.bev_extractor.gather_boxes(prev_bev_nhwc, prev_det_boxes, self.num_point, bufs["prev_feat"])
+        m1 = torch.empty(B, N, N + 2, device=dev)
+        m2 = torch.empty(B, N + 2, N, device=dev)
+        res = mat = None
+        if self.keep_intermediates:
+            res = torch.empty(B, N + 2, N + 2, device=dev)
+            mat = torch.empty(B, N + 2, N + 2, device=dev)
+        hip.check(lib.shasta_affinity_forward_f32(
+            C.byref(w), hip.ptr(self._packed), B, hip.ptr(bufs["feat"]), hip.ptr(bufs["prev_feat"]),
+            hip.ptr(det_boxes), hip.ptr(prev_det_boxes), det_boxes.shape[2], hip.ptr(bufs["det_tab"]),
+            hip.ptr(bufs["prev_tab"]), hip.ptr(m1), hip.ptr(m2), hip.ptr(res), hip.ptr(mat), hip.ptr(bufs["ws"]),
+            bufs["ws_bytes"], hip.stream_ptr()), "shasta_affinity_forward_f32")
+        self.newborn = bufs["prev_tab"][:, N:N + 1, :7]
+        self.fp = bufs["prev_tab"][:, N + 1:N + 2, :7]
+        self.dead_trk = bufs["det_tab"][:, N:N + 1, :7]
+        self.fn = bufs["det_tab"][:, N + 1:N + 2, :7]
+        if self.keep_intermediates:
+            self.last_intermediates = dict(feature=bufs["feat"], prev_feature=bufs["prev_feat"], residual=res,
+                                           matched=mat, det_tab=bufs["det_tab"], prev_tab=bufs["prev_tab"])
+        return m1, m2
+
+    def forward(self, example, train_mode=True, **kwargs):
+        det = example["det_boxes"]
+        prev = example["prev_det_boxes"]
+        if not det.is_cuda:
+            raise hip.ShastaHipError("Shasta.forward needs device tensors (example_to_device); there is no CPU path")
+        # BEV maps: precomputed NHWC features (synthetic / cached), or extract_feat + shared_conv like the reference
+        if self.backbone is None and "bev_map" not in example and "bev_feature" in example and "prev_bev_feature" in example:
+            bev = example["bev_feature"].float().contiguous()
+            prev_bev = example["prev_bev_feature"].float().contiguous()
+        else:
+            bev_map, _, prev_bev_map, _ = self.extract_feat(example)
+            bev = self.shared_conv(bev_map).permute(0, 2, 3, 1).contiguous()
+            prev_bev = self.shared_conv(prev_bev_map).permute(0, 2, 3, 1).contiguous()
+        example["bev_feature"] = bev
+        inplace = det.dtype == torch.float32 and det.is_contiguous() and det.shape[2] >= 10
+        det_k = det if inplace else det.float().contiguous()
+        prev_k = prev if (prev.dtype == torch.float32 and prev.is_contiguous()) else prev.float().contiguous()
+        m1, m2 = self.affinity_from_bev(bev, prev_bev, det_k, prev_k)
+        if not inplace:
+            det[:, :, :2] = det_k[:, :, :2].to(det.dtype)  # keep the reference's in-place side effect
+        return m1, m2, example
+
+
+def load_state_dict_permissive(module, state_dict, logger=None):
+    """det3d/torchie/trainer/checkpoint.py:67-104 semantics (unknown keys and shape mismatches are skipped) but every
+    skipped key is reported instead of silently dropped."""
+    own = module.state_dict()
+    skipped = []
+    for name, param in state_dict.items():
+        if name.startswith("module."):
+            name = name[7:]
+        if name not in own:
+            skipped.append((name, "unexpected"))
+            continue
+        if own[name].shape != param.shape:
+            skipped.append((name, "shape %s vs %s" % (tuple(param.shape), tuple(own[name].shape))))
+            continue
+        own[name].copy_(param)
+    missing = sorted(set(own.keys()) - {n[7:] if n.startswith("module.") else n for n in state_dict.keys()})
+    for name, why in skipped:
+        print("load_state_dict: skipped %s (%s)" % (name, why))
+    if missing:
+        print("load_state_dict: missing keys: %s" % ", ".join(missing))
+    return skipped, missing

@@ -1,0 +1,205 @@
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference (tsadja/ShaSTA at /root/reference) has no tests or golden vectors of its own
+(SURVEY.md section 4), so these fixtures are outputs of the reference's own `Shasta.forward`
+(det3d/models/tracker/shasta.py:213-327), `points_to_voxel`
+(det3d/ops/point_cloud/point_cloud_ops.py:112-184), `VoxelFeatureExtractorV3`
+(det3d/models/readers/voxel_encoder.py:18-28), `PubTracker` (tools/nusc_shasta/pub_tracker.py)
+and `mot_3d.association` on seeded synthetic inputs.  Fixtures are data only (inputs, expected
+outputs, weight checksums); weights above a few hundred KB are re-created from the seed
+(the Shasta module in shasta_amd mirrors the reference constructor's RNG consumption) and
+verified against the stored checksums before use.
+"""
+import copy
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import ref_import as R  # noqa: E402
+from oracle import shasta_oracle as O  # noqa: E402  (only for the shared synthetic-input generator)
+
+# n_real None = all rows real; `store` = keep weights and BEV inputs inside the npz (tiny only)
+CONFIGS = [
+    dict(name="tiny_4_7_5", max_obj=4, nf=7, np=5, B=2, n_real=None, cin=8, hw=24, stride=64, store=True),
+    dict(name="tiny_6_3_1", max_obj=6, nf=3, np=1, B=1, n_real=4, cin=8, hw=24, stride=64, store=True),
+    dict(name="small_32_7_4", max_obj=32, nf=7, np=4, B=2, n_real=None),   # BASELINE config 1 (F=256)
+    dict(name="small_32_3_5_pad", max_obj=32, nf=3, np=5, B=1, n_real=20),  # zero-padded rows, nf=3
+    dict(name="car_90_3_5", max_obj=90, nf=3, np=5, B=1, n_real=40),        # shipped car config, padded
+    dict(name="headline_500_7_4", max_obj=500, nf=7, np=4, B=1, n_real=None, inter=False),  # N=M=500
+]
+
+
+def checksums(sd):
+    return {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in sd.items()
+            if v.dtype.is_floating_point}
+
+
+def run_forward_config(name, max_obj, nf, np_, B, n_real, cin=512, hw=180, stride=8, store=False,
+                       inter=True, seed=0):
+    torch.manual_seed(seed)
+    m = R.build_ref_model(max_obj, nf, np_, in_channels=cin, out_stride=stride)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    bev, pbev, det, prev = O.synth_case(B, max_obj, n_real, cin, hw, hw, seed)
+    det_in = det.clone()
+    m.extract_feat = lambda ex: (bev, None, pbev, None)
+    grab = {}
+    m.aff.register_forward_hook(lambda mod, i, o: grab.update(residual=i[0].clone(), matched=o.clone()))
+    feats = []
+    m.bev_extractor.register_forward_hook(lambda mod, i, o: feats.append(torch.stack(o).clone()))
+    geoms = []
+    for i in range(4):
+        f0 = m.aug_shape[i].forward
+        m.aug_shape[i].forward = (lambda x, _f=f0: (geoms.append(_f(x).clone()) or geoms[-1]))
+    ex = dict(det_boxes=det, prev_det_boxes=prev)
+    with torch.no_grad():
+        m1, m2, out = m(ex, train_mode=False)
+        prev_bev_nhwc = m.shared_conv(pbev).permute(0, 2, 3, 1).contiguous()
+    assert out["det_boxes"] is det
+    arrays = dict(
+        cfg=np.array([max_obj, nf, np_, B, -1 if n_real is None else n_real, cin, hw, stride, seed],
+                     np.int64),
+        m1=m1.numpy(), m2=m2.numpy(), det_boxes_in=det_in.numpy(), det_boxes_out=det.numpy(),
+        prev_det_boxes=prev.numpy(),
+    )
+    step = max(1, hw // 4)
+    arrays["bev_probe"] = out["bev_feature"][:, ::step, ::step, :].numpy()
+    arrays["prev_bev_probe"] = prev_bev_nhwc[:, ::step, ::step, :].numpy()
+    if inter:
+        arrays.update(
+            feature=feats[0].numpy(), prev_feature=feats[1].numpy(),
+            geom=np.stack([torch.abs(g).numpy() for g in geoms]),  # newborn, fp, dead, fn: (4,B,F)
+            newborn=m.newborn.numpy(), fp=m.fp.numpy(), dead_trk=m.dead_trk.numpy(), fn=m.fn.numpy(),
+            residual=grab["residual"].numpy(), matched=grab["matched"].numpy(),
+        )
+    if store:
+        arrays["bev_in"] = bev.numpy()
+        arrays["prev_bev_in"] = pbev.numpy()
+        arrays["bev_feature"] = out["bev_feature"].numpy()
+        arrays["prev_bev_feature"] = prev_bev_nhwc.numpy()
+        for k, v in sd.items():
+            arrays["w::" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    with open(os.path.join(HERE, name + ".weights.json"), "w") as f:
+        json.dump(checksums(sd), f, indent=0)
+    print(name, "m1", tuple(m1.shape), "sum", float(m1.double().sum()))
+
+
+def run_voxel(seed=0):
+    pc = R.import_point_cloud_ops()
+    rng = np.random.default_rng(seed)
+    cases = {}
+    # case A: nuScenes grid, 12k points clustered so voxels hold several points; cap not hit
+    n = 12000
+    ctr = rng.uniform(-50, 50, size=(300, 2)).astype(np.float32)
+    idx = rng.integers(0, 300, size=n)
+    pts = np.zeros((n, 5), np.float32)
+    pts[:, :2] = ctr[idx] + rng.normal(0, 0.15, size=(n, 2)).astype(np.float32)
+    pts[:, 2] = rng.uniform(-5.5, 3.5, size=n)
+    pts[:, 3] = rng.uniform(0, 255, size=n)
+    pts[:, 4] = rng.integers(0, 10, size=n) * 0.05
+    pts[::97, 0] = 60.0  # out of range
+    pts[5::131, 2] = -5.0  # exactly on the lower z edge -> cell 0
+    cases["A"] = (pts, 10, 160000)
+    # case B: same cloud, voxel cap hit early, max_points 3
+    cases["B"] = (pts, 3, 500)
+    # case C: tiny, duplicates and exact boundaries
+    c = np.array([[-54, -54, -5, 1, 0], [-54, -54, -5, 2, 0], [53.999, 53.999, 2.999, 3, 0],
+                  [54, 0, 0, 4, 0], [0, 0, 3, 5, 0], [-54.0001, 0, 0, 6, 0], [0.01, 0.01, 0.01, 7, 0],
+                  [0.02, 0.02, 0.02, 8, 0], [0.03, 0.03, 0.03, 9, 0], [0.07, 0.07, 0.07, 10, 0]],
+                 np.float32)
+    cases["C"] = (c, 2, 3)
+    out = {}
+    vs = np.array([0.075, 0.075, 0.2], np.float32)
+    rg = np.array([-54, -54, -5, 54, 54, 3], np.float32)
+    vr = R.import_voxel_reader()
+    reader = vr.VoxelFeatureExtractorV3(num_input_features=5)
+    for k, (p, mp, mv) in cases.items():
+        voxels, coors, num = pc.points_to_voxel(p, vs, rg, mp, True, mv)
+        mean = reader(torch.from_numpy(voxels), torch.from_numpy(num)).numpy() if len(num) else \
+            np.zeros((0, 5), np.float32)
+        out[k + "_points"] = p
+        out[k + "_cfg"] = np.array([mp, mv], np.int64)
+        out[k + "_voxels"] = voxels
+        out[k + "_coors"] = coors
+        out[k + "_num"] = num
+        out[k + "_mean"] = mean
+        print("voxel case", k, voxels.shape, coors.shape, int(num.sum()))
+    np.savez_compressed(os.path.join(HERE, "voxelize.npz"), **out)
+
+
+def run_tracker(seed=0):
+    """Known-answer vectors for the consumers: PubTracker.step_centertrack and
+    mot_3d.association.associate_dets_to_tracks ('euler'/'m_dis' need no shapely)."""
+    T = R.import_pub_tracker()
+    rng = np.random.default_rng(seed)
+    frames = []
+    n_frames = 6
+    base = rng.uniform(-30, 30, size=(8, 2))
+    vel = rng.normal(0, 2, size=(8, 2))
+    for f in range(n_frames):
+        dets = []
+        for j in range(8):
+            if (f + j) % 5 == 4:
+                continue  # missed detection
+            pos = base[j] + vel[j] * 0.5 * f + rng.normal(0, 0.05, 2)
+            d = dict(sample_token="tok%d" % f, translation=[float(pos[0]), float(pos[1]), 0.0],
+                     size=[2.0, 4.0, 1.5], rotation=[1.0, 0.0, 0.0, 0.0],
+                     velocity=[float(vel[j][0]), float(vel[j][1])],
+                     detection_name="car", detection_score=float(rng.uniform(0.3, 0.9)),
+                     ref_detection_score=float(rng.uniform(0.3, 0.9)), attribute_name="")
+            if (f * 3 + j) % 7 == 0:
+                d["newborn"] = True
+            if (f * 5 + j) % 11 == 0:
+                d["dead"] = True
+            dets.append(d)
+        frames.append(dets)
+    results = {}
+    for hungarian in (False, True):
+        for refine in (False, True):
+            tr = T.PubTracker(hungarian=hungarian, max_age=3, alpha=0.3, beta=0.5, refine_confidence=refine) \
+                if _accepts(T.PubTracker, "refine_confidence") else T.PubTracker(hungarian=hungarian, max_age=3)
+            outs = []
+            for f, dets in enumerate(frames):
+                if f == 0:
+                    tr.reset()
+                o = tr.step_centertrack(copy.deepcopy(dets), 0.5)
+                outs.append([{k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in t.items()}
+                             for t in o])
+            results["h%d_r%d" % (hungarian, refine)] = outs
+    with open(os.path.join(HERE, "pub_tracker.json"), "w") as f:
+        json.dump(dict(frames=frames, outputs=results), f, default=_js)
+    print("pub_tracker golden written")
+
+
+def _accepts(cls, name):
+    import inspect
+    return name in inspect.signature(cls.__init__).parameters
+
+
+def _js(o):
+    if isinstance(o, (np.floating, np.integer)):
+        return o.item()
+    if isinstance(o, np.ndarray):
+        return o.tolist()
+    raise TypeError(type(o))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["forward", "voxel", "tracker"]
+    if "forward" in which:
+        for c in CONFIGS:
+            c = dict(c)
+            run_forward_config(c.pop("name"), c.pop("max_obj"), c.pop("nf"), c.pop("np"), c.pop("B"),
+                               c.pop("n_real"), **c)
+    if "voxel" in which:
+        run_voxel()
+    if "tracker" in which:
+        run_tracker()
