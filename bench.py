@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- affinity frame-pairs/s at N=M=500, F=256 (BASELINE.json metric) on N MI355X of one node.
+
+A "step" is one pass of the affinity hot path (BEV gather -> anchors -> pair residual ->
+aff + softmaxes) over one batch of `--batch` synthetic frame-pairs whose inputs (NHWC BEV feature maps, box tables,
+weights) are already resident in HBM.  Frame-pairs are independent, so with N GPUs every rank runs its own replica on
+its own batch (weak scaling, no data-path collective); the only collectives are the barrier and the MAX over ranks of
+the elapsed time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the definition of every field).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_OBJ, NF, NPOINT, CH = 500, 7, 4, 64  # N=M=500, F=256, nf=7
+HW = 180
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def l1_algorithmic_bytes(B):
+    """Dominant kernel = aug_shape first layer (anchor_l1_kernel): every weight of the four (N*F/64, N*F) matrices is
+    read once per launch per batch tile of 8, plus the two activation tables once per batch item, plus partials."""
+    K = N_OBJ * CH * NPOINT
+    H = K // 64
+    tiles = (B + 7) // 8
+    return 4 * H * K * 4 * tiles + 2 * B * K * 4
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="frame-pairs per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=12, help="frame-pairs timed on the host for cpu_baseline")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import shasta_amd
+    from shasta_amd import hip
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert args.gpus == world, "--gpus must equal the number of launched ranks"
+
+    lib = hip.load()
+    B = args.batch
+    torch.manual_seed(0)
+    with torch.device(dev):  # random-init weights of the named architecture, created directly in HBM (4.1 GB)
+        model = shasta_amd.build_simp_track(dict(
+            type="Shasta", reader=None, backbone=None, neck=None,
+            bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
+            max_obj=N_OBJ, num_feats=NF, num_point=NPOINT)).eval()
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    bev = torch.relu(torch.randn(B, HW, HW, CH, device=dev, generator=g))
+    pbev = torch.relu(torch.randn(B, HW, HW, CH, device=dev, generator=g))
+
+    def boxes():
+        b = torch.zeros(B, N_OBJ, 11, device=dev)
+        b[..., 0:2] = torch.rand(B, N_OBJ, 2, device=dev, generator=g) * 100 - 50
+        b[..., 2] = torch.randn(B, N_OBJ, device=dev, generator=g)
+        b[..., 3:6] = torch.rand(B, N_OBJ, 3, device=dev, generator=g) * 4 + 0.5
+        b[..., 6] = (torch.rand(B, N_OBJ, device=dev, generator=g) * 2 - 1) * 3.14159265
+        b[..., 7:9] = torch.randn(B, N_OBJ, 2, device=dev, generator=g)
+        b[..., 9] = 0.5
+        b[..., 10] = torch.rand(B, N_OBJ, device=dev, generator=g)
+        return b
+
+    det0, prev = boxes(), boxes()
+    det = det0.clone()
+
+    evs = []
+    for _ in range(args.steps):
+        a, b_ = C.c_void_p(), C.c_void_p()
+        hip.check(lib.shasta_event_create(C.byref(a)), "event_create")
+        hip.check(lib.shasta_event_create(C.byref(b_)), "event_create")
+        evs.append((a, b_))
+
+    def step(ev=None):
+        det.copy_(det0)  # forward back-projects det_boxes in place (shasta.py:270): restore the input
+        return model.affinity_from_bev(bev, pbev, det, prev, l1_events=ev)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            m1, m2 = step()
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            m1, m2 = step(evs[i])
+        sync_all()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(m1).all()) and abs(float(m1[0, 0].sum()) - 1.0) < 1e-4
+
+    ms = C.c_float()
+    l1 = []
+    for a, b_ in evs:
+        hip.check(lib.shasta_event_elapsed_ms(a, b_, C.byref(ms)), "event_elapsed")
+        l1.append(ms.value)
+        lib.shasta_event_destroy(a)
+        lib.shasta_event_destroy(b_)
+    l1_ms = sum(l1) / len(l1)
+    alg = l1_algorithmic_bytes(B)
+    achieved = alg / (l1_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "affinity frame-pairs/sec at N=M=500, F=256",
+        "value": world * B * args.steps / elapsed,
+        "unit": "frame-pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "synthetic N=M=500, F=256 (num_point=4, C=64), nf=7 affinity forward from HBM-resident "
+                               "NHWC BEV features (SURVEY 8a rows 4-16)", "frame_pairs_per_step_per_gpu": B,
+                   "max_obj": N_OBJ, "num_feats": NF, "num_point": NPOINT, "bev_hw": HW,
+                   "parallelism": "replica x%d (frame-parallel, no data-path collective)" % world},
+        "roofline": {"bound": "hbm", "kernel": "anchor_l1_kernel (aug_shape.*.0: 4 x 2000 x 128000 fp32 weight stream)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": _pmc_traffic(B), "algorithmic_bytes_per_launch": alg, "avg_launch_ms": l1_ms,
+                     "share_of_step": l1_ms / (elapsed / args.steps * 1e3)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model, args.cpu_sample)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic(B):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), corrected as
+    MI355X_MICROARCH.md prescribes (FETCH_SIZE doubled on gfx950); None when no profile for this batch size exists."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("batch_%d" % B)
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(model, sample):
+    """The CPU oracle (a restatement of the reference PyTorch forward, oracle/shasta_oracle.py) timed on this box's
+    host cores on a bounded sample of the same workload: `sample` frame-pairs, one at a time (the reference's
+    eval batch size, tools/nusc_shasta/eval.py:96-101), same timed region (rows 4-16, inputs resident in host memory)."""
+    import torch
+
+    from oracle import shasta_oracle as O
+    w = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith("shared_conv")}
+    g = torch.Generator().manual_seed(99)
+    bev = torch.relu(torch.randn(1, HW, HW, CH, generator=g))
+    pbev = torch.relu(torch.randn(1, HW, HW, CH, generator=g))
+    det, prev = O.synth_boxes(g, 1, N_OBJ), O.synth_boxes(g, 1, N_OBJ)
+    O.forward_from_bev(w, bev, pbev, det.clone(), prev, NF, NPOINT)  # warm-up (first call pays allocator/oneDNN setup)
+    t0 = time.perf_counter()
+    for _ in range(sample):
+        O.forward_from_bev(w, bev, pbev, det.clone(), prev, NF, NPOINT)
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "frame-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d frame-pairs at N=M=500,F=256, batch 1, torch-CPU fp32 oracle, %.1f s" % (sample, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -137,6 +137,19 @@ int shasta_affinity_forward_f32(const shasta_weights* w, const void* packed, int
                                 float* matched2, float* residual_out, float* matched_out,
                                 void* workspace, size_t workspace_bytes, shasta_stream_t stream);
 
+/* Measurement variant of the forward: identical work, plus hipEventRecord(ev_l1_start/stop) on `stream` around the
+ * launch of the dominant kernel (the aug_shape first-layer weight stream, anchor_l1_kernel), so that bench.py can
+ * read that kernel's duration live inside its timed region.  Events come from shasta_event_create (they are plain
+ * hipEvent_t); shasta_event_elapsed_ms needs both events completed (synchronise the stream first). */
+int shasta_affinity_forward_timed_f32(const shasta_weights* w, const void* packed, int B, float* feat,
+                                      float* prev_feat, float* det_boxes, const float* prev_det_boxes,
+                                      int box_stride, float* det_tab, float* prev_tab, float* matched1,
+                                      float* matched2, void* workspace, size_t workspace_bytes,
+                                      shasta_stream_t stream, void* ev_l1_start, void* ev_l1_stop);
+int shasta_event_create(void** ev);
+int shasta_event_destroy(void* ev);
+int shasta_event_elapsed_ms(void* start, void* stop, float* h_ms);
+
 /* Stage entry points (the forward above is exactly these in sequence; exposed for per-stage parity
  * tests and for callers that own the schedule).  Layouts as documented above. */
 int shasta_anchor_shape_f32(const shasta_weights* w, int B, float* feat, float* prev_feat, void* workspace,

@@ -209,7 +209,7 @@ static void launch_l1(const AnchorL1Args& a, hipStream_t st) {
 }
 
 int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes,
-                 hipStream_t st) {
+                 hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const int N = w->max_obj, F = w->feat_dim;
     const int K = N * F, H = K / 64;
     if (ws_bytes < anchor_shape_workspace_bytes(B, N, F)) {
@@ -235,10 +235,12 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     float* part = static_cast<float*>(ws);
     float* hidden = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)64 * B * 4 * H * sizeof(float), 256));
     a.part = part;
+    if (ev0) (void)hipEventRecord(ev0, st);
     if (B == 1) launch_l1<1, R>(a, st);
     else if (B == 2) launch_l1<2, R>(a, st);
     else if (B <= 4) launch_l1<4, R>(a, st);
     else launch_l1<8, R>(a, st);
+    if (ev1) (void)hipEventRecord(ev1, st);
     int rc = check_launch("anchor_l1");
     if (rc) return rc;
     const int total = B * 4 * H;

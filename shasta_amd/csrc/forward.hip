@@ -7,7 +7,8 @@ size_t anchor_shape_workspace_bytes(int B, int N, int F);
 size_t anchor_boxes_workspace_bytes(int B, int N);
 size_t pair_workspace_bytes(int B, int N, int F);
 size_t aff_workspace_bytes(int B, int N);
-int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes, hipStream_t st);
+int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes, hipStream_t st,
+                 hipEvent_t ev0, hipEvent_t ev1);
 int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes, int box_stride,
                  float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st);
 int pair_residual(const shasta_weights* w, const float* packed, int B, const float* feat, const float* prev_feat,
@@ -25,7 +26,10 @@ static int check_weights(const shasta_weights* w) {
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 2; ++j) {
             SHASTA_REQUIRE(w->aug_shape[i][j].weight && w->aug_shape[i][j].bias, "aug_shape weights missing");
-            SHASTA_REQUIRE(w->aug_dets[i][j].weight && w->aug_dets[i][j].bias, "aug_dets weights missing");
+            // aug_dets hidden width is 7N//32: zero for N < 5, then only the last bias exists
+            SHASTA_REQUIRE(7 * w->max_obj / 32 == 0 || (w->aug_dets[i][j].weight && w->aug_dets[i][j].bias),
+                           "aug_dets weights missing");
+            SHASTA_REQUIRE(j == 0 || w->aug_dets[i][j].bias, "aug_dets output bias missing");
         }
     for (int i = 0; i < 4; ++i) SHASTA_REQUIRE(w->fuse_shape[i].weight && w->fuse_shape[i].bias, "fuse_shape weights missing");
     for (int i = 0; i < 3; ++i) {
@@ -87,7 +91,7 @@ extern "C" int shasta_anchor_shape_f32(const shasta_weights* w, int B, float* fe
     if (rc) return rc;
     SHASTA_REQUIRE(B >= 0 && feat && prev_feat && workspace, "anchor_shape: bad argument");
     SHASTA_REQUIRE(((uintptr_t)feat | (uintptr_t)prev_feat) % 16 == 0, "anchor_shape: tables must be 16-byte aligned");
-    return anchor_shape(w, B, feat, prev_feat, workspace, workspace_bytes, as_stream(stream));
+    return anchor_shape(w, B, feat, prev_feat, workspace, workspace_bytes, as_stream(stream), nullptr, nullptr);
 }
 
 extern "C" int shasta_anchor_boxes_f32(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes,
@@ -130,11 +134,10 @@ extern "C" int shasta_aff_softmax_f32(const shasta_weights* w, const void* packe
                        workspace, workspace_bytes, as_stream(stream));
 }
 
-extern "C" int shasta_affinity_forward_f32(const shasta_weights* w, const void* packed, int B, float* feat,
-                                           float* prev_feat, float* det_boxes, const float* prev_det_boxes,
-                                           int box_stride, float* det_tab, float* prev_tab, float* matched1,
-                                           float* matched2, float* residual_out, float* matched_out, void* workspace,
-                                           size_t workspace_bytes, shasta_stream_t stream) {
+static int forward_impl(const shasta_weights* w, const void* packed, int B, float* feat, float* prev_feat,
+                        float* det_boxes, const float* prev_det_boxes, int box_stride, float* det_tab, float* prev_tab,
+                        float* matched1, float* matched2, float* residual_out, float* matched_out, void* workspace,
+                        size_t workspace_bytes, shasta_stream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     int rc = check_weights(w);
     if (rc) return rc;
     SHASTA_REQUIRE(B >= 0 && packed && feat && prev_feat && det_boxes && prev_det_boxes && det_tab && prev_tab &&
@@ -155,7 +158,7 @@ extern "C" int shasta_affinity_forward_f32(const shasta_weights* w, const void* 
     void* stage = static_cast<char*>(workspace) + L.residual;
     const size_t stage_bytes = L.total - L.residual;
     const float* pk = static_cast<const float*>(packed);
-    if ((rc = anchor_shape(w, B, feat, prev_feat, stage, stage_bytes, st))) return rc;
+    if ((rc = anchor_shape(w, B, feat, prev_feat, stage, stage_bytes, st, ev0, ev1))) return rc;
     if ((rc = anchor_boxes(w, B, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, static_cast<float*>(stage), st)))
         return rc;
     if ((rc = pair_residual(w, pk, B, feat, prev_feat, det_tab, prev_tab, residual, Dp, stage, stage_bytes, st))) return rc;
@@ -168,4 +171,51 @@ extern "C" int shasta_affinity_forward_f32(const shasta_weights* w, const void* 
         }
     }
     return aff_softmax(w, pk, B, residual, Dp, matched1, matched2, matched_out, stage, stage_bytes, st);
+}
+
+extern "C" int shasta_affinity_forward_f32(const shasta_weights* w, const void* packed, int B, float* feat,
+                                           float* prev_feat, float* det_boxes, const float* prev_det_boxes,
+                                           int box_stride, float* det_tab, float* prev_tab, float* matched1,
+                                           float* matched2, float* residual_out, float* matched_out, void* workspace,
+                                           size_t workspace_bytes, shasta_stream_t stream) {
+    return forward_impl(w, packed, B, feat, prev_feat, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, matched1,
+                        matched2, residual_out, matched_out, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int shasta_affinity_forward_timed_f32(const shasta_weights* w, const void* packed, int B, float* feat,
+                                                 float* prev_feat, float* det_boxes, const float* prev_det_boxes,
+                                                 int box_stride, float* det_tab, float* prev_tab, float* matched1,
+                                                 float* matched2, void* workspace, size_t workspace_bytes,
+                                                 shasta_stream_t stream, void* ev_l1_start, void* ev_l1_stop) {
+    SHASTA_REQUIRE(ev_l1_start && ev_l1_stop, "forward_timed: null event");
+    return forward_impl(w, packed, B, feat, prev_feat, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, matched1,
+                        matched2, nullptr, nullptr, workspace, workspace_bytes, stream,
+                        static_cast<hipEvent_t>(ev_l1_start), static_cast<hipEvent_t>(ev_l1_stop));
+}
+
+extern "C" int shasta_event_create(void** ev) {
+    SHASTA_REQUIRE(ev, "event_create: null");
+    hipEvent_t e;
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) {
+        set_error("event_create", rc);
+        return SHASTA_E_LAUNCH;
+    }
+    *ev = e;
+    return SHASTA_OK;
+}
+
+extern "C" int shasta_event_destroy(void* ev) {
+    if (ev) (void)hipEventDestroy(static_cast<hipEvent_t>(ev));
+    return SHASTA_OK;
+}
+
+extern "C" int shasta_event_elapsed_ms(void* start, void* stop, float* h_ms) {
+    SHASTA_REQUIRE(start && stop && h_ms, "event_elapsed: null");
+    hipError_t rc = hipEventElapsedTime(h_ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop));
+    if (rc != hipSuccess) {
+        set_error("event_elapsed", rc);
+        return SHASTA_E_LAUNCH;
+    }
+    return SHASTA_OK;
 }

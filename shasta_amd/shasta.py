@@ -190,7 +190,7 @@ class Shasta(BaseTrack):
                   "shasta_pack_weights_f32")
         self._packed_key = key
 
-    def _buffers(self, B, device):
+    def _work_buffers(self, B, device):
         k = (B, str(device))
         if k not in self._bufs:
             lib = hip.load()
@@ -202,7 +202,7 @@ class Shasta(BaseTrack):
                 ws=torch.empty((ws + 3) // 4, dtype=torch.float32, device=device), ws_bytes=ws)
         return self._bufs[k]
 
-    def affinity_from_bev(self, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes):
+    def affinity_from_bev(self, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes, l1_events=None):
         """Rows 4-16 of SURVEY.md 8(a) (shasta.py:231-325) on device.  bev maps (B,H,W,C) fp32 NHWC, boxes (B,N,>=10)
         fp32 contiguous; det_boxes[:, :, :2] is back-projected in place."""
         lib = hip.load()
@@ -214,7 +214,7 @@ class Shasta(BaseTrack):
         dev = det_boxes.device
         w = self._weights()
         self._ensure_packed(w, dev)
-        bufs = self._buffers(B, dev)
+        bufs = self._work_buffers(B, dev)
         self.bev_extractor.gather_boxes(bev_nhwc, det_boxes, self.num_point, bufs["feat"])
         self.bev_extractor.gather_boxes(prev_bev_nhwc, prev_det_boxes, self.num_point, bufs["prev_feat"])
         m1 = torch.empty(B, N, N + 2, device=dev)
@@ -223,11 +223,18 @@ class Shasta(BaseTrack):
         if self.keep_intermediates:
             res = torch.empty(B, N + 2, N + 2, device=dev)
             mat = torch.empty(B, N + 2, N + 2, device=dev)
-        hip.check(lib.shasta_affinity_forward_f32(
-            C.byref(w), hip.ptr(self._packed), B, hip.ptr(bufs["feat"]), hip.ptr(bufs["prev_feat"]),
-            hip.ptr(det_boxes), hip.ptr(prev_det_boxes), det_boxes.shape[2], hip.ptr(bufs["det_tab"]),
-            hip.ptr(bufs["prev_tab"]), hip.ptr(m1), hip.ptr(m2), hip.ptr(res), hip.ptr(mat), hip.ptr(bufs["ws"]),
-            bufs["ws_bytes"], hip.stream_ptr()), "shasta_affinity_forward_f32")
+        if l1_events is not None:  # bench.py: hipEvents around the dominant kernel, same work otherwise
+            hip.check(lib.shasta_affinity_forward_timed_f32(
+                C.byref(w), hip.ptr(self._packed), B, hip.ptr(bufs["feat"]), hip.ptr(bufs["prev_feat"]),
+                hip.ptr(det_boxes), hip.ptr(prev_det_boxes), det_boxes.shape[2], hip.ptr(bufs["det_tab"]),
+                hip.ptr(bufs["prev_tab"]), hip.ptr(m1), hip.ptr(m2), hip.ptr(bufs["ws"]), bufs["ws_bytes"],
+                hip.stream_ptr(), l1_events[0], l1_events[1]), "shasta_affinity_forward_timed_f32")
+        else:
+            hip.check(lib.shasta_affinity_forward_f32(
+                C.byref(w), hip.ptr(self._packed), B, hip.ptr(bufs["feat"]), hip.ptr(bufs["prev_feat"]),
+                hip.ptr(det_boxes), hip.ptr(prev_det_boxes), det_boxes.shape[2], hip.ptr(bufs["det_tab"]),
+                hip.ptr(bufs["prev_tab"]), hip.ptr(m1), hip.ptr(m2), hip.ptr(res), hip.ptr(mat), hip.ptr(bufs["ws"]),
+                bufs["ws_bytes"], hip.stream_ptr()), "shasta_affinity_forward_f32")
         self.newborn = bufs["prev_tab"][:, N:N + 1, :7]
         self.fp = bufs["prev_tab"][:, N + 1:N + 2, :7]
         self.dead_trk = bufs["det_tab"][:, N:N + 1, :7]

@@ -101,8 +101,9 @@ def run_voxel(seed=0):
     ctr = rng.uniform(-50, 50, size=(300, 2)).astype(np.float32)
     idx = rng.integers(0, 300, size=n)
     pts = np.zeros((n, 5), np.float32)
-    pts[:, :2] = ctr[idx] + rng.normal(0, 0.15, size=(n, 2)).astype(np.float32)
-    pts[:, 2] = rng.uniform(-5.5, 3.5, size=n)
+    pts[:, :2] = ctr[idx] + rng.normal(0, 0.06, size=(n, 2)).astype(np.float32)
+    pts[:, 2] = rng.normal(-1.0, 0.25, size=n)
+    pts[::53, 2] = rng.uniform(-5.5, 3.5, size=len(pts[::53]))
     pts[:, 3] = rng.uniform(0, 255, size=n)
     pts[:, 4] = rng.integers(0, 10, size=n) * 0.05
     pts[::97, 0] = 60.0  # out of range
