@@ -29,12 +29,12 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def l1_algorithmic_bytes(B):
-    """Dominant kernel = aug_shape first layer (anchor_l1_kernel): every weight of the four (N*F/64, N*F) matrices is
-    read once per launch per batch tile of 8, plus the two activation tables once per batch item, plus partials."""
+    """Dominant kernel = aug_shape first layer (anchor_l1*_kernel).  Algorithmic (minimum) HBM bytes of one launch:
+    every weight of the four (N*F/64, N*F) fp32 matrices once, the two (N*F) activation vectors of each of the B
+    batch items once, and one (4*N*F/64) partial vector per batch item written."""
     K = N_OBJ * CH * NPOINT
     H = K // 64
-    tiles = (B + 7) // 8
-    return 4 * H * K * 4 * tiles + 2 * B * K * 4
+    return 4 * H * K * 4 + 2 * B * K * 4 + B * 4 * H * 4
 
 
 def main():
@@ -146,7 +146,7 @@ def main():
                                "NHWC BEV features (SURVEY 8a rows 4-16)", "frame_pairs_per_step_per_gpu": B,
                    "max_obj": N_OBJ, "num_feats": NF, "num_point": NPOINT, "bev_hw": HW,
                    "parallelism": "replica x%d (frame-parallel, no data-path collective)" % world},
-        "roofline": {"bound": "hbm", "kernel": "anchor_l1_kernel (aug_shape.*.0: 4 x 2000 x 128000 fp32 weight stream)",
+        "roofline": {"bound": "hbm", "kernel": "anchor_l1_kernel / anchor_l1_mfma_kernel (aug_shape.*.0: 4 x 2000 x 128000 fp32 weight stream)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": _pmc_traffic(B), "algorithmic_bytes_per_launch": alg, "avg_launch_ms": l1_ms,
                      "share_of_step": l1_ms / (elapsed / args.steps * 1e3)},

@@ -5,6 +5,7 @@
 // The six layers are six launches of the generic matrix-core GEMM over the B*T rows (bias + ReLU fused).
 #include "common.hpp"
 #include "pair_layout.hpp"
+#include <stdlib.h>
 
 namespace shasta {
 
@@ -30,28 +31,173 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int d = lane; d < D; d += 64) o[d] = expf(x[d] - mx) / s;
 }
 
-// block = 64 detections x 4 track groups: softmax over the T rows of each column d < N
-__global__ __launch_bounds__(256) void softmax_cols_kernel(const float* __restrict__ matched, float* __restrict__ m2,
-                                                           int N, int T, int ld) {
-    __shared__ float red[4][64];
-    const int b = blockIdx.y, dl = threadIdx.x & 63, tq = threadIdx.x >> 6;
-    const int d = blockIdx.x * 64 + dl;
+// block = 16 detections x 64 track groups (1024 threads): softmax over the T rows of each column d < N.  Each thread
+// keeps its <= 32 rows of one column in registers (one pass over memory); max and sum are combined across the 64 groups
+// in a fixed order.  MAXR = ceil(T / 64) rounded up to 8 / 16 / 32 (T <= 2048).
+template <int MAXR>
+__global__ __launch_bounds__(1024) void softmax_cols_kernel(const float* __restrict__ matched, float* __restrict__ m2,
+                                                            int N, int T, int ld) {
+    __shared__ float red[16][65];
+    const int b = blockIdx.y, dl = threadIdx.x & 15, tg = threadIdx.x >> 4;
+    const int d = blockIdx.x * 16 + dl;
     const int dcl = min(d, N - 1);
     const float* x = matched + (size_t)b * T * ld + dcl;
+    float v[MAXR];
     float mx = -INFINITY;
-    for (int t = tq; t < T; t += 4) mx = fmaxf(mx, x[(size_t)t * ld]);
-    red[tq][dl] = mx;
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int t = tg + 64 * i;
+        v[i] = t < T ? x[(size_t)t * ld] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    red[dl][tg] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0][dl], red[1][dl]), fmaxf(red[2][dl], red[3][dl]));
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) mx = fmaxf(mx, red[dl][i]);
     __syncthreads();
     float s = 0.0f;
-    for (int t = tq; t < T; t += 4) s += expf(x[(size_t)t * ld] - mx);
-    red[tq][dl] = s;
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        v[i] = (tg + 64 * i < T) ? expf(v[i] - mx) : 0.0f;
+        s += v[i];
+    }
+    red[dl][tg] = s;
     __syncthreads();
-    s = (red[0][dl] + red[1][dl]) + (red[2][dl] + red[3][dl]);
+    s = 0.0f;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) s += red[dl][i];
     if (d >= N) return;
     float* o = m2 + (size_t)b * T * N + d;
-    for (int t = tq; t < T; t += 4) o[(size_t)t * N] = expf(x[(size_t)t * ld] - mx) / s;
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int t = tg + 64 * i;
+        if (t < T) o[(size_t)t * N] = v[i] / s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// aff_fused: the six aff layers (shasta.py:94-106) and the row softmax (:324) for 16 residual rows per workgroup.
+// Rows are independent, so a workgroup keeps its 16 rows on chip from the residual to matched1: activations live in LDS
+// as [row][feature] (row stride = width + 4 floats: the 16 lanes of a ds_read_b128 group then start 4 banks apart),
+// weights stream from L2 as MFMA A fragments, out^T[feature][row] = W[feature][k] . h^T[k][row] with
+// v_mfma_f32_16x16x4_f32 (lane l: A = W[16*blk + (l&15)][k + (l>>4)*4 + q], B = h[row l&15][same k]); the D registers of
+// lane (row, kq) are output features 16*blk + 4*kq + 0..3 = one float4 of the next layer's LDS image.
+// ------------------------------------------------------------------------------------------------------------------
+struct AffArgs {
+    const float* W[6];
+    const float* bias[6];
+    const float* residual;
+    float* matched;  // (M, ldm) pre-softmax, for the column softmax
+    float* m1;       // (B, N, D)
+    int M, T, N, D, Dp, ld, ldm;
+};
+
+constexpr int AFF_WAVES = 8;  // waves per workgroup
+
+// One work item = (16-feature output block, chunk of KG 16-wide k-groups).  The weight fragments of item i+1 are
+// requested before the MFMAs of item i, so the L2 / HBM latency of the (cold) weight rows overlaps the matrix work.
+// KFIX > 0: compile-time reduction length, one chunk per block; KFIX == 0: runtime Kp in chunks of 128.
+template <bool RELU, int KFIX>
+__device__ __forceinline__ void aff_layer(const float* __restrict__ W, int ldw, const float* __restrict__ bias, int Mout,
+                                          int Kp, const float* hin, int ldin, float* hout, int ldout, int out_limit,
+                                          int lane, int wid) {
+    constexpr int KG = KFIX > 0 ? KFIX / 16 : 8;
+    const int p = lane & 15, kq = lane >> 4;
+    const int nb = (Mout + 15) >> 4;
+    const int nchunk = KFIX > 0 ? 1 : (Kp + 127) / 128;
+    const int Kv = KFIX > 0 ? KFIX : Kp;
+    const float* hrow = hin + p * ldin + 4 * kq;
+    f32x4 cur[KG], nxt[KG];
+    auto load = [&](f32x4(&dst)[KG], int blk, int ch) {
+        const float* wrow = W + (size_t)min(16 * blk + p, Mout - 1) * ldw + 4 * kq + ch * 128;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            dst[g] = f32x4{0, 0, 0, 0};
+            if (ch * 128 + 16 * g + 4 * kq < Kv) dst[g] = *reinterpret_cast<const f32x4*>(wrow + 16 * g);
+        }
+    };
+    int blk = wid, ch = 0;
+    if (blk < nb) load(cur, blk, 0);
+    f32x4 acc = {0, 0, 0, 0};
+    while (blk < nb) {
+        int nblk = blk, nch = ch + 1;
+        if (nch == nchunk) {
+            nch = 0;
+            nblk += AFF_WAVES;
+        }
+        if (nblk < nb) load(nxt, nblk, nch);
+        const int f0 = 16 * blk + 4 * kq;
+        if (ch == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = (f0 + r < Mout) ? bias[f0 + r] : 0.0f;
+        }
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            f32x4 b4 = {0, 0, 0, 0};
+            if (ch * 128 + 16 * g + 4 * kq < Kv) b4 = *reinterpret_cast<const f32x4*>(hrow + ch * 128 + 16 * g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[g][q], b4[q], acc, 0, 0, 0);
+        }
+        if (ch == nchunk - 1) {
+            if (RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.0f);
+            }
+            if (f0 < out_limit) *reinterpret_cast<f32x4*>(hout + p * ldout + f0) = acc;
+        }
+#pragma unroll
+        for (int g = 0; g < KG; ++g) cur[g] = nxt[g];
+        blk = nblk;
+        ch = nch;
+    }
+}
+
+__global__ __launch_bounds__(64 * AFF_WAVES) void aff_fused_kernel(AffArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int XS = a.Dp + 4, HS = 132;
+    float* xb = sm;                 // [16][XS]  residual rows, later the matched rows
+    float* ha = sm + 16 * XS;       // [16][HS]
+    float* hb = ha + 16 * HS;       // [16][HS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g0 = blockIdx.x * 16;
+#pragma unroll 4
+    for (int e = tid; e < 16 * XS; e += 64 * AFF_WAVES) {
+        const int p = e / XS, c = e - p * XS;
+        xb[e] = (g0 + p < a.M && c < a.D) ? a.residual[(size_t)(g0 + p) * a.ld + c] : 0.0f;
+    }
+    __syncthreads();
+    aff_layer<true, 0>(a.W[0], a.Dp, a.bias[0], 128, a.Dp, xb, XS, ha, HS, 128, lane, wid);
+    __syncthreads();
+    aff_layer<true, 128>(a.W[1], 128, a.bias[1], 64, 128, ha, HS, hb, HS, 64, lane, wid);
+    __syncthreads();
+    aff_layer<true, 64>(a.W[2], 64, a.bias[2], 32, 64, hb, HS, ha, HS, 32, lane, wid);
+    __syncthreads();
+    aff_layer<true, 32>(a.W[3], 32, a.bias[3], 64, 32, ha, HS, hb, HS, 64, lane, wid);
+    __syncthreads();
+    aff_layer<true, 64>(a.W[4], 64, a.bias[4], 128, 64, hb, HS, ha, HS, 128, lane, wid);
+    __syncthreads();
+    aff_layer<false, 128>(a.W[5], 128, a.bias[5], a.D, 128, ha, HS, xb, XS, a.Dp, lane, wid);
+    __syncthreads();
+    // rows 2*wid, 2*wid+1: copy to `matched` (column softmax input) and row softmax for t < N
+    for (int pr = 0; pr < 16 / AFF_WAVES; ++pr) {
+        const int p = (16 / AFF_WAVES) * wid + pr, g = g0 + p;
+        if (g >= a.M) break;
+        const float* x = xb + p * XS;
+        float* mo = a.matched + (size_t)g * a.ldm;
+        for (int d = lane; d < a.D; d += 64) mo[d] = x[d];
+        const int b = g / a.T, t = g - b * a.T;
+        if (t >= a.N) continue;
+        float mx = -INFINITY;
+        for (int d = lane; d < a.D; d += 64) mx = fmaxf(mx, x[d]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        float s = 0.0f;
+        for (int d = lane; d < a.D; d += 64) s += expf(x[d] - mx);
+        s = wave_sum(s);
+        float* o = a.m1 + ((size_t)b * a.N + t) * a.D;
+        for (int d = lane; d < a.D; d += 64) o[d] = expf(x[d] - mx) / s;
+    }
 }
 
 size_t aff_workspace_bytes(int B, int N) {
@@ -76,20 +222,50 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
     float* matched = reinterpret_cast<float*>(base);
     const int M = B * T;
     int rc;
-    // aff.0 uses the zero-padded copy when the caller's residual rows are Dp-strided (16-byte aligned rows)
-    if (ld % 4 == 0)
-        rc = launch_gemm_nt(residual, ld, packed + P.aff0, Dp, w->aff[0].bias, h0, 128, M, 128, D, 1, st);
-    else
-        rc = launch_gemm_nt(residual, ld, w->aff[0].weight, D, w->aff[0].bias, h0, 128, M, 128, D, 1, st);
-    if (rc) return rc;
-    if ((rc = launch_gemm_nt(h0, 128, w->aff[1].weight, 128, w->aff[1].bias, h1, 128, M, 64, 128, 1, st))) return rc;
-    if ((rc = launch_gemm_nt(h1, 128, w->aff[2].weight, 64, w->aff[2].bias, h0, 128, M, 32, 64, 1, st))) return rc;
-    if ((rc = launch_gemm_nt(h0, 128, w->aff[3].weight, 32, w->aff[3].bias, h1, 128, M, 64, 32, 1, st))) return rc;
-    if ((rc = launch_gemm_nt(h1, 128, w->aff[4].weight, 64, w->aff[4].bias, h0, 128, M, 128, 64, 1, st))) return rc;
-    if ((rc = launch_gemm_nt(h0, 128, w->aff[5].weight, 128, w->aff[5].bias, matched, Dp, M, D, 128, 0, st))) return rc;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(B * N, 4)), dim3(256), 0, st, matched, m1, B, N, T, D, Dp);
-    if ((rc = check_launch("softmax_rows"))) return rc;
-    hipLaunchKernelGGL(softmax_cols_kernel, dim3(cdiv(N, 64), B), dim3(256), 0, st, matched, m2, N, T, Dp);
+    (void)h0;
+    (void)h1;
+    static const bool unfused = getenv("SHASTA_AFF_UNFUSED") != nullptr;
+    const size_t lds = (size_t)(16 * (Dp + 4) + 2 * 16 * 132) * sizeof(float);
+    if (!unfused && lds <= 160 * 1024) {
+        AffArgs fa;
+        fa.W[0] = packed + P.aff0;  // zero padded (128, Dp)
+        fa.bias[0] = w->aff[0].bias;
+        for (int i = 1; i < 6; ++i) {
+            fa.W[i] = w->aff[i].weight;
+            fa.bias[i] = w->aff[i].bias;
+        }
+        fa.residual = residual;
+        fa.matched = matched;
+        fa.m1 = m1;
+        fa.M = M;
+        fa.T = T;
+        fa.N = N;
+        fa.D = D;
+        fa.Dp = Dp;
+        fa.ld = ld;
+        fa.ldm = Dp;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)aff_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(aff_fused_kernel, dim3(cdiv(M, 16)), dim3(64 * AFF_WAVES), lds, st, fa);
+        if ((rc = check_launch("aff_fused"))) return rc;
+    } else {
+        // layer-by-layer path: six launches of the generic GEMM + a row softmax kernel
+        // aff.0 uses the zero-padded copy when the caller's residual rows are Dp-strided (16-byte aligned rows)
+        if (ld % 4 == 0)
+            rc = launch_gemm_nt(residual, ld, packed + P.aff0, Dp, w->aff[0].bias, h0, 128, M, 128, D, 1, st);
+        else
+            rc = launch_gemm_nt(residual, ld, w->aff[0].weight, D, w->aff[0].bias, h0, 128, M, 128, D, 1, st);
+        if (rc) return rc;
+        if ((rc = launch_gemm_nt(h0, 128, w->aff[1].weight, 128, w->aff[1].bias, h1, 128, M, 64, 128, 1, st))) return rc;
+        if ((rc = launch_gemm_nt(h1, 128, w->aff[2].weight, 64, w->aff[2].bias, h0, 128, M, 32, 64, 1, st))) return rc;
+        if ((rc = launch_gemm_nt(h0, 128, w->aff[3].weight, 32, w->aff[3].bias, h1, 128, M, 64, 32, 1, st))) return rc;
+        if ((rc = launch_gemm_nt(h1, 128, w->aff[4].weight, 64, w->aff[4].bias, h0, 128, M, 128, 64, 1, st))) return rc;
+        if ((rc = launch_gemm_nt(h0, 128, w->aff[5].weight, 128, w->aff[5].bias, matched, Dp, M, D, 128, 0, st))) return rc;
+        hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(B * N, 4)), dim3(256), 0, st, matched, m1, B, N, T, D, Dp);
+        if ((rc = check_launch("softmax_rows"))) return rc;
+    }
+    if (T <= 512) hipLaunchKernelGGL(softmax_cols_kernel<8>, dim3(cdiv(N, 16), B), dim3(1024), 0, st, matched, m2, N, T, Dp);
+    else if (T <= 1024) hipLaunchKernelGGL(softmax_cols_kernel<16>, dim3(cdiv(N, 16), B), dim3(1024), 0, st, matched, m2, N, T, Dp);
+    else hipLaunchKernelGGL(softmax_cols_kernel<32>, dim3(cdiv(N, 16), B), dim3(1024), 0, st, matched, m2, N, T, Dp);
     if ((rc = check_launch("softmax_cols"))) return rc;
     if (matched_out) {
         hipError_t e = hipMemcpy2DAsync(matched_out, (size_t)D * sizeof(float), matched, (size_t)Dp * sizeof(float),

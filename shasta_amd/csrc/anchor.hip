@@ -14,6 +14,7 @@
 // concurrently, and the split-K partials are summed in a fixed order afterwards (no float atomics -> bitwise
 // reproducible).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace shasta {
 
@@ -100,22 +101,34 @@ struct AnchorL2Args {
     int H, F, N, B;
 };
 
-// one wave per (b, mlp, j): out = abs(b2[j] + W2[j,:] . hidden[b, mlp, :])
+// one wave per (batch chunk of 8, mlp, j): out[b] = abs(b2[j] + W2[j,:] . hidden[b, mlp, :]); the weight row is read once
+// per 8 batch items
 __global__ __launch_bounds__(256) void anchor_l2_kernel(AnchorL2Args a) {
+    constexpr int BT = 8;
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= a.B * 4 * a.F) return;
-    const int j = item % a.F, mlp = (item / a.F) & 3, b = item / (4 * a.F);
+    const int nchunk = (a.B + BT - 1) / BT;
+    if (item >= nchunk * 4 * a.F) return;
+    const int j = item % a.F, mlp = (item / a.F) & 3, b0 = (item / (4 * a.F)) * BT;
     const float* w = a.W[mlp] + (size_t)j * a.H;
-    const float* h = a.hidden + (size_t)b * 4 * a.H + mlp * a.H;
-    float s = 0.0f;
-    for (int i = lane; i < a.H; i += 64) s = fmaf(w[i], h[i], s);
-    s = wave_sum(s);
-    if (lane == 0) {
-        const float v = fabsf(s + a.bias[mlp][j]);
-        // mlp 0,1 (newborn, fp) -> prev_feat rows N, N+1 ; mlp 2,3 (dead_trk, fn) -> feat rows N, N+1
-        float* tab = (mlp < 2) ? a.prev_feat : a.feat;
-        tab[((size_t)b * (a.N + 2) + a.N + (mlp & 1)) * a.F + j] = v;
+    const float* h[BT];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) h[b] = a.hidden + (size_t)min(b0 + b, a.B - 1) * 4 * a.H + mlp * a.H;
+    float s[BT];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) s[b] = 0.0f;
+    for (int i = lane; i < a.H; i += 64) {
+        const float wv = w[i];
+#pragma unroll
+        for (int b = 0; b < BT; ++b) s[b] = fmaf(wv, h[b][i], s[b]);
+    }
+    // mlp 0,1 (newborn, fp) -> prev_feat rows N, N+1 ; mlp 2,3 (dead_trk, fn) -> feat rows N, N+1
+    float* tab = (mlp < 2) ? a.prev_feat : a.feat;
+    const float bias = a.bias[mlp][j];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+        const float v = wave_sum(s[b]);
+        if (lane == 0 && b0 + b < a.B) tab[((size_t)(b0 + b) * (a.N + 2) + a.N + (mlp & 1)) * a.F + j] = fabsf(v + bias);
     }
 }
 
@@ -128,21 +141,37 @@ struct BoxL1Args {
     int HD, N, B, box_stride;
 };
 
-// one wave per (b, mlp, u): hid = relu(b1[u] + W1[u,:] . boxes7_flat)
+// one wave per (batch chunk of 8, mlp, u): hid[b] = relu(b1[u] + W1[u,:] . boxes7_flat[b]); the weight row is read once
+// per 8 batch items, 4 independent weight loads in flight per lane
 __global__ __launch_bounds__(256) void box_l1_kernel(BoxL1Args a) {
+    constexpr int BT = 8;
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= a.B * 4 * a.HD) return;
-    const int u = item % a.HD, mlp = (item / a.HD) & 3, b = item / (4 * a.HD);
+    const int nchunk = (a.B + BT - 1) / BT;
+    if (item >= nchunk * 4 * a.HD) return;
+    const int u = item % a.HD, mlp = (item / a.HD) & 3, b0 = (item / (4 * a.HD)) * BT;
     const float* w = a.W[mlp] + (size_t)u * 7 * a.N;
-    const float* x = ((mlp < 2) ? a.det : a.prev) + (size_t)b * a.N * a.box_stride;
-    float s = 0.0f;
+    const float* xb = ((mlp < 2) ? a.det : a.prev);
+    const float* x[BT];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) x[b] = xb + (size_t)min(b0 + b, a.B - 1) * a.N * a.box_stride;
+    float s[BT];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) s[b] = 0.0f;
+#pragma unroll 4
     for (int k = lane; k < 7 * a.N; k += 64) {
         const int n = k / 7, c = k - 7 * n;
-        s = fmaf(w[k], x[(size_t)n * a.box_stride + c], s);
+        const float wv = w[k];
+        const size_t off = (size_t)n * a.box_stride + c;
+#pragma unroll
+        for (int b = 0; b < BT; ++b) s[b] = fmaf(wv, x[b][off], s[b]);
     }
-    s = wave_sum(s);
-    if (lane == 0) a.hid[item] = fmaxf(s + a.bias[mlp][u], 0.0f);
+    const float bias = a.bias[mlp][u];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+        const float v = wave_sum(s[b]);
+        if (lane == 0 && b0 + b < a.B) a.hid[((size_t)(b0 + b) * 4 + mlp) * a.HD + u] = fmaxf(v + bias, 0.0f);
+    }
 }
 
 struct BoxL2Args {
@@ -160,20 +189,22 @@ struct BoxL2Args {
 // (N+2, 8) box tables (shasta.py:273-274; column 7 is padding and written as 0).
 __global__ __launch_bounds__(256) void box_l2_tables_kernel(BoxL2Args a) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (tid < 32) {
-        float v = 0.0f;
-        const int mlp = tid >> 3, c = tid & 7;
-        if (c < 7) {
-            const float* w = a.W[mlp] + (size_t)c * a.HD;
-            const float* h = a.hid + ((size_t)b * 4 + mlp) * a.HD;
-            float s = 0.0f;
-            for (int i = 0; i < a.HD; ++i) s = fmaf(w[i], h[i], s);
-            v = s + a.bias[mlp][c];
-            if (c >= 3 && c < 6) v = fabsf(v);
-        }
+    {
+        // wave `mlp` computes the 7 outputs of aug_dets[mlp].2, lanes across the hidden units
+        const int mlp = tid >> 6, lane = tid & 63;
+        const float* h = a.hid + ((size_t)b * 4 + mlp) * a.HD;
         // mlp 0,1 (newborn, fp) extend the PREVIOUS boxes; 2,3 (dead_trk, fn) extend the CURRENT ones
-        float* tab = (mlp < 2) ? a.prev_tab : a.det_tab;
-        tab[((size_t)b * (a.N + 2) + a.N + (mlp & 1)) * 8 + c] = v;
+        float* tab = ((mlp < 2) ? a.prev_tab : a.det_tab) + ((size_t)b * (a.N + 2) + a.N + (mlp & 1)) * 8;
+        for (int c = 0; c < 7; ++c) {
+            const float* w = a.W[mlp] + (size_t)c * a.HD;
+            float s = 0.0f;
+            for (int i = lane; i < a.HD; i += 64) s = fmaf(w[i], h[i], s);
+            s = wave_sum(s);
+            float v = s + a.bias[mlp][c];
+            if (c >= 3 && c < 6) v = fabsf(v);
+            if (lane == 0) tab[c] = v;
+        }
+        if (lane == 0) tab[7] = 0.0f;
     }
     for (int n = tid; n < a.N; n += blockDim.x) {
         float* d = a.det + ((size_t)b * a.N + n) * a.box_stride;
@@ -200,6 +231,9 @@ size_t anchor_shape_workspace_bytes(int B, int N, int F) {
     // worst-case KS is bounded by 64
     return align_up((size_t)64 * B * 4 * H * sizeof(float), 256) + align_up((size_t)B * 4 * H * sizeof(float), 256);
 }
+
+int launch_anchor_l1_mfma(const float* const W[4], const float* feat, const float* prev_feat, float* part, int H, int K,
+                          int B, int x_batch_stride, int* ks_out, hipStream_t st);
 
 template <int BT, int R>
 static void launch_l1(const AnchorL1Args& a, hipStream_t st) {
@@ -236,7 +270,11 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     float* hidden = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)64 * B * 4 * H * sizeof(float), 256));
     a.part = part;
     if (ev0) (void)hipEventRecord(ev0, st);
+    // B == 1: VALU weight-streaming GEMV (nothing to amortise; measured 6.5 TB/s).  B >= 2: the matrix-core kernel
+    // streams every weight once per 16 / 32 batch items (anchor_mfma.hip).  SHASTA_L1_VALU=1 forces the VALU kernels.
+    static const bool force_valu = getenv("SHASTA_L1_VALU") != nullptr;
     if (B == 1) launch_l1<1, R>(a, st);
+    else if (!force_valu && K % 32 == 0) launch_anchor_l1_mfma(a.W, feat, prev_feat, part, H, K, B, a.x_batch_stride, &a.KS, st);
     else if (B == 2) launch_l1<2, R>(a, st);
     else if (B <= 4) launch_l1<4, R>(a, st);
     else launch_l1<8, R>(a, st);
@@ -261,7 +299,7 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     l2.F = F;
     l2.N = N;
     l2.B = B;
-    hipLaunchKernelGGL(anchor_l2_kernel, dim3(cdiv(B * 4 * F, 4)), dim3(256), 0, st, l2);
+    hipLaunchKernelGGL(anchor_l2_kernel, dim3(cdiv(cdiv(B, 8) * 4 * F, 4)), dim3(256), 0, st, l2);
     return check_launch("anchor_l2");
 }
 
@@ -284,7 +322,7 @@ int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* 
         a.N = N;
         a.B = B;
         a.box_stride = box_stride;
-        hipLaunchKernelGGL(box_l1_kernel, dim3(cdiv(B * 4 * HD, 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(box_l1_kernel, dim3(cdiv(cdiv(B, 8) * 4 * HD, 4)), dim3(256), 0, st, a);
         int rc = check_launch("box_l1");
         if (rc) return rc;
     }

@@ -20,7 +20,7 @@ int pack_weights(const shasta_weights* w, float* packed, hipStream_t st);
 
 static int check_weights(const shasta_weights* w) {
     SHASTA_REQUIRE(w, "null weights");
-    SHASTA_REQUIRE(w->max_obj >= 1 && w->max_obj <= 4094, "max_obj out of range");
+    SHASTA_REQUIRE(w->max_obj >= 1 && w->max_obj <= 2046, "max_obj out of range (1..2046)");
     SHASTA_REQUIRE(w->num_feats >= 1 && w->num_feats <= 7, "num_feats must be 1..7");
     SHASTA_REQUIRE(w->feat_dim == 64 || w->feat_dim == 256 || w->feat_dim == 320, "feat_dim must be 64, 256 or 320");
     for (int i = 0; i < 4; ++i)

@@ -7,7 +7,8 @@
 //   pack_pair_weights   once per weight load: fragments + factorised first-layer matrices
 //   [gemm_nt_f32 x2]    UP = prev_feat . Wemb_prev^T ; UC = feat . Wemb_cur^T + b          (matrix cores)
 //   row_finish          per table row: box columns of res_coeff.0 / fuse_det.0, log-dims, cos/sin
-//   hand_dist           column L2 norm over tracks (F.normalize, dim=1) + dim + rot terms -> dist (B,T,D)
+//   col_norm            column L2 norm over tracks (F.normalize, dim=1) of the squared box distances
+//                       (the dim / rot terms and the normalised distance are evaluated inside pair_mfma)
 //   pair_mfma<F>        per 16 pairs: h1 = relu(UP[t]+UC[d]) then 44 (F=256) v_mfma_f32_16x16x4_f32 -> residual
 #include "common.hpp"
 #include "pair_layout.hpp"
@@ -181,64 +182,55 @@ __global__ __launch_bounds__(256) void row_finish_kernel(RowFinishArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// hand_dist (shasta.py:277-283): block = 16 detections x 16 track groups.
-//   d2[t][d] = sum_{k<nf} (prev_k - det_k)^2 ; r = d2 / max(||d2[:, d]||_2, 1e-12) ; + sum |dlog dims| ; + rot
+// col_norm (shasta.py:278-279): d2[t][d] = sum_{k<nf} (prev_k - det_k)^2 ; denom[d] = max(||d2[:, d]||_2, 1e-12)
+// (F.normalize acts along dim=1 = tracks).  block = 16 detections x 16 track groups; the previous boxes are read as
+// one float4 pair per track (first 8 floats of the 16-float hand row), 4 tracks in flight per thread.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void hand_dist_kernel(const float* __restrict__ hand_prev,
-                                                        const float* __restrict__ hand_det, float* __restrict__ dist,
-                                                        int T, int D, int ld, int nf) {
+__global__ __launch_bounds__(256) void col_norm_kernel(const float* __restrict__ hand_prev,
+                                                       const float* __restrict__ hand_det, float* __restrict__ denom,
+                                                       int T, int D, int nf) {
     __shared__ float red[16][17];
-    __shared__ float dcol[16][16];
     const int b = blockIdx.y, dl = threadIdx.x & 15, tg = threadIdx.x >> 4;
     const int d = blockIdx.x * 16 + dl;
-    const bool dv = d < D;
-    if (tg == 0) {
-        const float* h = hand_det + ((size_t)b * D + min(d, D - 1)) * 16;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) dcol[dl][c] = h[c];
+    float db[8];
+    {
+        const f32x4* h = reinterpret_cast<const f32x4*>(hand_det + ((size_t)b * D + min(d, D - 1)) * 16);
+        const f32x4 a = h[0], c = h[1];
+        db[0] = a[0]; db[1] = a[1]; db[2] = a[2]; db[3] = a[3]; db[4] = c[0]; db[5] = c[1]; db[6] = c[2]; db[7] = 0.0f;
     }
-    __syncthreads();
-    float db[16];
+    // columns >= nf do not take part: zero both sides
+    float mask[7];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) db[c] = dcol[dl][c];
-    const float* hp = hand_prev + (size_t)b * T * 16;
+    for (int k = 0; k < 7; ++k) mask[k] = k < nf ? 1.0f : 0.0f;
+    const f32x4* hp = reinterpret_cast<const f32x4*>(hand_prev + (size_t)b * T * 16);
     float ssq = 0.0f;
+#pragma unroll 4
     for (int t = tg; t < T; t += 16) {
-        const float* p = hp + (size_t)t * 16;
+        const f32x4 a = hp[(size_t)t * 4], c = hp[(size_t)t * 4 + 1];
+        const float p[7] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2]};
         float d2 = 0.0f;
-        for (int k = 0; k < nf; ++k) {
-            const float df = p[k] - db[k];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const float df = (p[k] - db[k]) * mask[k];
             d2 += df * df;
         }
         ssq += d2 * d2;
     }
     red[dl][tg] = ssq;
     __syncthreads();
-    float tot = 0.0f;
+    if (tg == 0 && d < D) {
+        float tot = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tot += red[dl][i];  // fixed order
-    const float denom = fmaxf(sqrtf(tot), 1e-12f);
-    if (!dv) return;
-    for (int t = tg; t < T; t += 16) {
-        const float* p = hp + (size_t)t * 16;
-        float d2 = 0.0f;
-        for (int k = 0; k < nf; ++k) {
-            const float df = p[k] - db[k];
-            d2 += df * df;
-        }
-        float r = d2 / denom;
-        const float dim = (fabsf(p[8] - db[8]) + fabsf(p[9] - db[9])) + fabsf(p[10] - db[10]);
-        const float dc = p[11] - db[11], dsn = p[12] - db[12];
-        const float rot = sqrtf(dc * dc + dsn * dsn);
-        r = (r + dim) + rot;
-        dist[((size_t)b * T + t) * ld + d] = r;
+        for (int i = 0; i < 16; ++i) tot += red[dl][i];  // fixed order
+        denom[(size_t)b * D + d] = fmaxf(sqrtf(tot), 1e-12f);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // pair_mfma
 // ------------------------------------------------------------------------------------------------------------
-constexpr int TT = 16;  // tracks per workgroup
+// tracks per workgroup: a runtime argument (8..64).  Larger values amortise the per-workgroup prologue (weight
+// fragments, detection-side embeddings, bias fragments) over more pairs; smaller ones give B=1 enough workgroups.
 
 template <int F, int L>
 struct Frags {
@@ -257,15 +249,20 @@ struct Frags {
 
 template <int F>
 __global__ __launch_bounds__(256) void pair_mfma_kernel(const float* __restrict__ packed, const float* __restrict__ UP,
-                                                        const float* __restrict__ UC, const float* __restrict__ dist,
-                                                        float* __restrict__ residual, int T, int D, int ld) {
+                                                        const float* __restrict__ UC, const float* __restrict__ hand_prev,
+                                                        const float* __restrict__ hand_det, const float* __restrict__ denom,
+                                                        float* __restrict__ residual, int T, int D, int ld, int nf,
+                                                        int TT) {
     constexpr PairDims dm(F);
     constexpr int H1 = dm.H1, R1 = dm.R1, ET = dm.ET;
     constexpr int S_FS = H1 / 4, S_RC = R1 / 4, S_FD = 8;
     constexpr int NBIAS = total_bias_blocks(F);
-    __shared__ __attribute__((aligned(16))) float s_up[TT * ET];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     __shared__ __attribute__((aligned(16))) float s_bias[NBIAS * 256];
-    __shared__ float s_dist[TT * 64];
+    __shared__ float s_hd[64 * 17];
+    float* s_up = s_dyn;                // [TT][ET]
+    float* s_dist = s_up + TT * ET;     // [TT][64]
+    float* s_hp = s_dist + TT * 64;     // [TT][16]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int p = lane & 15, kq = lane >> 4;
@@ -276,11 +273,25 @@ __global__ __launch_bounds__(256) void pair_mfma_kernel(const float* __restrict_
 
     // stage UP rows of this workgroup's tracks, the bias fragments and the dist tile
     const int nt = min(TT, T - t0);
-    for (int e = tid; e < nt * ET; e += 256) s_up[e] = UP[((size_t)b * T + t0) * ET + e];
-    for (int e = tid; e < NBIAS * 256; e += 256) s_bias[e] = packed[P.biasf + e];
-    for (int e = tid; e < TT * 64; e += 256) {
-        const int tt = e >> 6, dd = dblk + (e & 63);
-        s_dist[e] = (tt < nt && dd < D) ? dist[((size_t)b * T + t0 + tt) * ld + dd] : 0.0f;
+    {
+        // ET is a multiple of 4 and the tables are 16-byte aligned: stage with float4, several loads in flight
+        const f32x4* src = reinterpret_cast<const f32x4*>(UP + ((size_t)b * T + t0) * ET);
+        f32x4* dst = reinterpret_cast<f32x4*>(s_up);
+#pragma unroll 4
+        for (int e = tid; e < nt * (ET / 4); e += 256) dst[e] = src[e];
+        const f32x4* bsrc = reinterpret_cast<const f32x4*>(packed + P.biasf);
+        f32x4* bdst = reinterpret_cast<f32x4*>(s_bias);
+#pragma unroll
+        for (int e = tid; e < NBIAS * 64; e += 256) bdst[e] = bsrc[e];
+    }
+#pragma unroll 4
+    for (int e = tid; e < TT * 16; e += 256) s_hp[e] = hand_prev[((size_t)b * T + min(t0 + (e >> 4), T - 1)) * 16 + (e & 15)];
+#pragma unroll
+    for (int e = tid; e < 64 * 16; e += 256) {
+        const int dd = e >> 4, c = e & 15;
+        // slot 7 of a detection row (unused padding in the hand table) carries the column norm of shasta.py:279
+        s_hd[dd * 17 + c] = c == 7 ? denom[(size_t)b * D + min(dblk + dd, D - 1)]
+                                   : hand_det[((size_t)b * D + min(dblk + dd, D - 1)) * 16 + c];
     }
 
     Frags<F, L_FS2> w_fs2; Frags<F, L_FS3> w_fs3; Frags<F, L_FS4> w_fs4;
@@ -301,6 +312,24 @@ __global__ __launch_bounds__(256) void pair_mfma_kernel(const float* __restrict_
         for (int s = 0; s < S_RC; ++s) uc_rc[s] = u[H1 + kq * S_RC + s];
 #pragma unroll
         for (int s = 0; s < S_FD; ++s) uc_fd[s] = u[H1 + R1 + kq * S_FD + s];
+    }
+    __syncthreads();
+    // hand-designed residual (shasta.py:277-283) for the TT x 64 pairs of this workgroup, 4 pairs per thread
+    for (int e = tid; e < TT * 64; e += 256) {
+        const int tt = e >> 6, dd = e & 63;
+        const float* hp = s_hp + tt * 16;
+        const float* hd = s_hd + dd * 17;
+        float d2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (k < nf) {
+                const float df = hp[k] - hd[k];
+                d2 += df * df;
+            }
+        float r = d2 / hd[7];
+        const float dim = (fabsf(hp[8] - hd[8]) + fabsf(hp[9] - hd[9])) + fabsf(hp[10] - hd[10]);
+        const float dcs = hp[11] - hd[11], dsn = hp[12] - hd[12];
+        s_dist[e] = (r + dim) + sqrtf(dcs * dcs + dsn * dsn);
     }
     __syncthreads();
 
@@ -389,7 +418,8 @@ size_t pair_workspace_bytes(int B, int N, int F) {
     size_t s = 0;
     s += 2 * align_up((size_t)B * T * d.ET * sizeof(float), 256);  // UP, UC
     s += 2 * align_up((size_t)B * T * 16 * sizeof(float), 256);    // hand tables
-    s += align_up((size_t)B * T * Dp * sizeof(float), 256);        // dist
+    s += align_up((size_t)B * T * sizeof(float), 256);             // column norms
+    (void)Dp;
     return s;
 }
 
@@ -416,8 +446,7 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     base += align_up((size_t)B * T * 16 * sizeof(float), 256);
     float* hand_det = reinterpret_cast<float*>(base);
     base += align_up((size_t)B * T * 16 * sizeof(float), 256);
-    float* dist = reinterpret_cast<float*>(base);
-    const int Dp = (T + 3) / 4 * 4;
+    float* denom = reinterpret_cast<float*>(base);
 
     int rc = launch_gemm_nt(prev_feat, F, packed + P.wemb_prev, F, nullptr, UP, d.ET, B * T, P.E12, F, 0, st);
     if (rc) return rc;
@@ -439,14 +468,18 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     hipLaunchKernelGGL(row_finish_kernel, dim3(cdiv(2 * B * T, 4)), dim3(256), 0, st, rf);
     rc = check_launch("row_finish");
     if (rc) return rc;
-    hipLaunchKernelGGL(hand_dist_kernel, dim3(cdiv(D, 16), B), dim3(256), 0, st, hand_prev, hand_det, dist, T, D, Dp, nf);
-    rc = check_launch("hand_dist");
+    hipLaunchKernelGGL(col_norm_kernel, dim3(cdiv(D, 16), B), dim3(256), 0, st, hand_prev, hand_det, denom, T, D, nf);
+    rc = check_launch("col_norm");
     if (rc) return rc;
-    dim3 grid(cdiv(D, 64), cdiv(T, TT), B);
+    // tracks per workgroup: the largest of 64/32/16/8 that still yields >= 2 waves per SIMD on 256 CUs
+    int tt = 64;
+    while (tt > 8 && (long)B * cdiv(D, 64) * 4 * cdiv(T, tt) < 2048) tt >>= 1;
+    const size_t lds = (size_t)tt * (d.ET + 64 + 16) * sizeof(float);
+    dim3 grid(cdiv(D, 64), cdiv(T, tt), B);
     switch (F) {
-        case 64: hipLaunchKernelGGL(pair_mfma_kernel<64>, grid, dim3(256), 0, st, packed, UP, UC, dist, residual, T, D, ld); break;
-        case 256: hipLaunchKernelGGL(pair_mfma_kernel<256>, grid, dim3(256), 0, st, packed, UP, UC, dist, residual, T, D, ld); break;
-        case 320: hipLaunchKernelGGL(pair_mfma_kernel<320>, grid, dim3(256), 0, st, packed, UP, UC, dist, residual, T, D, ld); break;
+        case 64: hipLaunchKernelGGL(pair_mfma_kernel<64>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt); break;
+        case 256: hipLaunchKernelGGL(pair_mfma_kernel<256>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt); break;
+        case 320: hipLaunchKernelGGL(pair_mfma_kernel<320>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt); break;
         default: set_error_msg("pair_residual: feat_dim must be 64, 256 or 320"); return SHASTA_E_ARG;
     }
     return check_launch("pair_mfma");

@@ -149,10 +149,13 @@ def test_gemm_nt_vs_torch(M, N, K, act):
         assert (out[:, N:] == -7.0).all()
 
 
-@pytest.mark.parametrize("name", ["tiny_4_7_5", "small_32_7_4", "car_90_3_5"])
-@pytest.mark.parametrize("B", [1, 3, 9])
+@pytest.mark.parametrize("name,B", [("tiny_4_7_5", 1), ("tiny_4_7_5", 3), ("tiny_4_7_5", 9), ("tiny_4_7_5", 20),
+                                    ("tiny_4_7_5", 40), ("tiny_4_7_5", 70), ("small_32_7_4", 1), ("small_32_7_4", 3),
+                                    ("small_32_7_4", 9), ("small_32_7_4", 17), ("small_32_7_4", 33),
+                                    ("car_90_3_5", 1), ("car_90_3_5", 3), ("car_90_3_5", 9)])
 def test_batched_forward_vs_oracle(name, B):
-    """Batch sizes that exercise every batch-tile template of the anchor kernel, against the CPU oracle."""
+    """Batch sizes that exercise every variant of the anchor kernel (VALU B=1; MFMA 16 / 32 / 64 rows per pass, single
+    and multiple passes), against the CPU oracle."""
     dev = _dev()
     z, c, sums = load_golden(name)
     m = build_model(c)
