@@ -141,37 +141,22 @@ struct BoxL1Args {
     int HD, N, B, box_stride;
 };
 
-// one wave per (batch chunk of 8, mlp, u): hid[b] = relu(b1[u] + W1[u,:] . boxes7_flat[b]); the weight row is read once
-// per 8 batch items, 4 independent weight loads in flight per lane
+// one wave per (b, mlp, u): hid = relu(b1[u] + W1[u,:] . boxes7_flat)
 __global__ __launch_bounds__(256) void box_l1_kernel(BoxL1Args a) {
-    constexpr int BT = 8;
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nchunk = (a.B + BT - 1) / BT;
-    if (item >= nchunk * 4 * a.HD) return;
-    const int u = item % a.HD, mlp = (item / a.HD) & 3, b0 = (item / (4 * a.HD)) * BT;
+    if (item >= a.B * 4 * a.HD) return;
+    const int u = item % a.HD, mlp = (item / a.HD) & 3, b = item / (4 * a.HD);
     const float* w = a.W[mlp] + (size_t)u * 7 * a.N;
-    const float* xb = ((mlp < 2) ? a.det : a.prev);
-    const float* x[BT];
-#pragma unroll
-    for (int b = 0; b < BT; ++b) x[b] = xb + (size_t)min(b0 + b, a.B - 1) * a.N * a.box_stride;
-    float s[BT];
-#pragma unroll
-    for (int b = 0; b < BT; ++b) s[b] = 0.0f;
-#pragma unroll 4
-    for (int k = lane; k < 7 * a.N; k += 64) {
+    const float* x = ((mlp < 2) ? a.det : a.prev) + (size_t)b * a.N * a.box_stride;
+    float s = 0.0f;
+#pragma unroll 8
+    for (int k = lane; k < 7 * a.N; k += 64) {  // unrolled: the weight rows come from HBM, keep 8 loads in flight
         const int n = k / 7, c = k - 7 * n;
-        const float wv = w[k];
-        const size_t off = (size_t)n * a.box_stride + c;
-#pragma unroll
-        for (int b = 0; b < BT; ++b) s[b] = fmaf(wv, x[b][off], s[b]);
+        s = fmaf(w[k], x[(size_t)n * a.box_stride + c], s);
     }
-    const float bias = a.bias[mlp][u];
-#pragma unroll
-    for (int b = 0; b < BT; ++b) {
-        const float v = wave_sum(s[b]);
-        if (lane == 0 && b0 + b < a.B) a.hid[((size_t)(b0 + b) * 4 + mlp) * a.HD + u] = fmaxf(v + bias, 0.0f);
-    }
+    s = wave_sum(s);
+    if (lane == 0) a.hid[item] = fmaxf(s + a.bias[mlp][u], 0.0f);
 }
 
 struct BoxL2Args {
@@ -322,7 +307,7 @@ int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* 
         a.N = N;
         a.B = B;
         a.box_stride = box_stride;
-        hipLaunchKernelGGL(box_l1_kernel, dim3(cdiv(cdiv(B, 8) * 4 * HD, 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(box_l1_kernel, dim3(cdiv(B * 4 * HD, 4)), dim3(256), 0, st, a);
         int rc = check_launch("box_l1");
         if (rc) return rc;
     }

@@ -12,6 +12,7 @@
 //   pair_mfma<F>        per 16 pairs: h1 = relu(UP[t]+UC[d]) then 44 (F=256) v_mfma_f32_16x16x4_f32 -> residual
 #include "common.hpp"
 #include "pair_layout.hpp"
+#include <stdlib.h>
 
 namespace shasta {
 
@@ -247,7 +248,7 @@ struct Frags {
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-template <int F>
+template <int F, int UNROLL>
 __global__ __launch_bounds__(256) void pair_mfma_kernel(const float* __restrict__ packed, const float* __restrict__ UP,
                                                         const float* __restrict__ UC, const float* __restrict__ hand_prev,
                                                         const float* __restrict__ hand_det, const float* __restrict__ denom,
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void pair_mfma_kernel(const float* __restrict_
     __shared__ float s_hd[64 * 17];
     float* s_up = s_dyn;                // [TT][ET]
     float* s_dist = s_up + TT * ET;     // [TT][64]
-    float* s_hp = s_dist + TT * 64;     // [TT][16]
+    float* s_hp = s_dist + TT * 64;     // [TT][16], followed by 256 floats of scratch
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int p = lane & 15, kq = lane >> 4;
@@ -341,7 +342,10 @@ __global__ __launch_bounds__(256) void pair_mfma_kernel(const float* __restrict_
         return v;
     };
 
-    for (int tt = 0; tt < nt; ++tt) {
+    // One step = the 16 pairs (track t0+tt) x (this wave's 16 detections).  No branch inside: the result goes to the
+    // LDS tile (lanes kq != 0 write to a scratch slot), so two steps can be interleaved by the scheduler (UNROLL = 2)
+    // and the tile leaves the workgroup as whole 256-byte rows after the loop.
+    auto step = [&](int tt) {
         const float* up = s_up + tt * ET;
         // ---- layer 1 (factorised): h1 = relu(UP[t] + UC[d]) ----
         float h_fs[S_FS], h_rc[S_RC], h_fd[S_FD];
@@ -401,15 +405,30 @@ __global__ __launch_bounds__(256) void pair_mfma_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < (dm.H3 + 3) / 4; ++r) a_fs4 = MFMA16(w_fs4.w[0][r], a_fs3[r], a_fs4);
 
-        // ---- combine (shasta.py:316-319): alpha, beta, omega = res_coeff outputs 0,1,2 ----
-        if (kq == 0 && d < D) {
-            const float alpha = a_rc3[0], beta = a_rc3[1], omega = a_rc3[2];
-            const float fused = a_fd3[0], shape = a_fs4[0];
-            const float dst = s_dist[tt * 64 + wid * 16 + p];
-            const float r = (alpha * fused + beta * dst) + omega * shape;
-            residual[((size_t)b * T + t0 + tt) * ld + d] = r;
+        // ---- combine (shasta.py:316-319): alpha, beta, omega = res_coeff outputs 0,1,2 (valid in the kq == 0 lanes) ----
+        const float alpha = a_rc3[0], beta = a_rc3[1], omega = a_rc3[2];
+        const float fused = a_fd3[0], shape = a_fs4[0];
+        const int slot = tt * 64 + wid * 16 + p;
+        const float dst = s_dist[slot];
+        const float r = (alpha * fused + beta * dst) + omega * shape;
+        s_dist[kq == 0 ? slot : TT * 64 + TT * 16 + lane + 64 * wid] = r;  // scratch behind s_hp for the other lanes
+    };
+    if constexpr (UNROLL == 2) {
+        int tt = 0;
+        for (; tt + 1 < nt; tt += 2) {
+            step(tt);
+            step(tt + 1);
         }
+        if (tt < nt) step(tt);
+    } else {
+        for (int tt = 0; tt < nt; ++tt) step(tt);
     }
+    __syncthreads();
+    for (int e = tid; e < nt * 64; e += 256) {
+        const int tt = e >> 6, dd = dblk + (e & 63);
+        if (dd < D) residual[((size_t)b * T + t0 + tt) * ld + dd] = s_dist[e];
+    }
+    (void)d;
 }
 
 size_t pair_workspace_bytes(int B, int N, int F) {
@@ -471,15 +490,29 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     hipLaunchKernelGGL(col_norm_kernel, dim3(cdiv(D, 16), B), dim3(256), 0, st, hand_prev, hand_det, denom, T, D, nf);
     rc = check_launch("col_norm");
     if (rc) return rc;
-    // tracks per workgroup: the largest of 64/32/16/8 that still yields >= 2 waves per SIMD on 256 CUs
-    int tt = 64;
+    // tracks per workgroup: the largest of 32/16/8 that still yields >= 2 waves per SIMD on 256 CUs
+    int tt = 32;  // measured: 8..32 tie once the chip is full, 64 loses occupancy to its LDS footprint
     while (tt > 8 && (long)B * cdiv(D, 64) * 4 * cdiv(T, tt) < 2048) tt >>= 1;
-    const size_t lds = (size_t)tt * (d.ET + 64 + 16) * sizeof(float);
+    if (const char* e = getenv("SHASTA_PAIR_TT")) {  // tuning override
+        const int v = atoi(e);
+        if (v == 8 || v == 16 || v == 32 || v == 64) tt = v;
+    }
+    const size_t lds = ((size_t)tt * (d.ET + 64 + 16) + 256) * sizeof(float);
     dim3 grid(cdiv(D, 64), cdiv(T, tt), B);
+    static const bool unroll2 = getenv("SHASTA_PAIR_UNROLL2") != nullptr;
     switch (F) {
-        case 64: hipLaunchKernelGGL(pair_mfma_kernel<64>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt); break;
-        case 256: hipLaunchKernelGGL(pair_mfma_kernel<256>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt); break;
-        case 320: hipLaunchKernelGGL(pair_mfma_kernel<320>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt); break;
+        case 64:
+            if (unroll2) hipLaunchKernelGGL((pair_mfma_kernel<64, 2>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt);
+            else hipLaunchKernelGGL((pair_mfma_kernel<64, 1>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt);
+            break;
+        case 256:
+            if (unroll2) hipLaunchKernelGGL((pair_mfma_kernel<256, 2>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt);
+            else hipLaunchKernelGGL((pair_mfma_kernel<256, 1>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt);
+            break;
+        case 320:
+            if (unroll2) hipLaunchKernelGGL((pair_mfma_kernel<320, 2>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt);
+            else hipLaunchKernelGGL((pair_mfma_kernel<320, 1>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt);
+            break;
         default: set_error_msg("pair_residual: feat_dim must be 64, 256 or 320"); return SHASTA_E_ARG;
     }
     return check_launch("pair_mfma");

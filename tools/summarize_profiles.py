@@ -1,0 +1,62 @@
+"""Condense rocprofv3 outputs under gpurun_out/ into the small, committed summaries under profiles/ (round tag r01)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0][:80]
+
+
+def kernel_stats(src, dst):
+    rows = list(csv.DictReader(open(src)))
+    with open(dst, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+
+
+def pmc(dirs, dst):
+    out = []
+    for label, d in dirs:
+        for path in glob.glob(os.path.join(G, d, "*counter_collection.csv")):
+            acc = collections.defaultdict(list)
+            dur = collections.defaultdict(list)
+            for r in csv.DictReader(open(path)):
+                if "shasta" not in r["Kernel_Name"]:
+                    continue
+                k = (short(r["Kernel_Name"]), r["Counter_Name"])
+                acc[k].append(float(r["Counter_Value"]))
+                dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            for (k, c), v in sorted(acc.items()):
+                out.append([label, k, c, len(v), sum(v) / len(v), sum(dur[(k, c)]) / len(v)])
+    with open(dst, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["run", "kernel", "counter", "launches", "mean_value_per_launch", "mean_duration_ns"])
+        w.writerows(out)
+
+
+if __name__ == "__main__":
+    os.makedirs(P, exist_ok=True)
+    kernel_stats(os.path.join(G, "final1/prof_default/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_default_b64.csv"))
+    kernel_stats(os.path.join(G, "final1/prof_b1/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_b1.csv"))
+    pmc([("b1_fetch", "pmc_fetch_b1"), ("b1_write", "pmc_write_b1"), ("b32_fetch", "pmc_fetch_b32"), ("b32_write", "pmc_write_b32"),
+         ("b64_fetch", "pmc_fetch_b64"), ("b64_write", "pmc_write_b64"), ("b32_mfma", "pmc_mfma_b32")],
+        os.path.join(P, TAG + "_pmc_summary.csv"))
+    for b in ("default", "b1", "b32"):
+        src = os.path.join(G, "final1/bench_%s.json" % b)
+        if os.path.exists(src):
+            line = [l for l in open(src) if l.startswith("{")][-1]
+            json.dump(json.loads(line), open(os.path.join(P, TAG + "_bench_%s.json" % b), "w"), indent=1)
+    print(os.listdir(P))
