@@ -84,6 +84,25 @@ int shasta_bev_gather_f32(const float* bev, int B, int H, int W, int C, const fl
                           int out_row_stride, int out_batch_stride, shasta_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K0  shared_conv: Conv2d(Cin->64, 3x3, pad 1, bias) + BatchNorm2d(64) (eval) + ReLU -> NHWC
+ * replaces det3d/models/tracker/shasta.py:42-47 as applied at :223-228 (`self.shared_conv(bev_map)` followed by
+ * `.permute(0, 2, 3, 1).contiguous()`), i.e. produces example['bev_feature'].
+ *
+ *  weight (64, Cin, 3, 3), bias (64), bn_* (64) : the tensors shared_conv.0.* / shared_conv.1.* of the state_dict
+ *  packed : shasta_shared_conv_packed_bytes(Cin) bytes, 16-byte aligned; re-pack when any of the six tensors changes
+ *  x      : (B, Cin, H, W) fp32 NCHW (neck output), Cin a multiple of 8
+ *  out    : (B, H, W, 64) fp32 NHWC
+ *  x_prev, out_prev : the previous frame's map and output, processed in the same launch (both NULL to skip)
+ * ------------------------------------------------------------------------------------------ */
+size_t shasta_shared_conv_packed_bytes(int in_channels);
+int shasta_shared_conv_pack_f32(const float* weight, const float* bias, const float* bn_weight,
+                                const float* bn_bias, const float* bn_mean, const float* bn_var,
+                                float bn_eps, int in_channels, void* packed, size_t packed_bytes,
+                                shasta_stream_t stream);
+int shasta_shared_conv_f32(const float* x, const float* x_prev, int B, int in_channels, int H, int W,
+                           const void* packed, float* out, float* out_prev, shasta_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Weights of the affinity network, raw nn.Linear layout (out_features, in_features) row major,
  * exactly the tensors of the reference state_dict (det3d/models/tracker/shasta.py:49-106).
  * ------------------------------------------------------------------------------------------ */

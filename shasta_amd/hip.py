@@ -40,6 +40,9 @@ SYMBOLS = {
     "shasta_voxelize_workspace_bytes": (_Z, [_I, _I, _I]),
     "shasta_voxelize_mean_f32": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "shasta_bev_gather_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P, _I, _I, _P]),
+    "shasta_shared_conv_packed_bytes": (_Z, [_I]),
+    "shasta_shared_conv_pack_f32": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _P, _Z, _P]),
+    "shasta_shared_conv_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "shasta_packed_bytes": (_Z, [_I, _I, _I]),
     "shasta_pack_weights_f32": (_I, [_WP, _P, _Z, _P]),
     "shasta_forward_workspace_bytes": (_Z, [_I, _I, _I, _I]),

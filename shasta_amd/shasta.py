@@ -106,6 +106,8 @@ class Shasta(BaseTrack):
         # HIP-side state (not parameters, not in state_dict)
         self._packed = None
         self._packed_key = None
+        self._conv_packed = None
+        self._conv_key = None
         self._wstruct = None
         self._bufs = {}
         self.keep_intermediates = False  # tests: also return residual / matched via self.last_intermediates
@@ -202,6 +204,39 @@ class Shasta(BaseTrack):
                 ws=torch.empty((ws + 3) // 4, dtype=torch.float32, device=device), ws_bytes=ws)
         return self._bufs[k]
 
+    def shared_conv_nhwc(self, bev_map, prev_bev_map=None):
+        """shasta.py:223-228: relu(bn(conv3x3(map))) -> NHWC for the current (and, in the same launch, the previous) neck
+        output, by the hand-written implicit-GEMM kernel (csrc/shared_conv.hip).  Eval-mode BatchNorm (running
+        statistics) only: in train() mode the module's own nn.Sequential is used so that batch statistics behave like
+        the reference.  Returns one tensor, or a pair when prev_bev_map is given."""
+        conv, bn = self.shared_conv[0], self.shared_conv[1]
+        if self.training or conv.in_channels % 8 != 0 or not bev_map.is_cuda:
+            outs = [self.shared_conv(t).permute(0, 2, 3, 1).contiguous() for t in (bev_map, prev_bev_map) if t is not None]
+            return outs[0] if prev_bev_map is None else tuple(outs)
+        lib = hip.load()
+        tensors = [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        dev = bev_map.device
+        if self._conv_packed is None or self._conv_key != key or self._conv_packed.device != dev:
+            nbytes = lib.shasta_shared_conv_packed_bytes(conv.in_channels)
+            self._conv_packed = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            hip.check(lib.shasta_shared_conv_pack_f32(*[hip.ptr(t.detach()) for t in tensors], float(bn.eps),
+                                                      conv.in_channels, hip.ptr(self._conv_packed), nbytes,
+                                                      hip.stream_ptr()), "shasta_shared_conv_pack_f32")
+            self._conv_key = key
+        x = bev_map.float().contiguous()
+        B, Cin, H, W = x.shape
+        out = torch.empty(B, H, W, conv.out_channels, device=dev)
+        xp = outp = None
+        if prev_bev_map is not None:
+            xp = prev_bev_map.float().contiguous()
+            if xp.shape != x.shape:
+                raise ValueError("bev_map and prev_bev_map must have the same shape")
+            outp = torch.empty_like(out)
+        hip.check(lib.shasta_shared_conv_f32(hip.ptr(x), hip.ptr(xp), B, Cin, H, W, hip.ptr(self._conv_packed), hip.ptr(out),
+                                             hip.ptr(outp), hip.stream_ptr()), "shasta_shared_conv_f32")
+        return out if prev_bev_map is None else (out, outp)
+
     def affinity_from_bev(self, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes, l1_events=None):
         """Rows 4-16 of SURVEY.md 8(a) (shasta.py:231-325) on device.  bev maps (B,H,W,C) fp32 NHWC, boxes (B,N,>=10)
         fp32 contiguous; det_boxes[:, :, :2] is back-projected in place."""
@@ -255,8 +290,7 @@ class Shasta(BaseTrack):
             prev_bev = example["prev_bev_feature"].float().contiguous()
         else:
             bev_map, _, prev_bev_map, _ = self.extract_feat(example)
-            bev = self.shared_conv(bev_map).permute(0, 2, 3, 1).contiguous()
-            prev_bev = self.shared_conv(prev_bev_map).permute(0, 2, 3, 1).contiguous()
+            bev, prev_bev = self.shared_conv_nhwc(bev_map, prev_bev_map)
         example["bev_feature"] = bev
         inplace = det.dtype == torch.float32 and det.is_contiguous() and det.shape[2] >= 10
         det_k = det if inplace else det.float().contiguous()

@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "ref: needs the upstream reference at /root/reference (build container only)")
+    config.addinivalue_line("markers", "slow: builds the 1.03 G-parameter headline model on the CPU (~10 s, 4 GB)")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -94,6 +94,34 @@ def test_forward_with_shared_conv_on_device():
     np.testing.assert_allclose(m2.cpu().numpy(), z["m2"], rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("B,cin,H,W", [(1, 512, 180, 180), (2, 8, 24, 24), (1, 16, 7, 45), (3, 64, 33, 70)])
+def test_shared_conv_vs_oracle(B, cin, H, W):
+    """K0 against the oracle (conv2d + eval batch_norm + relu -> NHWC); K = 9*Cin sequential fp32 accumulation differs from
+    oneDNN's blocked order by ~1e-6 relative."""
+    import shasta_amd
+    dev = _dev()
+    torch.manual_seed(3)
+    m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54],
+                                                            voxel_size=[0.075, 0.075], out_stride=8),
+                                         max_obj=4, num_feats=7, num_point=5, in_channels=cin)).eval()
+    with torch.no_grad():  # non-trivial BatchNorm statistics
+        m.shared_conv[1].running_mean.copy_(torch.randn(64) * 0.3)
+        m.shared_conv[1].running_var.copy_(torch.rand(64) + 0.5)
+        m.shared_conv[1].weight.copy_(torch.rand(64) + 0.5)
+        m.shared_conv[1].bias.copy_(torch.randn(64) * 0.2)
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    x = torch.relu(torch.randn(B, cin, H, W, generator=g))
+    ref = O.shared_conv_nhwc(w, x)
+    m = m.to(dev)
+    with torch.no_grad():
+        got = m.shared_conv_nhwc(x.to(dev))
+    assert got.shape == ref.shape
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5 * max(1.0, scale))
+
+
 @pytest.mark.parametrize("B,N,n_real,npnt,hw,stride", [(2, 37, None, 5, 180, 8), (1, 500, None, 4, 180, 8),
                                                         (3, 16, 5, 1, 24, 64), (1, 64, 0, 4, 180, 8)])
 def test_bev_gather_vs_oracle(B, N, n_real, npnt, hw, stride):
