@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "pair_layout.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace shasta {
 
@@ -87,6 +88,34 @@ __global__ void pack_pair_weights_kernel(PackArgs a) {
             const int f = row_feature(L, bo, 4 * (lane >> 4) + r);
             bo_[e] = f >= 0 ? b[f] : 0.0f;
         }
+    }
+    // transposed, padded copies for the VALU pair kernel: Wt[k][HP] then bias[HP]
+    for (int l = 0; l < L_COUNT; ++l) {
+        const LayerDesc L = layer_desc(F, l);
+        const float *W, *b;
+        int ldw;
+        layer_src(a, l, W, b, ldw);
+        const int HP = vw_hp(F, l);
+        float* o = a.out + P.vw + vw_offset(F, l);
+        for (int e = tid; e < (L.kin + 1) * HP; e += nth) {
+            const int k = e / HP, j = e % HP;
+            o[e] = j < L.hout ? (k < L.kin ? W[(size_t)j * ldw + k] : b[j]) : 0.0f;
+        }
+    }
+    // 4x4x1 A operands: [ob][kg][i][kk], then bias [ob][i]
+    for (int l = 0; l < L_COUNT; ++l) {
+        const LayerDesc L = layer_desc(F, l);
+        const float *W, *b;
+        int ldw;
+        layer_src(a, l, W, b, ldw);
+        const int nob = a4_nob(F, l), kg = a4_kg(F, l);
+        float* o = a.out + P.a4 + a4_offset(F, l);
+        for (int e = tid; e < nob * kg * 16; e += nth) {
+            const int kk = e & 3, i = (e >> 2) & 3, g = (e >> 4) % kg, ob = (e >> 4) / kg;
+            const int f = 4 * ob + i, k = 4 * g + kk;
+            o[e] = (f < L.hout && k < L.kin) ? W[(size_t)f * ldw + k] : 0.0f;
+        }
+        for (int e = tid; e < nob * 4; e += nth) o[nob * kg * 16 + e] = e < L.hout ? b[e] : 0.0f;
     }
     // factorised first layers.  Input column order of the reference concatenations:
     //   fuse_shape.0 : [prev_feat F | feat F]                                  (shasta.py:286)
@@ -253,7 +282,7 @@ __global__ __launch_bounds__(256) void pair_mfma_kernel(const float* __restrict_
                                                         const float* __restrict__ UC, const float* __restrict__ hand_prev,
                                                         const float* __restrict__ hand_det, const float* __restrict__ denom,
                                                         float* __restrict__ residual, int T, int D, int ld, int nf,
-                                                        int TT) {
+                                                        int TT, int stagger) {
     constexpr PairDims dm(F);
     constexpr int H1 = dm.H1, R1 = dm.R1, ET = dm.ET;
     constexpr int S_FS = H1 / 4, S_RC = R1 / 4, S_FD = 8;
@@ -413,6 +442,8 @@ __global__ __launch_bounds__(256) void pair_mfma_kernel(const float* __restrict_
         const float r = (alpha * fused + beta * dst) + omega * shape;
         s_dist[kq == 0 ? slot : TT * 64 + TT * 16 + lane + 64 * wid] = r;  // scratch behind s_hp for the other lanes
     };
+    // de-synchronise the waves that share a SIMD's matrix pipe (same program, same phase otherwise)
+    for (int z = 0; z < stagger * (int)(blockIdx.y & 3); ++z) __builtin_amdgcn_s_sleep(8);
     if constexpr (UNROLL == 2) {
         int tt = 0;
         for (; tt + 1 < nt; tt += 2) {
@@ -429,6 +460,343 @@ __global__ __launch_bounds__(256) void pair_mfma_kernel(const float* __restrict_
         if (dd < D) residual[((size_t)b * T + t0 + tt) * ld + dd] = s_dist[e];
     }
     (void)d;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pair_valu: the same math with one lane per pair and the weights as scalar operands.
+// Measured on MI355X (profiles/README.md): f32-input MFMA runs at exactly the f32 VALU rate (64 FLOP/clk/SIMD) and does
+// not co-execute with VALU work (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so for these small layers the 16x16 tile padding of
+// the MFMA chain (44 MFMAs = 2816 MAC slots per pair for 1984 useful MACs) plus its ~115 VALU instructions per 16 pairs
+// cost 139 SIMD-cycles per pair.  Here every v_fmac_f32 does 64 useful MACs: lane = detection d (64 per wave), the
+// wave walks the tracks t; UP[t] and all weights are wave-uniform -> SGPR operands fed by s_load_dwordx4..x16 from the
+// transposed/padded weight block; the detection-side embeddings UC[d] come from an LDS tile shared by the 4 waves.
+//   per 64 pairs: 1984 FMA + 256 (add, relu of layer 1) + ~150 (bias, relu, hand residual, combine) VALU instructions.
+// Summation order per output: bias, then k ascending (a k-ordered fmaf chain, like the MFMA form).
+// ------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(4))) float cfloat;  // constant address space: uniform loads become s_load_dword*
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc[j] = fma(w[j], h, acc[j]) for one weight row, two outputs per instruction: plain v_fma_f32 issues at half the f32
+// rate of the SIMD (4 cycles per wave64 instruction); v_pk_fma_f32 does two FMAs per lane in the same 4 cycles.
+template <int HP>
+__device__ __forceinline__ void pk_fma_row(const float (&w)[HP], float h, float* acc) {
+    const f32x2 h2 = {h, h};
+#pragma unroll
+    for (int j = 0; j < HP; j += 2) {
+        const f32x2 w2 = {w[j], w[j + 1]};
+        f32x2 a2 = {acc[j], acc[j + 1]};
+        a2 = __builtin_elementwise_fma(w2, h2, a2);
+        acc[j] = a2[0];
+        acc[j + 1] = a2[1];
+    }
+}
+
+template <int F, int L>
+struct VW {
+    static constexpr LayerDesc D = layer_desc(F, L);
+    static constexpr int HP = vw_hp(F, L), OFF = vw_offset(F, L), KIN = D.kin, HOUT = D.hout;
+};
+
+template <int F>
+__global__ __launch_bounds__(256) void pair_valu_kernel(const float* __restrict__ packed, const float* __restrict__ UP,
+                                                        const float* __restrict__ UC, const float* __restrict__ hand_prev,
+                                                        const float* __restrict__ hand_det, const float* __restrict__ denom,
+                                                        float* __restrict__ residual, int T, int D, int ld, int nf,
+                                                        int TW) {
+    constexpr PairDims dm(F);
+    constexpr int H1 = dm.H1, R1 = dm.R1, ET = dm.ET, US = ET + 4;  // LDS row stride: +4 floats spreads the banks
+    extern __shared__ __attribute__((aligned(16))) float s_uc[];     // [64][US]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, d0 = blockIdx.x * 64;
+    const int d = d0 + lane, dcl = min(d, D - 1);
+    const PackedLayout P(0, 0, F);
+    const float* __restrict__ vw = packed + P.vw;
+
+    // stage the 64 detection-side embedding rows
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(UC);
+#pragma unroll 4
+        for (int e = tid; e < 64 * (ET / 4); e += 256) {
+            const int r = e / (ET / 4), c = e - r * (ET / 4);
+            const f32x4 v = src[((size_t)b * D + min(d0 + r, D - 1)) * (ET / 4) + c];
+            *reinterpret_cast<f32x4*>(&s_uc[r * US + 4 * c]) = v;
+        }
+    }
+    // this lane's detection: hand features and column norm
+    float hd[13];
+    {
+        const f32x4* h = reinterpret_cast<const f32x4*>(hand_det + ((size_t)b * D + dcl) * 16);
+        const f32x4 a = h[0], c = h[1], e = h[2], g = h[3];
+        hd[0] = a[0]; hd[1] = a[1]; hd[2] = a[2]; hd[3] = a[3]; hd[4] = c[0]; hd[5] = c[1]; hd[6] = c[2];
+        hd[7] = e[0]; hd[8] = e[1]; hd[9] = e[2]; hd[10] = e[3]; hd[11] = g[0]; hd[12] = 0.0f;
+    }
+    const float dnm = denom[(size_t)b * D + dcl];
+    __syncthreads();
+    const float* ucrow = s_uc + lane * US;
+
+    const int t_beg = (blockIdx.y * 4 + wid) * TW;
+    const int t_end = min(T, t_beg + TW);
+    for (int t = t_beg; t < t_end; ++t) {
+        // wave-uniform, read-only in this kernel: constant address space -> s_load
+        const cfloat* up = (const cfloat*)(UP + ((size_t)b * T + t) * ET);
+        const cfloat* hp = (const cfloat*)(hand_prev + ((size_t)b * T + t) * 16);
+        // The weights are loop invariant: without this the compiler hoists all ~2000 scalar loads out of the track loop
+        // and spills them.  An opaque copy of the base pointer per iteration keeps the s_loads next to their uses.
+        unsigned long long wbits = (unsigned long long)vw;
+        asm volatile("" : "+s"(wbits));
+        const cfloat* vwt = (const cfloat*)wbits;
+
+        // ---- one MLP branch: layer 1 (factorised) feeding layer 2 -------------------------------------------
+        // Scalar loads from the constant address space carry no ordering, so the compiler would float all ~130
+        // s_load_dwordx16 of an iteration to its top and spill ~2000 SGPRs.  Each weight row is therefore addressed
+        // through a pointer that passes an empty asm together with acc[0]: the row for input k+1 can only be requested
+        // once the FMAs of input k-1 have been issued -> one row of prefetch, <= 2*HP weights live in SGPRs.
+        auto tie = [&](const cfloat* w, float* a, auto hp_tag) -> const cfloat* {
+            constexpr int HP = decltype(hp_tag)::value;
+            unsigned long long bits = (unsigned long long)w;
+            // every accumulator pair of the group passes the asm: none of the group's FMAs can be postponed past it.
+            // Pairs are passed as 64-bit operands so that they stay in the aligned register pairs v_pk_fma_f32 needs.
+            f32x2* p = reinterpret_cast<f32x2*>(a);
+            if constexpr (HP == 4)
+                asm volatile("" : "+s"(bits), "+v"(p[0]), "+v"(p[1]));
+            else if constexpr (HP == 8)
+                asm volatile("" : "+s"(bits), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));
+            else if constexpr (HP == 12)
+                asm volatile("" : "+s"(bits), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]));
+            else if constexpr (HP == 16)
+                asm volatile("" : "+s"(bits), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
+            else {
+                static_assert(HP == 20, "unsupported padded width");
+                asm volatile("" : "+s"(bits), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]),
+                             "+v"(p[8]), "+v"(p[9]));
+            }
+            return (const cfloat*)bits;
+        };
+        auto layer12 = [&](auto tag, int seg, float* acc) {
+            using W2 = decltype(tag);
+            const cfloat* w = vwt + W2::OFF;
+            float wc[W2::HP], wn[W2::HP];
+#pragma unroll
+            for (int j = 0; j < W2::HP; ++j) acc[j] = w[W2::KIN * W2::HP + j];  // bias row
+#pragma unroll
+            for (int j = 0; j < W2::HP; ++j) wc[j] = w[j];
+#pragma unroll
+            for (int k = 0; k < W2::KIN; k += 4) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(ucrow + seg + k);
+                float upv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) upv[q] = up[seg + k + q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (k + q + 1 < W2::KIN) {
+                        const cfloat* wr = tie(w, acc, std::integral_constant<int, W2::HP>{}) + (k + q + 1) * W2::HP;
+#pragma unroll
+                        for (int j = 0; j < W2::HP; ++j) wn[j] = wr[j];
+                    }
+                    const float h = fmaxf(upv[q] + u[q], 0.0f);
+                    pk_fma_row<W2::HP>(wc, h, acc);
+#pragma unroll
+                    for (int j = 0; j < W2::HP; ++j) wc[j] = wn[j];
+                }
+            }
+        };
+        auto layer = [&](auto tag, const float* in, float* acc) {  // acc = bias + W . relu(in)
+            using WL = decltype(tag);
+            const cfloat* w = vwt + WL::OFF;
+            float wc[WL::HP], wn[WL::HP];
+#pragma unroll
+            for (int j = 0; j < WL::HP; ++j) acc[j] = w[WL::KIN * WL::HP + j];
+#pragma unroll
+            for (int j = 0; j < WL::HP; ++j) wc[j] = w[j];
+#pragma unroll
+            for (int k = 0; k < WL::KIN; ++k) {
+                if (k + 1 < WL::KIN) {
+                    const cfloat* wr = tie(w, acc, std::integral_constant<int, WL::HP>{}) + (k + 1) * WL::HP;
+#pragma unroll
+                    for (int j = 0; j < WL::HP; ++j) wn[j] = wr[j];
+                }
+                const float h = fmaxf(in[k], 0.0f);
+                pk_fma_row<WL::HP>(wc, h, acc);
+#pragma unroll
+                for (int j = 0; j < WL::HP; ++j) wc[j] = wn[j];
+            }
+        };
+        alignas(8) float a_rc2[VW<F, L_RC2>::HP], a_rc3[VW<F, L_RC3>::HP];
+        layer12(VW<F, L_RC2>{}, H1, a_rc2);
+        layer(VW<F, L_RC3>{}, a_rc2, a_rc3);
+        alignas(8) float a_fs2[VW<F, L_FS2>::HP], a_fs3[VW<F, L_FS3>::HP], a_fs4[VW<F, L_FS4>::HP];
+        layer12(VW<F, L_FS2>{}, 0, a_fs2);
+        layer(VW<F, L_FS3>{}, a_fs2, a_fs3);
+        layer(VW<F, L_FS4>{}, a_fs3, a_fs4);
+        alignas(8) float a_fd2[VW<F, L_FD2>::HP], a_fd3[VW<F, L_FD3>::HP];
+        layer12(VW<F, L_FD2>{}, H1 + R1, a_fd2);
+        layer(VW<F, L_FD3>{}, a_fd2, a_fd3);
+
+        // ---- hand-designed residual (shasta.py:277-283) ----
+        float d2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (k < nf) {
+                const float df = hp[k] - hd[k];
+                d2 += df * df;
+            }
+        float r = d2 / dnm;
+        const float dim = (fabsf(hp[8] - hd[7]) + fabsf(hp[9] - hd[8])) + fabsf(hp[10] - hd[9]);
+        const float dcs = hp[11] - hd[10], dsn = hp[12] - hd[11];
+        const float dist = (r + dim) + sqrtf(dcs * dcs + dsn * dsn);
+        // ---- combine (shasta.py:316-319) ----
+        const float res = (a_rc3[0] * a_fd3[0] + a_rc3[1] * dist) + a_rc3[2] * a_fs4[0];
+        if (d < D) residual[((size_t)b * T + t) * ld + d] = res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pair_mfma4: lane = pair, layers 2-4 on v_mfma_f32_4x4x1_16B_f32 (16 independent 4x4 blocks per instruction:
+// block = 4 consecutive lanes = 4 pairs, 4 output features, K = 1; 8.4 cycles measured, the same MAC rate as 16x16x4).
+//   D[i][pair] += A[i] * B[pair] : A = W[4*ob + i][k] (lane l supplies row i = l & 3), B = h[k] of the lane's own pair.
+// The result registers of a lane are 4 output features of ITS pair, so the next layer consumes them directly and the
+// lane = pair layout of the factorised first layer (UP[t] scalar, UC[d] per lane) is kept end to end.
+// Against the 16x16x4 chain: output widths only round up to 4 (not 16): 512 MFMAs x 8.4 = 4.3k cycles per 64 pairs
+// instead of 4 x 44 x 32 = 5.6k, and ~330 VALU instructions per 64 pairs instead of ~540.
+// ------------------------------------------------------------------------------------------------------------
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+
+template <int F, int L>
+struct A4 {
+    static constexpr LayerDesc D = layer_desc(F, L);
+    static constexpr int NOB = a4_nob(F, L), KG = a4_kg(F, L), OFF = a4_offset(F, L), KIN = D.kin, BIAS = NOB * KG * 16;
+};
+
+template <int F>
+__global__ __launch_bounds__(256) void pair_mfma4_kernel(const float* __restrict__ packed, const float* __restrict__ UP,
+                                                         const float* __restrict__ UC, const float* __restrict__ hand_prev,
+                                                         const float* __restrict__ hand_det, const float* __restrict__ denom,
+                                                         float* __restrict__ residual, int T, int D, int ld, int nf,
+                                                         int TW) {
+    constexpr PairDims dm(F);
+    constexpr int H1 = dm.H1, R1 = dm.R1, ET = dm.ET, US = ET + 4;
+    constexpr int NA4 = a4_total(F);
+    extern __shared__ __attribute__((aligned(16))) float s_dyn4[];
+    float* s_uc = s_dyn4;              // [64][US]
+    float* s_a4 = s_dyn4 + 64 * US;    // [NA4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, d0 = blockIdx.x * 64;
+    const int d = d0 + lane, dcl = min(d, D - 1);
+    const PackedLayout P(0, 0, F);
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(UC);
+#pragma unroll 4
+        for (int e = tid; e < 64 * (ET / 4); e += 256) {
+            const int r = e / (ET / 4), c = e - r * (ET / 4);
+            *reinterpret_cast<f32x4*>(&s_uc[r * US + 4 * c]) = src[((size_t)b * D + min(d0 + r, D - 1)) * (ET / 4) + c];
+        }
+        const f32x4* asrc = reinterpret_cast<const f32x4*>(packed + P.a4);
+#pragma unroll 2
+        for (int e = tid; e < NA4 / 4; e += 256) reinterpret_cast<f32x4*>(s_a4)[e] = asrc[e];
+    }
+    float hd[12];
+    {
+        const f32x4* h = reinterpret_cast<const f32x4*>(hand_det + ((size_t)b * D + dcl) * 16);
+        const f32x4 a = h[0], c = h[1], e = h[2], g = h[3];
+        hd[0] = a[0]; hd[1] = a[1]; hd[2] = a[2]; hd[3] = a[3]; hd[4] = c[0]; hd[5] = c[1]; hd[6] = c[2];
+        hd[7] = e[0]; hd[8] = e[1]; hd[9] = e[2]; hd[10] = e[3]; hd[11] = g[0];
+    }
+    const float dnm = denom[(size_t)b * D + dcl];
+    __syncthreads();
+    const float* ucrow = s_uc + lane * US;
+    typedef __attribute__((address_space(3))) float lfloat;
+    typedef __attribute__((address_space(3))) f32x4 lf32x4;
+    // LDS byte address of this lane's row i = lane & 3 inside every [i][kk] group of the A table
+    const unsigned arow_base = (unsigned)(unsigned long long)(s_a4 + (lane & 3) * 4);
+    const unsigned abias_base = (unsigned)(unsigned long long)(s_a4 + (lane & 3));
+    const f32x4 zero4 = {0, 0, 0, 0};
+
+    const int t_beg = (blockIdx.y * 4 + wid) * TW;
+    const int t_end = min(T, t_beg + TW);
+    for (int t = t_beg; t < t_end; ++t) {
+        const cfloat* up = (const cfloat*)(UP + ((size_t)b * T + t) * ET);        // wave-uniform -> s_load
+        const cfloat* hp = (const cfloat*)(hand_prev + ((size_t)b * T + t) * 16);
+        // the A table is loop invariant: an opaque copy of its address per track keeps the 128 ds_read_b128 inside the
+        // loop instead of 512 hoisted registers
+        unsigned ao = arow_base, bo = abias_base;
+        asm volatile("" : "+v"(ao), "+v"(bo));
+        const lfloat* arow = (const lfloat*)(unsigned long long)ao;
+        const lfloat* abias = (const lfloat*)(unsigned long long)bo;
+
+        // bias: acc[ob] = bias[4*ob + i] * 1
+        auto init = [&](auto tag, f32x4* acc) {
+            using AL = decltype(tag);
+#pragma unroll
+            for (int ob = 0; ob < AL::NOB; ++ob) acc[ob] = MFMA4(abias[AL::OFF + AL::BIAS + ob * 4], 1.0f, zero4);
+        };
+        // layer 1 (factorised) feeding layer 2
+        auto layer12 = [&](auto tag, int seg, f32x4* acc) {
+            using AL = decltype(tag);
+            init(tag, acc);
+#pragma unroll
+            for (int kg = 0; kg < AL::KG; ++kg) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(ucrow + seg + 4 * kg);
+                f32x4 a4[AL::NOB];
+#pragma unroll
+                for (int ob = 0; ob < AL::NOB; ++ob) a4[ob] = *reinterpret_cast<const lf32x4*>(arow + AL::OFF + (ob * AL::KG + kg) * 16);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (4 * kg + kk < AL::KIN) {
+                        const float h = fmaxf(up[seg + 4 * kg + kk] + u[kk], 0.0f);
+#pragma unroll
+                        for (int ob = 0; ob < AL::NOB; ++ob) acc[ob] = MFMA4(a4[ob][kk], h, acc[ob]);
+                    }
+                }
+            }
+        };
+        // acc = bias + W . relu(in): the k-th input is register k & 3 of the previous layer's block k >> 2
+        auto layer = [&](auto tag, const f32x4* in, f32x4* acc) {
+            using AL = decltype(tag);
+            init(tag, acc);
+#pragma unroll
+            for (int kg = 0; kg < AL::KG; ++kg) {
+                f32x4 a4[AL::NOB];
+#pragma unroll
+                for (int ob = 0; ob < AL::NOB; ++ob) a4[ob] = *reinterpret_cast<const lf32x4*>(arow + AL::OFF + (ob * AL::KG + kg) * 16);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (4 * kg + kk < AL::KIN) {
+                        const float h = fmaxf(in[kg][kk], 0.0f);
+#pragma unroll
+                        for (int ob = 0; ob < AL::NOB; ++ob) acc[ob] = MFMA4(a4[ob][kk], h, acc[ob]);
+                    }
+                }
+            }
+        };
+        f32x4 a_rc2[A4<F, L_RC2>::NOB], a_rc3[A4<F, L_RC3>::NOB];
+        f32x4 a_fs2[A4<F, L_FS2>::NOB], a_fs3[A4<F, L_FS3>::NOB], a_fs4[A4<F, L_FS4>::NOB];
+        f32x4 a_fd2[A4<F, L_FD2>::NOB], a_fd3[A4<F, L_FD3>::NOB];
+        layer12(A4<F, L_RC2>{}, H1, a_rc2);
+        layer12(A4<F, L_FS2>{}, 0, a_fs2);
+        layer12(A4<F, L_FD2>{}, H1 + R1, a_fd2);
+        layer(A4<F, L_RC3>{}, a_rc2, a_rc3);
+        layer(A4<F, L_FS3>{}, a_fs2, a_fs3);
+        layer(A4<F, L_FD3>{}, a_fd2, a_fd3);
+        layer(A4<F, L_FS4>{}, a_fs3, a_fs4);
+
+        // ---- hand-designed residual (shasta.py:277-283) ----
+        float d2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (k < nf) {
+                const float df = hp[k] - hd[k];
+                d2 += df * df;
+            }
+        float r = d2 / dnm;
+        const float dim = (fabsf(hp[8] - hd[7]) + fabsf(hp[9] - hd[8])) + fabsf(hp[10] - hd[9]);
+        const float dcs = hp[11] - hd[10], dsn = hp[12] - hd[11];
+        const float dist = (r + dim) + sqrtf(dcs * dcs + dsn * dsn);
+        // ---- combine (shasta.py:316-319) ----
+        const float res = (a_rc3[0][0] * a_fd3[0][0] + a_rc3[0][1] * dist) + a_rc3[0][2] * a_fs4[0][0];
+        if (d < D) residual[((size_t)b * T + t) * ld + d] = res;
+    }
 }
 
 size_t pair_workspace_bytes(int B, int N, int F) {
@@ -490,6 +858,36 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     hipLaunchKernelGGL(col_norm_kernel, dim3(cdiv(D, 16), B), dim3(256), 0, st, hand_prev, hand_det, denom, T, D, nf);
     rc = check_launch("col_norm");
     if (rc) return rc;
+    static const bool use_mfma_chain = getenv("SHASTA_PAIR_MFMA") != nullptr;
+    static const bool use_valu = getenv("SHASTA_PAIR_VALU") != nullptr;
+    if (!use_mfma_chain && !use_valu) {
+        // default: lane = pair, 4x4x1 MFMA
+        int tw = 16;
+        while (tw > 2 && (long)B * cdiv(D, 64) * 4 * cdiv(T, 4 * tw) < 3072) tw >>= 1;
+        const size_t lds = ((size_t)64 * (d.ET + 4) + a4_total(F)) * sizeof(float);
+        dim3 grid(cdiv(D, 64), cdiv(T, 4 * tw), B);
+        switch (F) {
+            case 64: hipLaunchKernelGGL(pair_mfma4_kernel<64>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
+            case 256: hipLaunchKernelGGL(pair_mfma4_kernel<256>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
+            case 320: hipLaunchKernelGGL(pair_mfma4_kernel<320>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
+            default: set_error_msg("pair_residual: feat_dim must be 64, 256 or 320"); return SHASTA_E_ARG;
+        }
+        return check_launch("pair_mfma4");
+    }
+    if (!use_mfma_chain) {
+        // tracks per wave: enough workgroups for >= 4 waves per SIMD when the batch allows it
+        int tw = 16;
+        while (tw > 2 && (long)B * cdiv(D, 64) * 4 * cdiv(T, 4 * tw) < 4096) tw >>= 1;
+        const size_t lds = (size_t)64 * (d.ET + 4) * sizeof(float);
+        dim3 grid(cdiv(D, 64), cdiv(T, 4 * tw), B);
+        switch (F) {
+            case 64: hipLaunchKernelGGL(pair_valu_kernel<64>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
+            case 256: hipLaunchKernelGGL(pair_valu_kernel<256>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
+            case 320: hipLaunchKernelGGL(pair_valu_kernel<320>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
+            default: set_error_msg("pair_residual: feat_dim must be 64, 256 or 320"); return SHASTA_E_ARG;
+        }
+        return check_launch("pair_valu");
+    }
     // tracks per workgroup: the largest of 32/16/8 that still yields >= 2 waves per SIMD on 256 CUs
     int tt = 32;  // measured: 8..32 tie once the chip is full, 64 loses occupancy to its LDS footprint
     while (tt > 8 && (long)B * cdiv(D, 64) * 4 * cdiv(T, tt) < 2048) tt >>= 1;
@@ -500,18 +898,19 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     const size_t lds = ((size_t)tt * (d.ET + 64 + 16) + 256) * sizeof(float);
     dim3 grid(cdiv(D, 64), cdiv(T, tt), B);
     static const bool unroll2 = getenv("SHASTA_PAIR_UNROLL2") != nullptr;
+    static const int stagger = getenv("SHASTA_PAIR_STAGGER") ? atoi(getenv("SHASTA_PAIR_STAGGER")) : 0;
     switch (F) {
         case 64:
-            if (unroll2) hipLaunchKernelGGL((pair_mfma_kernel<64, 2>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt);
-            else hipLaunchKernelGGL((pair_mfma_kernel<64, 1>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt);
+            if (unroll2) hipLaunchKernelGGL((pair_mfma_kernel<64, 2>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt, stagger);
+            else hipLaunchKernelGGL((pair_mfma_kernel<64, 1>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt, stagger);
             break;
         case 256:
-            if (unroll2) hipLaunchKernelGGL((pair_mfma_kernel<256, 2>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt);
-            else hipLaunchKernelGGL((pair_mfma_kernel<256, 1>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt);
+            if (unroll2) hipLaunchKernelGGL((pair_mfma_kernel<256, 2>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt, stagger);
+            else hipLaunchKernelGGL((pair_mfma_kernel<256, 1>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt, stagger);
             break;
         case 320:
-            if (unroll2) hipLaunchKernelGGL((pair_mfma_kernel<320, 2>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt);
-            else hipLaunchKernelGGL((pair_mfma_kernel<320, 1>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt);
+            if (unroll2) hipLaunchKernelGGL((pair_mfma_kernel<320, 2>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt, stagger);
+            else hipLaunchKernelGGL((pair_mfma_kernel<320, 1>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt, stagger);
             break;
         default: set_error_msg("pair_residual: feat_dim must be 64, 256 or 320"); return SHASTA_E_ARG;
     }

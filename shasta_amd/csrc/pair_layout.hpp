@@ -73,10 +73,34 @@ SH_HD constexpr int bias_offset(int F, int l) {  // in units of 256 floats ([64 
 }
 SH_HD constexpr int total_bias_blocks(int F) { return bias_offset(F, L_COUNT); }
 
+// VALU formulation (pair_valu_kernel): layer l is stored transposed and padded, Wt[kin][HP] followed by bias[HP],
+// HP = hout rounded up to 4, so that the HP weights that multiply one input feature are one aligned scalar load.
+SH_HD constexpr int vw_hp(int F, int l) { return (layer_desc(F, l).hout + 3) / 4 * 4; }
+SH_HD constexpr int vw_size(int F, int l) { return (layer_desc(F, l).kin + 1) * vw_hp(F, l); }
+SH_HD constexpr int vw_offset(int F, int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += vw_size(F, i);
+    return o;
+}
+SH_HD constexpr int vw_total(int F) { return (vw_offset(F, L_COUNT) + 3) / 4 * 4; }
+
+// 4x4x1 formulation (pair_mfma4_kernel): layer l as A operands of v_mfma_f32_4x4x1_16B_f32.  Per output block ob (4
+// features) and k-group kg (4 inputs): 16 floats [i][kk] = W[4*ob + i][4*kg + kk] (zero padded); after all blocks, the
+// bias as [ob][i].  Lane l reads the float4 of row i = l & 3.
+SH_HD constexpr int a4_nob(int F, int l) { return (layer_desc(F, l).hout + 3) / 4; }
+SH_HD constexpr int a4_kg(int F, int l) { return (layer_desc(F, l).kin + 3) / 4; }
+SH_HD constexpr int a4_size(int F, int l) { return a4_nob(F, l) * a4_kg(F, l) * 16 + a4_nob(F, l) * 4; }
+SH_HD constexpr int a4_offset(int F, int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += a4_size(F, i);
+    return o;
+}
+SH_HD constexpr int a4_total(int F) { return a4_offset(F, L_COUNT); }
+
 // Packed buffer sections (float offsets).  Dp = padded aff width (multiple of 4).
 struct PackedLayout {
     int F, nf, N, D, Dp, E12, ET;
-    size_t frags, biasf, wemb_prev, wemb_cur, bemb_cur, wbox_prev, wbox_cur, bbox_cur, aff0, total;
+    size_t frags, biasf, vw, a4, wemb_prev, wemb_cur, bemb_cur, wbox_prev, wbox_cur, bbox_cur, aff0, total;
     SH_HD PackedLayout(int max_obj, int num_feats, int f) {
         const PairDims d(f);
         F = f;
@@ -89,6 +113,8 @@ struct PackedLayout {
         size_t o = 0;
         frags = o;      o += (size_t)total_frags(f) * 64;
         biasf = o;      o += (size_t)total_bias_blocks(f) * 256;
+        vw = o;         o += (size_t)vw_total(f);      // transposed / padded layers 2-4 for the VALU pair kernel
+        a4 = o;         o += (size_t)a4_total(f);      // 4x4x1 MFMA A operands of layers 2-4
         wemb_prev = o;  o += (size_t)E12 * f;          // [E12][F]   fuse_shape.0 / res_coeff.0, prev feature cols
         wemb_cur = o;   o += (size_t)E12 * f;          // [E12][F]   ... cur feature cols
         bemb_cur = o;   o += (size_t)((E12 + 3) / 4 * 4);  // [E12]  fuse_shape.0.bias | res_coeff.0.bias

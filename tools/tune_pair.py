@@ -29,14 +29,14 @@ for _ in range(3): run()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): run()
 torch.cuda.synchronize(); dt_ = (time.perf_counter() - t0) / 20
-print("B=%d unroll2=%s TT=%s pair stage %.1f us (%.2f us per frame-pair)" % (B, os.environ.get("SHASTA_PAIR_UNROLL2", "0"), os.environ.get("SHASTA_PAIR_TT", "auto"), dt_ * 1e6, dt_ * 1e6 / B))
+print("B=%d stagger=%s TT=%s pair stage %.1f us (%.2f us per frame-pair)" % (B, os.environ.get("SHASTA_PAIR_STAGGER", "0"), os.environ.get("SHASTA_PAIR_TT", "auto"), dt_ * 1e6, dt_ * 1e6 / B))
 '''
-for B in (1, 32):
-    for tt, un in (("auto", 0), ("auto", 1), ("16", 1), ("8", 1)):
+for B in (1, 8, 32, 64):
+    for mf in (0, 1, 2):
         env = dict(os.environ)
-        if un:
-            env["SHASTA_PAIR_UNROLL2"] = "1"
-        if tt != "auto":
-            env["SHASTA_PAIR_TT"] = tt
+        if mf == 1:
+            env["SHASTA_PAIR_MFMA"] = "1"
+        if mf == 2:
+            env["SHASTA_PAIR_VALU"] = "1"
         r = subprocess.run([sys.executable, "-c", CODE, str(B)], env=env, capture_output=True, text=True)
-        print(r.stdout.strip() or r.stderr[-800:], flush=True)
+        print(("mfma4x4   ", "mfma16-chain", "valu-pk  ")[mf] + " "  + (r.stdout.strip() or r.stderr[-800:]), flush=True)
