@@ -184,6 +184,15 @@ int shasta_aff_softmax_f32(const shasta_weights* w, const void* packed, int B, c
                            int ld_residual, float* matched1, float* matched2, float* matched_out,
                            void* workspace, size_t workspace_bytes, shasta_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Rotated 3-D IoU / GIoU distance matrix (float64, like the reference)
+ * replaces mot_3d/association.py:108-120 (`compute_iou_distance`): dist[d][t] = 1 - iou3d(det_d, trk_t)[1]
+ * (mot_3d/utils/geometry.py:161-176) or 1 - giou3d(det_d, trk_t) (:208-231), boxes [x, y, z, o, l, w, h]
+ * (mot_3d/data_protos/bbox.py:27-33), `box_stride` doubles per row.
+ * ------------------------------------------------------------------------------------------ */
+int shasta_iou3d_distance_f64(const double* dets, int num_dets, const double* tracks, int num_tracks,
+                              int box_stride, int giou, double* dist, shasta_stream_t stream);
+
 /* Generic fp32 MFMA GEMM used by the stages above: C[m][n] = act(sum_k A[m][k]*W[n][k] + bias[n]).
  * act: 0 none, 1 relu, 2 abs.  lda/ldw multiples of 4 and 16-byte aligned bases. */
 int shasta_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C,

@@ -10,7 +10,7 @@ so SimpleTrack-style bookkeeping (mot_3d/mot.py:149-150,208-209) consumes the re
                       matchers.
   asso = 'euler' / 'm_dis' : L2 / Mahalanobis on the 7-vector [x,y,z,o,l,w,h] with the reference's yaw folding
                       (mot_3d/utils/geometry.py:246-271).
-  asso = 'iou' / 'giou' need the rotated 3-D IoU matrix (not built yet): NotImplementedError.
+  asso = 'iou' / 'giou' : 1 - rotated 3-D IoU / GIoU for all pairs at once on the GPU (csrc/iou3d.hip, float64).
 """
 import numpy as np
 from scipy.optimize import linear_sum_assignment
@@ -42,6 +42,27 @@ def compute_affinity_distance(dets, tracks, affinity):
     return 1.0 - a[:len(tracks), :len(dets)].T
 
 
+def compute_iou_distance(dets, tracks, asso="iou"):
+    """mot_3d/association.py:108-120 for all pairs at once on the GPU (csrc/iou3d.hip, float64): 1 - iou3d / 1 - giou3d.
+    There is no CPU path: without a device this raises."""
+    import torch
+
+    from . import hip
+    lib = hip.load()
+    nd, nt = len(dets), len(tracks)
+    if nd == 0 or nt == 0:
+        return np.zeros((nd, nt))
+    if not torch.cuda.is_available():
+        raise hip.ShastaHipError("asso=%r needs a GPU (rotated IoU kernel); there is no CPU fallback" % asso)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    D = torch.from_numpy(np.stack([_array7(d) for d in dets])).to(dev)
+    T = torch.from_numpy(np.stack([_array7(t) for t in tracks])).to(dev)
+    out = torch.empty(nd, nt, dtype=torch.float64, device=dev)
+    hip.check(lib.shasta_iou3d_distance_f64(hip.ptr(D), nd, hip.ptr(T), nt, 7, 1 if asso == "giou" else 0, hip.ptr(out),
+                                            hip.stream_ptr()), "shasta_iou3d_distance_f64")
+    return out.cpu().numpy()
+
+
 def _dist_matrix(dets, tracks, asso, trk_innovation_matrix, affinity):
     if asso == "affinity":
         if affinity is None:
@@ -52,7 +73,7 @@ def _dist_matrix(dets, tracks, asso, trk_innovation_matrix, affinity):
     if asso == "euler":
         return compute_m_distance(dets, tracks, None)
     if asso in ("iou", "giou"):
-        raise NotImplementedError("asso=%r needs the rotated 3-D IoU matrix (SURVEY.md 8(f)-2), not built yet" % asso)
+        return compute_iou_distance(dets, tracks, asso)
     raise ValueError("unknown asso %r" % (asso,))
 
 

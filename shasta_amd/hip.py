@@ -55,6 +55,7 @@ SYMBOLS = {
     "shasta_anchor_boxes_f32": (_I, [_WP, _I, _P, _P, _I, _P, _P, _P, _Z, _P]),
     "shasta_pair_residual_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "shasta_aff_softmax_f32": (_I, [_WP, _P, _I, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    "shasta_iou3d_distance_f64": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     "shasta_gemm_nt_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
 }
 
@@ -90,7 +91,7 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise ShastaHipError("expected a device tensor (the HIP path has no CPU fallback)")
-    if t.dtype != torch.float32 and t.dtype != torch.int32 and t.dtype != torch.uint8:
+    if t.dtype not in (torch.float32, torch.float64, torch.int32, torch.uint8):
         raise ShastaHipError("unexpected dtype %s" % t.dtype)
     if not t.is_contiguous():
         raise ShastaHipError("expected a contiguous tensor")

@@ -292,3 +292,18 @@ def test_voxelize_vs_oracle_full_size(P, mp, mv, seed):
         first = v[:, 0, :3].cpu().numpy()
         cell = np.floor((first - RG[:3]) / VS).astype(np.int32)
         assert np.array_equal(cell[:, ::-1], rc)
+
+
+@pytest.mark.parametrize("flag", ["SHASTA_PAIR_MFMA", "SHASTA_PAIR_VALU", "SHASTA_AFF_UNFUSED", "SHASTA_L1_VALU"])
+def test_alternative_kernel_variants_match_goldens(flag):
+    """The selectable variants (16x16x4 MFMA chain / packed-VALU pair kernels, layer-by-layer aff, VALU batch kernels for
+    the anchor stream) stay parity-green: rerun the golden tests in a subprocess with the variant's switch set."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env[flag] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                        "test_forward_matches_reference_golden or (test_batched_forward_vs_oracle and small)"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
