@@ -247,6 +247,8 @@ class Shasta(BaseTrack):
         if N != self.max_obj or prev_det_boxes.shape[1] != N:
             raise ValueError("det_boxes must be padded to max_obj=%d rows (got %d)" % (self.max_obj, N))
         dev = det_boxes.device
+        if B == 0:  # nothing to launch
+            return torch.empty(0, N, N + 2, device=dev), torch.empty(0, N + 2, N, device=dev)
         w = self._weights()
         self._ensure_packed(w, dev)
         bufs = self._work_buffers(B, dev)

@@ -307,3 +307,42 @@ def test_alternative_kernel_variants_match_goldens(flag):
                         "test_forward_matches_reference_golden or (test_batched_forward_vs_oracle and small)"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("N,nf,npnt,B,n_real", [(1, 7, 1, 2, None), (2, 3, 4, 18, 1), (5, 7, 5, 3, 0), (33, 1, 1, 2, 7),
+                                                 (64, 7, 4, 1, None)])
+def test_edge_shapes_vs_oracle(N, nf, npnt, B, n_real):
+    """Smallest tables (max_obj = 1, 2: the aug_dets hidden layer has width 0), every-row-padded inputs (n_real = 0),
+    nf = 1, and a max_obj that is an exact multiple of the 64-wide tiles."""
+    import shasta_amd
+    dev = _dev()
+    torch.manual_seed(N * 100 + nf)
+    m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54],
+                                                            voxel_size=[0.075, 0.075], out_stride=8),
+                                         max_obj=N, num_feats=nf, num_point=npnt, in_channels=8)).eval()
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    bev = torch.relu(torch.randn(B, 180, 180, 64, generator=g))
+    pbev = torch.relu(torch.randn(B, 180, 180, 64, generator=g))
+    det, prev = O.synth_boxes(g, B, N, n_real), O.synth_boxes(g, B, N, n_real)
+    r1, r2 = O.forward_from_bev(w, bev, pbev, det.clone(), prev.clone(), nf, npnt)
+    m = m.to(dev)
+    ex = dict(det_boxes=det.to(dev), prev_det_boxes=prev.to(dev), bev_feature=bev.to(dev), prev_bev_feature=pbev.to(dev))
+    with torch.no_grad():
+        m1, m2, _ = m(ex, train_mode=False)
+    assert m1.shape == (B, N, N + 2) and m2.shape == (B, N + 2, N)
+    assert bool(torch.isfinite(m1).all()) and bool(torch.isfinite(m2).all())
+    np.testing.assert_allclose(m1.cpu().numpy(), r1.numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(m2.cpu().numpy(), r2.numpy(), rtol=0, atol=TOL)
+
+
+def test_empty_batch_is_a_no_op():
+    dev = _dev()
+    z, c, m, bev, pbev, det, prev = _case("tiny_4_7_5")
+    m = m.to(dev)
+    ex = dict(det_boxes=torch.zeros(0, 4, 11, device=dev), prev_det_boxes=torch.zeros(0, 4, 11, device=dev),
+              bev_feature=torch.zeros(0, 24, 24, 64, device=dev), prev_bev_feature=torch.zeros(0, 24, 24, 64, device=dev))
+    with torch.no_grad():
+        m1, m2, _ = m(ex, train_mode=False)
+    assert m1.shape == (0, 4, 6) and m2.shape == (0, 6, 4)
