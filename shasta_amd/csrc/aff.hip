@@ -97,7 +97,9 @@ constexpr int AFF_WAVES = 8;  // waves per workgroup
 // One work item = (16-feature output block, chunk of KG 16-wide k-groups).  The weight fragments of item i+1 are
 // requested before the MFMAs of item i, so the L2 / HBM latency of the (cold) weight rows overlaps the matrix work.
 // KFIX > 0: compile-time reduction length, one chunk per block; KFIX == 0: runtime Kp in chunks of 128.
-template <bool RELU, int KFIX>
+// RG = 16-row groups per workgroup: every weight fragment feeds RG MFMAs (the L2 -> register weight traffic per row, the
+// limiter at large batch, drops by RG).
+template <bool RELU, int KFIX, int RG>
 __device__ __forceinline__ void aff_layer(const float* __restrict__ W, int ldw, const float* __restrict__ bias, int Mout,
                                           int Kp, const float* hin, int ldin, float* hout, int ldout, int out_limit,
                                           int lane, int wid) {
@@ -106,7 +108,7 @@ __device__ __forceinline__ void aff_layer(const float* __restrict__ W, int ldw, 
     const int nb = (Mout + 15) >> 4;
     const int nchunk = KFIX > 0 ? 1 : (Kp + 127) / 128;
     const int Kv = KFIX > 0 ? KFIX : Kp;
-    const float* hrow = hin + p * ldin + 4 * kq;
+    const float* hrow = hin + p * ldin + 4 * kq;  // row group rg adds 16 * rg * ldin
     f32x4 cur[KG], nxt[KG];
     auto load = [&](f32x4(&dst)[KG], int blk, int ch) {
         const float* wrow = W + (size_t)min(16 * blk + p, Mout - 1) * ldw + 4 * kq + ch * 128;
@@ -118,7 +120,7 @@ __device__ __forceinline__ void aff_layer(const float* __restrict__ W, int ldw, 
     };
     int blk = wid, ch = 0;
     if (blk < nb) load(cur, blk, 0);
-    f32x4 acc = {0, 0, 0, 0};
+    f32x4 acc[RG];
     while (blk < nb) {
         int nblk = blk, nch = ch + 1;
         if (nch == nchunk) {
@@ -129,21 +131,33 @@ __device__ __forceinline__ void aff_layer(const float* __restrict__ W, int ldw, 
         const int f0 = 16 * blk + 4 * kq;
         if (ch == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = (f0 + r < Mout) ? bias[f0 + r] : 0.0f;
+            for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[rg][r] = (f0 + r < Mout) ? bias[f0 + r] : 0.0f;
         }
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
-            f32x4 b4 = {0, 0, 0, 0};
-            if (ch * 128 + 16 * g + 4 * kq < Kv) b4 = *reinterpret_cast<const f32x4*>(hrow + ch * 128 + 16 * g);
+            f32x4 b4[RG];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[g][q], b4[q], acc, 0, 0, 0);
+            for (int rg = 0; rg < RG; ++rg) {
+                b4[rg] = f32x4{0, 0, 0, 0};
+                if (ch * 128 + 16 * g + 4 * kq < Kv)
+                    b4[rg] = *reinterpret_cast<const f32x4*>(hrow + 16 * rg * ldin + ch * 128 + 16 * g);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[g][q], b4[rg][q], acc[rg], 0, 0, 0);
         }
         if (ch == nchunk - 1) {
-            if (RELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.0f);
+            for (int rg = 0; rg < RG; ++rg) {
+                if (RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[rg][r] = fmaxf(acc[rg][r], 0.0f);
+                }
+                if (f0 < out_limit) *reinterpret_cast<f32x4*>(hout + (p + 16 * rg) * ldout + f0) = acc[rg];
             }
-            if (f0 < out_limit) *reinterpret_cast<f32x4*>(hout + p * ldout + f0) = acc;
         }
 #pragma unroll
         for (int g = 0; g < KG; ++g) cur[g] = nxt[g];
@@ -152,36 +166,38 @@ __device__ __forceinline__ void aff_layer(const float* __restrict__ W, int ldw, 
     }
 }
 
+template <int RG>
 __global__ __launch_bounds__(64 * AFF_WAVES) void aff_fused_kernel(AffArgs a) {
+    constexpr int ROWS = 16 * RG;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int XS = a.Dp + 4, HS = 132;
-    float* xb = sm;                 // [16][XS]  residual rows, later the matched rows
-    float* ha = sm + 16 * XS;       // [16][HS]
-    float* hb = ha + 16 * HS;       // [16][HS]
+    float* xb = sm;                   // [ROWS][XS]  residual rows, later the matched rows
+    float* ha = sm + ROWS * XS;       // [ROWS][HS]
+    float* hb = ha + ROWS * HS;       // [ROWS][HS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g0 = blockIdx.x * 16;
+    const int g0 = blockIdx.x * ROWS;
 #pragma unroll 4
-    for (int e = tid; e < 16 * XS; e += 64 * AFF_WAVES) {
+    for (int e = tid; e < ROWS * XS; e += 64 * AFF_WAVES) {
         const int p = e / XS, c = e - p * XS;
         xb[e] = (g0 + p < a.M && c < a.D) ? a.residual[(size_t)(g0 + p) * a.ld + c] : 0.0f;
     }
     __syncthreads();
-    aff_layer<true, 0>(a.W[0], a.Dp, a.bias[0], 128, a.Dp, xb, XS, ha, HS, 128, lane, wid);
+    aff_layer<true, 0, RG>(a.W[0], a.Dp, a.bias[0], 128, a.Dp, xb, XS, ha, HS, 128, lane, wid);
     __syncthreads();
-    aff_layer<true, 128>(a.W[1], 128, a.bias[1], 64, 128, ha, HS, hb, HS, 64, lane, wid);
+    aff_layer<true, 128, RG>(a.W[1], 128, a.bias[1], 64, 128, ha, HS, hb, HS, 64, lane, wid);
     __syncthreads();
-    aff_layer<true, 64>(a.W[2], 64, a.bias[2], 32, 64, hb, HS, ha, HS, 32, lane, wid);
+    aff_layer<true, 64, RG>(a.W[2], 64, a.bias[2], 32, 64, hb, HS, ha, HS, 32, lane, wid);
     __syncthreads();
-    aff_layer<true, 32>(a.W[3], 32, a.bias[3], 64, 32, ha, HS, hb, HS, 64, lane, wid);
+    aff_layer<true, 32, RG>(a.W[3], 32, a.bias[3], 64, 32, ha, HS, hb, HS, 64, lane, wid);
     __syncthreads();
-    aff_layer<true, 64>(a.W[4], 64, a.bias[4], 128, 64, hb, HS, ha, HS, 128, lane, wid);
+    aff_layer<true, 64, RG>(a.W[4], 64, a.bias[4], 128, 64, hb, HS, ha, HS, 128, lane, wid);
     __syncthreads();
-    aff_layer<false, 128>(a.W[5], 128, a.bias[5], a.D, 128, ha, HS, xb, XS, a.Dp, lane, wid);
+    aff_layer<false, 128, RG>(a.W[5], 128, a.bias[5], a.D, 128, ha, HS, xb, XS, a.Dp, lane, wid);
     __syncthreads();
-    // rows 2*wid, 2*wid+1: copy to `matched` (column softmax input) and row softmax for t < N
-    for (int pr = 0; pr < 16 / AFF_WAVES; ++pr) {
-        const int p = (16 / AFF_WAVES) * wid + pr, g = g0 + p;
+    // each wave: ROWS / AFF_WAVES rows: copy to `matched` (column softmax input) and row softmax for t < N
+    for (int pr = 0; pr < ROWS / AFF_WAVES; ++pr) {
+        const int p = (ROWS / AFF_WAVES) * wid + pr, g = g0 + p;
         if (g >= a.M) break;
         const float* x = xb + p * XS;
         float* mo = a.matched + (size_t)g * a.ldm;
@@ -225,7 +241,11 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
     (void)h0;
     (void)h1;
     static const bool unfused = getenv("SHASTA_AFF_UNFUSED") != nullptr;
-    const size_t lds = (size_t)(16 * (Dp + 4) + 2 * 16 * 132) * sizeof(float);
+    // 32 rows per workgroup halve the weight traffic per row but leave one workgroup per CU (99 KB LDS); measured at
+    // B=64: 251 us against 226 us for 16 rows -> 16 rows stay the default, SHASTA_AFF_RG2=1 selects the other form.
+    static const bool rg2 = getenv("SHASTA_AFF_RG2") != nullptr;
+    const int rg = (rg2 && (size_t)(32 * (Dp + 4) + 2 * 32 * 132) * sizeof(float) <= 160 * 1024) ? 2 : 1;
+    const size_t lds = (size_t)(16 * rg * (Dp + 4) + 2 * 16 * rg * 132) * sizeof(float);
     if (!unfused && lds <= 160 * 1024) {
         AffArgs fa;
         fa.W[0] = packed + P.aff0;  // zero padded (128, Dp)
@@ -244,8 +264,13 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
         fa.Dp = Dp;
         fa.ld = ld;
         fa.ldm = Dp;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)aff_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(aff_fused_kernel, dim3(cdiv(M, 16)), dim3(64 * AFF_WAVES), lds, st, fa);
+        if (rg == 2) {
+            (void)hipFuncSetAttribute((const void*)aff_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(aff_fused_kernel<2>, dim3(cdiv(M, 32)), dim3(64 * AFF_WAVES), lds, st, fa);
+        } else {
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)aff_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(aff_fused_kernel<1>, dim3(cdiv(M, 16)), dim3(64 * AFF_WAVES), lds, st, fa);
+        }
         if ((rc = check_launch("aff_fused"))) return rc;
     } else {
         // layer-by-layer path: six launches of the generic GEMM + a row softmax kernel

@@ -4,8 +4,8 @@
 // (det3d/models/second_stage/bird_eye_view.py:18-41) and bilinear_interpolate_torch
 // (det3d/core/utils/center_utils.py:92-121).
 //
-// Layout: one wavefront per (batch, object, point); lane c owns channels c, c+64, ...  so each of
-// the four corner fetches is one coalesced C*4-byte row of the NHWC map (256 B at C=64).  The
+// Layout: 16 lanes per (batch, object, point); lane c owns channels 4c..4c+3 (+64, ...), so each of the four corner
+// fetches is one coalesced C*4-byte row of the NHWC map (256 B at C=64) read with 16-byte loads; 4 points per wave.  The
 // output row [pt0 C | pt1 C | ...] is written directly in the packed (N, num_point*C) order the
 // reference builds with a cat of sections (bird_eye_view.py:35-37).
 // HBM-bound: 4*C*4 B read + C*4 B written per point.
@@ -22,8 +22,9 @@ __global__ __launch_bounds__(256) void bev_gather_kernel(
     int box_stride, int box_batch_stride, int num_point, float pc_x0, float pc_y0, float vs_x,
     float vs_y, float out_stride_px, float* __restrict__ out, int out_row_stride,
     int out_batch_stride, int total_points) {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
+    // 16 lanes per point: each lane owns 4 consecutive channels (one 16-byte load per corner), 4 points per wave
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int lane = threadIdx.x & 15;
     if (wave >= total_points) return;
     const int pt = wave % num_point;
     const int n = (wave / num_point) % N;
@@ -85,12 +86,29 @@ __global__ __launch_bounds__(256) void bev_gather_kernel(
     const float* Ic = im + ((size_t)y0 * W + x1) * C;
     const float* Id = im + ((size_t)y1 * W + x1) * C;
     float* o = out + (size_t)b * out_batch_stride + (size_t)n * out_row_stride + (size_t)pt * C;
-    for (int ch = lane; ch < C; ch += 64) {
-        float v = __fmul_rn(Ia[ch], wa);
-        v = __fadd_rn(v, __fmul_rn(Ib[ch], wb));
-        v = __fadd_rn(v, __fmul_rn(Ic[ch], wc));
-        v = __fadd_rn(v, __fmul_rn(Id[ch], wd));
-        o[ch] = v;
+    if ((C & 3) == 0) {
+        for (int c4 = lane; c4 < C / 4; c4 += 16) {
+            const f32x4 a = reinterpret_cast<const f32x4*>(Ia)[c4], b4 = reinterpret_cast<const f32x4*>(Ib)[c4];
+            const f32x4 c = reinterpret_cast<const f32x4*>(Ic)[c4], d = reinterpret_cast<const f32x4*>(Id)[c4];
+            f32x4 r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = __fmul_rn(a[q], wa);
+                v = __fadd_rn(v, __fmul_rn(b4[q], wb));
+                v = __fadd_rn(v, __fmul_rn(c[q], wc));
+                v = __fadd_rn(v, __fmul_rn(d[q], wd));
+                r[q] = v;
+            }
+            reinterpret_cast<f32x4*>(o)[c4] = r;
+        }
+    } else {
+        for (int ch = lane; ch < C; ch += 16) {
+            float v = __fmul_rn(Ia[ch], wa);
+            v = __fadd_rn(v, __fmul_rn(Ib[ch], wb));
+            v = __fadd_rn(v, __fmul_rn(Ic[ch], wc));
+            v = __fadd_rn(v, __fmul_rn(Id[ch], wd));
+            o[ch] = v;
+        }
     }
 }
 
@@ -109,9 +127,9 @@ extern "C" int shasta_bev_gather_f32(const float* bev, int B, int H, int W, int 
     const long total = (long)B * N * num_point;
     if (total == 0) return SHASTA_OK;
     SHASTA_REQUIRE(total < (1L << 30), "bev_gather: too many points");
-    const int waves_per_block = 4;
-    const int blocks = cdiv((int)total, waves_per_block);
-    hipLaunchKernelGGL(bev_gather_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, as_stream(stream), bev,
+    const int points_per_block = 16;  // 256 threads, 16 lanes per point
+    const int blocks = cdiv((int)total, points_per_block);
+    hipLaunchKernelGGL(bev_gather_kernel, dim3(blocks), dim3(16 * points_per_block), 0, as_stream(stream), bev,
                        H, W, C, boxes, N, box_stride, box_batch_stride, num_point, pc_x0, pc_y0, vs_x, vs_y,
                        out_stride, out, out_row_stride, out_batch_stride, (int)total);
     return check_launch("bev_gather");
