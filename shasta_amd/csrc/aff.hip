@@ -31,46 +31,46 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int d = lane; d < D; d += 64) o[d] = expf(x[d] - mx) / s;
 }
 
-// block = 16 detections x 64 track groups (1024 threads): softmax over the T rows of each column d < N.  Each thread
-// keeps its <= 32 rows of one column in registers (one pass over memory); max and sum are combined across the 64 groups
-// in a fixed order.  MAXR = ceil(T / 64) rounded up to 8 / 16 / 32 (T <= 2048).
+// block = 64 detections x 16 track groups (1024 threads): softmax over the T rows of each column d < N.  A wave reads
+// 64 consecutive columns of one row (256 B, coalesced) and keeps its <= MAXR rows of the column in registers (one pass
+// over memory); max and sum are combined across the 16 groups in a fixed order.  MAXR = ceil(T / 16) <= 128.
 template <int MAXR>
 __global__ __launch_bounds__(1024) void softmax_cols_kernel(const float* __restrict__ matched, float* __restrict__ m2,
                                                             int N, int T, int ld) {
-    __shared__ float red[16][65];
-    const int b = blockIdx.y, dl = threadIdx.x & 15, tg = threadIdx.x >> 4;
-    const int d = blockIdx.x * 16 + dl;
+    __shared__ float red[64][17];
+    const int b = blockIdx.y, dl = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + dl;
     const int dcl = min(d, N - 1);
     const float* x = matched + (size_t)b * T * ld + dcl;
     float v[MAXR];
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
-        const int t = tg + 64 * i;
+        const int t = tg + 16 * i;
         v[i] = t < T ? x[(size_t)t * ld] : -INFINITY;
         mx = fmaxf(mx, v[i]);
     }
     red[dl][tg] = mx;
     __syncthreads();
-#pragma unroll 8
-    for (int i = 0; i < 64; ++i) mx = fmaxf(mx, red[dl][i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, red[dl][i]);
     __syncthreads();
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
-        v[i] = (tg + 64 * i < T) ? expf(v[i] - mx) : 0.0f;
+        v[i] = (tg + 16 * i < T) ? expf(v[i] - mx) : 0.0f;
         s += v[i];
     }
     red[dl][tg] = s;
     __syncthreads();
     s = 0.0f;
-#pragma unroll 8
-    for (int i = 0; i < 64; ++i) s += red[dl][i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[dl][i];
     if (d >= N) return;
     float* o = m2 + (size_t)b * T * N + d;
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
-        const int t = tg + 64 * i;
+        const int t = tg + 16 * i;
         if (t < T) o[(size_t)t * N] = v[i] / s;
     }
 }
@@ -288,9 +288,9 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
         hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(B * N, 4)), dim3(256), 0, st, matched, m1, B, N, T, D, Dp);
         if ((rc = check_launch("softmax_rows"))) return rc;
     }
-    if (T <= 512) hipLaunchKernelGGL(softmax_cols_kernel<8>, dim3(cdiv(N, 16), B), dim3(1024), 0, st, matched, m2, N, T, Dp);
-    else if (T <= 1024) hipLaunchKernelGGL(softmax_cols_kernel<16>, dim3(cdiv(N, 16), B), dim3(1024), 0, st, matched, m2, N, T, Dp);
-    else hipLaunchKernelGGL(softmax_cols_kernel<32>, dim3(cdiv(N, 16), B), dim3(1024), 0, st, matched, m2, N, T, Dp);
+    if (T <= 512) hipLaunchKernelGGL(softmax_cols_kernel<32>, dim3(cdiv(N, 64), B), dim3(1024), 0, st, matched, m2, N, T, Dp);
+    else if (T <= 1024) hipLaunchKernelGGL(softmax_cols_kernel<64>, dim3(cdiv(N, 64), B), dim3(1024), 0, st, matched, m2, N, T, Dp);
+    else hipLaunchKernelGGL(softmax_cols_kernel<128>, dim3(cdiv(N, 64), B), dim3(1024), 0, st, matched, m2, N, T, Dp);
     if ((rc = check_launch("softmax_cols"))) return rc;
     if (matched_out) {
         hipError_t e = hipMemcpy2DAsync(matched_out, (size_t)D * sizeof(float), matched, (size_t)Dp * sizeof(float),

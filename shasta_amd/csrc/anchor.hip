@@ -141,22 +141,51 @@ struct BoxL1Args {
     int HD, N, B, box_stride;
 };
 
-// one wave per (b, mlp, u): hid = relu(b1[u] + W1[u,:] . boxes7_flat)
+// one wave per (chunk of 4 batch items, mlp, 4 hidden units): a 4x4 register tile of hid = relu(b1[u] + W1[u,:] . boxes7_flat),
+// lanes across k: 4 weight loads + 4 box loads feed 16 FMAs
 __global__ __launch_bounds__(256) void box_l1_kernel(BoxL1Args a) {
+    constexpr int BT = 4, UT = 4;
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= a.B * 4 * a.HD) return;
-    const int u = item % a.HD, mlp = (item / a.HD) & 3, b = item / (4 * a.HD);
-    const float* w = a.W[mlp] + (size_t)u * 7 * a.N;
-    const float* x = ((mlp < 2) ? a.det : a.prev) + (size_t)b * a.N * a.box_stride;
-    float s = 0.0f;
-#pragma unroll 8
-    for (int k = lane; k < 7 * a.N; k += 64) {  // unrolled: the weight rows come from HBM, keep 8 loads in flight
+    const int ugroups = (a.HD + UT - 1) / UT, bchunks = (a.B + BT - 1) / BT;
+    if (item >= bchunks * 4 * ugroups) return;
+    const int ug = item % ugroups, mlp = (item / ugroups) & 3, b0 = (item / (4 * ugroups)) * BT;
+    const int K = 7 * a.N;
+    const float* w[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) w[u] = a.W[mlp] + (size_t)min(ug * UT + u, a.HD - 1) * K;
+    const float* xs = (mlp < 2) ? a.det : a.prev;
+    const float* x[BT];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) x[b] = xs + (size_t)min(b0 + b, a.B - 1) * a.N * a.box_stride;
+    float s[UT][BT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u)
+#pragma unroll
+        for (int b = 0; b < BT; ++b) s[u][b] = 0.0f;
+#pragma unroll 2
+    for (int k = lane; k < K; k += 64) {
         const int n = k / 7, c = k - 7 * n;
-        s = fmaf(w[k], x[(size_t)n * a.box_stride + c], s);
+        const size_t off = (size_t)n * a.box_stride + c;
+        float wv[UT], xv[BT];
+#pragma unroll
+        for (int u = 0; u < UT; ++u) wv[u] = w[u][k];
+#pragma unroll
+        for (int b = 0; b < BT; ++b) xv[b] = x[b][off];
+#pragma unroll
+        for (int u = 0; u < UT; ++u)
+#pragma unroll
+            for (int b = 0; b < BT; ++b) s[u][b] = fmaf(wv[u], xv[b], s[u][b]);
     }
-    s = wave_sum(s);
-    if (lane == 0) a.hid[item] = fmaxf(s + a.bias[mlp][u], 0.0f);
+#pragma unroll
+    for (int u = 0; u < UT; ++u)
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            const float v = wave_sum(s[u][b]);
+            const int uu = ug * UT + u;
+            if (lane == 0 && uu < a.HD && b0 + b < a.B)
+                a.hid[((size_t)(b0 + b) * 4 + mlp) * a.HD + uu] = fmaxf(v + a.bias[mlp][uu], 0.0f);
+        }
 }
 
 struct BoxL2Args {
@@ -307,7 +336,7 @@ int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* 
         a.N = N;
         a.B = B;
         a.box_stride = box_stride;
-        hipLaunchKernelGGL(box_l1_kernel, dim3(cdiv(B * 4 * HD, 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(box_l1_kernel, dim3(cdiv(cdiv(B, 4) * 4 * cdiv(HD, 4), 4)), dim3(256), 0, st, a);
         int rc = check_launch("box_l1");
         if (rc) return rc;
     }
