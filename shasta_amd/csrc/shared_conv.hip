@@ -13,6 +13,7 @@
 // in the epilogue exactly as PyTorch's eval kernel does: y = (acc + bias) * alpha + beta', alpha = gamma / sqrt(var + eps),
 // beta' = beta - mean * alpha.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace shasta {
 
@@ -147,6 +148,129 @@ __global__ __launch_bounds__(256) void shared_conv_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Flattened-pixel variant (maps up to 256 columns wide, i.e. every shipped config): a workgroup owns 128 CONSECUTIVE
+// pixels of the flattened (y*W + x) image instead of a 4 x 32 rectangle, each wave 32 of them.  No column padding
+// (180 = 5.6 x 32 wasted 6 % in the rectangular tiling) and 254 workgroups per 180 x 180 map instead of 270, so one map
+// is exactly one wave per SIMD and a frame pair (two maps) two.  The staged input tile covers the <= 128/W + 2 image
+// rows the pixels touch plus a one-pixel halo, full width; K chunks are 4 channels (k pair = same tap of channels c and
+// c + 2) so that the double-buffered tiles (2 x (11.6 + 9.2) KB at W = 180) leave room for 3 workgroups per CU.
+// The packed weights are the same buffer: [Cin/8][72][64] read as [Cin/4][36][64].
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int CF_CK = 4;
+constexpr int CF_WT = CF_CK * 9 * 64;  // 2304 floats per chunk
+constexpr int CF_IN_PT = 18;           // staged input floats per thread (upper bound, W <= 256)
+
+__global__ __launch_bounds__(256) void shared_conv_flat_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
+                                                               const float* __restrict__ packed, float* __restrict__ outa,
+                                                               float* __restrict__ outb, int B, int Cin, int H, int W,
+                                                               int rt_max) {
+    extern __shared__ __attribute__((aligned(16))) float s_cf[];
+    const int WT = W + 2;
+    const int in_cap = CF_CK * rt_max * WT;          // floats per input buffer
+    float* s_in0 = s_cf;
+    float* s_in1 = s_cf + in_cap;
+    float* s_w0 = s_cf + 2 * in_cap;
+    float* s_w1 = s_w0 + CF_WT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool second = (int)blockIdx.z >= B;
+    const int b = second ? blockIdx.z - B : blockIdx.z;
+    const float* x = second ? xb : xa;
+    float* out = second ? outb : outa;
+    const int npix = H * W, p0 = blockIdx.x * 128;
+    const int y_first = p0 / W, y_last = min(H - 1, (min(p0 + 127, npix - 1)) / W);
+    const int RT = y_last - y_first + 3;             // rows of the tile incl. halo
+    const int plane = RT * WT;
+    const int nchunk = Cin / CF_CK;
+    const float* xin = x + (size_t)b * Cin * npix;
+
+    int in_off[CF_IN_PT];  // offset inside one 4-channel chunk of the input, -1 = zero (outside the image), -2 = unused slot
+#pragma unroll
+    for (int j = 0; j < CF_IN_PT; ++j) {
+        const int e = tid + 256 * j;
+        int off = -2;
+        if (e < CF_CK * plane) {
+            const int c = e / plane, rem = e - c * plane;
+            const int r = rem / WT, col = rem - r * WT;
+            const int gy = y_first - 1 + r, gx = col - 1;
+            off = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? c * npix + gy * W + gx : -1;
+        }
+        in_off[j] = off;
+    }
+    float rin[CF_IN_PT];
+    f32x4 rwt[3];
+    auto load_chunk = [&](int ch) {
+        const float* xc = xin + (size_t)ch * CF_CK * npix;
+#pragma unroll
+        for (int j = 0; j < CF_IN_PT; ++j) rin[j] = in_off[j] >= 0 ? xc[in_off[j]] : 0.0f;
+        const f32x4* wc = reinterpret_cast<const f32x4*>(packed + (size_t)ch * CF_WT);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int e = tid + 256 * j;
+            rwt[j] = e < CF_WT / 4 ? wc[e] : f32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_chunk = [&](float* si, float* sw) {
+#pragma unroll
+        for (int j = 0; j < CF_IN_PT; ++j)
+            if (in_off[j] != -2) si[tid + 256 * j] = rin[j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int e = tid + 256 * j;
+            if (e < CF_WT / 4) reinterpret_cast<f32x4*>(sw)[e] = rwt[j];
+        }
+    };
+
+    f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int i = lane & 31, h = lane >> 5;
+    const int p = min(p0 + 32 * wv + i, npix - 1);
+    const int py = p / W, px = p - py * W;
+    // A: tile[c = c_lo + 2h][py - y_first + 1 + dy][px + 1 + dx] ; B: s_w[kp + 18h][32*nb + i]
+    const int a_base = (2 * h) * plane + (py - y_first + 1) * WT + px + 1;
+    const int b_base = (18 * h) * 64 + i;
+
+    load_chunk(0);
+    store_chunk(s_in0, s_w0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const float* si = (ch & 1) ? s_in1 : s_in0;
+        const float* sw = (ch & 1) ? s_w1 : s_w0;
+        if (ch + 1 < nchunk) load_chunk(ch + 1);
+        const float* ain = si + a_base;
+        const float* bw = sw + b_base;
+#pragma unroll
+        for (int kp = 0; kp < 18; ++kp) {
+            const int c_lo = kp / 9, tap = kp % 9, dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const float av = ain[c_lo * plane + dy * WT + dx];
+            const float b0 = bw[kp * 64], b1 = bw[kp * 64 + 32];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+        }
+        if (ch + 1 < nchunk) {
+            store_chunk((ch & 1) ? s_in0 : s_in1, (ch & 1) ? s_w0 : s_w1);
+            __syncthreads();
+        }
+    }
+    const float* par = packed + (size_t)Cin * 9 * 64;
+    float* obase = out + (size_t)b * npix * 64;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int chn = 32 * nb + (lane & 31);
+        const float alpha = par[chn], beta2 = par[64 + chn], bias = par[128 + chn];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pp = p0 + 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (pp < npix) {
+                const float a = nb ? acc1[r] : acc0[r];
+                const float v = (a + bias) * alpha + beta2;
+                obase[(size_t)pp * 64 + chn] = fmaxf(v, 0.0f);
+            }
+        }
+    }
+}
+
 }  // namespace shasta
 
 using namespace shasta;
@@ -180,6 +304,15 @@ extern "C" int shasta_shared_conv_f32(const float* x, const float* x_prev, int B
     SHASTA_REQUIRE((uintptr_t)packed % 16 == 0, "shared_conv: packed buffer must be 16-byte aligned");
     SHASTA_REQUIRE((long)in_channels * H * W < (1L << 31), "shared_conv: one image exceeds 2^31 elements");
     if (B == 0) return SHASTA_OK;
+    static const bool force_rect = getenv("SHASTA_CONV_RECT") != nullptr;
+    const int rt_max = min(H, 128 / W + 2) + 2;
+    const size_t lds = ((size_t)2 * CF_CK * rt_max * (W + 2) + 2 * CF_WT) * sizeof(float);
+    if (!force_rect && W <= 256 && CF_CK * rt_max * (W + 2) <= 256 * CF_IN_PT && lds <= 64 * 1024) {
+        dim3 grid(cdiv(H * W, 128), 1, x_prev ? 2 * B : B);
+        hipLaunchKernelGGL(shared_conv_flat_kernel, grid, dim3(256), lds, as_stream(stream), x, x_prev,
+                           static_cast<const float*>(packed), out, out_prev, B, in_channels, H, W, rt_max);
+        return check_launch("shared_conv_flat");
+    }
     dim3 grid(cdiv(W, CV_TC), cdiv(H, CV_TR), x_prev ? 2 * B : B);
     hipLaunchKernelGGL(shared_conv_kernel, grid, dim3(256), 0, as_stream(stream), x, x_prev, static_cast<const float*>(packed),
                        out, out_prev, B, in_channels, H, W);

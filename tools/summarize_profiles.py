@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+SRC = sys.argv[2] if len(sys.argv) > 2 else "final2"  # sub-directory of gpurun_out holding the measurement pass
 
 
 def short(name):
@@ -49,13 +50,14 @@ def pmc(dirs, dst):
 
 if __name__ == "__main__":
     os.makedirs(P, exist_ok=True)
-    kernel_stats(os.path.join(G, "final1/prof_default/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_default_b64.csv"))
-    kernel_stats(os.path.join(G, "final1/prof_b1/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_b1.csv"))
-    pmc([("b1_fetch", "pmc_fetch_b1"), ("b1_write", "pmc_write_b1"), ("b32_fetch", "pmc_fetch_b32"), ("b32_write", "pmc_write_b32"),
-         ("b64_fetch", "pmc_fetch_b64"), ("b64_write", "pmc_write_b64"), ("b32_mfma", "pmc_mfma_b32")],
+    kernel_stats(os.path.join(G, SRC, "prof_default/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_default_b64.csv"))
+    kernel_stats(os.path.join(G, SRC, "prof_b1/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_b1.csv"))
+    pmc([("b1_fetch", SRC + "/pmc_fetch_b1"), ("b1_write", SRC + "/pmc_write_b1"), ("b32_fetch", SRC + "/pmc_fetch_b32"),
+         ("b32_write", SRC + "/pmc_write_b32"), ("b64_fetch", SRC + "/pmc_fetch_b64"), ("b64_write", SRC + "/pmc_write_b64"),
+         ("b64_mfma", SRC + "/pmc_mfma_b64"), ("pair_b64_sq", "pmc_pair3"), ("pair_b64_mfma", "pmc_pair4")],
         os.path.join(P, TAG + "_pmc_summary.csv"))
     for b in ("default", "b1", "b32"):
-        src = os.path.join(G, "final1/bench_%s.json" % b)
+        src = os.path.join(G, SRC, "bench_%s.json" % b)
         if os.path.exists(src):
             line = [l for l in open(src) if l.startswith("{")][-1]
             json.dump(json.loads(line), open(os.path.join(P, TAG + "_bench_%s.json" % b), "w"), indent=1)
