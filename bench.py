@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="frame-pairs per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (no HIP-event roofline)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="frame-pairs timed on the host for cpu_baseline")
     args = ap.parse_args()
 
@@ -109,13 +110,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    graph = None
     with torch.no_grad():
+        if args.graph:
+            # capture one step (all launches go through the C ABI on the capture stream; outputs are static tensors)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    m1, m2 = step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                m1, m2 = step()
         for _ in range(args.warmup):
-            m1, m2 = step()
+            if graph is not None:
+                graph.replay()
+            else:
+                m1, m2 = step()
         sync_all()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            m1, m2 = step(evs[i])
+            if graph is not None:
+                graph.replay()
+            else:
+                m1, m2 = step(evs[i])
         sync_all()
         elapsed = time.perf_counter() - t0
     if world > 1:
@@ -126,6 +145,11 @@ def main():
 
     ms = C.c_float()
     l1 = []
+    if graph is not None:  # the per-step events were not recorded under graph replay: time the dominant kernel separately
+        with torch.no_grad():
+            for i in range(args.steps):
+                step(evs[i])
+        torch.cuda.synchronize()
     for a, b_ in evs:
         hip.check(lib.shasta_event_elapsed_ms(a, b_, C.byref(ms)), "event_elapsed")
         l1.append(ms.value)
@@ -160,7 +184,8 @@ def main():
         "config": {"workload": "synthetic N=M=500, F=256 (num_point=4, C=64), nf=7 affinity forward from HBM-resident "
                                "NHWC BEV features (SURVEY 8a rows 4-16)", "frame_pairs_per_step_per_gpu": B,
                    "max_obj": N_OBJ, "num_feats": NF, "num_point": NPOINT, "bev_hw": HW,
-                   "parallelism": "replica x%d (frame-parallel, no data-path collective)" % world},
+                   "parallelism": "replica x%d (frame-parallel, no data-path collective)" % world,
+                   "hip_graph": bool(args.graph)},
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -346,3 +346,33 @@ def test_empty_batch_is_a_no_op():
     with torch.no_grad():
         m1, m2, _ = m(ex, train_mode=False)
     assert m1.shape == (0, 4, 6) and m2.shape == (0, 6, 4)
+
+
+def test_forward_can_be_captured_in_a_hip_graph():
+    """Every launch goes through the C ABI on the caller's stream, without allocation or synchronisation inside, so the
+    forward is capturable; replay must reproduce the eager result bit for bit."""
+    dev = _dev()
+    z, c, m, bev, pbev, det, prev = _case("small_32_7_4")
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(5)
+    f = torch.relu(torch.randn(c["B"], 180, 180, 64, generator=g)).to(dev)
+    det0, prevd = det.to(dev), prev.to(dev)
+    work = det0.clone()
+    with torch.no_grad():
+        work.copy_(det0)
+        e1, e2 = m.affinity_from_bev(f, f, work, prevd)
+        e1, e2 = e1.clone(), e2.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            work.copy_(det0)
+            m.affinity_from_bev(f, f, work, prevd)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            work.copy_(det0)
+            g1, g2 = m.affinity_from_bev(f, f, work, prevd)
+        for _ in range(3):
+            graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(g1, e1) and torch.equal(g2, e2)
