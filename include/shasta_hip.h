@@ -198,6 +198,14 @@ int shasta_iou3d_distance_f64(const double* dets, int num_dets, const double* tr
 int shasta_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C,
                        int ldc, int M, int N, int K, int act, shasta_stream_t stream);
 
+/* Strided form (training path: dX = dY.W and dW = dY^T.X of every nn.Linear, torch autograd's addmm backward):
+ *   C[m][n] = act(sum_k A[m*sa_m + k*sa_k] * W[n*sw_n + k*sw_k] + bias[n]) * (relu_mask[m][n] > 0)
+ * splitk_ws (optional): scratch for a deterministic split of long reductions (weight gradients). */
+int shasta_gemm_strided_f32(const float* A, long sa_m, long sa_k, const float* W, long sw_n, long sw_k,
+                            const float* bias, const float* relu_mask, int ldmask, float* C, int ldc, int M,
+                            int N, int K, int act, void* splitk_ws, size_t splitk_ws_bytes,
+                            shasta_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,3 +112,176 @@ extern "C" int shasta_gemm_nt_f32(const float* A, int lda, const float* W, int l
     SHASTA_REQUIRE(act >= 0 && act <= 2, "gemm_nt: bad activation");
     return launch_gemm_nt(A, lda, W, ldw, bias, C, ldc, M, N, K, act, as_stream(stream));
 }
+
+namespace shasta {
+
+// ------------------------------------------------------------------------------------------------------------------
+// Strided form for the training path (backward of every nn.Linear):
+//   C[m][n] (+)= sum_k A(m, k) * W(n, k),  A(m, k) = A[m*sa_m + k*sa_k], W(n, k) = W[n*sw_n + k*sw_k]
+//   forward  Y  = X . W^T        : sa = (ldx, 1),  sw = (ldw, 1)           (the NT kernel above)
+//   dX = dY . W                  : A = dY (ldy, 1), "W" = W^T  -> sw = (1, ldw)          reduction over out features
+//   dW = dY^T . X                : A = dY^T -> sa = (1, ldy), "W" = X^T -> sw = (1, ldx)  reduction over rows
+// Optional epilogue: bias, activation, and a ReLU mask (C *= mask > 0) for the backward through a ReLU.
+// Split-K (grid.z slices of the reduction) writes partial tiles to `C + z*slice_stride`; the caller sums them in a fixed
+// order (gemm_reduce_kernel) -> deterministic, no float atomics.
+// ------------------------------------------------------------------------------------------------------------------
+struct GemmS {
+    const float* A;
+    const float* W;
+    const float* bias;
+    const float* mask;  // (M, ldmask) or nullptr
+    float* C;
+    long sa_m, sa_k, sw_n, sw_k;
+    int ldc, ldmask, M, N, K, act, kslice;  // kslice: reduction elements per grid.z slice (multiple of BK)
+    long slice_stride;
+};
+
+__device__ __forceinline__ void load_slice_strided(const float* __restrict__ P, long s_r, long s_k, int rows, int K, int r0,
+                                                   int k0, int tid, float (&reg)[2][4]) {
+    if (s_k == 1 || s_r != 1) {  // k-contiguous (or general): thread -> (row, 4 consecutive k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 3, c4 = idx & 7;
+            const int gr = r0 + row, gk = k0 + 4 * c4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) reg[i][j] = (gr < rows && gk + j < K) ? P[(long)gr * s_r + (long)(gk + j) * s_k] : 0.0f;
+        }
+    } else {  // row-contiguous: adjacent threads read adjacent rows of the same k (coalesced)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // element e = (i*4 + j)*256 + tid of the 64 x 32 tile: row = e & 63, k = e >> 6
+                const int e = (i * 4 + j) * 256 + tid;
+                const int row = e & 63, kk = e >> 6;
+                const int gr = r0 + row, gk = k0 + kk;
+                reg[i][j] = (gr < rows && gk < K) ? P[(long)gr + (long)gk * s_k] : 0.0f;
+            }
+    }
+}
+
+__device__ __forceinline__ void store_slice_strided(float* S, long s_r, long s_k, int tid, const float (&reg)[2][4]) {
+    if (s_k == 1 || s_r != 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 3, c4 = idx & 7;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) S[row * LDS_LD + 4 * c4 + j] = reg[i][j];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = (i * 4 + j) * 256 + tid;
+                S[(e & 63) * LDS_LD + (e >> 6)] = reg[i][j];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_strided_f32_kernel(GemmS g) {
+    __shared__ float As[BM * LDS_LD];
+    __shared__ float Ws[BN * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.kslice, kend = min(g.K, kbeg + g.kslice);
+    float ra[2][4], rw[2][4];
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        load_slice_strided(g.A, g.sa_m, g.sa_k, g.M, kend, m0, kbeg, tid, ra);
+        load_slice_strided(g.W, g.sw_n, g.sw_k, g.N, kend, n0, kbeg, tid, rw);
+    }
+    const float* af = As + (wm * 32 + (lane & 31)) * LDS_LD + (lane >> 5);
+    const float* wf = Ws + (wn * 32 + (lane & 31)) * LDS_LD + (lane >> 5);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        store_slice_strided(As, g.sa_m, g.sa_k, tid, ra);
+        store_slice_strided(Ws, g.sw_n, g.sw_k, tid, rw);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            load_slice_strided(g.A, g.sa_m, g.sa_k, g.M, kend, m0, kbeg + (kt + 1) * BK, tid, ra);
+            load_slice_strided(g.W, g.sw_n, g.sw_k, g.N, kend, n0, kbeg + (kt + 1) * BK, tid, rw);
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2 * s], wf[2 * s], acc, 0, 0, 0);
+    }
+    float* C = g.C + (long)blockIdx.z * g.slice_stride;
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col < g.N) {
+        const float bv = (g.bias && blockIdx.z == 0) ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < g.M) {
+                float v = acc[r] + bv;
+                if (g.act == 1) v = fmaxf(v, 0.0f);
+                else if (g.act == 2) v = fabsf(v);
+                if (g.mask && !(g.mask[(long)row * g.ldmask + col] > 0.0f)) v = 0.0f;
+                C[(long)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+// C[i] = sum_z part[z*stride + i] (fixed order), optional ReLU mask
+__global__ void gemm_reduce_kernel(const float* __restrict__ part, long stride, int nz, float* __restrict__ C, long n,
+                                   const float* __restrict__ mask) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = part[i];
+    for (int z = 1; z < nz; ++z) s += part[(long)z * stride + i];
+    if (mask && !(mask[i] > 0.0f)) s = 0.0f;
+    C[i] = s;
+}
+
+int launch_gemm_strided(const float* A, long sa_m, long sa_k, const float* W, long sw_n, long sw_k, const float* bias,
+                        const float* mask, int ldmask, float* C, int ldc, int M, int N, int K, int act, float* splitk_ws,
+                        size_t splitk_ws_bytes, hipStream_t st) {
+    if (M == 0 || N == 0) return SHASTA_OK;
+    GemmS g;
+    g.A = A; g.W = W; g.bias = bias; g.mask = mask; g.C = C;
+    g.sa_m = sa_m; g.sa_k = sa_k; g.sw_n = sw_n; g.sw_k = sw_k;
+    g.ldc = ldc; g.ldmask = ldmask; g.M = M; g.N = N; g.K = K; g.act = act;
+    const int tiles = cdiv(M, BM) * cdiv(N, BN);
+    int nz = 1;
+    // long reductions with few output tiles (weight gradients): split the reduction over grid.z
+    if (splitk_ws && K >= 4096 && tiles < 128 && ldc == N && !mask && act == 0) {
+        nz = min(min(64, cdiv(512, tiles)), cdiv(K, 1024));
+        while (nz > 1 && (size_t)nz * M * N * sizeof(float) > splitk_ws_bytes) --nz;
+    }
+    if (nz <= 1) {
+        g.kslice = cdiv(max(K, 1), BK) * BK;
+        g.slice_stride = 0;
+        hipLaunchKernelGGL(gemm_strided_f32_kernel, dim3(cdiv(N, BN), cdiv(M, BM), 1), dim3(256), 0, st, g);
+        return check_launch("gemm_strided_f32");
+    }
+    g.kslice = cdiv(cdiv(K, nz), BK) * BK;
+    nz = cdiv(K, g.kslice);
+    g.C = splitk_ws;
+    g.slice_stride = (long)M * N;
+    hipLaunchKernelGGL(gemm_strided_f32_kernel, dim3(cdiv(N, BN), cdiv(M, BM), nz), dim3(256), 0, st, g);
+    int rc = check_launch("gemm_strided_f32(split-K)");
+    if (rc) return rc;
+    const long n = (long)M * N;
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, splitk_ws, g.slice_stride, nz, C, n,
+                       (const float*)nullptr);
+    return check_launch("gemm_reduce");
+}
+
+}  // namespace shasta
+
+extern "C" int shasta_gemm_strided_f32(const float* A, long sa_m, long sa_k, const float* W, long sw_n, long sw_k, const float* bias,
+                                       const float* relu_mask, int ldmask, float* C, int ldc, int M, int N, int K, int act,
+                                       void* splitk_ws, size_t splitk_ws_bytes, shasta_stream_t stream) {
+    using namespace shasta;
+    SHASTA_REQUIRE(A && W && C, "gemm_strided: null pointer");
+    SHASTA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && ldc >= N, "gemm_strided: bad size");
+    SHASTA_REQUIRE(act >= 0 && act <= 2, "gemm_strided: bad activation");
+    return launch_gemm_strided(A, sa_m, sa_k, W, sw_n, sw_k, bias, relu_mask, ldmask, C, ldc, M, N, K, act,
+                               static_cast<float*>(splitk_ws), splitk_ws_bytes, as_stream(stream));
+}

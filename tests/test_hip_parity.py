@@ -376,3 +376,36 @@ def test_forward_can_be_captured_in_a_hip_graph():
             graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(g1, e1) and torch.equal(g2, e2)
+
+
+@pytest.mark.parametrize("M,N,K", [(92, 128, 92), (8464, 40, 646), (70, 33, 5000), (3, 450, 28800)])
+def test_gemm_strided_backward_forms(M, N, K):
+    """The strided GEMM in the three forms of an nn.Linear (Y = X W^T, dX = dY W, dW = dY^T X), incl. the deterministic
+    split of long reductions and the ReLU-mask epilogue, against float64 matmuls."""
+    from shasta_amd import hip
+    dev = _dev()
+    lib = hip.load()
+    g = torch.Generator().manual_seed(M + N)
+    X = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    dY = torch.randn(M, N, generator=g)
+    Xd, Wd, dYd = X.to(dev), W.to(dev), dY.to(dev)
+    ws = torch.empty(64 * 1024 * 1024 // 4, device=dev)
+
+    def run(A, sa, Wt, sw, m, n, k, mask=None, ldmask=0):
+        out = torch.empty(m, n, device=dev)
+        hip.check(lib.shasta_gemm_strided_f32(hip.ptr(A), sa[0], sa[1], hip.ptr(Wt), sw[0], sw[1], None, hip.ptr(mask), ldmask,
+                                              hip.ptr(out), n, m, n, k, 0, hip.ptr(ws), ws.numel() * 4, hip.stream_ptr()), "gemm_strided")
+        return out.cpu()
+
+    y = run(Xd, (K, 1), Wd, (K, 1), M, N, K)                       # forward: Y = X W^T
+    np.testing.assert_allclose(y.numpy(), (X.double() @ W.double().t()).float().numpy(), rtol=1e-4, atol=1e-4)
+    mask = torch.randn(M, K, generator=g)
+    dx = run(dYd, (N, 1), Wd, (1, K), M, K, N, mask.to(dev), K)    # dX = (dY W) * (mask > 0)
+    ref = (dY.double() @ W.double()) * (mask > 0)
+    np.testing.assert_allclose(dx.numpy(), ref.float().numpy(), rtol=1e-4, atol=1e-4)
+    dw = run(dYd, (1, N), Xd, (1, K), N, K, M)                     # dW = dY^T X  (reduction over the M rows)
+    ref = dY.double().t() @ X.double()
+    np.testing.assert_allclose(dw.numpy(), ref.float().numpy(), rtol=1e-4, atol=2e-4 * max(1.0, float(ref.abs().max())))
+    dw2 = run(dYd, (1, N), Xd, (1, K), N, K, M)
+    assert torch.equal(dw, dw2)                                    # split-K partials are summed in a fixed order
