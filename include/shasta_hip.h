@@ -198,6 +198,20 @@ int shasta_iou3d_distance_f64(const double* dets, int num_dets, const double* tr
 int shasta_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C,
                        int ldc, int M, int N, int K, int act, shasta_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Batched decode decisions (consumer of the affinity matrices)
+ * replaces the per-element .item() loop of tools/nusc_shasta/eval.py:127-173 (== validate.py:68-114) by compact
+ * per-row / per-column decisions; thresholds 0.5 / 0.7 are the reference's hard-coded ones (eval.py:137,141,161,163).
+ *  n_prev, n_cur (B,) int32 : number of real previous / current detections of each frame pair
+ *  prev_class (B,N) int32   : 0 keep, 1 dead track, 2 false negative, -1 row >= n_prev
+ *  prev_score (B,N) fp32    : matched1[n, dead column]; ref_detection_score of a propagated FN box is 1 - this
+ *  det_flags  (B,N) int32   : bit 0 kept (not a false positive), bit 1 newborn, -1 column >= n_cur
+ *  det_score  (B,N) fp32    : matched2[FP row, k]; ref_detection_score of a kept detection is 1 - this
+ * ------------------------------------------------------------------------------------------ */
+int shasta_decode_flags_f32(const float* matched1, const float* matched2, const int32_t* n_prev,
+                            const int32_t* n_cur, int B, int max_obj, int32_t* prev_class, float* prev_score,
+                            int32_t* det_flags, float* det_score, shasta_stream_t stream);
+
 /* Strided form (training path: dX = dY.W and dW = dY^T.X of every nn.Linear, torch autograd's addmm backward):
  *   C[m][n] = act(sum_k A[m*sa_m + k*sa_k] * W[n*sw_n + k*sw_k] + bias[n]) * (relu_mask[m][n] > 0)
  * splitk_ws (optional): scratch for a deterministic split of long reductions (weight gradients). */

@@ -54,6 +54,53 @@ def decode_frame(matched1, matched2, cls_det_boxes, prev_cls_det_boxes, token, t
     return annos, dead_prev, keep_dets
 
 
+def decode_flags_device(matched1, matched2, n_prev, n_cur):
+    """Batched decisions of the decode loop on the GPU (csrc/decode.hip): returns CPU numpy arrays
+    (prev_class (B,N), prev_score (B,N), det_flags (B,N), det_score (B,N)) after ONE device->host copy per array."""
+    import ctypes as C  # noqa: F401
+
+    from . import hip
+    lib = hip.load()
+    B, N = matched1.shape[0], matched1.shape[1]
+    dev = matched1.device
+    npv = torch.as_tensor(n_prev, dtype=torch.int32).to(dev).contiguous()
+    ncv = torch.as_tensor(n_cur, dtype=torch.int32).to(dev).contiguous()
+    pc = torch.empty(B, N, dtype=torch.int32, device=dev)
+    ps = torch.empty(B, N, dtype=torch.float32, device=dev)
+    df = torch.empty(B, N, dtype=torch.int32, device=dev)
+    ds = torch.empty(B, N, dtype=torch.float32, device=dev)
+    hip.check(lib.shasta_decode_flags_f32(hip.ptr(matched1.contiguous()), hip.ptr(matched2.contiguous()), hip.ptr(npv), hip.ptr(ncv),
+                                          B, N, hip.ptr(pc), hip.ptr(ps), hip.ptr(df), hip.ptr(ds), hip.stream_ptr()),
+              "shasta_decode_flags_f32")
+    return pc.cpu().numpy(), ps.cpu().numpy(), df.cpu().numpy(), ds.cpu().numpy()
+
+
+def decode_frame_from_flags(prev_class, prev_score, det_flags, det_score, cls_det_boxes, prev_cls_det_boxes, token, time_lag):
+    """Same result as decode_frame, built from the device decisions of one frame (rows of decode_flags_device)."""
+    annos, fn_annos, dead_prev, keep_dets = [], [], [], []
+    for n in range(len(prev_cls_det_boxes)):
+        c = int(prev_class[n])
+        if c == 1:
+            dead_prev.append(n)
+        elif c == 2:
+            box = prev_cls_det_boxes[n]
+            box["translation"][:2] = [t + time_lag * v for t, v in zip(box["translation"][:2], box["velocity"])]
+            box["FN"] = True
+            box["token"] = token
+            box["ref_detection_score"] = 1 - float(prev_score[n])
+            fn_annos.append(box)
+    for k in range(len(cls_det_boxes)):
+        f = int(det_flags[k])
+        if f & 1:
+            if f & 2:
+                cls_det_boxes[k]["newborn"] = True
+            cls_det_boxes[k]["ref_detection_score"] = 1 - float(det_score[k])
+            keep_dets.append(k)
+            annos.append(cls_det_boxes[k])
+    annos.extend(fn_annos)
+    return annos, dead_prev, keep_dets
+
+
 class AffinityDecoder:
     """Accumulates frames like eval.py's main loop: results dict token -> annos, plus the dead-track post-pass."""
 

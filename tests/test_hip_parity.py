@@ -409,3 +409,37 @@ def test_gemm_strided_backward_forms(M, N, K):
     np.testing.assert_allclose(dw.numpy(), ref.float().numpy(), rtol=1e-4, atol=2e-4 * max(1.0, float(ref.abs().max())))
     dw2 = run(dYd, (1, N), Xd, (1, K), N, K, M)
     assert torch.equal(dw, dw2)                                    # split-K partials are summed in a fixed order
+
+
+def test_device_decode_flags_match_host_decode():
+    """f-4: batched decode decisions on the GPU vs the restated host loop (eval.py:127-173), incl. ties, empty frames and
+    every threshold branch; the resulting anno lists must be identical."""
+    import copy
+    from shasta_amd import decode as Dm
+    dev = _dev()
+    rng = np.random.default_rng(0)
+    B, N = 24, 12
+    m1 = rng.dirichlet(np.full(N + 2, 0.12), size=(B, N)).astype(np.float32)
+    m2 = np.swapaxes(rng.dirichlet(np.full(N + 2, 0.12), size=(B, N)).astype(np.float32), 1, 2).copy()
+    m1[0, 0, :] = 0.0
+    m1[0, 0, 3] = m1[0, 0, N] = 0.6       # tie between a detection and the dead column: first maximum wins
+    m2[1, :, 2] = 0.0
+    m2[1, N, 2] = m2[1, N + 1, 2] = 0.8   # tie newborn / FP
+    n_prev = rng.integers(0, N + 1, size=B)
+    n_cur = rng.integers(0, N + 1, size=B)
+    n_prev[2], n_cur[2] = 0, 5
+    n_prev[3], n_cur[3] = 4, 0
+    n_prev[0], n_cur[0] = N, N
+    n_prev[1], n_cur[1] = N, N
+    pc, ps, df, ds = Dm.decode_flags_device(torch.from_numpy(m1).to(dev), torch.from_numpy(m2).to(dev), n_prev, n_cur)
+
+    def boxes(n, tag):
+        return [dict(sample_token=tag, translation=[float(i), float(-i), 0.5], velocity=[0.5 * i, -0.25 * i]) for i in range(n)]
+
+    for b in range(B):
+        c1, p1 = boxes(int(n_cur[b]), "c"), boxes(int(n_prev[b]), "p")
+        c2, p2 = copy.deepcopy(c1), copy.deepcopy(p1)
+        ref = Dm.decode_frame(m1[b], m2[b], c1, p1, "tok", 0.5)
+        got = Dm.decode_frame_from_flags(pc[b], ps[b], df[b], ds[b], c2, p2, "tok", 0.5)
+        assert got[1] == ref[1] and got[2] == ref[2], b
+        assert got[0] == ref[0], b
