@@ -214,11 +214,49 @@ int shasta_decode_flags_f32(const float* matched1, const float* matched2, const 
 
 /* Strided form (training path: dX = dY.W and dW = dY^T.X of every nn.Linear, torch autograd's addmm backward):
  *   C[m][n] = act(sum_k A[m*sa_m + k*sa_k] * W[n*sw_n + k*sw_k] + bias[n]) * (relu_mask[m][n] > 0)
- * splitk_ws (optional): scratch for a deterministic split of long reductions (weight gradients). */
+ * act: 0 none, 1 relu, 2 abs, +4: accumulate into C.  splitk_ws (optional): scratch for a deterministic split of long
+ * reductions (weight gradients). */
 int shasta_gemm_strided_f32(const float* A, long sa_m, long sa_k, const float* W, long sw_n, long sw_k,
                             const float* bias, const float* relu_mask, int ldmask, float* C, int ldc, int M,
                             int N, int K, int act, void* splitk_ws, size_t splitk_ws_bytes,
                             shasta_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training path, backward helpers (first version: reference/dense formulation of the pair MLPs; the nn.Linear layers run
+ * on shasta_gemm_strided_f32).  Replaces what torch autograd derives from det3d/models/tracker/shasta.py:241-325 in
+ * tools/nusc_shasta/train.py:198-213.
+ * ------------------------------------------------------------------------------------------ */
+/* pair tensor X[(b,t,d)][:ld]: kind 0 = fuse_shape input (shasta.py:286), 1 = res_coeff input (:310-312), 2 = fuse_det (:303) */
+int shasta_pair_concat_f32(const float* prev_feat, const float* feat, const float* prev_tab, const float* det_tab, int B,
+                           int T, int D, int F, int nf, int kind, int ld, float* X, shasta_stream_t stream);
+/* its transpose: table gradients += sums of pair gradients (fixed order) */
+int shasta_pair_concat_bwd_f32(const float* dX, int B, int T, int D, int F, int nf, int kind, int ld, float* dprev_feat,
+                               float* dfeat, float* dprev_tab, float* ddet_tab, shasta_stream_t stream);
+/* hand-designed residual (shasta.py:277-283) materialised: dist (B,T,ld), denom (>= 2*B*D floats: column norms, scratch) */
+int shasta_hand_dist_f32(const float* prev_tab, const float* det_tab, int B, int T, int D, int nf, float* dist, int ld,
+                         float* denom, shasta_stream_t stream);
+/* gradient of dist w.r.t. table rows row0 .. row0+nrows-1 of both box tables (the anchor rows), accumulated */
+int shasta_hand_dist_bwd_f32(const float* gdist, int ldg, const float* prev_tab, const float* det_tab, float* denom, int B,
+                             int T, int D, int nf, int row0, int nrows, float* dprev_tab, float* ddet_tab,
+                             shasta_stream_t stream);
+/* residual = alpha*fused + beta*dist + omega*shape (shasta.py:319) and its gradient */
+int shasta_combine_f32(const float* coeff, int ldc, const float* fused, int ldf, const float* shape, int lds, const float* dist,
+                       int B, int T, int D, int ld, float* residual, shasta_stream_t stream);
+int shasta_combine_bwd_f32(const float* gres, const float* coeff, int ldc, const float* fused, int ldf, const float* shape,
+                           int lds, const float* dist, int B, int T, int D, int ld, float* gcoeff, float* gfused,
+                           float* gshape, float* gdist, shasta_stream_t stream);
+/* gradient of the two softmaxes (shasta.py:324-325) w.r.t. matched (B, N+2, ld) */
+int shasta_softmax_bwd_f32(const float* m1, const float* g1, const float* m2, const float* g2, int B, int N, float* gmatched,
+                           int ld, shasta_stream_t stream);
+/* out[n] = sum_m Y[m][n] (bias gradients) */
+int shasta_colsum_f32(const float* Y, int ldy, int M, int N, float* out, shasta_stream_t stream);
+/* columns [c0,c1) of rows of width `cols`: forward out = |x|, backward out = g*sign(x); other columns pass through */
+int shasta_abs_f32(const float* x, const float* g, float* out, long n, int cols, int c0, int c1, int backward,
+                   shasta_stream_t stream);
+/* gradient of shasta_bev_gather_f32 w.r.t. the BEV map (scatter-add with float atomics; dbev must be zeroed by the caller) */
+int shasta_bev_gather_bwd_f32(const float* dfeat, int B, int H, int W, int C, const float* boxes, int N, int box_stride,
+                              int box_batch_stride, int num_point, float pc_x0, float pc_y0, float vs_x, float vs_y,
+                              float out_stride, int row_stride, int batch_stride, float* dbev, shasta_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -221,11 +221,13 @@ def affinity(w, residual):
 # --------------------------------------------------------------------------------------
 def forward_from_bev(w, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes, num_feats, num_point,
                      pc_start=(-54.0, -54.0), voxel_size=(0.075, 0.075), out_stride=8,
-                     return_intermediates=False):
+                     return_intermediates=False, grad=False):
     """det_boxes / prev_det_boxes: (B,N,11) fp32.  det_boxes[:,:,:2] is back-projected IN PLACE,
     like the reference does to example["det_boxes"] (shasta.py:216,270).
-    Returns (matched1 (B,N,N+2), matched2 (B,N+2,N)[, intermediates])."""
-    with torch.no_grad():
+    Returns (matched1 (B,N,N+2), matched2 (B,N+2,N)[, intermediates]).  grad=True keeps the autograd graph
+    (tests of the training path differentiate this restatement with torch autograd, as the reference's train.py does
+    with the original)."""
+    with (torch.enable_grad() if grad else torch.no_grad()):
         prev7 = prev_det_boxes[:, :, :7]
         det7 = det_boxes[:, :, :7]  # a view: the in-place update below reaches the caller
         vel = det_boxes[:, :, 7:9]

@@ -132,7 +132,7 @@ struct GemmS {
     const float* mask;  // (M, ldmask) or nullptr
     float* C;
     long sa_m, sa_k, sw_n, sw_k;
-    int ldc, ldmask, M, N, K, act, kslice;  // kslice: reduction elements per grid.z slice (multiple of BK)
+    int ldc, ldmask, M, N, K, act, kslice;  // kslice: reduction elements per grid.z slice (multiple of BK); act & 4: C += result
     long slice_stride;
 };
 
@@ -219,9 +219,10 @@ __global__ __launch_bounds__(256) void gemm_strided_f32_kernel(GemmS g) {
             const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < g.M) {
                 float v = acc[r] + bv;
-                if (g.act == 1) v = fmaxf(v, 0.0f);
-                else if (g.act == 2) v = fabsf(v);
+                if ((g.act & 3) == 1) v = fmaxf(v, 0.0f);
+                else if ((g.act & 3) == 2) v = fabsf(v);
                 if (g.mask && !(g.mask[(long)row * g.ldmask + col] > 0.0f)) v = 0.0f;
+                if (g.act & 4) v += C[(long)row * g.ldc + col];
                 C[(long)row * g.ldc + col] = v;
             }
         }
@@ -250,7 +251,7 @@ int launch_gemm_strided(const float* A, long sa_m, long sa_k, const float* W, lo
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     int nz = 1;
     // long reductions with few output tiles (weight gradients): split the reduction over grid.z
-    if (splitk_ws && K >= 4096 && tiles < 128 && ldc == N && !mask && act == 0) {
+    if (splitk_ws && K >= 4096 && tiles < 128 && ldc == N && !mask && act == 0 && !bias) {
         nz = min(min(64, cdiv(512, tiles)), cdiv(K, 1024));
         while (nz > 1 && (size_t)nz * M * N * sizeof(float) > splitk_ws_bytes) --nz;
     }
@@ -281,7 +282,7 @@ extern "C" int shasta_gemm_strided_f32(const float* A, long sa_m, long sa_k, con
     using namespace shasta;
     SHASTA_REQUIRE(A && W && C, "gemm_strided: null pointer");
     SHASTA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && ldc >= N, "gemm_strided: bad size");
-    SHASTA_REQUIRE(act >= 0 && act <= 2, "gemm_strided: bad activation");
+    SHASTA_REQUIRE(act >= 0 && act <= 6 && (act & 3) != 3, "gemm_strided: bad activation (0 none, 1 relu, 2 abs, +4 accumulate into C)");
     return launch_gemm_strided(A, sa_m, sa_k, W, sw_n, sw_k, bias, relu_mask, ldmask, C, ldc, M, N, K, act,
                                static_cast<float*>(splitk_ws), splitk_ws_bytes, as_stream(stream));
 }

@@ -56,6 +56,16 @@ SYMBOLS = {
     "shasta_pair_residual_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "shasta_aff_softmax_f32": (_I, [_WP, _P, _I, _P, _I, _P, _P, _P, _P, _Z, _P]),
     "shasta_iou3d_distance_f64": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
+    "shasta_pair_concat_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "shasta_pair_concat_bwd_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "shasta_hand_dist_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "shasta_hand_dist_bwd_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "shasta_combine_f32": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
+    "shasta_combine_bwd_f32": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "shasta_softmax_bwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _I, _P]),
+    "shasta_colsum_f32": (_I, [_P, _I, _I, _I, _P, _P]),
+    "shasta_abs_f32": (_I, [_P, _P, _P, C.c_long, _I, _I, _I, _I, _P]),
+    "shasta_bev_gather_bwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
     "shasta_decode_flags_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "shasta_gemm_strided_f32": (_I, [_P, C.c_long, C.c_long, _P, C.c_long, C.c_long, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "shasta_gemm_nt_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -237,12 +237,13 @@ class Shasta(BaseTrack):
                                              hip.ptr(outp), hip.stream_ptr()), "shasta_shared_conv_f32")
         return out if prev_bev_map is None else (out, outp)
 
-    def affinity_from_bev(self, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes, l1_events=None):
+    def affinity_from_bev(self, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes, l1_events=None, _allow_grad=False):
         """Rows 4-16 of SURVEY.md 8(a) (shasta.py:231-325) on device.  bev maps (B,H,W,C) fp32 NHWC, boxes (B,N,>=10)
         fp32 contiguous; det_boxes[:, :, :2] is back-projected in place."""
         lib = hip.load()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self._small_params()):
-            raise hip.ShastaHipError("the HIP affinity path is forward-only in this build: call under torch.no_grad()")
+        if not _allow_grad and torch.is_grad_enabled() and any(p.requires_grad for p in self._small_params()):
+            raise hip.ShastaHipError("Shasta.forward is the inference path: call it under torch.no_grad(), or use "
+                                     "shasta_amd.training.affinity_train for a differentiable forward")
         B, N = det_boxes.shape[0], det_boxes.shape[1]
         if N != self.max_obj or prev_det_boxes.shape[1] != N:
             raise ValueError("det_boxes must be padded to max_obj=%d rows (got %d)" % (self.max_obj, N))
@@ -297,7 +298,11 @@ class Shasta(BaseTrack):
         inplace = det.dtype == torch.float32 and det.is_contiguous() and det.shape[2] >= 10
         det_k = det if inplace else det.float().contiguous()
         prev_k = prev if (prev.dtype == torch.float32 and prev.is_contiguous()) else prev.float().contiguous()
-        m1, m2 = self.affinity_from_bev(bev, prev_bev, det_k, prev_k)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._small_params()):
+            from .training import affinity_train  # differentiable: same forward kernels + the HIP backward (training.py)
+            m1, m2 = affinity_train(self, bev, prev_bev, det_k, prev_k)
+        else:
+            m1, m2 = self.affinity_from_bev(bev, prev_bev, det_k, prev_k)
         if not inplace:
             det[:, :, :2] = det_k[:, :, :2].to(det.dtype)  # keep the reference's in-place side effect
         return m1, m2, example

@@ -1,0 +1,292 @@
+"""Training path of the affinity network (BASELINE config 5): `affinity_train(model, example)`
+returns (matched1, matched2) that carry autograd history, so the reference's training loop
+(tools/nusc_shasta/train.py:198-218: masked NLL in both directions, Adam) runs unchanged on top of it.
+
+Forward = the inference kernels (identical values).  Backward (`_AffinityTrainFn.backward`) recomputes the activations it
+needs with the REFERENCE (dense) formulation of the pair MLPs - the pair tensor is materialised - and back-propagates
+with hand-written HIP kernels only: every nn.Linear through the strided matrix-core GEMM (dX = dY W, dW = dY^T X, fixed
+order split-K), everything else through csrc/train.hip.  No torch autograd op runs inside the Function; torch is used for
+buffer allocation.  Gradients flow to every parameter of rows 6-16 and to the NHWC BEV maps (so `shared_conv`, which stays
+a torch module in train() mode with batch statistics like the reference, trains through ordinary autograd).
+First version: correctness first (checked against torch autograd of the CPU oracle), the factorised backward is future work.
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+
+
+def _gemm(lib, A, sa, W, sw, M, N, K, out, ldc=None, bias=None, act=0, mask=None, ldmask=0, accum=False, ws=None):
+    hip.check(lib.shasta_gemm_strided_f32(hip.ptr(A), sa[0], sa[1], hip.ptr(W), sw[0], sw[1], hip.ptr(bias), hip.ptr(mask), ldmask,
+                                          hip.ptr(out), ldc if ldc is not None else N, M, N, K, act + (4 if accum else 0),
+                                          hip.ptr(ws), ws.numel() * 4 if ws is not None else 0, hip.stream_ptr()),
+              "shasta_gemm_strided_f32")
+    return out
+
+
+class _Mlp:
+    """Recompute-and-backprop helper for a Sequential(Linear, ReLU, ..., Linear) applied to the rows of X (M, ldx)."""
+
+    def __init__(self, lib, layers, ws):
+        self.lib, self.layers, self.ws = lib, layers, ws  # layers: list of (weight (out,in), bias (out,))
+
+    def forward(self, X, ldx, M):
+        acts = [X]
+        ld = ldx
+        for i, (w, b) in enumerate(self.layers):
+            out = torch.empty(M, w.shape[0], device=X.device)
+            last = i + 1 == len(self.layers)
+            _gemm(self.lib, acts[-1], (ld, 1), w, (w.shape[1], 1), M, w.shape[0], w.shape[1], out, bias=b, act=0 if last else 1)
+            acts.append(out)
+            ld = w.shape[0]
+        self.acts, self.ldx, self.M = acts, ldx, M
+        return acts[-1]
+
+    def backward(self, gY, need_gx=True, gx_ld=None):
+        """gY (M, out_last).  Returns (list of (gW, gb)), gX (M, gx_ld) or None."""
+        lib, M = self.lib, self.M
+        grads = [None] * len(self.layers)
+        g = gY
+        for i in range(len(self.layers) - 1, -1, -1):
+            w, b = self.layers[i]
+            x = self.acts[i]
+            ldx = self.ldx if i == 0 else self.layers[i - 1][0].shape[0]
+            nout, nin = w.shape
+            gW = torch.empty_like(w)
+            _gemm(lib, g, (1, nout), x, (1, ldx), nout, nin, M, gW, ws=self.ws)          # dW = dY^T X
+            gb = torch.empty_like(b)
+            hip.check(lib.shasta_colsum_f32(hip.ptr(g), nout, M, nout, hip.ptr(gb), hip.stream_ptr()), "shasta_colsum_f32")
+            grads[i] = (gW, gb)
+            if i > 0:
+                gx = torch.empty(M, nin, device=g.device)
+                _gemm(lib, g, (nout, 1), w, (1, nin), M, nin, nout, gx, mask=x, ldmask=ldx)  # dX = (dY W) * relu'(x)
+                g = gx
+            elif need_gx:
+                ld = gx_ld if gx_ld is not None else nin
+                gx = torch.zeros(M, ld, device=g.device) if ld != nin else torch.empty(M, nin, device=g.device)
+                _gemm(lib, g, (nout, 1), w, (1, nin), M, nin, nout, gx, ldc=ld)
+                g = gx
+            else:
+                g = None
+        return grads, g
+
+
+class _AffinityTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, bev, prev_bev, det_boxes, prev_det_boxes, *params):
+        det_pre = det_boxes.detach().clone()  # the gather and aug_dets see the boxes BEFORE back-projection
+        with torch.no_grad():
+            keep = model.keep_intermediates
+            model.keep_intermediates = True
+            try:
+                m1, m2 = model.affinity_from_bev(bev.detach(), prev_bev.detach(), det_boxes, prev_det_boxes, _allow_grad=True)
+            finally:
+                model.keep_intermediates = keep
+            im = model.last_intermediates
+            ctx.saved = dict(bev_shape=bev.shape, det_pre=det_pre, prev=prev_det_boxes.detach().clone(),
+                             feat=im["feature"].clone(), prev_feat=im["prev_feature"].clone(), det_tab=im["det_tab"].clone(),
+                             prev_tab=im["prev_tab"].clone(), residual=im["residual"].clone(), m1=m1.clone(), m2=m2.clone())
+        ctx.model = model
+        ctx.mark_non_differentiable()
+        return m1, m2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        model, S = ctx.model, ctx.saved
+        lib = hip.load()
+        dev = S["m1"].device
+        B, N = S["m1"].shape[0], model.max_obj
+        T = D = N + 2
+        F, nf = model.aug_shape_output, model.num_feats
+        Dp = (D + 3) // 4 * 4
+        P = B * T * D
+        ws = torch.empty(64 * 1024 * 1024 // 4, device=dev)  # split-K scratch
+        st = hip.stream_ptr
+        g1 = g1.contiguous().float()
+        g2 = g2.contiguous().float()
+
+        # ---- softmaxes (shasta.py:324-325) ----
+        gm = torch.empty(B * T, Dp, device=dev)
+        hip.check(lib.shasta_softmax_bwd_f32(hip.ptr(S["m1"]), hip.ptr(g1), hip.ptr(S["m2"]), hip.ptr(g2), B, N, hip.ptr(gm), Dp, st()),
+                  "shasta_softmax_bwd_f32")
+        # ---- aff (shasta.py:323): recompute the hidden activations, then back-propagate ----
+        residual = S["residual"].reshape(B * T, D).contiguous()
+        aff = _Mlp(lib, [(model.aff[k].weight.detach(), model.aff[k].bias.detach()) for k in (0, 2, 4, 6, 8, 10)], ws)
+        aff.forward(residual, D, B * T)
+        gmc = gm[:, :D].contiguous()
+        aff_grads, gres = aff.backward(gmc, need_gx=True, gx_ld=Dp)  # gres (B*T, Dp)
+
+        # ---- pair MLPs, dense recompute (shasta.py:286-316) ----
+        def concat(kind, ld):
+            X = torch.empty(P, ld, device=dev)
+            hip.check(lib.shasta_pair_concat_f32(hip.ptr(S["prev_feat"]), hip.ptr(S["feat"]), hip.ptr(S["prev_tab"]), hip.ptr(S["det_tab"]),
+                                                 B, T, D, F, nf, kind, ld, hip.ptr(X), st()), "shasta_pair_concat_f32")
+            return X
+
+        ld_fs, ld_rc, ld_fd = 2 * F, 2 * F + 2 * nf, 2 * nf
+        Xfs, Xrc, Xfd = concat(0, ld_fs), concat(1, ld_rc), concat(2, ld_fd)
+        lin = lambda m, ks: [(m[k].weight.detach(), m[k].bias.detach()) for k in ks]  # noqa: E731
+        fs, rc, fd = _Mlp(lib, lin(model.fuse_shape, (0, 2, 4, 6)), ws), _Mlp(lib, lin(model.res_coeff, (0, 2, 4)), ws), \
+            _Mlp(lib, lin(model.fuse_det, (0, 2, 4)), ws)
+        shape = fs.forward(Xfs, ld_fs, P)      # (P,1)
+        coeff = rc.forward(Xrc, ld_rc, P)      # (P,3)
+        fused = fd.forward(Xfd, ld_fd, P)      # (P,1)
+        dist = torch.empty(B * T, Dp, device=dev)
+        denom = torch.empty(2 * B * D, device=dev)
+        hip.check(lib.shasta_hand_dist_f32(hip.ptr(S["prev_tab"]), hip.ptr(S["det_tab"]), B, T, D, nf, hip.ptr(dist), Dp, hip.ptr(denom), st()),
+                  "shasta_hand_dist_f32")
+        gcoeff, gfused, gshape = torch.empty(P, 3, device=dev), torch.empty(P, 1, device=dev), torch.empty(P, 1, device=dev)
+        gdist = torch.zeros(B * T, Dp, device=dev)
+        hip.check(lib.shasta_combine_bwd_f32(hip.ptr(gres), hip.ptr(coeff), 3, hip.ptr(fused), 1, hip.ptr(shape), 1, hip.ptr(dist), B, T, D, Dp,
+                                             hip.ptr(gcoeff), hip.ptr(gfused), hip.ptr(gshape), hip.ptr(gdist), st()), "shasta_combine_bwd_f32")
+        fs_grads, gXfs = fs.backward(gshape)
+        rc_grads, gXrc = rc.backward(gcoeff)
+        fd_grads, gXfd = fd.backward(gfused)
+        del Xfs, Xrc, Xfd
+        dfeat = torch.zeros(B, T, F, device=dev)
+        dprev_feat = torch.zeros(B, T, F, device=dev)
+        ddet_tab = torch.zeros(B, T, 8, device=dev)
+        dprev_tab = torch.zeros(B, T, 8, device=dev)
+        for kind, gX, ld in ((0, gXfs, ld_fs), (1, gXrc, ld_rc), (2, gXfd, ld_fd)):
+            hip.check(lib.shasta_pair_concat_bwd_f32(hip.ptr(gX), B, T, D, F, nf, kind, ld, hip.ptr(dprev_feat), hip.ptr(dfeat),
+                                                     hip.ptr(dprev_tab), hip.ptr(ddet_tab), st()), "shasta_pair_concat_bwd_f32")
+        del gXfs, gXrc, gXfd
+        # ---- hand-designed residual -> anchor boxes (rows N, N+1 of both tables) ----
+        hip.check(lib.shasta_hand_dist_bwd_f32(hip.ptr(gdist), Dp, hip.ptr(S["prev_tab"]), hip.ptr(S["det_tab"]), hip.ptr(denom), B, T, D, nf,
+                                               N, 2, hip.ptr(dprev_tab), hip.ptr(ddet_tab), st()), "shasta_hand_dist_bwd_f32")
+
+        # ---- anchor MLPs (shasta.py:241-247, 260-267) ----
+        def anchor_bwd(seq, x, sx_m, K, g_out, c0, c1):
+            """seq = Sequential(Linear, ReLU, Linear); x rows at stride sx_m; g_out (B, out) gradient of the |.| output."""
+            w1, b1, w2, b2 = seq[0].weight.detach(), seq[0].bias.detach(), seq[2].weight.detach(), seq[2].bias.detach()
+            H, nout = w1.shape[0], w2.shape[0]
+            hid = torch.empty(B, max(H, 1), device=dev)
+            if H > 0:
+                _gemm(lib, x, (sx_m, 1), w1, (K, 1), B, H, K, hid, ldc=max(H, 1), bias=b1, act=1)
+            pre = torch.empty(B, nout, device=dev)
+            if H > 0:
+                _gemm(lib, hid, (max(H, 1), 1), w2, (H, 1), B, nout, H, pre, bias=b2)
+            else:
+                pre.copy_(b2.expand(B, nout))
+            gpre = torch.empty(B, nout, device=dev)
+            hip.check(lib.shasta_abs_f32(hip.ptr(pre), hip.ptr(g_out), hip.ptr(gpre), B * nout, nout, c0, c1, 1, st()), "shasta_abs_f32")
+            gb2 = torch.empty_like(b2)
+            hip.check(lib.shasta_colsum_f32(hip.ptr(gpre), nout, B, nout, hip.ptr(gb2), st()), "shasta_colsum_f32")
+            gW2, gW1, gb1 = torch.zeros_like(w2), torch.zeros_like(w1), torch.zeros_like(b1)
+            gx = None
+            if H > 0:
+                _gemm(lib, gpre, (1, nout), hid, (1, max(H, 1)), nout, H, B, gW2)
+                ghid = torch.empty(B, H, device=dev)
+                _gemm(lib, gpre, (nout, 1), w2, (1, H), B, H, nout, ghid, mask=hid, ldmask=max(H, 1))
+                _gemm(lib, ghid, (1, H), x, (1, sx_m), H, K, B, gW1)
+                hip.check(lib.shasta_colsum_f32(hip.ptr(ghid), H, B, H, hip.ptr(gb1), st()), "shasta_colsum_f32")
+                gx = ghid
+            return (gW1, gb1, gW2, gb2), gx, w1
+
+        shape_grads, box_grads = [None] * 4, [None] * 4
+        for i in range(4):
+            # aug_shape[i]: input = rows < N of feat (i<2) / prev_feat (i>=2); output row N + (i&1) of prev_feat (i<2) / feat (i>=2)
+            x = S["feat"] if i < 2 else S["prev_feat"]
+            gtab = dprev_feat if i < 2 else dfeat
+            g_out = gtab[:, N + (i & 1), :].contiguous()
+            grads, ghid, w1 = anchor_bwd(model.aug_shape[i], x, T * F, N * F, g_out, 0, F)
+            shape_grads[i] = grads
+            if ghid is not None:  # dx = ghid W1 accumulated into the rows < N of the INPUT table's gradient
+                gin = dfeat if i < 2 else dprev_feat
+                _gemm(lib, ghid, (ghid.shape[1], 1), w1, (1, N * F), B, N * F, ghid.shape[1], gin, ldc=T * F, accum=True)
+            # aug_dets[i]: input = boxes[:, :, :7] before back-projection (det for i<2, prev for i>=2), output anchor box row
+            xb = (S["det_pre"] if i < 2 else S["prev"])[:, :, :7].contiguous()
+            gbt = dprev_tab if i < 2 else ddet_tab
+            g_box = gbt[:, N + (i & 1), :7].contiguous()
+            grads, _, _ = anchor_bwd(model.aug_dets[i], xb, 7 * N, 7 * N, g_box, 3, 6)
+            box_grads[i] = grads
+
+        # ---- gather (shasta.py:231-238) -> gradient of the two NHWC maps ----
+        def gather_bwd(gtab, boxes):
+            Bb, H_, W_, Cc = S["bev_shape"]
+            dbev = torch.zeros(Bb, H_, W_, Cc, device=dev)
+            x0, y0, vx, vy, stv = model.bev_extractor._geom()
+            hip.check(lib.shasta_bev_gather_bwd_f32(hip.ptr(gtab), B, H_, W_, Cc, hip.ptr(boxes), N, boxes.shape[2], N * boxes.shape[2],
+                                                    model.num_point, x0, y0, vx, vy, stv, F, T * F, hip.ptr(dbev), st()),
+                      "shasta_bev_gather_bwd_f32")
+            return dbev
+
+        dbev = gather_bwd(dfeat, S["det_pre"])
+        dprev_bev = gather_bwd(dprev_feat, S["prev"])
+
+        # ---- gradients in the order of affinity_params(model) ----
+        out = []
+        for i in range(4):
+            out += list(shape_grads[i])
+        for gW, gb in fs_grads:
+            out += [gW, gb]
+        for i in range(4):
+            out += list(box_grads[i])
+        for gW, gb in fd_grads:
+            out += [gW, gb]
+        for gW, gb in rc_grads:
+            out += [gW, gb]
+        for gW, gb in aff_grads:
+            out += [gW, gb]
+        return (None, dbev, dprev_bev, None, None) + tuple(out)
+
+
+def affinity_params(model):
+    """Trainable parameters of rows 6-16 in the order the backward returns their gradients."""
+    ps = []
+    for i in range(4):
+        ps += [model.aug_shape[i][0].weight, model.aug_shape[i][0].bias, model.aug_shape[i][2].weight, model.aug_shape[i][2].bias]
+    for k in (0, 2, 4, 6):
+        ps += [model.fuse_shape[k].weight, model.fuse_shape[k].bias]
+    for i in range(4):
+        ps += [model.aug_dets[i][0].weight, model.aug_dets[i][0].bias, model.aug_dets[i][2].weight, model.aug_dets[i][2].bias]
+    for k in (0, 2, 4):
+        ps += [model.fuse_det[k].weight, model.fuse_det[k].bias]
+    for k in (0, 2, 4):
+        ps += [model.res_coeff[k].weight, model.res_coeff[k].bias]
+    for k in (0, 2, 4, 6, 8, 10):
+        ps += [model.aff[k].weight, model.aff[k].bias]
+    return ps
+
+
+def affinity_train(model, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes):
+    """Differentiable rows 4-16: returns (matched1, matched2) with autograd history to the affinity parameters and to the two
+    NHWC BEV maps.  det_boxes[:, :, :2] is back-projected in place like the reference forward does."""
+    return _AffinityTrainFn.apply(model, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes, *affinity_params(model))
+
+
+def affinity_loss(m1, m2, gt):
+    """tools/nusc_shasta/train.py:200-211."""
+    gt1, gt2 = gt[:, :-2, :], gt[:, :, :-2]
+    lf = (gt1 * (-torch.log(m1 + 1e-10))).sum() / gt1.sum()
+    lb = (gt2 * (-torch.log(m2 + 1e-10))).sum() / gt2.sum()
+    return (lf + lb) / 2
+
+
+def allreduce_gradients(params, world_size=None, bucket_bytes=256 << 20, group=None):
+    """Data-parallel gradient averaging over torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the
+    CPU tests): gradients are packed into flat buckets (few, large collectives: the per-link bound of the point-to-point
+    xGMI topology favours large messages), summed with one all_reduce per bucket and divided by the world size, like
+    apex DDP does for the reference (tools/nusc_shasta/train.py:156)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world = world_size or dist.get_world_size(group)
+    if world == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    i = 0
+    while i < len(grads):
+        j, nbytes = i, 0
+        while j < len(grads) and (j == i or nbytes + grads[j].numel() * grads[j].element_size() <= bucket_bytes):
+            nbytes += grads[j].numel() * grads[j].element_size()
+            j += 1
+        flat = torch.cat([g.reshape(-1) for g in grads[i:j]])
+        dist.all_reduce(flat, group=group)
+        flat.div_(world)
+        off = 0
+        for g in grads[i:j]:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        i = j

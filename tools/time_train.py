@@ -1,0 +1,62 @@
+"""Times one training step (forward + HIP backward + Adam) of the affinity network on synthetic data.
+usage: python tools/time_train.py [--max-obj 90] [--feats 3] [--points 5] [--batch 4] [--steps 5]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import shasta_amd  # noqa: E402
+from shasta_amd import training  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--max-obj", type=int, default=90)
+ap.add_argument("--feats", type=int, default=3)
+ap.add_argument("--points", type=int, default=5)
+ap.add_argument("--batch", type=int, default=4)
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--hw", type=int, default=180)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+cfg = dict(type="Shasta", reader=None, backbone=None, neck=None,
+           bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
+           max_obj=a.max_obj, num_feats=a.feats, num_point=a.points, in_channels=512)
+model = shasta_amd.build_simp_track(cfg).to(dev).train()
+params = training.affinity_params(model)
+opt = torch.optim.Adam(params, lr=1e-4)
+N, B = a.max_obj, a.batch
+g = torch.Generator(device="cpu").manual_seed(1)
+bev = torch.relu(torch.randn(B, a.hw, a.hw, 64, generator=g)).to(dev)
+pbev = torch.relu(torch.randn(B, a.hw, a.hw, 64, generator=g)).to(dev)
+
+
+def boxes():
+    t = torch.zeros(B, N, 11)
+    t[:, :, :2] = (torch.rand(B, N, 2, generator=g) - 0.5) * 100
+    t[:, :, 2] = torch.randn(B, N, generator=g)
+    t[:, :, 3:6] = torch.rand(B, N, 3, generator=g) * 3 + 0.5
+    t[:, :, 6] = (torch.rand(B, N, generator=g) - 0.5) * 6.28
+    t[:, :, 7:9] = torch.randn(B, N, 2, generator=g)
+    t[:, :, 9] = 0.5
+    return t.to(dev)
+
+
+det0, prev0 = boxes(), boxes()
+gt = (torch.rand(B, N + 2, N + 2, generator=g) < 0.02).float().to(dev)
+gt[:, 0, 0] = 1
+for it in range(a.steps + 2):
+    if it == 2:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+    opt.zero_grad(set_to_none=True)
+    m1, m2 = training.affinity_train(model, bev, pbev, det0.clone(), prev0.clone())
+    loss = training.affinity_loss(m1, m2, gt)
+    loss.backward()
+    opt.step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+print("max_obj=%d F=%d B=%d: %.2f ms/step, %.1f frame-pairs/s, loss %.4f, peak mem %.2f GB" % (
+    N, model.aug_shape_output, B, dt * 1e3, B / dt, float(loss.detach()), torch.cuda.max_memory_allocated() / 2**30))
