@@ -222,16 +222,15 @@ int shasta_gemm_strided_f32(const float* A, long sa_m, long sa_k, const float* W
                             shasta_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * Training path, backward helpers (first version: reference/dense formulation of the pair MLPs; the nn.Linear layers run
- * on shasta_gemm_strided_f32).  Replaces what torch autograd derives from det3d/models/tracker/shasta.py:241-325 in
+ * Training path, backward helpers (the nn.Linear layers run on shasta_gemm_strided_f32; the first layer of each pair MLP
+ * is factorised over the table rows).  Replaces what torch autograd derives from det3d/models/tracker/shasta.py:241-325 in
  * tools/nusc_shasta/train.py:198-213.
  * ------------------------------------------------------------------------------------------ */
-/* pair tensor X[(b,t,d)][:ld]: kind 0 = fuse_shape input (shasta.py:286), 1 = res_coeff input (:310-312), 2 = fuse_det (:303) */
-int shasta_pair_concat_f32(const float* prev_feat, const float* feat, const float* prev_tab, const float* det_tab, int B,
-                           int T, int D, int F, int nf, int kind, int ld, float* X, shasta_stream_t stream);
-/* its transpose: table gradients += sums of pair gradients (fixed order) */
-int shasta_pair_concat_bwd_f32(const float* dX, int B, int T, int D, int F, int nf, int kind, int ld, float* dprev_feat,
-                               float* dfeat, float* dprev_tab, float* ddet_tab, shasta_stream_t stream);
+/* factorised first layer of a pair MLP: H[(b,t,d)][:E] = relu(UP[(b,t)][:E] + UC[(b,d)][:E]) (H is (B*T*D, E) dense) */
+int shasta_pair_hidden_f32(const float* UP, int ldp, const float* UC, int ldc, int B, int T, int D, int E, float* H,
+                           shasta_stream_t stream);
+/* its transpose: gUP[(b,t)] = sum_d gZ[(b,t,d)], gUC[(b,d)] = sum_t gZ[(b,t,d)]  (dense (B*T, E) outputs, fixed order) */
+int shasta_pair_reduce_f32(const float* gZ, int B, int T, int D, int E, float* gUP, float* gUC, shasta_stream_t stream);
 /* hand-designed residual (shasta.py:277-283) materialised: dist (B,T,ld), denom (>= 2*B*D floats: column norms, scratch) */
 int shasta_hand_dist_f32(const float* prev_tab, const float* det_tab, int B, int T, int D, int nf, float* dist, int ld,
                          float* denom, shasta_stream_t stream);
@@ -239,17 +238,15 @@ int shasta_hand_dist_f32(const float* prev_tab, const float* det_tab, int B, int
 int shasta_hand_dist_bwd_f32(const float* gdist, int ldg, const float* prev_tab, const float* det_tab, float* denom, int B,
                              int T, int D, int nf, int row0, int nrows, float* dprev_tab, float* ddet_tab,
                              shasta_stream_t stream);
-/* residual = alpha*fused + beta*dist + omega*shape (shasta.py:319) and its gradient */
-int shasta_combine_f32(const float* coeff, int ldc, const float* fused, int ldf, const float* shape, int lds, const float* dist,
-                       int B, int T, int D, int ld, float* residual, shasta_stream_t stream);
+/* gradient of residual = alpha*fused + beta*dist + omega*shape (shasta.py:319) */
 int shasta_combine_bwd_f32(const float* gres, const float* coeff, int ldc, const float* fused, int ldf, const float* shape,
                            int lds, const float* dist, int B, int T, int D, int ld, float* gcoeff, float* gfused,
                            float* gshape, float* gdist, shasta_stream_t stream);
 /* gradient of the two softmaxes (shasta.py:324-325) w.r.t. matched (B, N+2, ld) */
 int shasta_softmax_bwd_f32(const float* m1, const float* g1, const float* m2, const float* g2, int B, int N, float* gmatched,
                            int ld, shasta_stream_t stream);
-/* out[n] = sum_m Y[m][n] (bias gradients) */
-int shasta_colsum_f32(const float* Y, int ldy, int M, int N, float* out, shasta_stream_t stream);
+/* out[n] = sum_m Y[m][n] (bias gradients); ws (optional, up to 1024*N floats used) lets the rows be split over the chip */
+int shasta_colsum_f32(const float* Y, int ldy, int M, int N, float* out, float* ws, size_t ws_bytes, shasta_stream_t stream);
 /* columns [c0,c1) of rows of width `cols`: forward out = |x|, backward out = g*sign(x); other columns pass through */
 int shasta_abs_f32(const float* x, const float* g, float* out, long n, int cols, int c0, int c1, int backward,
                    shasta_stream_t stream);

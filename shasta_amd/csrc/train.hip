@@ -1,72 +1,55 @@
 // Training path (SURVEY.md 8(a) row 19 / BASELINE config 5): auxiliary kernels of the backward pass.
 // The dense layers run on the strided matrix-core GEMM (gemm_f32.hip: Y = X W^T, dX = dY W, dW = dY^T X); this file holds
-// what is not a GEMM: pair-tensor assembly and its transpose (the cat/expand of det3d/models/tracker/shasta.py:286-313
-// and their autograd), the hand-designed residual and its gradient (:277-283), the combine (:319), the two softmax
-// backward passes (:324-325), bias-gradient column sums, |x| backward and the gather's scatter-add.
-// First version of the training path: the pair tensor IS materialised here (reference formulation), so that every saved
-// activation is a plain matrix; the factorised backward is future work.  All reductions have a fixed order except the
-// scatter-add into the BEV gradient, which uses float atomics (documented, gradient of inputs only).
+// what is not a GEMM: the factorised first layer of the pair MLPs and its transpose (the cat/expand of
+// det3d/models/tracker/shasta.py:286-313 and their autograd), the hand-designed residual and its gradient (:277-283), the
+// combine's gradient (:319), the two softmax backward passes (:324-325), bias-gradient column sums, |x| backward and the
+// gather's scatter-add.  The (B, T*D, 2F) pair tensor of the reference is not materialised; the narrow hidden activations
+// of each pair are.  All reductions have a fixed order except the scatter-add into the BEV gradient, which uses float
+// atomics (gradient of an input only).
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace shasta {
 
-// ---- pair tensor assembly: X[(b,t,d)][:] ---------------------------------------------------------------------------
-// kind 0 (fuse_shape): [prev_feat_t F | feat_d F]
-// kind 1 (res_coeff) : [prev_feat_t F | prev_box_t nf | feat_d F | det_box_d nf]
-// kind 2 (fuse_det)  : [prev_box_t nf | det_box_d nf]
-__device__ __forceinline__ void pair_col(int kind, int F, int nf, int c, int& src, int& off) {
-    // src: 0 prev_feat, 1 prev_box, 2 feat, 3 det_box, -1 padding
-    if (kind == 0) {
-        if (c < F) { src = 0; off = c; } else if (c < 2 * F) { src = 2; off = c - F; } else src = -1;
-    } else if (kind == 1) {
-        if (c < F) { src = 0; off = c; }
-        else if (c < F + nf) { src = 1; off = c - F; }
-        else if (c < 2 * F + nf) { src = 2; off = c - F - nf; }
-        else if (c < 2 * F + 2 * nf) { src = 3; off = c - 2 * F - nf; }
-        else src = -1;
-    } else {
-        if (c < nf) { src = 1; off = c; } else if (c < 2 * nf) { src = 3; off = c - nf; } else src = -1;
-    }
+// ---- factorised first layer of the pair MLPs ---------------------------------------------------------------------------
+// W0 . [prev_t ; cur_d] + b0 = UP[t] + UC[d] (pair_layout.hpp): the hidden activations of every pair are
+//   H[(b,t,d)][j] = relu(UP[(b,t)][j] + UC[(b,d)][j]),
+// and the gradient of the pre-activation Z folds back onto the table rows by two fixed-order sums,
+//   gUP[(b,t)][j] = sum_d gZ[(b,t,d)][j],   gUC[(b,d)][j] = sum_t gZ[(b,t,d)][j],
+// after which dW0, db0 and the table gradients are small GEMMs over B*T rows instead of B*T*D pairs.
+__global__ __launch_bounds__(256) void pair_hidden_kernel(const float* __restrict__ UP, int ldp, const float* __restrict__ UC, int ldc,
+                                                          int T, int D, int E, long total, float* __restrict__ H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // element (b,t,d,j)
+    if (i >= total) return;
+    const int j = i % E;
+    const long pr = i / E;
+    const int d = pr % D;
+    const long bt = pr / D;
+    const long b = bt / T;
+    H[i] = fmaxf(UP[bt * ldp + j] + UC[(b * D + d) * ldc + j], 0.0f);
 }
 
-__global__ void pair_concat_kernel(const float* __restrict__ prev_feat, const float* __restrict__ feat,
-                                   const float* __restrict__ prev_tab, const float* __restrict__ det_tab, int B, int T, int D,
-                                   int F, int nf, int kind, int ld, float* __restrict__ X) {
-    const long row = blockIdx.x;  // (b, t, d)
-    const int d = row % D, t = (row / D) % T, b = row / ((long)T * D);
-    for (int c = threadIdx.x; c < ld; c += blockDim.x) {
-        int src, off = 0;
-        pair_col(kind, F, nf, c, src, off);
-        float v = 0.0f;
-        if (src == 0) v = prev_feat[((size_t)b * T + t) * F + off];
-        else if (src == 1) v = prev_tab[((size_t)b * T + t) * 8 + off];
-        else if (src == 2) v = feat[((size_t)b * D + d) * F + off];
-        else if (src == 3) v = det_tab[((size_t)b * D + d) * 8 + off];
-        X[row * ld + c] = v;
-    }
-}
-
-// transpose of the assembly: every table element sums the gradients of the pairs it was copied into (fixed order)
-//   dprev_feat[b,t,:] += sum_d dX[(b,t,d)][prev cols] ; dfeat[b,d,:] += sum_t dX[(b,t,d)][cur cols] ; boxes likewise
-__global__ void pair_concat_bwd_kernel(const float* __restrict__ dX, int B, int T, int D, int F, int nf, int kind, int ld,
-                                       float* __restrict__ dprev_feat, float* __restrict__ dfeat,
-                                       float* __restrict__ dprev_tab, float* __restrict__ ddet_tab) {
-    const int which = blockIdx.y;  // 0: previous-side rows (b,t), 1: current-side rows (b,d)
-    const int rows = which == 0 ? T : D;
-    const int r = blockIdx.x % rows, b = blockIdx.x / rows;
-    for (int c = threadIdx.x; c < ld; c += blockDim.x) {
-        int src, off = 0;
-        pair_col(kind, F, nf, c, src, off);
-        if (src < 0 || (which == 0 && src >= 2) || (which == 1 && src < 2)) continue;
-        float s = 0.0f;
+// block = (row r of side `which`, batch b); threads = E columns x G row groups
+__global__ __launch_bounds__(256) void pair_reduce_kernel(const float* __restrict__ gZ, int T, int D, int E, int EP,
+                                                          float* __restrict__ gUP, float* __restrict__ gUC) {
+    __shared__ float red[256];
+    const int which = blockIdx.y, b = blockIdx.z, r = blockIdx.x;
+    const int j = threadIdx.x % EP, q = threadIdx.x / EP, G = 256 / EP;
+    const int n = which == 0 ? D : T;
+    float s = 0.0f;
+    if (j < E) {
         if (which == 0)
-            for (int d = 0; d < D; ++d) s += dX[(((size_t)b * T + r) * D + d) * ld + c];
+            for (int d = q; d < n; d += G) s += gZ[(((size_t)b * T + r) * D + d) * E + j];
         else
-            for (int t = 0; t < T; ++t) s += dX[(((size_t)b * T + t) * D + r) * ld + c];
-        if (src == 0) dprev_feat[((size_t)b * T + r) * F + off] += s;
-        else if (src == 1) dprev_tab[((size_t)b * T + r) * 8 + off] += s;
-        else if (src == 2) dfeat[((size_t)b * D + r) * F + off] += s;
-        else ddet_tab[((size_t)b * D + r) * 8 + off] += s;
+            for (int t = q; t < n; t += G) s += gZ[(((size_t)b * T + t) * D + r) * E + j];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (q == 0 && j < E) {
+        float t = 0.0f;
+        for (int k = 0; k < G; ++k) t += red[k * EP + j];
+        (which == 0 ? gUP : gUC)[((size_t)b * (which == 0 ? T : D) + r) * E + j] = t;
     }
 }
 
@@ -194,17 +177,6 @@ __global__ __launch_bounds__(256) void hand_gs_kernel(const float* __restrict__ 
 
 // ---- combine (shasta.py:319) ------------------------------------------------------------------------------------------
 // residual = alpha*fused + beta*dist + omega*shape ; coeff (P, ldc>=3), fused (P), shape (P), dist/residual (B,T,ld)
-__global__ void combine_fwd_kernel(const float* __restrict__ coeff, int ldc, const float* __restrict__ fused, int ldf,
-                                   const float* __restrict__ shape, int lds_, const float* __restrict__ dist, int T, int D, int ld,
-                                   long P, float* __restrict__ residual) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const int d = i % D;
-    const long bt = i / D;
-    const float a = coeff[i * ldc], be = coeff[i * ldc + 1], om = coeff[i * ldc + 2];
-    residual[bt * ld + d] = (a * fused[i * ldf] + be * dist[bt * ld + d]) + om * shape[i * lds_];
-}
-
 __global__ void combine_bwd_kernel(const float* __restrict__ gres, const float* __restrict__ coeff, int ldc,
                                    const float* __restrict__ fused, int ldf, const float* __restrict__ shape, int lds_,
                                    const float* __restrict__ dist, int D, int ld, long P, float* __restrict__ gcoeff,
@@ -265,16 +237,53 @@ __global__ __launch_bounds__(256) void softmax_bwd_cols_kernel(const float* __re
 }
 
 // ---- small helpers ------------------------------------------------------------------------------------------------------
-// out[n] = sum_m Y[m][n] (bias gradient), one block per 64 columns, fixed order
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Y, int ldy, int M, int N, float* __restrict__ out) {
+// out[n] = sum_m Y[m][n] (bias gradient): block (x: 64 columns, y: row chunk) sums its rows in a fixed order into
+// part[chunk][n]; a second launch adds the chunks in order (single chunk: written directly).  Deterministic.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Y, int ldy, int M, int N, int rows_per_chunk,
+                                                     float* __restrict__ out) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+    float s0 = 0.0f, s1 = 0.0f;
+    if (c < N) {
+        int m = m0 + q;
+        for (; m + 4 < m1; m += 8) {
+            s0 += Y[(size_t)m * ldy + c];
+            s1 += Y[(size_t)(m + 4) * ldy + c];
+        }
+        if (m < m1) s0 += Y[(size_t)m * ldy + c];
+    }
+    red[q][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (q == 0 && c < N)
+        out[(size_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// narrow matrices (N < 64): one wave per row chunk would idle most lanes, so lanes split the rows instead: lane l of a
+// 256-thread block owns column l % NP and every (256/NP)-th row of the chunk
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* __restrict__ Y, int ldy, int M, int N, int NP,
+                                                            int rows_per_chunk, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int c = threadIdx.x % NP, q = threadIdx.x / NP, nq = 256 / NP;
+    const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
     float s = 0.0f;
     if (c < N)
-        for (int m = q; m < M; m += 4) s += Y[(size_t)m * ldy + c];
-    red[q][threadIdx.x & 63] = s;
+        for (int m = m0 + q; m < m1; m += nq) s += Y[(size_t)m * ldy + c];
+    red[threadIdx.x] = s;
     __syncthreads();
-    if (q == 0 && c < N) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (q == 0 && c < N) {
+        float t = 0.0f;
+        for (int k = 0; k < nq; ++k) t += red[k * NP + c];
+        out[(size_t)blockIdx.y * N + c] = t;
+    }
+}
+
+__global__ void colsum_finish_kernel(const float* __restrict__ part, int chunks, int N, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.0f;
+    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * N + c];
+    out[c] = s;
 }
 
 // y = |x| (mode 0) ; g_out = g * sign(x) (mode 1) over `cols` columns of each row, columns [c0, c1) only (others copied / passed)
@@ -345,26 +354,24 @@ __global__ __launch_bounds__(256) void bev_gather_bwd_kernel(const float* __rest
 
 using namespace shasta;
 
-extern "C" int shasta_pair_concat_f32(const float* prev_feat, const float* feat, const float* prev_tab, const float* det_tab, int B,
-                                      int T, int D, int F, int nf, int kind, int ld, float* X, shasta_stream_t stream) {
-    SHASTA_REQUIRE(prev_feat && feat && prev_tab && det_tab && X, "pair_concat: null pointer");
-    SHASTA_REQUIRE(kind >= 0 && kind <= 2 && nf >= 1 && nf <= 7, "pair_concat: bad kind / nf");
-    const long rows = (long)B * T * D;
-    SHASTA_REQUIRE(rows < (1L << 31), "pair_concat: too many pairs");
-    if (rows == 0) return SHASTA_OK;
-    hipLaunchKernelGGL(pair_concat_kernel, dim3((unsigned)rows), dim3(128), 0, as_stream(stream), prev_feat, feat, prev_tab, det_tab, B,
-                       T, D, F, nf, kind, ld, X);
-    return check_launch("pair_concat");
+extern "C" int shasta_pair_hidden_f32(const float* UP, int ldp, const float* UC, int ldc, int B, int T, int D, int E, float* H,
+                                      shasta_stream_t stream) {
+    SHASTA_REQUIRE(UP && UC && H && E >= 1 && ldp >= E && ldc >= E, "pair_hidden: bad argument");
+    const long total = (long)B * T * D * E;
+    if (total == 0) return SHASTA_OK;
+    SHASTA_REQUIRE((total + 255) / 256 < (1L << 31), "pair_hidden: too many pairs");
+    hipLaunchKernelGGL(pair_hidden_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), UP, ldp, UC, ldc, T, D, E,
+                       total, H);
+    return check_launch("pair_hidden");
 }
 
-extern "C" int shasta_pair_concat_bwd_f32(const float* dX, int B, int T, int D, int F, int nf, int kind, int ld, float* dprev_feat,
-                                          float* dfeat, float* dprev_tab, float* ddet_tab, shasta_stream_t stream) {
-    SHASTA_REQUIRE(dX && dprev_feat && dfeat && dprev_tab && ddet_tab, "pair_concat_bwd: null pointer");
-    SHASTA_REQUIRE(T == D, "pair_concat_bwd: T must equal D");
-    if (B == 0) return SHASTA_OK;
-    hipLaunchKernelGGL(pair_concat_bwd_kernel, dim3(B * T, 2), dim3(128), 0, as_stream(stream), dX, B, T, D, F, nf, kind, ld,
-                       dprev_feat, dfeat, dprev_tab, ddet_tab);
-    return check_launch("pair_concat_bwd");
+extern "C" int shasta_pair_reduce_f32(const float* gZ, int B, int T, int D, int E, float* gUP, float* gUC, shasta_stream_t stream) {
+    SHASTA_REQUIRE(gZ && gUP && gUC && E >= 1 && E <= 256 && T == D, "pair_reduce: bad argument (E <= 256, T == D)");
+    if (B == 0 || T == 0) return SHASTA_OK;
+    int EP = 1;
+    while (EP < E) EP *= 2;
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3(T, 2, B), dim3(256), 0, as_stream(stream), gZ, T, D, E, EP, gUP, gUC);
+    return check_launch("pair_reduce");
 }
 
 extern "C" int shasta_hand_dist_f32(const float* prev_tab, const float* det_tab, int B, int T, int D, int nf, float* dist, int ld,
@@ -387,16 +394,6 @@ extern "C" int shasta_hand_dist_bwd_f32(const float* gdist, int ldg, const float
     hipLaunchKernelGGL(hand_dist_bwd_kernel, dim3(nrows, 2, B), dim3(256), 0, as_stream(stream), gdist, ldg, prev_tab, det_tab, denom,
                        T, D, nf, row0, dprev_tab, ddet_tab);
     return check_launch("hand_dist_bwd");
-}
-
-extern "C" int shasta_combine_f32(const float* coeff, int ldc, const float* fused, int ldf, const float* shape, int lds_, const float* dist,
-                                  int B, int T, int D, int ld, float* residual, shasta_stream_t stream) {
-    SHASTA_REQUIRE(coeff && fused && shape && dist && residual && ldc >= 3, "combine: bad argument");
-    const long P = (long)B * T * D;
-    if (P == 0) return SHASTA_OK;
-    hipLaunchKernelGGL(combine_fwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, as_stream(stream), coeff, ldc, fused, ldf,
-                       shape, lds_, dist, T, D, ld, P, residual);
-    return check_launch("combine_fwd");
 }
 
 extern "C" int shasta_combine_bwd_f32(const float* gres, const float* coeff, int ldc, const float* fused, int ldf, const float* shape,
@@ -422,11 +419,30 @@ extern "C" int shasta_softmax_bwd_f32(const float* m1, const float* g1, const fl
     return check_launch("softmax_bwd_cols");
 }
 
-extern "C" int shasta_colsum_f32(const float* Y, int ldy, int M, int N, float* out, shasta_stream_t stream) {
+extern "C" int shasta_colsum_f32(const float* Y, int ldy, int M, int N, float* out, float* ws, size_t ws_bytes,
+                                 shasta_stream_t stream) {
     SHASTA_REQUIRE(Y && out && M >= 0 && N >= 0, "colsum: bad argument");
     if (N == 0) return SHASTA_OK;
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(256), 0, as_stream(stream), Y, ldy, M, N, out);
-    return check_launch("colsum");
+    // row chunks: enough blocks to fill the chip, at least 64 rows each, bounded by the scratch the caller gave
+    const int colblocks = N >= 64 ? cdiv(N, 64) : 1;
+    int chunks = std::min(std::max(1, 1024 / colblocks), std::max(1, M / 64));
+    if (!ws) chunks = 1;
+    else chunks = (int)std::min<size_t>((size_t)chunks, ws_bytes / (sizeof(float) * (size_t)N));
+    chunks = std::max(chunks, 1);
+    const int rpc = cdiv(std::max(M, 1), chunks);
+    chunks = cdiv(std::max(M, 1), rpc);
+    float* dst = chunks == 1 ? out : ws;
+    if (N >= 64) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(colblocks, chunks), dim3(256), 0, as_stream(stream), Y, ldy, M, N, rpc, dst);
+    } else {
+        int NP = 1;
+        while (NP < N) NP *= 2;
+        hipLaunchKernelGGL(colsum_narrow_kernel, dim3(1, chunks), dim3(256), 0, as_stream(stream), Y, ldy, M, N, NP, rpc, dst);
+    }
+    int rc = check_launch("colsum");
+    if (rc || chunks == 1) return rc;
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), ws, chunks, N, out);
+    return check_launch("colsum_finish");
 }
 
 extern "C" int shasta_abs_f32(const float* x, const float* g, float* out, long n, int cols, int c0, int c1, int backward,

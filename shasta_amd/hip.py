@@ -56,14 +56,13 @@ SYMBOLS = {
     "shasta_pair_residual_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "shasta_aff_softmax_f32": (_I, [_WP, _P, _I, _P, _I, _P, _P, _P, _P, _Z, _P]),
     "shasta_iou3d_distance_f64": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
-    "shasta_pair_concat_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    "shasta_pair_concat_bwd_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "shasta_hand_dist_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "shasta_hand_dist_bwd_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "shasta_combine_f32": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "shasta_combine_bwd_f32": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "shasta_softmax_bwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _I, _P]),
-    "shasta_colsum_f32": (_I, [_P, _I, _I, _I, _P, _P]),
+    "shasta_pair_hidden_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "shasta_pair_reduce_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "shasta_colsum_f32": (_I, [_P, _I, _I, _I, _P, _P, C.c_size_t, _P]),
     "shasta_abs_f32": (_I, [_P, _P, _P, C.c_long, _I, _I, _I, _I, _P]),
     "shasta_bev_gather_bwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
     "shasta_decode_flags_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
@@ -107,6 +106,15 @@ def ptr(t):
         raise ShastaHipError("unexpected dtype %s" % t.dtype)
     if not t.is_contiguous():
         raise ShastaHipError("expected a contiguous tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def ptr_view(t):
+    """Pointer to the first element of a strided VIEW (column block of a matrix): the caller passes the strides."""
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise ShastaHipError("expected an fp32 device tensor (the HIP path has no CPU fallback)")
     return C.c_void_p(t.data_ptr())
 
 

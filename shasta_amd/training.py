@@ -8,7 +8,10 @@ with hand-written HIP kernels only: every nn.Linear through the strided matrix-c
 order split-K), everything else through csrc/train.hip.  No torch autograd op runs inside the Function; torch is used for
 buffer allocation.  Gradients flow to every parameter of rows 6-16 and to the NHWC BEV maps (so `shared_conv`, which stays
 a torch module in train() mode with batch statistics like the reference, trains through ordinary autograd).
-First version: correctness first (checked against torch autograd of the CPU oracle), the factorised backward is future work.
+The first layer of each pair MLP is factorised over the table rows in both directions (forward UP[t] + UC[d], backward
+row/column sums of the hidden gradient), so the (B, T*D, 2F) pair tensor of the reference is not materialised in training
+either; only the narrow hidden activations (F/8, F/8+32, 32 floats per pair) are.  Checked against torch autograd of the CPU
+oracle (tests/test_training.py).
 """
 import ctypes as C
 
@@ -18,11 +21,16 @@ from . import hip
 
 
 def _gemm(lib, A, sa, W, sw, M, N, K, out, ldc=None, bias=None, act=0, mask=None, ldmask=0, accum=False, ws=None):
-    hip.check(lib.shasta_gemm_strided_f32(hip.ptr(A), sa[0], sa[1], hip.ptr(W), sw[0], sw[1], hip.ptr(bias), hip.ptr(mask), ldmask,
-                                          hip.ptr(out), ldc if ldc is not None else N, M, N, K, act + (4 if accum else 0),
+    hip.check(lib.shasta_gemm_strided_f32(hip.ptr_view(A), sa[0], sa[1], hip.ptr_view(W), sw[0], sw[1], hip.ptr(bias), hip.ptr(mask), ldmask,
+                                          hip.ptr_view(out), ldc if ldc is not None else N, M, N, K, act + (4 if accum else 0),
                                           hip.ptr(ws), ws.numel() * 4 if ws is not None else 0, hip.stream_ptr()),
               "shasta_gemm_strided_f32")
     return out
+
+
+def _colsum(lib, Y, ldy, M, N, out, ws):
+    hip.check(lib.shasta_colsum_f32(hip.ptr(Y), ldy, M, N, hip.ptr(out), hip.ptr(ws), ws.numel() * 4 if ws is not None else 0,
+                                    hip.stream_ptr()), "shasta_colsum_f32")
 
 
 class _Mlp:
@@ -43,8 +51,9 @@ class _Mlp:
         self.acts, self.ldx, self.M = acts, ldx, M
         return acts[-1]
 
-    def backward(self, gY, need_gx=True, gx_ld=None):
-        """gY (M, out_last).  Returns (list of (gW, gb)), gX (M, gx_ld) or None."""
+    def backward(self, gY, need_gx=True, gx_ld=None, mask_input=False):
+        """gY (M, out_last).  Returns (list of (gW, gb)), gX (M, gx_ld) or None.  mask_input: X is itself a ReLU output and
+        the returned gradient is the one of its pre-activation."""
         lib, M = self.lib, self.M
         grads = [None] * len(self.layers)
         g = gY
@@ -56,7 +65,7 @@ class _Mlp:
             gW = torch.empty_like(w)
             _gemm(lib, g, (1, nout), x, (1, ldx), nout, nin, M, gW, ws=self.ws)          # dW = dY^T X
             gb = torch.empty_like(b)
-            hip.check(lib.shasta_colsum_f32(hip.ptr(g), nout, M, nout, hip.ptr(gb), hip.stream_ptr()), "shasta_colsum_f32")
+            _colsum(lib, g, nout, M, nout, gb, self.ws)
             grads[i] = (gW, gb)
             if i > 0:
                 gx = torch.empty(M, nin, device=g.device)
@@ -65,7 +74,7 @@ class _Mlp:
             elif need_gx:
                 ld = gx_ld if gx_ld is not None else nin
                 gx = torch.zeros(M, ld, device=g.device) if ld != nin else torch.empty(M, nin, device=g.device)
-                _gemm(lib, g, (nout, 1), w, (1, nin), M, nin, nout, gx, ldc=ld)
+                _gemm(lib, g, (nout, 1), w, (1, nin), M, nin, nout, gx, ldc=ld, mask=x if mask_input else None, ldmask=ldx)
                 g = gx
             else:
                 g = None
@@ -117,41 +126,76 @@ class _AffinityTrainFn(torch.autograd.Function):
         gmc = gm[:, :D].contiguous()
         aff_grads, gres = aff.backward(gmc, need_gx=True, gx_ld=Dp)  # gres (B*T, Dp)
 
-        # ---- pair MLPs, dense recompute (shasta.py:286-316) ----
-        def concat(kind, ld):
-            X = torch.empty(P, ld, device=dev)
-            hip.check(lib.shasta_pair_concat_f32(hip.ptr(S["prev_feat"]), hip.ptr(S["feat"]), hip.ptr(S["prev_tab"]), hip.ptr(S["det_tab"]),
-                                                 B, T, D, F, nf, kind, ld, hip.ptr(X), st()), "shasta_pair_concat_f32")
-            return X
-
-        ld_fs, ld_rc, ld_fd = 2 * F, 2 * F + 2 * nf, 2 * nf
-        Xfs, Xrc, Xfd = concat(0, ld_fs), concat(1, ld_rc), concat(2, ld_fd)
+        # ---- pair MLPs (shasta.py:286-316): first layers factorised over the table rows, later layers dense over pairs ----
+        pf, cf, pt, ct = S["prev_feat"], S["feat"], S["prev_tab"], S["det_tab"]
+        dfeat = torch.zeros(B, T, F, device=dev)
+        dprev_feat = torch.zeros(B, T, F, device=dev)
+        ddet_tab = torch.zeros(B, T, 8, device=dev)
+        dprev_tab = torch.zeros(B, T, 8, device=dev)
+        # column blocks of each first layer: (source table, its row stride, width, gradient table) for the previous / current side
+        parts = {
+            "fs": ([(pf, F, F, dprev_feat)], [(cf, F, F, dfeat)]),
+            "rc": ([(pf, F, F, dprev_feat), (pt, 8, nf, dprev_tab)], [(cf, F, F, dfeat), (ct, 8, nf, ddet_tab)]),
+            "fd": ([(pt, 8, nf, dprev_tab)], [(ct, 8, nf, ddet_tab)]),
+        }
         lin = lambda m, ks: [(m[k].weight.detach(), m[k].bias.detach()) for k in ks]  # noqa: E731
-        fs, rc, fd = _Mlp(lib, lin(model.fuse_shape, (0, 2, 4, 6)), ws), _Mlp(lib, lin(model.res_coeff, (0, 2, 4)), ws), \
-            _Mlp(lib, lin(model.fuse_det, (0, 2, 4)), ws)
-        shape = fs.forward(Xfs, ld_fs, P)      # (P,1)
-        coeff = rc.forward(Xrc, ld_rc, P)      # (P,3)
-        fused = fd.forward(Xfd, ld_fd, P)      # (P,1)
+        mods = {"fs": lin(model.fuse_shape, (0, 2, 4, 6)), "rc": lin(model.res_coeff, (0, 2, 4)), "fd": lin(model.fuse_det, (0, 2, 4))}
+        R = B * T
+
+        def first_layer(name):
+            """H (P, E) = relu(UP[t] + UC[d]); returns H and the column offsets of the parts inside W0."""
+            w0, b0 = mods[name][0]
+            E, kin = w0.shape
+            UP, UC = torch.empty(R, E, device=dev), torch.empty(R, E, device=dev)
+            col, offs = 0, []
+            for side, U in ((0, UP), (1, UC)):
+                for k, (tab, ld, wd, _) in enumerate(parts[name][side]):
+                    _gemm(lib, tab, (ld, 1), w0[:, col:], (kin, 1), R, E, wd, U, bias=b0 if (side == 1 and k == 0) else None, accum=k > 0)
+                    offs.append(col)
+                    col += wd
+            H = torch.empty(P, E, device=dev)
+            hip.check(lib.shasta_pair_hidden_f32(hip.ptr(UP), E, hip.ptr(UC), E, B, T, D, E, hip.ptr(H), st()), "shasta_pair_hidden_f32")
+            return H, offs
+
+        def first_layer_bwd(name, gZ, offs):
+            """gZ (P, E) gradient of the first layer's pre-activation -> (gW0, gb0); table gradients accumulated."""
+            w0, b0 = mods[name][0]
+            E, kin = w0.shape
+            gUP, gUC = torch.empty(R, E, device=dev), torch.empty(R, E, device=dev)
+            hip.check(lib.shasta_pair_reduce_f32(hip.ptr(gZ), B, T, D, E, hip.ptr(gUP), hip.ptr(gUC), st()), "shasta_pair_reduce_f32")
+            gW0, gb0 = torch.empty_like(w0), torch.empty_like(b0)
+            _colsum(lib, gUC, E, R, E, gb0, ws)
+            k = 0
+            for side, gU in ((0, gUP), (1, gUC)):
+                for tab, ld, wd, gtab in parts[name][side]:
+                    col = offs[k]
+                    k += 1
+                    _gemm(lib, gU, (1, E), tab, (1, ld), E, wd, R, gW0[:, col:], ldc=kin)                 # dW0 block = gU^T X
+                    _gemm(lib, gU, (E, 1), w0[:, col:], (1, kin), R, wd, E, gtab, ldc=ld, accum=True)      # dX += gU W0 block
+            return gW0, gb0
+
+        tails, Hs, offs_ = {}, {}, {}
+        outs = {}
+        for name in ("fs", "rc", "fd"):
+            Hs[name], offs_[name] = first_layer(name)
+            tails[name] = _Mlp(lib, mods[name][1:], ws)
+            outs[name] = tails[name].forward(Hs[name], Hs[name].shape[1], P)
+        shape, coeff, fused = outs["fs"], outs["rc"], outs["fd"]  # (P,1), (P,3), (P,1)
         dist = torch.empty(B * T, Dp, device=dev)
         denom = torch.empty(2 * B * D, device=dev)
-        hip.check(lib.shasta_hand_dist_f32(hip.ptr(S["prev_tab"]), hip.ptr(S["det_tab"]), B, T, D, nf, hip.ptr(dist), Dp, hip.ptr(denom), st()),
+        hip.check(lib.shasta_hand_dist_f32(hip.ptr(pt), hip.ptr(ct), B, T, D, nf, hip.ptr(dist), Dp, hip.ptr(denom), st()),
                   "shasta_hand_dist_f32")
         gcoeff, gfused, gshape = torch.empty(P, 3, device=dev), torch.empty(P, 1, device=dev), torch.empty(P, 1, device=dev)
         gdist = torch.zeros(B * T, Dp, device=dev)
         hip.check(lib.shasta_combine_bwd_f32(hip.ptr(gres), hip.ptr(coeff), 3, hip.ptr(fused), 1, hip.ptr(shape), 1, hip.ptr(dist), B, T, D, Dp,
                                              hip.ptr(gcoeff), hip.ptr(gfused), hip.ptr(gshape), hip.ptr(gdist), st()), "shasta_combine_bwd_f32")
-        fs_grads, gXfs = fs.backward(gshape)
-        rc_grads, gXrc = rc.backward(gcoeff)
-        fd_grads, gXfd = fd.backward(gfused)
-        del Xfs, Xrc, Xfd
-        dfeat = torch.zeros(B, T, F, device=dev)
-        dprev_feat = torch.zeros(B, T, F, device=dev)
-        ddet_tab = torch.zeros(B, T, 8, device=dev)
-        dprev_tab = torch.zeros(B, T, 8, device=dev)
-        for kind, gX, ld in ((0, gXfs, ld_fs), (1, gXrc, ld_rc), (2, gXfd, ld_fd)):
-            hip.check(lib.shasta_pair_concat_bwd_f32(hip.ptr(gX), B, T, D, F, nf, kind, ld, hip.ptr(dprev_feat), hip.ptr(dfeat),
-                                                     hip.ptr(dprev_tab), hip.ptr(ddet_tab), st()), "shasta_pair_concat_bwd_f32")
-        del gXfs, gXrc, gXfd
+        pair_grads = {}
+        for name, gout in (("fs", gshape), ("rc", gcoeff), ("fd", gfused)):
+            tail_grads, gZ = tails[name].backward(gout, mask_input=True)
+            pair_grads[name] = [first_layer_bwd(name, gZ, offs_[name])] + tail_grads
+            del gZ
+        fs_grads, rc_grads, fd_grads = pair_grads["fs"], pair_grads["rc"], pair_grads["fd"]
+        del Hs, tails, outs
         # ---- hand-designed residual -> anchor boxes (rows N, N+1 of both tables) ----
         hip.check(lib.shasta_hand_dist_bwd_f32(hip.ptr(gdist), Dp, hip.ptr(S["prev_tab"]), hip.ptr(S["det_tab"]), hip.ptr(denom), B, T, D, nf,
                                                N, 2, hip.ptr(dprev_tab), hip.ptr(ddet_tab), st()), "shasta_hand_dist_bwd_f32")
@@ -172,7 +216,7 @@ class _AffinityTrainFn(torch.autograd.Function):
             gpre = torch.empty(B, nout, device=dev)
             hip.check(lib.shasta_abs_f32(hip.ptr(pre), hip.ptr(g_out), hip.ptr(gpre), B * nout, nout, c0, c1, 1, st()), "shasta_abs_f32")
             gb2 = torch.empty_like(b2)
-            hip.check(lib.shasta_colsum_f32(hip.ptr(gpre), nout, B, nout, hip.ptr(gb2), st()), "shasta_colsum_f32")
+            _colsum(lib, gpre, nout, B, nout, gb2, ws)
             gW2, gW1, gb1 = torch.zeros_like(w2), torch.zeros_like(w1), torch.zeros_like(b1)
             gx = None
             if H > 0:
@@ -180,7 +224,7 @@ class _AffinityTrainFn(torch.autograd.Function):
                 ghid = torch.empty(B, H, device=dev)
                 _gemm(lib, gpre, (nout, 1), w2, (1, H), B, H, nout, ghid, mask=hid, ldmask=max(H, 1))
                 _gemm(lib, ghid, (1, H), x, (1, sx_m), H, K, B, gW1)
-                hip.check(lib.shasta_colsum_f32(hip.ptr(ghid), H, B, H, hip.ptr(gb1), st()), "shasta_colsum_f32")
+                _colsum(lib, ghid, H, B, H, gb1, ws)
                 gx = ghid
             return (gW1, gb1, gW2, gb2), gx, w1
 

@@ -117,3 +117,101 @@ def test_model_forward_is_differentiable_like_the_reference_module():
     for name, p in model.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
     assert float(model.shared_conv[0].weight.grad.abs().sum()) > 0
+
+
+# ---- helper kernels of csrc/train.hip, one by one, against torch ---------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N", [(1, 1), (5000, 1), (70001, 3), (4097, 40), (300, 64), (20000, 130)])
+def test_colsum(M, N):
+    from shasta_amd import hip
+    lib = hip.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M + N)
+    Y = torch.randn(M, N + 2, device=dev)  # leading dimension wider than N
+    out = torch.empty(N, device=dev)
+    ws = torch.empty(1024 * 130, device=dev)
+    for w in (ws, None):
+        out.fill_(-1)
+        hip.check(lib.shasta_colsum_f32(hip.ptr(Y), N + 2, M, N, hip.ptr(out), hip.ptr(w), ws.numel() * 4 if w is not None else 0,
+                                        hip.stream_ptr()), "colsum")
+        want = Y[:, :N].double().sum(0)
+        assert float((out.double() - want).abs().max()) <= 1e-5 * max(1.0, float(Y[:, :N].abs().sum(0).max()))
+    a = out.clone()
+    hip.check(lib.shasta_colsum_f32(hip.ptr(Y), N + 2, M, N, hip.ptr(out), hip.ptr(ws), ws.numel() * 4, hip.stream_ptr()), "colsum")
+    assert torch.equal(a, out) or True  # ws / no-ws may differ in rounding; repeated runs must not
+    b = out.clone()
+    hip.check(lib.shasta_colsum_f32(hip.ptr(Y), N + 2, M, N, hip.ptr(out), hip.ptr(ws), ws.numel() * 4, hip.stream_ptr()), "colsum")
+    assert torch.equal(b, out)
+
+
+@pytest.mark.gpu
+def test_abs_forward_and_backward():
+    from shasta_amd import hip
+    lib = hip.load()
+    dev = torch.device("cuda:0")
+    x = torch.randn(33, 7, device=dev)
+    x[0, 4] = 0.0
+    g = torch.randn(33, 7, device=dev)
+    out = torch.empty_like(x)
+    hip.check(lib.shasta_abs_f32(hip.ptr(x), None, hip.ptr(out), x.numel(), 7, 3, 6, 0, hip.stream_ptr()), "abs")
+    want = x.clone()
+    want[:, 3:6] = want[:, 3:6].abs()
+    assert torch.equal(out, want)
+    hip.check(lib.shasta_abs_f32(hip.ptr(x), hip.ptr(g), hip.ptr(out), x.numel(), 7, 3, 6, 1, hip.stream_ptr()), "abs")
+    wg = g.clone()
+    wg[:, 3:6] = g[:, 3:6] * torch.sign(x[:, 3:6])
+    assert torch.equal(out, wg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,E", [(1, 3, 1), (2, 22, 40), (3, 92, 72), (1, 130, 64)])
+def test_pair_hidden_and_reduce(B, T, E):
+    from shasta_amd import hip
+    lib = hip.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(E)
+    UP, UC = torch.randn(B * T, E + 4, device=dev), torch.randn(B * T, E, device=dev)
+    H = torch.empty(B * T * T, E, device=dev)
+    hip.check(lib.shasta_pair_hidden_f32(hip.ptr(UP), E + 4, hip.ptr(UC), E, B, T, T, E, hip.ptr(H), hip.stream_ptr()), "pair_hidden")
+    want = torch.relu(UP[:, :E].view(B, T, 1, E) + UC.view(B, 1, T, E))
+    assert torch.equal(H.view(B, T, T, E), want)
+    gZ = torch.randn(B * T * T, E, device=dev)
+    gUP, gUC = torch.empty(B * T, E, device=dev), torch.empty(B * T, E, device=dev)
+    hip.check(lib.shasta_pair_reduce_f32(hip.ptr(gZ), B, T, T, E, hip.ptr(gUP), hip.ptr(gUC), hip.stream_ptr()), "pair_reduce")
+    g4 = gZ.view(B, T, T, E).double()
+    assert float((gUP.view(B, T, E).double() - g4.sum(2)).abs().max()) < 1e-4
+    assert float((gUC.view(B, T, E).double() - g4.sum(1)).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nf", [3, 7])
+def test_hand_dist_forward_and_anchor_gradient(nf):
+    """shasta.py:277-283 materialised + its gradient w.r.t. the two anchor rows of both box tables."""
+    from shasta_amd import hip
+    lib = hip.load()
+    dev = torch.device("cuda:0")
+    B, N = 2, 18
+    T = N + 2
+    gen = torch.Generator().manual_seed(nf)
+    p7 = O.synth_boxes(gen, B, T, None)[:, :, :7].contiguous()
+    q7 = O.synth_boxes(gen, B, T, None)[:, :, :7].contiguous()
+    pa, qa = p7[:, N:].clone().requires_grad_(True), q7[:, N:].clone().requires_grad_(True)
+    want = O.hand_residual(torch.cat([p7[:, :N], pa], 1), torch.cat([q7[:, :N], qa], 1), nf)
+    g = torch.randn(B, T, T, generator=gen)
+    (want * g).sum().backward()
+    ptab, qtab = torch.zeros(B, T, 8), torch.zeros(B, T, 8)
+    ptab[:, :, :7], qtab[:, :, :7] = p7, q7
+    ptab, qtab = ptab.to(dev), qtab.to(dev)
+    Dp = (T + 3) // 4 * 4
+    dist = torch.zeros(B * T, Dp, device=dev)
+    denom = torch.empty(2 * B * T, device=dev)
+    hip.check(lib.shasta_hand_dist_f32(hip.ptr(ptab), hip.ptr(qtab), B, T, T, nf, hip.ptr(dist), Dp, hip.ptr(denom), hip.stream_ptr()), "hand_dist")
+    np.testing.assert_allclose(dist.view(B, T, Dp)[:, :, :T].cpu().numpy(), want.detach().numpy(), rtol=2e-5, atol=2e-5)
+    gd = torch.zeros(B, T, Dp, device=dev)
+    gd[:, :, :T] = g.to(dev)
+    dp, dq = torch.zeros(B, T, 8, device=dev), torch.zeros(B, T, 8, device=dev)
+    hip.check(lib.shasta_hand_dist_bwd_f32(hip.ptr(gd), Dp, hip.ptr(ptab), hip.ptr(qtab), hip.ptr(denom), B, T, T, nf, N, 2, hip.ptr(dp),
+                                           hip.ptr(dq), hip.stream_ptr()), "hand_dist_bwd")
+    _close("d prev anchors", dp[:, N:, :7], pa.grad, rtol=1e-3)
+    _close("d det anchors", dq[:, N:, :7], qa.grad, rtol=1e-3)
+    assert float(dp[:, :N].abs().max()) == 0.0 and float(dq[:, :N].abs().max()) == 0.0
