@@ -156,6 +156,15 @@ int shasta_affinity_forward_f32(const shasta_weights* w, const void* packed, int
                                 float* matched2, float* residual_out, float* matched_out,
                                 void* workspace, size_t workspace_bytes, shasta_stream_t stream);
 
+/* Training forward: the same kernels and values as shasta_affinity_forward_f32; additionally keeps what the backward
+ * needs and the inference path throws away: residual_out (B, N+2, N+2) and shape_hidden_out (B, 4*H), H = N*F/64, the ReLU
+ * outputs of aug_shape.{0..3}.0 (row b = [mlp0 H | mlp1 H | mlp2 H | mlp3 H]), so that the 4 x (H, N*F) first-layer weights
+ * are not streamed a second time to recompute them. */
+int shasta_affinity_forward_train_f32(const shasta_weights* w, const void* packed, int B, float* feat, float* prev_feat,
+                                      float* det_boxes, const float* prev_det_boxes, int box_stride, float* det_tab,
+                                      float* prev_tab, float* matched1, float* matched2, float* residual_out,
+                                      float* shape_hidden_out, void* workspace, size_t workspace_bytes,
+                                      shasta_stream_t stream);
 /* Measurement variant of the forward: identical work, plus hipEventRecord(ev_l1_start/stop) on `stream` around the
  * launch of the dominant kernel (the aug_shape first-layer weight stream, anchor_l1_kernel), so that bench.py can
  * read that kernel's duration live inside its timed region.  Events come from shasta_event_create (they are plain

@@ -256,6 +256,12 @@ static void launch_l1(const AnchorL1Args& a, hipStream_t st) {
     hipLaunchKernelGGL((anchor_l1_kernel<BT, R>), grid, dim3(256), 0, st, a);
 }
 
+// where anchor_shape leaves relu(W1 x + b1): (B, 4H), MLP-major inside a row; valid until the workspace is re-used
+const float* anchor_shape_hidden(const void* ws, int B, int N, int F) {
+    const size_t H = (size_t)N * F / 64;
+    return reinterpret_cast<const float*>(static_cast<const char*>(ws) + align_up((size_t)64 * B * 4 * H * sizeof(float), 256));
+}
+
 int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes,
                  hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const int N = w->max_obj, F = w->feat_dim;

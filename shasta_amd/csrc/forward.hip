@@ -7,6 +7,7 @@ size_t anchor_shape_workspace_bytes(int B, int N, int F);
 size_t anchor_boxes_workspace_bytes(int B, int N);
 size_t pair_workspace_bytes(int B, int N, int F);
 size_t aff_workspace_bytes(int B, int N);
+const float* anchor_shape_hidden(const void* ws, int B, int N, int F);
 int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes, hipStream_t st,
                  hipEvent_t ev0, hipEvent_t ev1);
 int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes, int box_stride,
@@ -137,7 +138,8 @@ extern "C" int shasta_aff_softmax_f32(const shasta_weights* w, const void* packe
 static int forward_impl(const shasta_weights* w, const void* packed, int B, float* feat, float* prev_feat,
                         float* det_boxes, const float* prev_det_boxes, int box_stride, float* det_tab, float* prev_tab,
                         float* matched1, float* matched2, float* residual_out, float* matched_out, void* workspace,
-                        size_t workspace_bytes, shasta_stream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+                        size_t workspace_bytes, shasta_stream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                        float* shape_hidden_out = nullptr) {
     int rc = check_weights(w);
     if (rc) return rc;
     SHASTA_REQUIRE(B >= 0 && packed && feat && prev_feat && det_boxes && prev_det_boxes && det_tab && prev_tab &&
@@ -159,6 +161,15 @@ static int forward_impl(const shasta_weights* w, const void* packed, int B, floa
     const size_t stage_bytes = L.total - L.residual;
     const float* pk = static_cast<const float*>(packed);
     if ((rc = anchor_shape(w, B, feat, prev_feat, stage, stage_bytes, st, ev0, ev1))) return rc;
+    if (shape_hidden_out) {  // training: the backward re-uses the hidden activations instead of re-streaming the weights
+        const size_t H = (size_t)N * F / 64;
+        hipError_t e = hipMemcpyAsync(shape_hidden_out, anchor_shape_hidden(stage, B, N, F), (size_t)B * 4 * H * sizeof(float),
+                                      hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) {
+            set_error("forward: copy anchor hidden", e);
+            return SHASTA_E_LAUNCH;
+        }
+    }
     if ((rc = anchor_boxes(w, B, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, static_cast<float*>(stage), st)))
         return rc;
     if ((rc = pair_residual(w, pk, B, feat, prev_feat, det_tab, prev_tab, residual, Dp, stage, stage_bytes, st))) return rc;
@@ -180,6 +191,17 @@ extern "C" int shasta_affinity_forward_f32(const shasta_weights* w, const void* 
                                            size_t workspace_bytes, shasta_stream_t stream) {
     return forward_impl(w, packed, B, feat, prev_feat, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, matched1,
                         matched2, residual_out, matched_out, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int shasta_affinity_forward_train_f32(const shasta_weights* w, const void* packed, int B, float* feat,
+                                                 float* prev_feat, float* det_boxes, const float* prev_det_boxes,
+                                                 int box_stride, float* det_tab, float* prev_tab, float* matched1,
+                                                 float* matched2, float* residual_out, float* shape_hidden_out,
+                                                 void* workspace, size_t workspace_bytes, shasta_stream_t stream) {
+    SHASTA_REQUIRE(residual_out && shape_hidden_out, "forward_train: null output");
+    return forward_impl(w, packed, B, feat, prev_feat, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, matched1,
+                        matched2, residual_out, nullptr, workspace, workspace_bytes, stream, nullptr, nullptr,
+                        shape_hidden_out);
 }
 
 extern "C" int shasta_affinity_forward_timed_f32(const shasta_weights* w, const void* packed, int B, float* feat,

@@ -237,11 +237,11 @@ class Shasta(BaseTrack):
                                              hip.ptr(outp), hip.stream_ptr()), "shasta_shared_conv_f32")
         return out if prev_bev_map is None else (out, outp)
 
-    def affinity_from_bev(self, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes, l1_events=None, _allow_grad=False):
+    def affinity_from_bev(self, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes, l1_events=None, _train_keep=None):
         """Rows 4-16 of SURVEY.md 8(a) (shasta.py:231-325) on device.  bev maps (B,H,W,C) fp32 NHWC, boxes (B,N,>=10)
         fp32 contiguous; det_boxes[:, :, :2] is back-projected in place."""
         lib = hip.load()
-        if not _allow_grad and torch.is_grad_enabled() and any(p.requires_grad for p in self._small_params()):
+        if _train_keep is None and torch.is_grad_enabled() and any(p.requires_grad for p in self._small_params()):
             raise hip.ShastaHipError("Shasta.forward is the inference path: call it under torch.no_grad(), or use "
                                      "shasta_amd.training.affinity_train for a differentiable forward")
         B, N = det_boxes.shape[0], det_boxes.shape[1]
@@ -261,7 +261,19 @@ class Shasta(BaseTrack):
         if self.keep_intermediates:
             res = torch.empty(B, N + 2, N + 2, device=dev)
             mat = torch.empty(B, N + 2, N + 2, device=dev)
-        if l1_events is not None:  # bench.py: hipEvents around the dominant kernel, same work otherwise
+        if _train_keep is not None:  # training.py: same kernels, keeps the residual and the anchor hidden activations
+            H4 = 4 * (N * self.aug_shape_output // 64)
+            _train_keep["residual"] = torch.empty(B, N + 2, N + 2, device=dev)
+            _train_keep["shape_hidden"] = torch.empty(B, max(H4, 1), device=dev)
+            hip.check(lib.shasta_affinity_forward_train_f32(
+                C.byref(w), hip.ptr(self._packed), B, hip.ptr(bufs["feat"]), hip.ptr(bufs["prev_feat"]),
+                hip.ptr(det_boxes), hip.ptr(prev_det_boxes), det_boxes.shape[2], hip.ptr(bufs["det_tab"]),
+                hip.ptr(bufs["prev_tab"]), hip.ptr(m1), hip.ptr(m2), hip.ptr(_train_keep["residual"]),
+                hip.ptr(_train_keep["shape_hidden"]), hip.ptr(bufs["ws"]), bufs["ws_bytes"], hip.stream_ptr()),
+                "shasta_affinity_forward_train_f32")
+            for k in ("feat", "prev_feat", "det_tab", "prev_tab"):
+                _train_keep[k] = bufs[k].clone()
+        elif l1_events is not None:  # bench.py: hipEvents around the dominant kernel, same work otherwise
             hip.check(lib.shasta_affinity_forward_timed_f32(
                 C.byref(w), hip.ptr(self._packed), B, hip.ptr(bufs["feat"]), hip.ptr(bufs["prev_feat"]),
                 hip.ptr(det_boxes), hip.ptr(prev_det_boxes), det_boxes.shape[2], hip.ptr(bufs["det_tab"]),

@@ -85,19 +85,13 @@ class _AffinityTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, bev, prev_bev, det_boxes, prev_det_boxes, *params):
         det_pre = det_boxes.detach().clone()  # the gather and aug_dets see the boxes BEFORE back-projection
+        keep = {}
         with torch.no_grad():
-            keep = model.keep_intermediates
-            model.keep_intermediates = True
-            try:
-                m1, m2 = model.affinity_from_bev(bev.detach(), prev_bev.detach(), det_boxes, prev_det_boxes, _allow_grad=True)
-            finally:
-                model.keep_intermediates = keep
-            im = model.last_intermediates
-            ctx.saved = dict(bev_shape=bev.shape, det_pre=det_pre, prev=prev_det_boxes.detach().clone(),
-                             feat=im["feature"].clone(), prev_feat=im["prev_feature"].clone(), det_tab=im["det_tab"].clone(),
-                             prev_tab=im["prev_tab"].clone(), residual=im["residual"].clone(), m1=m1.clone(), m2=m2.clone())
+            m1, m2 = model.affinity_from_bev(bev.detach(), prev_bev.detach(), det_boxes, prev_det_boxes, _train_keep=keep)
+        ctx.saved = dict(bev_shape=bev.shape, det_pre=det_pre, prev=prev_det_boxes.detach().clone(), feat=keep["feat"],
+                         prev_feat=keep["prev_feat"], det_tab=keep["det_tab"], prev_tab=keep["prev_tab"],
+                         residual=keep["residual"], shape_hidden=keep["shape_hidden"], m1=m1.clone(), m2=m2.clone())
         ctx.model = model
-        ctx.mark_non_differentiable()
         return m1, m2
 
     @staticmethod
@@ -201,13 +195,15 @@ class _AffinityTrainFn(torch.autograd.Function):
                                                N, 2, hip.ptr(dprev_tab), hip.ptr(ddet_tab), st()), "shasta_hand_dist_bwd_f32")
 
         # ---- anchor MLPs (shasta.py:241-247, 260-267) ----
-        def anchor_bwd(seq, x, sx_m, K, g_out, c0, c1):
-            """seq = Sequential(Linear, ReLU, Linear); x rows at stride sx_m; g_out (B, out) gradient of the |.| output."""
+        def anchor_bwd(seq, x, sx_m, K, g_out, c0, c1, hid=None):
+            """seq = Sequential(Linear, ReLU, Linear); x rows at stride sx_m; g_out (B, out) gradient of the |.| output;
+            hid: the hidden activations when the forward kept them (recomputed otherwise)."""
             w1, b1, w2, b2 = seq[0].weight.detach(), seq[0].bias.detach(), seq[2].weight.detach(), seq[2].bias.detach()
             H, nout = w1.shape[0], w2.shape[0]
-            hid = torch.empty(B, max(H, 1), device=dev)
-            if H > 0:
-                _gemm(lib, x, (sx_m, 1), w1, (K, 1), B, H, K, hid, ldc=max(H, 1), bias=b1, act=1)
+            if hid is None:
+                hid = torch.empty(B, max(H, 1), device=dev)
+                if H > 0:
+                    _gemm(lib, x, (sx_m, 1), w1, (K, 1), B, H, K, hid, ldc=max(H, 1), bias=b1, act=1)
             pre = torch.empty(B, nout, device=dev)
             if H > 0:
                 _gemm(lib, hid, (max(H, 1), 1), w2, (H, 1), B, nout, H, pre, bias=b2)
@@ -234,7 +230,9 @@ class _AffinityTrainFn(torch.autograd.Function):
             x = S["feat"] if i < 2 else S["prev_feat"]
             gtab = dprev_feat if i < 2 else dfeat
             g_out = gtab[:, N + (i & 1), :].contiguous()
-            grads, ghid, w1 = anchor_bwd(model.aug_shape[i], x, T * F, N * F, g_out, 0, F)
+            Hs_ = N * F // 64
+            hid = S["shape_hidden"][:, i * Hs_:(i + 1) * Hs_].contiguous() if Hs_ > 0 else None
+            grads, ghid, w1 = anchor_bwd(model.aug_shape[i], x, T * F, N * F, g_out, 0, F, hid=hid)
             shape_grads[i] = grads
             if ghid is not None:  # dx = ghid W1 accumulated into the rows < N of the INPUT table's gradient
                 gin = dfeat if i < 2 else dprev_feat
