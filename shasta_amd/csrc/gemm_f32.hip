@@ -229,15 +229,24 @@ __global__ __launch_bounds__(256) void gemm_strided_f32_kernel(GemmS g) {
     }
 }
 
-// C[i] = sum_z part[z*stride + i] (fixed order), optional ReLU mask
-__global__ void gemm_reduce_kernel(const float* __restrict__ part, long stride, int nz, float* __restrict__ C, long n,
-                                   const float* __restrict__ mask) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = part[i];
-    for (int z = 1; z < nz; ++z) s += part[(long)z * stride + i];
-    if (mask && !(mask[i] > 0.0f)) s = 0.0f;
-    C[i] = s;
+// C[row][col] = sum_z part[z*stride + i], i = row*N + col: 16 elements x 16 z-groups per block, each group sums its
+// slices in order and the groups are combined in order (fixed association -> deterministic)
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, long stride, int nz, float* __restrict__ C,
+                                                          long n, int N, int ldc) {
+    __shared__ float red[16][17];
+    const int e = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + e;
+    float s = 0.0f;
+    if (i < n)
+        for (int z = q; z < nz; z += 16) s += part[(long)z * stride + i];
+    red[q][e] = s;
+    __syncthreads();
+    if (q == 0 && i < n) {
+        float t = red[0][e];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][e];
+        C[(i / N) * ldc + (i % N)] = t;
+    }
 }
 
 int launch_gemm_strided(const float* A, long sa_m, long sa_k, const float* W, long sw_n, long sw_k, const float* bias,
@@ -251,8 +260,8 @@ int launch_gemm_strided(const float* A, long sa_m, long sa_k, const float* W, lo
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     int nz = 1;
     // long reductions with few output tiles (weight gradients): split the reduction over grid.z
-    if (splitk_ws && K >= 4096 && tiles < 128 && ldc == N && !mask && act == 0 && !bias) {
-        nz = min(min(64, cdiv(512, tiles)), cdiv(K, 1024));
+    if (splitk_ws && K >= 4096 && tiles < 128 && !mask && act == 0 && !bias) {
+        nz = min(min(512, cdiv(1024, tiles)), cdiv(K, 512));
         while (nz > 1 && (size_t)nz * M * N * sizeof(float) > splitk_ws_bytes) --nz;
     }
     if (nz <= 1) {
@@ -264,13 +273,13 @@ int launch_gemm_strided(const float* A, long sa_m, long sa_k, const float* W, lo
     g.kslice = cdiv(cdiv(K, nz), BK) * BK;
     nz = cdiv(K, g.kslice);
     g.C = splitk_ws;
+    g.ldc = N;
     g.slice_stride = (long)M * N;
     hipLaunchKernelGGL(gemm_strided_f32_kernel, dim3(cdiv(N, BN), cdiv(M, BM), nz), dim3(256), 0, st, g);
     int rc = check_launch("gemm_strided_f32(split-K)");
     if (rc) return rc;
     const long n = (long)M * N;
-    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, splitk_ws, g.slice_stride, nz, C, n,
-                       (const float*)nullptr);
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, splitk_ws, g.slice_stride, nz, C, n, N, ldc);
     return check_launch("gemm_reduce");
 }
 

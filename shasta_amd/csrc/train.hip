@@ -7,6 +7,7 @@
 // of each pair are.  All reductions have a fixed order except the scatter-add into the BEV gradient, which uses float
 // atomics (gradient of an input only).
 #include <algorithm>
+#include <math.h>
 
 #include "common.hpp"
 
@@ -278,12 +279,14 @@ __global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* __restr
     }
 }
 
-__global__ void colsum_finish_kernel(const float* __restrict__ part, int chunks, int N, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per column: lanes stride over the chunks, then a fixed-order wave reduction
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int chunks, int N, float* __restrict__ out) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= N) return;
     float s = 0.0f;
-    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * N + c];
-    out[c] = s;
+    for (int k = lane; k < chunks; k += 64) s += part[(size_t)k * N + c];
+    s = wave_sum(s);
+    if (lane == 0) out[c] = s;
 }
 
 // y = |x| (mode 0) ; g_out = g * sign(x) (mode 1) over `cols` columns of each row, columns [c0, c1) only (others copied / passed)
@@ -295,6 +298,45 @@ __global__ void abs_kernel(const float* __restrict__ x, const float* __restrict_
     const bool in = c >= c0 && c < c1;
     if (mode == 0) out[i] = in ? fabsf(x[i]) : x[i];
     else out[i] = in ? (x[i] > 0.0f ? g[i] : (x[i] < 0.0f ? -g[i] : 0.0f)) : g[i];
+}
+
+// Adam step (torch.optim.Adam semantics as used by tools/nusc_shasta/train.py:147: L2 weight decay added to the gradient,
+// no amsgrad), one pass over p, g, m, v instead of the seven multi-tensor passes of the unfused optimizer:
+//   g' = g + wd*p ; m += (g' - m)*(1-b1) ; v = b2*v + (1-b2)*g'*g' ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+struct AdamArgs {
+    float lr_over_bc1, beta1, beta2, eps, weight_decay, rsqrt_bc2;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a) {
+    g = fmaf(a.weight_decay, p, g);
+    m = fmaf(g - m, 1.0f - a.beta1, m);
+    v = fmaf(1.0f - a.beta2, g * g, a.beta2 * v);
+    const float denom = fmaf(sqrtf(v), a.rsqrt_bc2, a.eps);
+    p = p - a.lr_over_bc1 * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, AdamArgs a) {
+    const long n4 = n >> 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+        f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float pk = pp[k], mk = mm[k], vk = vv[k];
+            adam_one(pk, gg[k], mk, vk, a);
+            pp[k] = pk;
+            mm[k] = mk;
+            vv[k] = vk;
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pp;
+        reinterpret_cast<f32x4*>(m)[i] = mm;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    const long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x;  // tail
+    if (i < n) adam_one(p[i], g[i], m[i], v[i], a);
 }
 
 // gather backward: dBEV[b, y, x, :] += w * dfeat[b, n, pt*C : (pt+1)*C] for the four corners of every point (atomics)
@@ -441,7 +483,7 @@ extern "C" int shasta_colsum_f32(const float* Y, int ldy, int M, int N, float* o
     }
     int rc = check_launch("colsum");
     if (rc || chunks == 1) return rc;
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), ws, chunks, N, out);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(N, 4)), dim3(256), 0, as_stream(stream), ws, chunks, N, out);
     return check_launch("colsum_finish");
 }
 
@@ -465,4 +507,23 @@ extern "C" int shasta_bev_gather_bwd_f32(const float* dfeat, int B, int H, int W
                        box_stride, box_batch_stride, num_point, pc_x0, pc_y0, vs_x, vs_y, out_stride, row_stride, batch_stride,
                        (int)total, dbev);
     return check_launch("bev_gather_bwd");
+}
+
+extern "C" int shasta_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int step, shasta_stream_t stream) {
+    SHASTA_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "adam_step: bad argument");
+    SHASTA_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                   "adam_step: tensors must be 16-byte aligned");
+    if (n == 0) return SHASTA_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamArgs a;
+    a.lr_over_bc1 = (float)((double)lr / bc1);
+    a.beta1 = beta1;
+    a.beta2 = beta2;
+    a.eps = eps;
+    a.weight_decay = weight_decay;
+    a.rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const long blocks = std::min<long>((n / 4 + 255) / 256 + 1, 256L * 16);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, a);
+    return check_launch("adam_step");
 }

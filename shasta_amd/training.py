@@ -306,6 +306,42 @@ def affinity_loss(m1, m2, gt):
     return (lf + lb) / 2
 
 
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr, betas, eps, weight_decay) of tools/nusc_shasta/train.py:147 with the update done by one
+    HIP kernel per tensor (`shasta_adam_step_f32`): a single pass over p, g, m, v (28 bytes per parameter) instead of the
+    unfused optimizer's seven.  Same param_groups keys (so OneCycleLR, which cycles `lr` and `betas`, train.py:172, drives
+    it unchanged) and the same state names (`step`, `exp_avg`, `exp_avg_sq`)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = hip.load()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise hip.ShastaHipError("FusedAdam needs contiguous fp32 device parameters (no CPU path)")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] = int(st["step"]) + 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                hip.check(lib.shasta_adam_step_f32(hip.ptr(p), hip.ptr(g), hip.ptr(st["exp_avg"]), hip.ptr(st["exp_avg_sq"]), p.numel(),
+                                                   float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                   float(group["weight_decay"]), st["step"], hip.stream_ptr()), "shasta_adam_step_f32")
+        return loss
+
+
 def allreduce_gradients(params, world_size=None, bucket_bytes=256 << 20, group=None):
     """Data-parallel gradient averaging over torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the
     CPU tests): gradients are packed into flat buckets (few, large collectives: the per-link bound of the point-to-point

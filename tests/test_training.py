@@ -215,3 +215,29 @@ def test_hand_dist_forward_and_anchor_gradient(nf):
     _close("d prev anchors", dp[:, N:, :7], pa.grad, rtol=1e-3)
     _close("d det anchors", dq[:, N:, :7], qa.grad, rtol=1e-3)
     assert float(dp[:, :N].abs().max()) == 0.0 and float(dq[:, :N].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_fused_adam_matches_torch_adam(wd):
+    from shasta_amd.training import FusedAdam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    shapes = [(7,), (33, 5), (1000, 129), (1,)]
+    pa = [torch.nn.Parameter(torch.randn(*s, device=dev)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = FusedAdam(pa, lr=3e-3, weight_decay=wd)
+    ob = torch.optim.Adam(pb, lr=3e-3, weight_decay=wd)
+    sa = torch.optim.lr_scheduler.OneCycleLR(oa, max_lr=1e-2, total_steps=12)
+    sb = torch.optim.lr_scheduler.OneCycleLR(ob, max_lr=1e-2, total_steps=12)
+    for it in range(10):
+        for x, y in zip(pa, pb):
+            g = torch.randn_like(x) * (0.1 + it)
+            x.grad, y.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+        sa.step()
+        sb.step()
+    for x, y in zip(pa, pb):
+        assert float((x - y).abs().max()) <= 2e-6 * max(1.0, float(y.abs().max()))
+    assert set(oa.state[pa[0]].keys()) == {"step", "exp_avg", "exp_avg_sq"}

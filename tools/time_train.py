@@ -18,6 +18,7 @@ ap.add_argument("--points", type=int, default=5)
 ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--hw", type=int, default=180)
+ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused HIP step")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -26,7 +27,7 @@ cfg = dict(type="Shasta", reader=None, backbone=None, neck=None,
            max_obj=a.max_obj, num_feats=a.feats, num_point=a.points, in_channels=512)
 model = shasta_amd.build_simp_track(cfg).to(dev).train()
 params = training.affinity_params(model)
-opt = torch.optim.Adam(params, lr=1e-4)
+opt = torch.optim.Adam(params, lr=1e-4) if a.torch_adam else training.FusedAdam(params, lr=1e-4)
 N, B = a.max_obj, a.batch
 g = torch.Generator(device="cpu").manual_seed(1)
 bev = torch.relu(torch.randn(B, a.hw, a.hw, 64, generator=g)).to(dev)
