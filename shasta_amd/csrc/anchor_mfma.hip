@@ -10,9 +10,13 @@
 // chunk position c ^ ((r>>1)&7) (swizzle applied on the SOURCE address, the LDS destination of an LDS-DMA cannot be
 // scattered) so that the ds_read_b128 fragment reads (16 different rows per lane group) hit distinct banks.
 // Every wave owns a private ring of NS tiles and runs ahead of its own MFMAs by NS-1 tiles with counted
-// s_waitcnt vmcnt(N): no workgroup barrier anywhere.  Split-K partials are reduced afterwards in a fixed order.
+// s_waitcnt vmcnt(N): no workgroup barrier anywhere.  (A variant that shared the x tile between the four waves of a
+// workgroup to afford a 6-8 deep ring was slower, 1.37 vs 1.18 ms at 64 rows: the per-tile barrier costs more than the
+// depth buys; the prefetch depth is not what limits this kernel.)  Split-K partials are reduced afterwards in a fixed order.
 #include "common.hpp"
 #include <stdlib.h>
+
+#include <type_traits>
 
 namespace shasta {
 
@@ -60,100 +64,148 @@ __global__ __launch_bounds__(256) void anchor_l1_mfma_kernel(AnchorMfmaArgs a) {
     const int kbeg = ks * a.Kc, kend = min(a.K, kbeg + a.Kc);
     const int NT = (kend - kbeg) >> 5;  // 32-float tiles in this chunk
 
-    // staging roles: instruction j covers rows 8j..8j+7, lane -> (row 8j + lane/8, chunk position lane%8)
-    const float* wsrc[4];
-    const float* xsrc[XI];
+    // staging roles: instruction j covers rows 8j..8j+7, lane -> (row 8j + lane/8, chunk position lane%8).
+    // Source address = wave-uniform base (advanced per tile on the scalar unit) + a 32-bit per-lane byte offset.
     const float* wbase = mlp == 0 ? a.W[0] : mlp == 1 ? a.W[1] : mlp == 2 ? a.W[2] : a.W[3];
     const float* xbase = mlp < 2 ? a.x[0] : a.x[1];
+    const char* wub = reinterpret_cast<const char*>(wbase + (size_t)r0 * a.K + kbeg);
+    const char* xub = reinterpret_cast<const char*>(xbase + (size_t)b0 * a.x_batch_stride + kbeg);
+    uint32_t woff[4], xoff[XI];
     {
         const int cpos = lane & 7, rl = lane >> 3;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = 8 * j + rl;
             const int c = cpos ^ ((r >> 1) & 7);
-            wsrc[j] = wbase + (size_t)min(r0 + r, a.H - 1) * a.K + kbeg + 4 * c;
+            woff[j] = (uint32_t)(((min(r0 + r, a.H - 1) - r0) * a.K + 4 * c) * 4);
         }
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
             const int r = 8 * j + rl;  // row of the staged x tile (0..XR-1); sub-tile u = r / 32 keeps the same swizzle
             const int c = cpos ^ (((r & 31) >> 1) & 7);
-            xsrc[j] = xbase + (size_t)min(b0 + r, a.B - 1) * a.x_batch_stride + kbeg + 4 * c;
+            xoff[j] = (uint32_t)(((min(b0 + r, a.B - 1) - b0) * a.x_batch_stride + 4 * c) * 4);
         }
     }
-    auto issue = [&](int t) {
+    constexpr int ND = 4 + XI;                         // LDS-DMA instructions per tile
+    constexpr int NR = WIDE ? 4 + 4 * XT : 6;          // ds_read_b128 per tile
+    constexpr int NM = WIDE ? 16 * XT : 16;            // MFMAs per tile
+    constexpr int DPS = XT == 2 ? 1 : 2;               // DMA instructions issued behind one MFMA
+    constexpr int DSLOTS = (ND + DPS - 1) / DPS;
+    static_assert(DSLOTS + NR < NM, "the fragment reads must end a few MFMAs before the tile does");
+    auto dma = [&](int t, int idx) {  // instruction idx of tile t
         float* s = ring + (t % NS) * SLOT;
-        const int ko = t * 32;
+        const size_t ko = (size_t)t * 128;
+        if (idx < 4) GLDS16_NT(wub + ko + woff[idx], s + idx * 256);
+        else GLDS16(xub + ko + xoff[idx - 4], s + 1024 + (idx - 4) * 256);
+    };
+    auto issue = [&](int t) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) GLDS16_NT(wsrc[j] + ko, s + j * 256);
-#pragma unroll
-        for (int j = 0; j < XI; ++j) GLDS16(xsrc[j] + ko, s + 1024 + j * 256);
+        for (int j = 0; j < ND; ++j) dma(t, j);
     };
 
-    int issued = 0;
-#pragma unroll 1
-    for (; issued < NS - 1 && issued < NT; ++issued) issue(issued);
+    // Fragment registers of one tile.  Two sets ping-pong: the MFMAs of tile t run from one set while the other receives
+    // tile t+1.  One wave per SIMD issues in order, so anything that is not an MFMA only hides if it sits BETWEEN two MFMAs
+    // (it issues while the matrix pipe is busy with the previous one): the LDS-DMA instructions of tile t+NS follow the
+    // first MFMAs one by one, then the counted wait, then one ds_read_b128 of tile t+1 behind each following MFMA, and the
+    // last MFMAs cover the latency of the last read.  Before this interleave ~600 of every 2650 cycles per tile (64 batch
+    // rows) had the matrix pipe idle behind DMA issue, the wait and the fragment reads.
+    struct Frag {
+        f32x4 w[4];                     // WIDE: w[m]; else w[2*rb + u]
+        f32x4 x[WIDE ? XT : 1][4];      // WIDE: x[u][m]; else x[0][u] (u < 2)
+    };
+    const int frag_row = WIDE ? (lane & 31) : (lane & 15);
+    auto read_one = [&](const float* s, Frag& f, int idx) {
+        if constexpr (WIDE) {
+            const int h = lane >> 5, sw = (frag_row >> 1) & 7;
+            const int m = idx / (1 + XT), k = idx % (1 + XT);
+            const int pos = (2 * m + h) ^ sw;
+            if (k == 0) f.w[m] = *reinterpret_cast<const f32x4*>(s + frag_row * 32 + pos * 4);
+            else f.x[k - 1][m] = *reinterpret_cast<const f32x4*>(s + 1024 + (k - 1) * 1024 + frag_row * 32 + pos * 4);
+        } else {
+            const int kq = lane >> 4;
+            const int u = idx / 3, k = idx % 3;
+            const int c = 4 * u + kq;
+            if (k == 0) f.x[0][u] = *reinterpret_cast<const f32x4*>(s + 1024 + frag_row * 32 + (c ^ ((frag_row >> 1) & 7)) * 4);
+            else {
+                const int row = 16 * (k - 1) + frag_row;
+                f.w[2 * (k - 1) + u] = *reinterpret_cast<const f32x4*>(s + row * 32 + (c ^ ((row >> 1) & 7)) * 4);
+            }
+        }
+    };
+    auto read_frags = [&](const float* s, Frag& f) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) read_one(s, f, i);
+    };
 
     f32x16 acc32[WIDE ? XT : 1];
 #pragma unroll
     for (int u = 0; u < (WIDE ? XT : 1); ++u) acc32[u] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     f32x4 acc16[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 
-#pragma unroll 1
-    for (int t = 0; t < NT; ++t) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragment reads of tile t-1 retired before its slot is refilled
-        if (issued < NT) {
-            issue(issued);
-            ++issued;
-        }
-        // tiles issued after tile t may stay in flight
-        const int ahead = issued - (t + 1);
-        if (ahead >= NS - 1) wait_vm<PER_TILE*(NS - 1)>();
-        else if (ahead == 2 && NS > 3) wait_vm<PER_TILE * 2>();
-        else if (ahead == 1) wait_vm<PER_TILE>();
-        else if (ahead == 0) wait_vm<0>();
-        else if (ahead == 3 && NS > 4) wait_vm<PER_TILE * 3>();
-        else if (ahead == 4 && NS > 5) wait_vm<PER_TILE * 4>();
-        else wait_vm<0>();
-        const float* s = ring + (t % NS) * SLOT;
+    auto mma_one = [&](const Frag& f, int i) {
         if constexpr (WIDE) {
-            const int i = lane & 31, h = lane >> 5, f = (i >> 1) & 7;
-            f32x4 wv[4], xv[XT > 0 ? XT : 1][4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int pos = (2 * m + h) ^ f;
-                wv[m] = *reinterpret_cast<const f32x4*>(s + i * 32 + pos * 4);
-#pragma unroll
-                for (int u = 0; u < XT; ++u) xv[u][m] = *reinterpret_cast<const f32x4*>(s + 1024 + u * 1024 + i * 32 + pos * 4);
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int u = 0; u < XT; ++u)
-                        acc32[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[m][q], xv[u][m][q], acc32[u], 0, 0, 0);
+            const int m = i / (4 * XT), q = (i / XT) % 4, u = i % XT;
+            acc32[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w[m][q], f.x[u][m][q], acc32[u], 0, 0, 0);
         } else {
-            const int i = lane & 15, kq = lane >> 4;
-            f32x4 wv[2][2], xv[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int c = 4 * u + kq;
-                xv[u] = *reinterpret_cast<const f32x4*>(s + 1024 + i * 32 + (c ^ ((i >> 1) & 7)) * 4);
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    const int row = 16 * rb + i;
-                    wv[rb][u] = *reinterpret_cast<const f32x4*>(s + row * 32 + (c ^ ((row >> 1) & 7)) * 4);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
-                        acc16[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[rb][u][q], xv[u][q], acc16[rb], 0, 0, 0);
+            const int u = i / 8, q = (i / 2) % 4, rb = i % 2;
+            acc16[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[2 * rb + u][q], f.x[0][u][q], acc16[rb], 0, 0, 0);
         }
+    };
+
+    // Prologue: fill the ring, fetch the fragments of tile 0.
+    int issued = 0;
+#pragma unroll 1
+    for (; issued < NS && issued < NT; ++issued) issue(issued);
+    Frag fa, fb;
+    if (NT >= NS) wait_vm<PER_TILE*(NS - 1)>();
+    else wait_vm<0>();
+    if (NT > 0) read_frags(ring, fa);
+    // One tile: `cur` holds tile t (so its ring slot is free again), `nxt` receives tile t+1.
+    // STEADY: tile t+NS exists, so exactly NS tiles are in flight at the wait and the vmcnt immediate is a compile-time
+    // constant; the last NS+1 tiles (STEADY == false) issue what is left up front and drain the queue.  Straight-line
+    // bodies on purpose: a data-dependent choice of the immediate inside the loop made the register allocator shuttle all
+    // 32 accumulators AGPR -> VGPR -> AGPR every iteration.
+    auto step = [&](const Frag& cur, Frag& nxt, int t, auto steady) {
+        constexpr bool STEADY = decltype(steady)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the fragment reads of tile t have retired
+        if constexpr (!STEADY) {
+            if (t + NS < NT) issue(t + NS);  // at most one tile is still unissued when the steady loop ends
+        }
+        const float* sn = ring + ((t + 1) % NS) * SLOT;  // past the last tile: a harmless read of a stale slot
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            mma_one(cur, i);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < DSLOTS) {
+                if constexpr (STEADY) {
+#pragma unroll
+                    for (int d = 0; d < DPS; ++d)
+                        if (i * DPS + d < ND) dma(t + NS, i * DPS + d);
+                }
+                if (i == DSLOTS - 1) {
+                    if constexpr (STEADY) wait_vm<PER_TILE*(NS - 1)>();
+                    else wait_vm<0>();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (i - DSLOTS < NR) {
+                read_one(sn, nxt, i - DSLOTS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    int t = 0;
+#pragma unroll 1
+    for (; t + NS + 1 < NT; t += 2) {
+        step(fa, fb, t, std::true_type{});
+        step(fb, fa, t + 1, std::true_type{});
     }
+#pragma unroll 1
+    for (; t + 1 < NT; t += 2) {
+        step(fa, fb, t, std::false_type{});
+        step(fb, fa, t + 1, std::false_type{});
+    }
+    if (t < NT) step(fa, fb, t, std::false_type{});
     // D[i = weight row][j = batch item]
     if constexpr (WIDE) {
         const int h = lane >> 5;
