@@ -11,9 +11,17 @@
 // scattered) so that the ds_read_b128 fragment reads (16 different rows per lane group) hit distinct banks.
 // Every wave owns a private ring of NS tiles and runs ahead of its own MFMAs by NS-1 tiles with counted
 // s_waitcnt vmcnt(N): no workgroup barrier anywhere.  (A variant that shared the x tile between the four waves of a
-// workgroup to afford a 6-8 deep ring was slower, 1.37 vs 1.18 ms at 64 rows: the per-tile barrier costs more than the
-// depth buys; the prefetch depth is not what limits this kernel.)  Split-K partials are reduced afterwards in a fixed order.
+// workgroup to afford a 6-8 deep ring - 2.5x the weight bytes in flight - was not faster, 2450 vs 2200 cycles per tile at
+// 64 rows with the per-tile barrier: the prefetch depth is not what limits this kernel.)
+// What limited it at 32/64 rows was VALU work between the MFMAs: the f32 MFMA runs at the vector rate and does not overlap
+// VALU instructions, so the 64-bit address arithmetic of every LDS-DMA instruction stretched a 2048-cycle tile to 2560
+// cycles.  The loop below is VALU-free (scalar base + 32-bit lane offset addressing); in-kernel stamps
+// (tools/probes/l1_clock_probe.hip) read 2200 cycles per tile at 64 rows = 93 % of the matrix pipe, at an in-kernel clock
+// of 1.98 GHz (32 rows: 1140 of 1024 cycles at 1.72 GHz - the chip lowers its clock under the combined HBM + MFMA load).  Split-K partials are reduced afterwards in a fixed order.
 #include "common.hpp"
+
+// the LDS-DMA asm below names m0 in its clobber list on purpose (it writes it)
+#pragma clang diagnostic ignored "-Winline-asm"
 #include <stdlib.h>
 
 #include <type_traits>
@@ -36,6 +44,10 @@ struct AnchorMfmaArgs {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),        \
                                      (__attribute__((address_space(3))) void*)(ldst), 16, 0, 2)
 
+#ifdef SHASTA_L1_STAMP
+__device__ unsigned long long g_l1_stamp[4096][3];
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -48,12 +60,16 @@ __global__ __launch_bounds__(256) void anchor_l1_mfma_kernel(AnchorMfmaArgs a) {
     constexpr bool WIDE = XT > 0;
     constexpr int XR = WIDE ? 32 * XT : 16;     // batch rows staged per tile
     constexpr int XI = XR / 8;                  // LDS-DMA instructions per x tile
-    constexpr int SLOT = 1024 + XR * 32;        // floats per ring slot: W tile (32 x 32) + x tile (XR x 32)
+    constexpr int XSLOT = XR * 32;
+    constexpr int SLOT = 1024 + XSLOT;          // floats per private ring slot: W tile (32 x 32) + x tile (XR x 32)
     constexpr int PER_TILE = 4 + XI;            // vmcnt units per tile
+    static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt is 6 bits");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform -> scalar control flow
-    float* ring = lds + (size_t)wid * NS * SLOT;
+    float* const wring = lds + (size_t)wid * NS * SLOT;  // slot = [W tile | x tile]
+    float* const xring = wring + 1024;
+    constexpr int WSTRIDE = SLOT, XSTRIDE = SLOT;  // floats between consecutive slots
 
     const int item = blockIdx.x * 4 + wid;
     const int G = 4 * a.groups_per_mlp;  // 32-row blocks over the four MLPs
@@ -86,17 +102,31 @@ __global__ __launch_bounds__(256) void anchor_l1_mfma_kernel(AnchorMfmaArgs a) {
             xoff[j] = (uint32_t)(((min(b0 + r, a.B - 1) - b0) * a.x_batch_stride + 4 * c) * 4);
         }
     }
-    constexpr int ND = 4 + XI;                         // LDS-DMA instructions per tile
+    constexpr int ND = PER_TILE;                       // LDS-DMA instructions per tile
     constexpr int NR = WIDE ? 4 + 4 * XT : 6;          // ds_read_b128 per tile
     constexpr int NM = WIDE ? 16 * XT : 16;            // MFMAs per tile
     constexpr int DPS = XT == 2 ? 1 : 2;               // DMA instructions issued behind one MFMA
     constexpr int DSLOTS = (ND + DPS - 1) / DPS;
     static_assert(DSLOTS + NR < NM, "the fragment reads must end a few MFMAs before the tile does");
+    // The f32 MFMA does not overlap VALU work, so the loop must not contain any: the tile advance is added to the uniform
+    // base on the scalar unit and the per-lane 32-bit offset goes into the instruction's VGPR-offset field
+    // (global_load_lds_dwordx4 voff, s[base:base+1]).  hipcc only emits the 64-bit-VGPR-address form for the LDS-DMA
+    // builtin (two v_lshl_add_u64 per instruction: measured 2560 instead of 2048 cycles per tile at 64 rows), hence the asm.
+    const uint32_t wlds = (uint32_t)(size_t)((__attribute__((address_space(3))) float*)wring);
+    const uint32_t xlds = (uint32_t)(size_t)((__attribute__((address_space(3))) float*)xring);
     auto dma = [&](int t, int idx) {  // instruction idx of tile t
-        float* s = ring + (t % NS) * SLOT;
         const size_t ko = (size_t)t * 128;
-        if (idx < 4) GLDS16_NT(wub + ko + woff[idx], s + idx * 256);
-        else GLDS16(xub + ko + xoff[idx - 4], s + 1024 + (idx - 4) * 256);
+        if (idx < 4) {
+            const char* base = wub + ko;
+            const uint32_t dst = wlds + (uint32_t)(((t % NS) * WSTRIDE + idx * 256) * 4);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(woff[idx]), "s"(base), "s"(dst)
+                         : "memory", "m0");
+        } else {
+            const char* base = xub + ko;
+            const uint32_t dst = xlds + (uint32_t)(((t % NS) * XSTRIDE + (idx - 4) * 256) * 4);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(xoff[idx - 4]), "s"(base), "s"(dst)
+                         : "memory", "m0");
+        }
     };
     auto issue = [&](int t) {
 #pragma unroll
@@ -114,27 +144,29 @@ __global__ __launch_bounds__(256) void anchor_l1_mfma_kernel(AnchorMfmaArgs a) {
         f32x4 x[WIDE ? XT : 1][4];      // WIDE: x[u][m]; else x[0][u] (u < 2)
     };
     const int frag_row = WIDE ? (lane & 31) : (lane & 15);
-    auto read_one = [&](const float* s, Frag& f, int idx) {
+    auto read_one = [&](int slot, Frag& f, int idx) {
+        const float* sw_ = wring + slot * WSTRIDE;
+        const float* sx_ = xring + slot * XSTRIDE;
         if constexpr (WIDE) {
             const int h = lane >> 5, sw = (frag_row >> 1) & 7;
             const int m = idx / (1 + XT), k = idx % (1 + XT);
             const int pos = (2 * m + h) ^ sw;
-            if (k == 0) f.w[m] = *reinterpret_cast<const f32x4*>(s + frag_row * 32 + pos * 4);
-            else f.x[k - 1][m] = *reinterpret_cast<const f32x4*>(s + 1024 + (k - 1) * 1024 + frag_row * 32 + pos * 4);
+            if (k == 0) f.w[m] = *reinterpret_cast<const f32x4*>(sw_ + frag_row * 32 + pos * 4);
+            else f.x[k - 1][m] = *reinterpret_cast<const f32x4*>(sx_ + (k - 1) * 1024 + frag_row * 32 + pos * 4);
         } else {
             const int kq = lane >> 4;
             const int u = idx / 3, k = idx % 3;
             const int c = 4 * u + kq;
-            if (k == 0) f.x[0][u] = *reinterpret_cast<const f32x4*>(s + 1024 + frag_row * 32 + (c ^ ((frag_row >> 1) & 7)) * 4);
+            if (k == 0) f.x[0][u] = *reinterpret_cast<const f32x4*>(sx_ + frag_row * 32 + (c ^ ((frag_row >> 1) & 7)) * 4);
             else {
                 const int row = 16 * (k - 1) + frag_row;
-                f.w[2 * (k - 1) + u] = *reinterpret_cast<const f32x4*>(s + row * 32 + (c ^ ((row >> 1) & 7)) * 4);
+                f.w[2 * (k - 1) + u] = *reinterpret_cast<const f32x4*>(sw_ + row * 32 + (c ^ ((row >> 1) & 7)) * 4);
             }
         }
     };
-    auto read_frags = [&](const float* s, Frag& f) {
+    auto read_frags = [&](int slot, Frag& f) {
 #pragma unroll
-        for (int i = 0; i < NR; ++i) read_one(s, f, i);
+        for (int i = 0; i < NR; ++i) read_one(slot, f, i);
     };
 
     f32x16 acc32[WIDE ? XT : 1];
@@ -152,6 +184,9 @@ __global__ __launch_bounds__(256) void anchor_l1_mfma_kernel(AnchorMfmaArgs a) {
         }
     };
 
+#ifdef SHASTA_L1_STAMP  // diagnostic build only (tools/probes/l1_clock_probe.hip): in-kernel clock and cycles per tile
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // Prologue: fill the ring, fetch the fragments of tile 0.
     int issued = 0;
 #pragma unroll 1
@@ -159,7 +194,7 @@ __global__ __launch_bounds__(256) void anchor_l1_mfma_kernel(AnchorMfmaArgs a) {
     Frag fa, fb;
     if (NT >= NS) wait_vm<PER_TILE*(NS - 1)>();
     else wait_vm<0>();
-    if (NT > 0) read_frags(ring, fa);
+    if (NT > 0) read_frags(0, fa);
     // One tile: `cur` holds tile t (so its ring slot is free again), `nxt` receives tile t+1.
     // STEADY: tile t+NS exists, so exactly NS tiles are in flight at the wait and the vmcnt immediate is a compile-time
     // constant; the last NS+1 tiles (STEADY == false) issue what is left up front and drain the queue.  Straight-line
@@ -171,7 +206,7 @@ __global__ __launch_bounds__(256) void anchor_l1_mfma_kernel(AnchorMfmaArgs a) {
         if constexpr (!STEADY) {
             if (t + NS < NT) issue(t + NS);  // at most one tile is still unissued when the steady loop ends
         }
-        const float* sn = ring + ((t + 1) % NS) * SLOT;  // past the last tile: a harmless read of a stale slot
+        const int sn = (t + 1) % NS;  // past the last tile: a harmless read of a stale slot
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
@@ -206,6 +241,13 @@ __global__ __launch_bounds__(256) void anchor_l1_mfma_kernel(AnchorMfmaArgs a) {
         step(fb, fa, t + 1, std::false_type{});
     }
     if (t < NT) step(fa, fb, t, std::false_type{});
+#ifdef SHASTA_L1_STAMP
+    if (lane == 0 && wid == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+        g_l1_stamp[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - st0;
+        g_l1_stamp[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - sr0;
+        g_l1_stamp[blockIdx.x][2] = (unsigned long long)NT;
+    }
+#endif
     // D[i = weight row][j = batch item]
     if constexpr (WIDE) {
         const int h = lane >> 5;
