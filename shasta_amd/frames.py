@@ -1,0 +1,170 @@
+"""Input formats of the affinity path: the per-frame detection files the reference's dataset reads and the
+(max_obj, 11) box rows / (max_obj+2)^2 ground-truth matrix it builds from them, restated from
+det3d/datasets/nuscenes/nuscenes.py:198-349 (`NuScenesDataset.get_sensor_data`, the part before the LiDAR pipeline).
+
+On-disk layout (written by the reference's preprocessing/):
+  <det_path>/<token>.json        list of 13-float rows [t(3), wlh(3), quaternion wxyz(4), vxy(2), score]   (LiDAR frame)
+  <cls_info_path>/<token>.json   list of nuScenes detection dicts ('detection_name', 'detection_score', ...)
+  <frame_info>.json              {token: {'prev': token | '', 'timestamp': us, 'prev_timestamp': us, ...}}
+  <labels_path>/<token>.npz      matched (N_prev, K+2) one-hot rows [K current detections | dead track | unused], newborn (K,)
+
+Box row: [x, y, z, w, l, h, yaw, vx, vy, dt, score] (nuscenes.py:230-233).  The random sub-sampling (more than max_obj
+detections, dead-track / false-positive ratios) draws from `rng` in the same order as the reference draws from the global
+`random` module, so `random.seed(s)` reproduces the reference's sample exactly (tests/test_frames.py).
+"""
+import json
+import math
+import os
+import random as _random
+
+import numpy as np
+
+
+def quaternion_yaw(q_wxyz):
+    """nuscenes.py:35-49: yaw of the rotated x axis, v = R(q) [1,0,0], atan2(v_y, v_x).  pyquaternion normalises the quaternion
+    before building the rotation matrix; so does this."""
+    w, x, y, z = (float(v) for v in q_wxyz)
+    n = math.sqrt(w * w + x * x + y * y + z * z)
+    if n > 0.0:
+        w, x, y, z = w / n, x / n, y / n, z / n
+    return math.atan2(2.0 * (x * y + w * z), 1.0 - 2.0 * (y * y + z * z))
+
+
+def det_rows(boxes13, cls_info, det_type, time_diff, max_objects, rng=_random):
+    """nuscenes.py:220-246 / 263-294 for one frame.  Returns (rows (max_objects, 11) float64 zero padded, keep: indices into
+    the file's detection list, kept class dicts, number of valid rows).  With no detection left, `keep` is
+    range(max_objects), as in the reference."""
+    rows = np.zeros((max_objects, 11))
+    keep = list(range(max_objects))
+    kept_cls = []
+    if len(boxes13) == 0:
+        return rows, keep, kept_cls, 0
+    keep, dets = [], []
+    for i, (b, ci) in enumerate(zip(boxes13, cls_info)):
+        if det_type is not None and ci["detection_name"] not in det_type:
+            continue
+        dets.append(np.concatenate((np.asarray(b[:3], dtype=float), np.asarray(b[3:6], dtype=float),
+                                    np.array([quaternion_yaw(b[6:10])]), np.asarray(b[10:12], dtype=float),
+                                    np.array([time_diff]), np.array([ci["detection_score"]], dtype=float))))
+        kept_cls.append(ci)
+        keep.append(i)
+    n = 0
+    if len(dets) > 0:
+        if len(dets) > max_objects:
+            pick = rng.sample(range(len(dets)), max_objects)
+            pick.sort()
+            dets = [dets[i] for i in pick]
+            kept_cls = [kept_cls[i] for i in pick]
+            keep = [keep[i] for i in pick]
+        n = len(dets)
+        rows[:n, :] = np.array(dets)
+    return rows, keep, kept_cls, n
+
+
+def assemble_gt(matched, newborn, prev_keep, keep, has_prev, max_objects, fp_ratio, dead_trk_ratio, rng=_random):
+    """nuscenes.py:297-349: the (max_objects+2)^2 target [tracks | newborn | false positive] x [detections | dead | false
+    negative] with dead tracks and false positives sub-sampled to a ratio of the true positives.
+    Returns (gt, num_prev_det_boxes or None (unchanged), num_det_boxes)."""
+    N = max_objects
+    gt = np.zeros((N + 2, N + 2))
+    num_prev = None
+    if has_prev:
+        P = len(prev_keep)
+        gt[:P, :] = 0
+        temp = matched[prev_keep][:, keep]
+        gt[:P, :len(keep)] = temp
+        gt[:P, -2] = matched[prev_keep, -2]
+        gt[:P, -1] = 1 - gt[:P, :].sum(axis=1)
+        dead_trk, fn = gt[:P, -2], gt[:P, -1]
+        prev_tp = gt[:P, :-2].sum(axis=1) + fn
+        prev_tp_idx = list(np.nonzero(prev_tp == 1)[0])
+        dead_trk_idx = list(np.nonzero(dead_trk == 1)[0])
+        rng.shuffle(dead_trk_idx)
+        keep_dead = dead_trk_idx[:int(dead_trk_ratio * prev_tp.sum())]
+        tpk = keep_dead + prev_tp_idx
+        tpk.sort()
+        num_prev = len(tpk)
+        gt[:len(tpk), :] = gt[tpk, :]
+        gt[len(tpk):-2, :] = np.zeros((N - len(tpk), N + 2))
+    K = len(keep)
+    gt[-2, :K] = newborn[keep]
+    fp = 1 - gt[:, :K].sum(axis=0)
+    gt[-1, :K] = fp
+    tp = gt[:-1, :K].sum(axis=0)
+    tp_idx = list(np.nonzero(tp == 1)[0])
+    fp_idx = list(np.nonzero(fp == 1)[0])
+    rng.shuffle(fp_idx)
+    keep_fp = fp_idx[:int(fp_ratio * tp.sum())]
+    tk = keep_fp + tp_idx
+    tk.sort()
+    gt[:, :len(tk)] = gt[:, tk]
+    gt[:, len(tk):-2] = np.zeros((N + 2, N - len(tk)))
+    return gt, num_prev, len(tk)
+
+
+class FramePairs:
+    """The detection side of `NuScenesDataset` (constructor names follow nuscenes.py:57-110): `load(token)` returns what
+    `get_sensor_data` puts into `info` before the LiDAR pipeline runs - det_boxes, prev_det_boxes, their class dicts and
+    counts, and in training mode the ground-truth matrix."""
+
+    def __init__(self, det_path, cls_info_path, frame_info_path, labels_path=None, det_type=None, max_objects=500,
+                 fp_ratio=1.0, dead_trk_ratio=1.0, test_mode=False, rng=_random):
+        self.det_path, self.cls_info_path, self.labels_path = det_path, cls_info_path, labels_path
+        self.det_type, self.max_objects = det_type, max_objects
+        self.fp_ratio, self.dead_trk_ratio, self.test_mode, self.rng = fp_ratio, dead_trk_ratio, test_mode, rng
+        with open(frame_info_path) as f:
+            self.frame_info = json.load(f)
+
+    def _read(self, token):
+        with open(os.path.join(self.det_path, token + ".json")) as f:
+            boxes = json.load(f)
+        with open(os.path.join(self.cls_info_path, token + ".json")) as f:
+            cls_info = json.load(f)
+        return boxes, cls_info
+
+    def load(self, token, known_tokens=None):
+        fi = self.frame_info[token]
+        prev_token = fi["prev"]
+        if known_tokens is not None and prev_token not in known_tokens:
+            prev_token = ""  # nuscenes.py:202-204: previous frame not part of this split
+        N = self.max_objects
+        time_diff = 1e-6 * fi["timestamp"] - 1e-6 * fi["prev_timestamp"] if "prev_timestamp" in fi else 0.0
+        out = dict(token=token, prev_token=prev_token)
+        prev_rows, prev_keep, prev_cls, n_prev = np.zeros((N, 11)), list(range(N)), [], 0
+        if prev_token != "":
+            b, c = self._read(prev_token)
+            prev_rows, prev_keep, prev_cls, n_prev = det_rows(b, c, self.det_type, time_diff, N, self.rng)
+        b, c = self._read(token)
+        rows, keep, cls, n = det_rows(b, c, self.det_type, time_diff, N, self.rng)
+        out.update(prev_det_boxes=prev_rows, prev_cls_det_boxes=prev_cls, num_prev_det_boxes=n_prev, det_boxes=rows,
+                   cls_det_boxes=cls, num_det_boxes=n)
+        if not self.test_mode:
+            lab = np.load(os.path.join(self.labels_path, token + ".npz"), allow_pickle=True)
+            gt, np_, nd = assemble_gt(lab["matched"], lab["newborn"], prev_keep, keep, prev_token != "", N, self.fp_ratio,
+                                      self.dead_trk_ratio, self.rng)
+            out["gt"] = gt
+            if np_ is not None:
+                out["num_prev_det_boxes"] = np_
+            out["num_det_boxes"] = nd
+        return out
+
+
+def collate_pairs(samples, device=None):
+    """Stack loaded frame pairs into the batch the model consumes (det3d/torchie/parallel/collate.py keeps these keys as
+    stacked float tensors; example_to_device casts to fp32): det_boxes / prev_det_boxes (B, max_obj, 11) fp32, gt
+    (B, max_obj+2, max_obj+2) fp32 when present.  Any number of frames and detection classes can be stacked: every pair is an
+    independent batch row of the affinity forward (B >> 1 is what the device path is built for)."""
+    import torch
+    batch = dict(
+        det_boxes=torch.from_numpy(np.stack([s["det_boxes"] for s in samples]).astype(np.float32)),
+        prev_det_boxes=torch.from_numpy(np.stack([s["prev_det_boxes"] for s in samples]).astype(np.float32)),
+        num_det_boxes=[s["num_det_boxes"] for s in samples], num_prev_det_boxes=[s["num_prev_det_boxes"] for s in samples],
+        cls_det_boxes=[s["cls_det_boxes"] for s in samples], prev_cls_det_boxes=[s["prev_cls_det_boxes"] for s in samples],
+        metadata=[dict(token=s["token"]) for s in samples])
+    if all("gt" in s for s in samples):
+        batch["gt"] = torch.from_numpy(np.stack([s["gt"] for s in samples]).astype(np.float32))
+    if device is not None:
+        for k in ("det_boxes", "prev_det_boxes", "gt"):
+            if k in batch:
+                batch[k] = batch[k].pin_memory().to(device, non_blocking=True) if device.type == "cuda" else batch[k].to(device)
+    return batch
