@@ -264,6 +264,9 @@ int shasta_bev_gather_bwd_f32(const float* dfeat, int B, int H, int W, int C, co
                               int box_batch_stride, int num_point, float pc_x0, float pc_y0, float vs_x, float vs_y,
                               float out_stride, int row_stride, int batch_stride, float* dbev, shasta_stream_t stream);
 
+/* x *= alpha (gradient averaging over data-parallel ranks) */
+int shasta_scale_f32(float* x, long n, float alpha, shasta_stream_t stream);
+
 /* One fused Adam update of a parameter tensor (torch.optim.Adam semantics of tools/nusc_shasta/train.py:147,215: L2
  * weight decay folded into the gradient, bias correction with `step` (1-based), no amsgrad).  16-byte aligned pointers. */
 int shasta_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,

@@ -339,6 +339,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     if (i < n) adam_one(p[i], g[i], m[i], v[i], a);
 }
 
+__global__ void scale_kernel(float* __restrict__ x, long n, float alpha) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= alpha;
+}
+
 // gather backward: dBEV[b, y, x, :] += w * dfeat[b, n, pt*C : (pt+1)*C] for the four corners of every point (atomics)
 __global__ __launch_bounds__(256) void bev_gather_bwd_kernel(const float* __restrict__ dfeat, int H, int W, int C,
                                                              const float* __restrict__ boxes, int N, int box_stride,
@@ -526,4 +531,11 @@ extern "C" int shasta_adam_step_f32(float* param, const float* grad, float* exp_
     const long blocks = std::min<long>((n / 4 + 255) / 256 + 1, 256L * 16);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, a);
     return check_launch("adam_step");
+}
+
+extern "C" int shasta_scale_f32(float* x, long n, float alpha, shasta_stream_t stream) {
+    SHASTA_REQUIRE(x && n >= 0, "scale: bad argument");
+    if (n == 0) return SHASTA_OK;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, n, alpha);
+    return check_launch("scale");
 }

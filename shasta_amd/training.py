@@ -195,9 +195,10 @@ class _AffinityTrainFn(torch.autograd.Function):
                                                N, 2, hip.ptr(dprev_tab), hip.ptr(ddet_tab), st()), "shasta_hand_dist_bwd_f32")
 
         # ---- anchor MLPs (shasta.py:241-247, 260-267) ----
-        def anchor_bwd(seq, x, sx_m, K, g_out, c0, c1, hid=None):
+        def anchor_bwd(seq, x, sx_m, K, g_out, c0, c1, hid=None, defer_w1=False):
             """seq = Sequential(Linear, ReLU, Linear); x rows at stride sx_m; g_out (B, out) gradient of the |.| output;
-            hid: the hidden activations when the forward kept them (recomputed otherwise)."""
+            hid: the hidden activations when the forward kept them (recomputed otherwise); defer_w1: leave the first
+            layer's weight gradient to the caller (returned as None), who gets its factor ghid."""
             w1, b1, w2, b2 = seq[0].weight.detach(), seq[0].bias.detach(), seq[2].weight.detach(), seq[2].bias.detach()
             H, nout = w1.shape[0], w2.shape[0]
             if hid is None:
@@ -213,18 +214,25 @@ class _AffinityTrainFn(torch.autograd.Function):
             hip.check(lib.shasta_abs_f32(hip.ptr(pre), hip.ptr(g_out), hip.ptr(gpre), B * nout, nout, c0, c1, 1, st()), "shasta_abs_f32")
             gb2 = torch.empty_like(b2)
             _colsum(lib, gpre, nout, B, nout, gb2, ws)
-            gW2, gW1, gb1 = torch.zeros_like(w2), torch.zeros_like(w1), torch.zeros_like(b1)
+            gW2, gb1 = torch.zeros_like(w2), torch.zeros_like(b1)
+            gW1 = None if (defer_w1 and H > 0) else (torch.empty_like(w1) if H > 0 else torch.zeros_like(w1))
             gx = None
             if H > 0:
                 _gemm(lib, gpre, (1, nout), hid, (1, max(H, 1)), nout, H, B, gW2)
                 ghid = torch.empty(B, H, device=dev)
                 _gemm(lib, gpre, (nout, 1), w2, (1, H), B, H, nout, ghid, mask=hid, ldmask=max(H, 1))
-                _gemm(lib, ghid, (1, H), x, (1, sx_m), H, K, B, gW1)
+                if gW1 is not None:
+                    _gemm(lib, ghid, (1, H), x, (1, sx_m), H, K, B, gW1)
                 _colsum(lib, ghid, H, B, H, gb1, ws)
                 gx = ghid
             return (gW1, gb1, gW2, gb2), gx, w1
 
-        shape_grads, box_grads = [None] * 4, [None] * 4
+        # Data-parallel training: dW1 of an aug_shape MLP is ghid^T x, a rank-B update of a (N*F/64, N*F) matrix (1 GB at
+        # N=500).  Instead of all-reducing 4 x 1 GB of gradients, the ranks exchange the FACTORS (all_gather of B x (4H + 2K)
+        # floats per rank, ~1 MB per frame-pair) and every rank forms the averaged gradient with one GEMM over world*B rows.
+        world, group = _exchange_world(model)
+        exchange = world > 1 or getattr(model, "_force_factor_exchange", False)  # the latter: single-rank test of the path
+        shape_grads, box_grads, ghids = [None] * 4, [None] * 4, [None] * 4
         for i in range(4):
             # aug_shape[i]: input = rows < N of feat (i<2) / prev_feat (i>=2); output row N + (i&1) of prev_feat (i<2) / feat (i>=2)
             x = S["feat"] if i < 2 else S["prev_feat"]
@@ -232,8 +240,9 @@ class _AffinityTrainFn(torch.autograd.Function):
             g_out = gtab[:, N + (i & 1), :].contiguous()
             Hs_ = N * F // 64
             hid = S["shape_hidden"][:, i * Hs_:(i + 1) * Hs_].contiguous() if Hs_ > 0 else None
-            grads, ghid, w1 = anchor_bwd(model.aug_shape[i], x, T * F, N * F, g_out, 0, F, hid=hid)
+            grads, ghid, w1 = anchor_bwd(model.aug_shape[i], x, T * F, N * F, g_out, 0, F, hid=hid, defer_w1=exchange)
             shape_grads[i] = grads
+            ghids[i] = ghid
             if ghid is not None:  # dx = ghid W1 accumulated into the rows < N of the INPUT table's gradient
                 gin = dfeat if i < 2 else dprev_feat
                 _gemm(lib, ghid, (ghid.shape[1], 1), w1, (1, N * F), B, N * F, ghid.shape[1], gin, ldc=T * F, accum=True)
@@ -243,6 +252,19 @@ class _AffinityTrainFn(torch.autograd.Function):
             g_box = gbt[:, N + (i & 1), :7].contiguous()
             grads, _, _ = anchor_bwd(model.aug_dets[i], xb, 7 * N, 7 * N, g_box, 3, 6)
             box_grads[i] = grads
+
+        if exchange and ghids[0] is not None:
+            Hs_, K = N * F // 64, N * F
+            gh_all = _all_gather_rows(torch.cat(ghids, dim=1), world, group)             # (world*B, 4H)
+            xs = [_all_gather_rows(S[k][:, :N, :].reshape(B, K), world, group) for k in ("feat", "prev_feat")]  # (world*B, K)
+            hip.check(lib.shasta_scale_f32(hip.ptr(gh_all), gh_all.numel(), 1.0 / world, st()), "shasta_scale_f32")
+            for i in range(4):
+                w1p = model.aug_shape[i][0].weight
+                gW1 = torch.empty_like(w1p)
+                _gemm(lib, gh_all[:, i * Hs_:], (1, 4 * Hs_), xs[0 if i < 2 else 1], (1, K), Hs_, K, world * B, gW1)
+                g = shape_grads[i]
+                shape_grads[i] = (gW1, g[1], g[2], g[3])
+                w1p._shasta_grad_is_global = True  # allreduce_gradients must not reduce it again
 
         # ---- gather (shasta.py:231-238) -> gradient of the two NHWC maps ----
         def gather_bwd(gtab, boxes):
@@ -272,6 +294,25 @@ class _AffinityTrainFn(torch.autograd.Function):
         for gW, gb in aff_grads:
             out += [gW, gb]
         return (None, dbev, dprev_bev, None, None) + tuple(out)
+
+
+def _exchange_world(model):
+    """(world size, group) of the low-rank gradient exchange; (1, None) when not running data-parallel or switched off
+    with model.low_rank_grad_exchange = False."""
+    import torch.distributed as dist
+    if not getattr(model, "low_rank_grad_exchange", True) or not (dist.is_available() and dist.is_initialized()):
+        return 1, None
+    group = getattr(model, "grad_exchange_group", None)
+    return dist.get_world_size(group), group
+
+
+def _all_gather_rows(t, world, group=None):
+    """(B, C) on every rank -> (world*B, C), rank-major (RCCL all_gather on the GPUs)."""
+    import torch.distributed as dist
+    t = t.contiguous()
+    out = torch.empty(world * t.shape[0], t.shape[1], dtype=t.dtype, device=t.device)
+    dist.all_gather(list(out.chunk(world, dim=0)), t, group=group)
+    return out
 
 
 def affinity_params(model):
@@ -344,16 +385,24 @@ class FusedAdam(torch.optim.Optimizer):
 
 def allreduce_gradients(params, world_size=None, bucket_bytes=256 << 20, group=None):
     """Data-parallel gradient averaging over torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the
-    CPU tests): gradients are packed into flat buckets (few, large collectives: the per-link bound of the point-to-point
-    xGMI topology favours large messages), summed with one all_reduce per bucket and divided by the world size, like
-    apex DDP does for the reference (tools/nusc_shasta/train.py:156)."""
+    CPU tests).  The four 1 GB aug_shape first-layer gradients were already averaged inside the backward by exchanging their
+    rank-B factors (_AffinityTrainFn.backward) and are skipped.  The rest is packed into flat buckets (few, large
+    collectives: the per-link bound of the point-to-point xGMI topology favours large messages), summed with one all_reduce
+    per bucket and divided by the world size, like apex DDP does for the reference (tools/nusc_shasta/train.py:156)."""
     import torch.distributed as dist
+    params = list(params)
+    grads = []
+    for p in params:
+        if getattr(p, "_shasta_grad_is_global", False):  # already the average over the ranks (low-rank factor exchange)
+            p._shasta_grad_is_global = False
+            continue
+        if p.grad is not None:
+            grads.append(p.grad)
     if not (dist.is_available() and dist.is_initialized()):
         return
     world = world_size or dist.get_world_size(group)
     if world == 1:
         return
-    grads = [p.grad for p in params if p.grad is not None]
     i = 0
     while i < len(grads):
         j, nbytes = i, 0

@@ -241,3 +241,37 @@ def test_fused_adam_matches_torch_adam(wd):
     for x, y in zip(pa, pb):
         assert float((x - y).abs().max()) <= 2e-6 * max(1.0, float(y.abs().max()))
     assert set(oa.state[pa[0]].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+@pytest.mark.gpu
+def test_low_rank_factor_exchange_path_equals_local_gradients():
+    """The data-parallel path (all_gather of the rank-B factors of the aug_shape first-layer gradients + one GEMM) on a
+    single-rank RCCL group: same gradients as the local path, and allreduce_gradients leaves the flagged tensors alone."""
+    import torch.distributed as dist
+    from shasta_amd import training
+    from tests.test_training_ddp import _free_port
+    c, model, w, a, b, det, prev, gt = _case(12, 7, 4, 3, seed=21)
+    dev = torch.device("cuda:0")
+    model = model.to(dev).train()
+    ad, bd, gtd = a.to(dev), b.to(dev), gt.to(dev)
+
+    def grads(force):
+        model._force_factor_exchange = force
+        for p in model.parameters():
+            p.grad = None
+        m1, m2 = training.affinity_train(model, ad, bd, det.to(dev).contiguous(), prev.to(dev).contiguous())
+        training.affinity_loss(m1, m2, gtd).backward()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    local = grads(False)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    try:
+        glob = grads(True)
+        assert all(getattr(model.aug_shape[i][0].weight, "_shasta_grad_is_global", False) for i in range(4))
+        training.allreduce_gradients(list(model.parameters()))
+        assert not any(getattr(model.aug_shape[i][0].weight, "_shasta_grad_is_global", False) for i in range(4))
+    finally:
+        model._force_factor_exchange = False
+        dist.destroy_process_group()
+    for k in local:
+        _close(k, glob[k], local[k], rtol=1e-5)

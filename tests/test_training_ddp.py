@@ -27,7 +27,24 @@ def _worker(rank, world, port, q):
     params.append(torch.nn.Parameter(torch.zeros(2)))  # no gradient: skipped
     allreduce_gradients(params, bucket_bytes=64 * 1024)  # forces several buckets
     ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params[:4]))
-    q.put((rank, ok and params[4].grad is None))
+    ok = ok and params[4].grad is None
+    # low-rank factor exchange: gathering the rank-B factors and one product over world*B rows == the all-reduced average of
+    # the local outer products; a tensor flagged as already global is skipped by allreduce_gradients (and the flag is cleared)
+    from shasta_amd.training import _all_gather_rows
+    g = torch.Generator().manual_seed(100 + rank)
+    gh, x = torch.randn(3, 5, generator=g), torch.randn(3, 7, generator=g)
+    gh_all, x_all = _all_gather_rows(gh, world), _all_gather_rows(x, world)
+    ok = ok and gh_all.shape == (world * 3, 5) and torch.equal(gh_all[rank * 3:(rank + 1) * 3], gh)
+    low_rank = (gh_all / world).t() @ x_all
+    dense = gh.t() @ x
+    dist.all_reduce(dense)
+    ok = ok and torch.allclose(low_rank, dense / world, atol=1e-6)
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.full((4,), float(rank))
+    p._shasta_grad_is_global = True
+    allreduce_gradients([p])
+    ok = ok and torch.equal(p.grad, torch.full((4,), float(rank))) and p._shasta_grad_is_global is False
+    q.put((rank, ok))
     dist.destroy_process_group()
 
 
