@@ -231,6 +231,18 @@ int shasta_gemm_strided_f32(const float* A, long sa_m, long sa_k, const float* W
                             shasta_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Public tracker step, device part: centre-distance matrix + greedy assignment for `scenes` independent scenes
+ * replaces tools/nusc_shasta/pub_tracker.py:94-108 (`dist`, `invalid`, `dist + invalid * 1e18`) and
+ * tools/nusc_shasta/track_utils.py:3-14 (`greedy_assignment`), same float32 / float64 arithmetic and tie-breaking.
+ *  det_xy (S,Nmax,2) fp32 = ct + tracking of every detection, trk_xy (S,Mmax,2), det_cat / trk_cat int32 class ids,
+ *  max_diff (S,Nmax) fp32 per-detection gate, n / m (S,) int32 valid counts (device), Mmax <= 4096
+ *  dist (S,Nmax,Mmax) float64 or NULL (rows >= n, columns >= m are not written), match (S,Nmax) int32: track index or -1
+ * ------------------------------------------------------------------------------------------ */
+int shasta_center_greedy_f32(const float* det_xy, const float* trk_xy, const int32_t* det_cat, const int32_t* trk_cat,
+                             const float* max_diff, const int32_t* n, const int32_t* m, int scenes, int Nmax, int Mmax,
+                             double* dist, int32_t* match, shasta_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Training path, backward helpers (the nn.Linear layers run on shasta_gemm_strided_f32; the first layer of each pair MLP
  * is factorised over the table rows).  Replaces what torch autograd derives from det3d/models/tracker/shasta.py:241-325 in
  * tools/nusc_shasta/train.py:198-213.
