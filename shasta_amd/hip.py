@@ -9,6 +9,7 @@ import os
 
 import torch
 
+ABI_VERSION = 2  # must equal shasta_abi_version() of the loaded library
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libshasta_hip.so")
 _lib = None
 
@@ -92,6 +93,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.shasta_abi_version() != ABI_VERSION:
+        raise ShastaHipError("%s has ABI version %d, this binding needs %d: rebuild with `python -m shasta_amd.build`"
+                             % (_LIB_PATH, lib.shasta_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

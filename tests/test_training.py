@@ -145,6 +145,16 @@ def test_colsum(M, N):
 
 
 @pytest.mark.gpu
+def test_scale():
+    from shasta_amd import hip
+    lib = hip.load()
+    x = torch.randn(1000003, device="cuda:0")
+    want = x * 0.25
+    hip.check(lib.shasta_scale_f32(hip.ptr(x), x.numel(), 0.25, hip.stream_ptr()), "scale")
+    assert torch.equal(x, want)
+
+
+@pytest.mark.gpu
 def test_abs_forward_and_backward():
     from shasta_amd import hip
     lib = hip.load()
