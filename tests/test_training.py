@@ -43,7 +43,7 @@ def _close(name, got, want, rtol=2e-3):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,nf,npnt,B,n_real", [(6, 7, 1, 2, None), (12, 3, 4, 3, 9), (20, 7, 5, 2, None)])
+@pytest.mark.parametrize("N,nf,npnt,B,n_real", [(6, 7, 1, 2, None), (12, 3, 4, 3, 9), (20, 7, 5, 2, None), (8, 7, 4, 1, None), (33, 5, 1, 18, 20)])
 def test_backward_matches_autograd_of_oracle(N, nf, npnt, B, n_real):
     from shasta_amd import training
     c, model, w, a, b, det, prev, gt = _case(N, nf, npnt, B, seed=5, n_real=n_real)
