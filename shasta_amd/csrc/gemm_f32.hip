@@ -132,18 +132,25 @@ struct GemmS {
     const float* mask;  // (M, ldmask) or nullptr
     float* C;
     long sa_m, sa_k, sw_n, sw_k;
+    int vec_a, vec_w;  // operand rows are k-contiguous and 16-byte aligned: vector loads
     int ldc, ldmask, M, N, K, act, kslice;  // kslice: reduction elements per grid.z slice (multiple of BK); act & 4: C += result
     long slice_stride;
 };
 
 __device__ __forceinline__ void load_slice_strided(const float* __restrict__ P, long s_r, long s_k, int rows, int K, int r0,
-                                                   int k0, int tid, float (&reg)[2][4]) {
+                                                   int k0, int tid, bool vec, float (&reg)[2][4]) {
     if (s_k == 1 || s_r != 1) {  // k-contiguous (or general): thread -> (row, 4 consecutive k)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx >> 3, c4 = idx & 7;
             const int gr = r0 + row, gk = k0 + 4 * c4;
+            if (vec && gr < rows && gk + 3 < K) {  // k-contiguous, 16-byte aligned rows: one dwordx4 load
+                const f32x4 v = *reinterpret_cast<const f32x4*>(P + (long)gr * s_r + gk);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) reg[i][j] = v[j];
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) reg[i][j] = (gr < rows && gk + j < K) ? P[(long)gr * s_r + (long)(gk + j) * s_k] : 0.0f;
         }
@@ -192,8 +199,8 @@ __global__ __launch_bounds__(256) void gemm_strided_f32_kernel(GemmS g) {
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
-        load_slice_strided(g.A, g.sa_m, g.sa_k, g.M, kend, m0, kbeg, tid, ra);
-        load_slice_strided(g.W, g.sw_n, g.sw_k, g.N, kend, n0, kbeg, tid, rw);
+        load_slice_strided(g.A, g.sa_m, g.sa_k, g.M, kend, m0, kbeg, tid, g.vec_a != 0, ra);
+        load_slice_strided(g.W, g.sw_n, g.sw_k, g.N, kend, n0, kbeg, tid, g.vec_w != 0, rw);
     }
     const float* af = As + (wm * 32 + (lane & 31)) * LDS_LD + (lane >> 5);
     const float* wf = Ws + (wn * 32 + (lane & 31)) * LDS_LD + (lane >> 5);
@@ -203,8 +210,8 @@ __global__ __launch_bounds__(256) void gemm_strided_f32_kernel(GemmS g) {
         store_slice_strided(Ws, g.sw_n, g.sw_k, tid, rw);
         __syncthreads();
         if (kt + 1 < nk) {
-            load_slice_strided(g.A, g.sa_m, g.sa_k, g.M, kend, m0, kbeg + (kt + 1) * BK, tid, ra);
-            load_slice_strided(g.W, g.sw_n, g.sw_k, g.N, kend, n0, kbeg + (kt + 1) * BK, tid, rw);
+            load_slice_strided(g.A, g.sa_m, g.sa_k, g.M, kend, m0, kbeg + (kt + 1) * BK, tid, g.vec_a != 0, ra);
+            load_slice_strided(g.W, g.sw_n, g.sw_k, g.N, kend, n0, kbeg + (kt + 1) * BK, tid, g.vec_w != 0, rw);
         }
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s)
@@ -257,11 +264,13 @@ int launch_gemm_strided(const float* A, long sa_m, long sa_k, const float* W, lo
     g.A = A; g.W = W; g.bias = bias; g.mask = mask; g.C = C;
     g.sa_m = sa_m; g.sa_k = sa_k; g.sw_n = sw_n; g.sw_k = sw_k;
     g.ldc = ldc; g.ldmask = ldmask; g.M = M; g.N = N; g.K = K; g.act = act;
+    g.vec_a = (sa_k == 1 && sa_m % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
+    g.vec_w = (sw_k == 1 && sw_n % 4 == 0 && ((uintptr_t)W & 15) == 0) ? 1 : 0;
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     int nz = 1;
     // long reductions with few output tiles (weight gradients): split the reduction over grid.z
-    if (splitk_ws && K >= 4096 && tiles < 128 && !mask && act == 0 && !bias) {
-        nz = min(min(512, cdiv(1024, tiles)), cdiv(K, 512));
+    if (splitk_ws && K >= 1024 && tiles < 128 && !mask && act == 0 && !bias) {
+        nz = min(min(512, cdiv(1024, tiles)), cdiv(K, 256));
         while (nz > 1 && (size_t)nz * M * N * sizeof(float) > splitk_ws_bytes) --nz;
     }
     if (nz <= 1) {

@@ -164,7 +164,7 @@ class _AffinityTrainFn(torch.autograd.Function):
                 for tab, ld, wd, gtab in parts[name][side]:
                     col = offs[k]
                     k += 1
-                    _gemm(lib, gU, (1, E), tab, (1, ld), E, wd, R, gW0[:, col:], ldc=kin)                 # dW0 block = gU^T X
+                    _gemm(lib, gU, (1, E), tab, (1, ld), E, wd, R, gW0[:, col:], ldc=kin, ws=ws)          # dW0 block = gU^T X
                     _gemm(lib, gU, (E, 1), w0[:, col:], (1, kin), R, wd, E, gtab, ldc=ld, accum=True)      # dX += gU W0 block
             return gW0, gb0
 
