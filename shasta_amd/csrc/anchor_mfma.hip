@@ -35,15 +35,8 @@ struct AnchorMfmaArgs {
     int H, K, B, KS, Kc, x_batch_stride, groups_per_mlp;
 };
 
-#define GLDS16(gsrc, ldst)                                                                         \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),        \
-                                     (__attribute__((address_space(3))) void*)(ldst), 16, 0, 0)
-// weights are read exactly once per launch: non-temporal (aux = 2) keeps the activation vectors and the small
-// weights of the following kernels resident in L2 / Infinity Cache (MI355X_MICROARCH.md, row nt-weights)
-#define GLDS16_NT(gsrc, ldst)                                                                      \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),        \
-                                     (__attribute__((address_space(3))) void*)(ldst), 16, 0, 2)
-
+// weights are read exactly once per launch: the weight stream is issued non-temporal (nt) so that the activation vectors
+// and the small weights of the following kernels stay resident in L2 / Infinity Cache (MI355X_MICROARCH.md, row nt-weights)
 #ifdef SHASTA_L1_STAMP
 __device__ unsigned long long g_l1_stamp[4096][3];
 #endif
