@@ -231,6 +231,19 @@ int shasta_gemm_strided_f32(const float* A, long sa_m, long sa_k, const float* W
                             shasta_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Rotated BEV NMS
+ * replaces det3d/ops/iou3d_nms: `nms_gpu` (src/iou3d_nms.cpp:100-143 with nms_kernel, src/iou3d_nms_kernel.cu:267-311 and
+ * iou_bev :226-233) as called from det3d/ops/iou3d_nms/iou3d_nms_utils.py:74-89 and
+ * det3d/core/bbox/box_torch_ops.py:248-276 (`rotate_nms_pcdet`).
+ *  boxes_sorted (N,7) fp32 [x, y, z, dx, dy, dz, heading], already ordered by descending score; N <= 32768
+ *  keep (N,) int32: indices (into boxes_sorted) of the kept boxes in score order; num_keep (1,) int32 device scalar
+ *  workspace: shasta_nms_workspace_bytes(N) bytes (the N x ceil(N/64) suppression bitmask)
+ * ------------------------------------------------------------------------------------------ */
+size_t shasta_nms_workspace_bytes(int num_boxes);
+int shasta_nms_rotated_f32(const float* boxes_sorted, int num_boxes, float thresh, void* workspace, size_t workspace_bytes,
+                           int32_t* keep, int32_t* num_keep, shasta_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Public tracker step, device part: centre-distance matrix + greedy assignment for `scenes` independent scenes
  * replaces tools/nusc_shasta/pub_tracker.py:94-108 (`dist`, `invalid`, `dist + invalid * 1e18`) and
  * tools/nusc_shasta/track_utils.py:3-14 (`greedy_assignment`), same float32 / float64 arithmetic and tie-breaking.

@@ -5,12 +5,9 @@
 // One thread per pair: corners -> Sutherland-Hodgman clip of quad A by quad B (<= 8 vertices) -> shoelace area;
 // GIoU additionally the convex hull of the 8 corners (monotone chain) and its area.
 #include "common.hpp"
+#include "geom2d.hpp"
 
 namespace shasta {
-
-struct P2 {
-    double x, y;
-};
 
 __device__ __forceinline__ void corners2d(const double* b, P2* c) {
     const double x = b[0], y = b[1], o = b[3], l = b[4], w = b[5];
@@ -19,45 +16,6 @@ __device__ __forceinline__ void corners2d(const double* b, P2* c) {
     c[1] = {x + cs * l / 2 - sn * w / 2, y + sn * l / 2 + cs * w / 2};
     c[2] = {2 * x - c[0].x, 2 * y - c[0].y};
     c[3] = {2 * x - c[1].x, 2 * y - c[1].y};
-}
-
-__device__ __forceinline__ double shoelace(const P2* p, int n) {
-    if (n < 3) return 0.0;
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const P2 a = p[i], b = p[(i + 1) % n];
-        s += a.x * b.y - a.y * b.x;
-    }
-    return s * 0.5;
-}
-
-__device__ double clip_area(const P2* subj, const P2* clip) {
-    P2 buf0[10], buf1[10];
-    P2* in = buf0;
-    P2* out = buf1;
-    int n = 4;
-    for (int i = 0; i < 4; ++i) in[i] = subj[i];
-    const double sgn = shoelace(clip, 4) >= 0 ? 1.0 : -1.0;
-    for (int e = 0; e < 4 && n > 0; ++e) {
-        const P2 a = clip[e], b = clip[(e + 1) & 3];
-        const double ex = b.x - a.x, ey = b.y - a.y;
-        int m = 0;
-        for (int j = 0; j < n; ++j) {
-            const P2 p = in[j], q = in[(j + 1) % n];
-            const double sp = sgn * (ex * (p.y - a.y) - ey * (p.x - a.x));
-            const double sq = sgn * (ex * (q.y - a.y) - ey * (q.x - a.x));
-            if (sp >= 0) out[m++] = p;
-            if ((sp >= 0) != (sq >= 0)) {
-                const double t = sp / (sp - sq);
-                out[m++] = {p.x + t * (q.x - p.x), p.y + t * (q.y - p.y)};
-            }
-        }
-        P2* tmp = in;
-        in = out;
-        out = tmp;
-        n = m;
-    }
-    return fabs(shoelace(in, n));
 }
 
 __device__ double hull_area8(const P2* a4, const P2* b4) {

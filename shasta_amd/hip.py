@@ -69,6 +69,8 @@ SYMBOLS = {
     "shasta_adam_step_f32": (_I, [_P, _P, _P, _P, C.c_long, _F, _F, _F, _F, _F, _I, _P]),
     "shasta_abs_f32": (_I, [_P, _P, _P, C.c_long, _I, _I, _I, _I, _P]),
     "shasta_bev_gather_bwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
+    "shasta_nms_workspace_bytes": (_Z, [_I]),
+    "shasta_nms_rotated_f32": (_I, [_P, _I, _F, _P, _Z, _P, _P, _P]),
     "shasta_center_greedy_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "shasta_decode_flags_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "shasta_gemm_strided_f32": (_I, [_P, C.c_long, C.c_long, _P, C.c_long, C.c_long, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
