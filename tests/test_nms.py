@@ -68,3 +68,30 @@ def test_device_nms_edges_and_pcdet_wrapper():
     assert nms.nms_gpu(b, s, 0.5, pre_maxsize=2)[0].tolist() == [1, 6]
     assert nms.rotate_nms_pcdet(b.clone(), s, 0.5, post_max_size=2).tolist() == [1, 6]
     assert torch.equal(b[0], torch.tensor([0, 0, 0, 2, 4, 1, 0.3], device=dev))  # caller's boxes untouched
+
+
+@pytest.mark.gpu
+def test_device_nms_many_boxes_analytic_chain():
+    """6000 unit squares on a line, 0.6 apart: only neighbours overlap (IoU = 0.4 / 1.6 = 0.25), so the greedy result is
+    computable without an N x N matrix.  Exercises more than one 64-word slot per lane of the reduction kernel."""
+    from shasta_amd import nms
+    n = 6000
+    rng = np.random.default_rng(0)
+    boxes = np.zeros((n, 7), np.float32)
+    boxes[:, 0] = 0.6 * np.arange(n)
+    boxes[:, 3:6] = 1.0
+    scores = rng.permutation(n).astype(np.float32)
+    dev = torch.device("cuda:0")
+    sel, _ = nms.nms_gpu(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), 0.2)
+    removed = np.zeros(n, bool)
+    want = []
+    for k in np.argsort(-scores, kind="stable"):
+        if removed[k]:
+            continue
+        want.append(k)
+        for j in (k - 1, k + 1):
+            if 0 <= j < n:
+                removed[j] = True
+    assert sel.cpu().numpy().tolist() == want
+    sel2, _ = nms.nms_gpu(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), 0.3)  # above every IoU
+    assert sel2.numel() == n
