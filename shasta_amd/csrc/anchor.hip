@@ -103,8 +103,8 @@ struct AnchorL2Args {
 
 // one wave per (batch chunk of 8, mlp, j): out[b] = abs(b2[j] + W2[j,:] . hidden[b, mlp, :]); the weight row is read once
 // per 8 batch items
+template <int BT>
 __global__ __launch_bounds__(256) void anchor_l2_kernel(AnchorL2Args a) {
-    constexpr int BT = 8;
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nchunk = (a.B + BT - 1) / BT;
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void anchor_l2_kernel(AnchorL2Args a) {
     float s[BT];
 #pragma unroll
     for (int b = 0; b < BT; ++b) s[b] = 0.0f;
+#pragma unroll 4
     for (int i = lane; i < a.H; i += 64) {
         const float wv = w[i];
 #pragma unroll
@@ -188,6 +189,35 @@ __global__ __launch_bounds__(256) void box_l1_kernel(BoxL1Args a) {
         }
 }
 
+// Small batches (B <= 4): the register-tile kernel above only launches 28 workgroups per 4 batch items and each lane walks a
+// 55-step dependent load chain (27 us at B = 1).  Here one workgroup owns one (batch item, mlp, hidden unit): its four waves
+// take a quarter of K each with every load in flight at once, and the quarters are added in a fixed order through LDS.
+__global__ __launch_bounds__(256) void box_l1_small_kernel(BoxL1Args a) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int u = blockIdx.x % a.HD, mlp = (blockIdx.x / a.HD) & 3, b = blockIdx.x / (4 * a.HD);
+    const int K = 7 * a.N;
+    const float* w = a.W[mlp] + (size_t)u * K;
+    const float* x = ((mlp < 2) ? a.det : a.prev) + (size_t)b * a.N * a.box_stride;
+    const int kq = (K + 3) / 4, k0 = q * kq, k1 = min(K, k0 + kq);
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll 4
+    for (int k = k0 + lane; k < k1; k += 128) {
+        const int k2 = k + 64;
+        const int n = k / 7, c = k - 7 * n;
+        s0 = fmaf(w[k], x[(size_t)n * a.box_stride + c], s0);
+        if (k2 < k1) {
+            const int n2 = k2 / 7, c2 = k2 - 7 * n2;
+            s1 = fmaf(w[k2], x[(size_t)n2 * a.box_stride + c2], s1);
+        }
+    }
+    const float v = wave_sum(s0 + s1);
+    if (lane == 0) part[q] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        a.hid[((size_t)b * 4 + mlp) * a.HD + u] = fmaxf(((part[0] + part[1]) + (part[2] + part[3])) + a.bias[mlp][u], 0.0f);
+}
+
 struct BoxL2Args {
     const float* W[4];  // aug_dets.i.2.weight (7, HD)
     const float* bias[4];
@@ -199,11 +229,12 @@ struct BoxL2Args {
     int HD, N, B, box_stride;
 };
 
-// one workgroup per batch item: the 4x7 anchor outputs, then back-projection (shasta.py:270) and the
-// (N+2, 8) box tables (shasta.py:273-274; column 7 is padding and written as 0).
+// the 4x7 anchor outputs, back-projection (shasta.py:270) and the (N+2, 8) box tables (shasta.py:273-274; column 7 is
+// padding and written as 0).
+// grid (B, 1 + ceil(N / 256)): block y == 0 computes the anchors, blocks y >= 1 copy / back-project 256 table rows each.
 __global__ __launch_bounds__(256) void box_l2_tables_kernel(BoxL2Args a) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    {
+    if (blockIdx.y == 0) {
         // wave `mlp` computes the 7 outputs of aug_dets[mlp].2, lanes across the hidden units
         const int mlp = tid >> 6, lane = tid & 63;
         const float* h = a.hid + ((size_t)b * 4 + mlp) * a.HD;
@@ -219,8 +250,10 @@ __global__ __launch_bounds__(256) void box_l2_tables_kernel(BoxL2Args a) {
             if (lane == 0) tab[c] = v;
         }
         if (lane == 0) tab[7] = 0.0f;
+        return;
     }
-    for (int n = tid; n < a.N; n += blockDim.x) {
+    const int n = (blockIdx.y - 1) * 256 + tid;
+    if (n < a.N) {
         float* d = a.det + ((size_t)b * a.N + n) * a.box_stride;
         const float* p = a.prev + ((size_t)b * a.N + n) * a.box_stride;
         const float dt = d[9];
@@ -319,7 +352,11 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     l2.F = F;
     l2.N = N;
     l2.B = B;
-    hipLaunchKernelGGL(anchor_l2_kernel, dim3(cdiv(cdiv(B, 8) * 4 * F, 4)), dim3(256), 0, st, l2);
+    // small batches: no duplicated activation loads (BT = batch items that share one weight row read)
+    if (B == 1) hipLaunchKernelGGL(anchor_l2_kernel<1>, dim3(cdiv(B * 4 * F, 4)), dim3(256), 0, st, l2);
+    else if (B == 2) hipLaunchKernelGGL(anchor_l2_kernel<2>, dim3(cdiv(cdiv(B, 2) * 4 * F, 4)), dim3(256), 0, st, l2);
+    else if (B <= 4) hipLaunchKernelGGL(anchor_l2_kernel<4>, dim3(cdiv(cdiv(B, 4) * 4 * F, 4)), dim3(256), 0, st, l2);
+    else hipLaunchKernelGGL(anchor_l2_kernel<8>, dim3(cdiv(cdiv(B, 8) * 4 * F, 4)), dim3(256), 0, st, l2);
     return check_launch("anchor_l2");
 }
 
@@ -342,7 +379,8 @@ int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* 
         a.N = N;
         a.B = B;
         a.box_stride = box_stride;
-        hipLaunchKernelGGL(box_l1_kernel, dim3(cdiv(cdiv(B, 4) * 4 * cdiv(HD, 4), 4)), dim3(256), 0, st, a);
+        if (B <= 4) hipLaunchKernelGGL(box_l1_small_kernel, dim3(B * 4 * HD), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(box_l1_kernel, dim3(cdiv(cdiv(B, 4) * 4 * cdiv(HD, 4), 4)), dim3(256), 0, st, a);
         int rc = check_launch("box_l1");
         if (rc) return rc;
     }
@@ -360,7 +398,7 @@ int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* 
     b2.N = N;
     b2.B = B;
     b2.box_stride = box_stride;
-    hipLaunchKernelGGL(box_l2_tables_kernel, dim3(B), dim3(256), 0, st, b2);
+    hipLaunchKernelGGL(box_l2_tables_kernel, dim3(B, 1 + cdiv(N, 256)), dim3(256), 0, st, b2);
     return check_launch("box_l2_tables");
 }
 

@@ -44,12 +44,9 @@ __device__ __forceinline__ void store_slice(float* S, int tid, const float (&reg
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, int lda,
-                                                          const float* __restrict__ W, int ldw,
-                                                          const float* __restrict__ bias, float* __restrict__ C,
-                                                          int ldc, int M, int N, int K, int act) {
-    __shared__ float As[BM * LDS_LD];
-    __shared__ float Ws[BN * LDS_LD];
+__device__ __forceinline__ void gemm_nt_tile(float* As, float* Ws, const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                             int ldw, const float* __restrict__ bias, float* __restrict__ C, int ldc, int M, int N,
+                                             int K, int act) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -90,6 +87,33 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     }
 }
 
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ W, int ldw,
+                                                          const float* __restrict__ bias, float* __restrict__ C,
+                                                          int ldc, int M, int N, int K, int act) {
+    __shared__ float As[BM * LDS_LD];
+    __shared__ float Ws[BN * LDS_LD];
+    gemm_nt_tile<VEC>(As, Ws, A, lda, W, ldw, bias, C, ldc, M, N, K, act);
+}
+
+// two independent problems of the same shape in one launch (blockIdx.z picks the problem): the two row-embedding GEMMs of
+// the pair stage are small (16 workgroups each at one frame pair), one launch runs them side by side
+struct GemmNtDual {
+    const float* A[2];
+    const float* W[2];
+    const float* bias[2];
+    float* C[2];
+};
+
+__global__ __launch_bounds__(256) void gemm_nt_f32_dual_kernel(GemmNtDual p, int lda, int ldw, int ldc, int M, int N, int K, int act) {
+    __shared__ float As[BM * LDS_LD];
+    __shared__ float Ws[BN * LDS_LD];
+    const int z = blockIdx.z;
+    gemm_nt_tile<true>(As, Ws, z ? p.A[1] : p.A[0], lda, z ? p.W[1] : p.W[0], ldw, z ? p.bias[1] : p.bias[0], z ? p.C[1] : p.C[0], ldc, M,
+                       N, K, act);
+}
+
 int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
                    int N, int K, int act, hipStream_t st) {
     if (M == 0 || N == 0) return SHASTA_OK;
@@ -100,6 +124,22 @@ int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float
     else
         hipLaunchKernelGGL(gemm_nt_f32_kernel<false>, grid, dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, act);
     return check_launch("gemm_nt_f32");
+}
+
+// C0 = A0 W0^T (+bias0), C1 = A1 W1^T (+bias1), same shapes and leading dimensions; falls back to two launches when the
+// vector-load preconditions do not hold
+int launch_gemm_nt_dual(const float* A0, const float* W0, const float* bias0, float* C0, const float* A1, const float* W1,
+                        const float* bias1, float* C1, int lda, int ldw, int ldc, int M, int N, int K, int act, hipStream_t st) {
+    if (M == 0 || N == 0) return SHASTA_OK;
+    const bool vec = (lda % 4 == 0) && (ldw % 4 == 0) && (((uintptr_t)A0 | (uintptr_t)W0 | (uintptr_t)A1 | (uintptr_t)W1) % 16 == 0);
+    if (!vec) {
+        int rc = launch_gemm_nt(A0, lda, W0, ldw, bias0, C0, ldc, M, N, K, act, st);
+        if (rc) return rc;
+        return launch_gemm_nt(A1, lda, W1, ldw, bias1, C1, ldc, M, N, K, act, st);
+    }
+    GemmNtDual p{{A0, A1}, {W0, W1}, {bias0, bias1}, {C0, C1}};
+    hipLaunchKernelGGL(gemm_nt_f32_dual_kernel, dim3(cdiv(N, BN), cdiv(M, BM), 2), dim3(256), 0, st, p, lda, ldw, ldc, M, N, K, act);
+    return check_launch("gemm_nt_f32_dual");
 }
 
 }  // namespace shasta

@@ -812,6 +812,8 @@ size_t pair_workspace_bytes(int B, int N, int F) {
 
 int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
                    int N, int K, int act, hipStream_t st);
+int launch_gemm_nt_dual(const float* A0, const float* W0, const float* bias0, float* C0, const float* A1, const float* W1,
+                        const float* bias1, float* C1, int lda, int ldw, int ldc, int M, int N, int K, int act, hipStream_t st);
 
 int pair_residual(const shasta_weights* w, const float* packed, int B, const float* feat, const float* prev_feat,
                   const float* det_tab, const float* prev_tab, float* residual, int ld, void* ws, size_t ws_bytes,
@@ -835,9 +837,8 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     base += align_up((size_t)B * T * 16 * sizeof(float), 256);
     float* denom = reinterpret_cast<float*>(base);
 
-    int rc = launch_gemm_nt(prev_feat, F, packed + P.wemb_prev, F, nullptr, UP, d.ET, B * T, P.E12, F, 0, st);
-    if (rc) return rc;
-    rc = launch_gemm_nt(feat, F, packed + P.wemb_cur, F, packed + P.bemb_cur, UC, d.ET, B * D, P.E12, F, 0, st);
+    int rc = launch_gemm_nt_dual(prev_feat, packed + P.wemb_prev, nullptr, UP, feat, packed + P.wemb_cur, packed + P.bemb_cur, UC, F, F,
+                                 d.ET, B * T, P.E12, F, 0, st);
     if (rc) return rc;
     RowFinishArgs rf;
     rf.packed = packed;
