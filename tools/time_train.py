@@ -18,10 +18,17 @@ ap.add_argument("--points", type=int, default=5)
 ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--hw", type=int, default=180)
+ap.add_argument("--json", action="store_true", help="print one JSON line instead of text")
 ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused HIP step")
 a = ap.parse_args()
-dev = torch.device("cuda:0")
-torch.manual_seed(0)
+rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+torch.cuda.set_device(local_rank)
+dev = torch.device("cuda", local_rank)
+if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="nccl", device_id=dev)
+torch.manual_seed(0)  # identical initial weights on every rank
 cfg = dict(type="Shasta", reader=None, backbone=None, neck=None,
            bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
            max_obj=a.max_obj, num_feats=a.feats, num_point=a.points, in_channels=512)
@@ -29,7 +36,7 @@ model = shasta_amd.build_simp_track(cfg).to(dev).train()
 params = training.affinity_params(model)
 opt = torch.optim.Adam(params, lr=1e-4) if a.torch_adam else training.FusedAdam(params, lr=1e-4)
 N, B = a.max_obj, a.batch
-g = torch.Generator(device="cpu").manual_seed(1)
+g = torch.Generator(device="cpu").manual_seed(1 + rank)
 bev = torch.relu(torch.randn(B, a.hw, a.hw, 64, generator=g)).to(dev)
 pbev = torch.relu(torch.randn(B, a.hw, a.hw, 64, generator=g)).to(dev)
 
@@ -56,8 +63,26 @@ for it in range(a.steps + 2):
     m1, m2 = training.affinity_train(model, bev, pbev, det0.clone(), prev0.clone())
     loss = training.affinity_loss(m1, m2, gt)
     loss.backward()
+    training.allreduce_gradients(params)  # no-op on one rank
     opt.step()
 torch.cuda.synchronize()
+if world > 1:
+    dist.barrier()
 dt = (time.perf_counter() - t0) / a.steps
-print("max_obj=%d F=%d B=%d: %.2f ms/step, %.1f frame-pairs/s, loss %.4f, peak mem %.2f GB" % (
-    N, model.aug_shape_output, B, dt * 1e3, B / dt, float(loss.detach()), torch.cuda.max_memory_allocated() / 2**30))
+if world > 1:
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+if rank == 0 and a.json:
+    import json
+    print(json.dumps({"metric": "affinity-net training frame-pairs/sec", "value": world * B / dt, "unit": "frame-pairs/s", "n_gpus": world,
+                      "steps": a.steps, "ms_per_step": dt * 1e3, "dtype": "f32", "data": "synthetic", "scaling": "weak",
+                      "config": {"workload": "synthetic training step (forward + HIP backward + factor exchange + fused Adam)",
+                                 "max_obj": N, "feat_dim": model.aug_shape_output, "num_feats": a.feats,
+                                 "frame_pairs_per_step_per_gpu": B, "optimizer": "torch Adam" if a.torch_adam else "FusedAdam"},
+                      "loss": float(loss.detach()), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30}))
+elif rank == 0:
+    print("max_obj=%d F=%d B=%d: %.2f ms/step, %.1f frame-pairs/s, loss %.4f, peak mem %.2f GB" % (
+        N, model.aug_shape_output, B, dt * 1e3, world * B / dt, float(loss.detach()), torch.cuda.max_memory_allocated() / 2**30))
+if world > 1:
+    dist.destroy_process_group()
