@@ -173,7 +173,9 @@ __global__ __launch_bounds__(64 * AFF_WAVES) void aff_fused_kernel(AffArgs a) {
     const int XS = a.Dp + 4, HS = 132;
     float* xb = sm;                   // [ROWS][XS]  residual rows, later the matched rows
     float* ha = sm + ROWS * XS;       // [ROWS][HS]
-    float* hb = ha + ROWS * HS;       // [ROWS][HS]
+    // the second hidden buffer lives in xb: xb is dead between layer 0 (its last reader) and layer 5 (its next writer), which
+    // is exactly the lifetime of hb (written by layers 1 and 3, read by layers 2 and 4)
+    float* hb = xb;                   // [ROWS][HS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g0 = blockIdx.x * ROWS;
@@ -241,11 +243,18 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
     (void)h0;
     (void)h1;
     static const bool unfused = getenv("SHASTA_AFF_UNFUSED") != nullptr;
-    // 32 rows per workgroup halve the weight traffic per row but leave one workgroup per CU (99 KB LDS); measured at
-    // B=64: 251 us against 226 us for 16 rows -> 16 rows stay the default, SHASTA_AFF_RG2=1 selects the other form.
-    static const bool rg2 = getenv("SHASTA_AFF_RG2") != nullptr;
-    const int rg = (rg2 && (size_t)(32 * (Dp + 4) + 2 * 32 * 132) * sizeof(float) <= 160 * 1024) ? 2 : 1;
-    const size_t lds = (size_t)(16 * rg * (Dp + 4) + 2 * 16 * rg * 132) * sizeof(float);
+    // 32 rows per workgroup (RG = 2) halve the L2 -> register weight traffic per row, the limiter of this kernel (29 % matrix-
+    // pipe utilisation at 16 rows).  With the second hidden buffer aliased into xb two such workgroups fit one CU (80 KB each
+    // at N = 500); measured at B = 64: 187 us against 230 us for 16 rows.  16 rows stay the choice when there are too few
+    // rows to give every CU two workgroups (small batches: parallelism matters more than traffic) or when 32 rows do not
+    // fit twice.  SHASTA_AFF_RG1 / SHASTA_AFF_RG2 force one form.
+    static const bool rg1_forced = getenv("SHASTA_AFF_RG1") != nullptr;
+    static const bool rg2_forced = getenv("SHASTA_AFF_RG2") != nullptr;
+    const size_t lds2 = (size_t)(32 * (Dp + 4) + 32 * 132) * sizeof(float);
+    int rg = (lds2 <= 80 * 1024 && M >= 32 * 512) ? 2 : 1;
+    if (rg2_forced && lds2 <= 160 * 1024) rg = 2;
+    if (rg1_forced) rg = 1;
+    const size_t lds = (size_t)(16 * rg * (Dp + 4) + 16 * rg * 132) * sizeof(float);
     if (!unfused && lds <= 160 * 1024) {
         AffArgs fa;
         fa.W[0] = packed + P.aff0;  // zero padded (128, Dp)
