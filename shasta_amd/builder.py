@@ -1,41 +1,32 @@
-"""Builders mirroring det3d/models/builder.py:20-75 for the registries this path uses.
+"""`build_*` entry points of det3d/models/builder.py:20-75 for the registries this path uses.
 
-`build_backbone` / `build_neck` return None for a None config: the spconv backbone and the RPN neck are
-CenterPoint upstream code outside this package.  A user who has them can
-register their classes in BACKBONES / NECKS and the Shasta module will call them exactly like the reference.
-"""
+A None config builds nothing (returns None): the spconv backbone and the RPN neck are CenterPoint upstream code outside
+this package; a user who has them registers their classes in BACKBONES / NECKS and the
+Shasta module calls them exactly like the reference.  A list of configs becomes an nn.Sequential, like the reference."""
 from torch import nn
 
-from .registry import BACKBONES, NECKS, READERS, SECOND_STAGE, TRACK, build_from_cfg
+from . import registry as R
 
 
 def build(cfg, registry, default_args=None):
     if cfg is None:
         return None
-    if isinstance(cfg, list):
-        return nn.Sequential(*[build_from_cfg(c, registry, default_args) for c in cfg])
-    return build_from_cfg(cfg, registry, default_args)
+    if isinstance(cfg, (list, tuple)):
+        return nn.Sequential(*(R.build_from_cfg(one, registry, default_args) for one in cfg))
+    return R.build_from_cfg(cfg, registry, default_args)
 
 
-def build_second_stage_module(cfg):
-    return build(cfg, SECOND_STAGE)
+def _plain(registry):
+    return lambda cfg: build(cfg, registry)
 
 
-def build_reader(cfg):
-    return build(cfg, READERS)
+def _with_run_cfgs(registry):
+    return lambda cfg, train_cfg=None, test_cfg=None: build(cfg, registry, {"train_cfg": train_cfg, "test_cfg": test_cfg})
 
 
-def build_backbone(cfg):
-    return build(cfg, BACKBONES)
-
-
-def build_neck(cfg):
-    return build(cfg, NECKS)
-
-
-def build_simp_track(cfg, train_cfg=None, test_cfg=None):
-    return build(cfg, TRACK, dict(train_cfg=train_cfg, test_cfg=test_cfg))
-
-
-def build_track(cfg, train_cfg=None, test_cfg=None):
-    return build(cfg, TRACK, dict(train_cfg=train_cfg, test_cfg=test_cfg))
+build_reader = _plain(R.READERS)
+build_backbone = _plain(R.BACKBONES)
+build_neck = _plain(R.NECKS)
+build_second_stage_module = _plain(R.SECOND_STAGE)
+build_simp_track = _with_run_cfgs(R.TRACK)
+build_track = _with_run_cfgs(R.TRACK)

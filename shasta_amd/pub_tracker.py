@@ -70,82 +70,68 @@ class PubTracker(object):
         self.id_count = 0
         self.tracks = []
 
-    # ---- the three phases of pub_tracker.py:55-210 -------------------------------------------------------------------
-    def _prepare(self, results, time_lag):
-        """:55-93: filter to tracking classes, annotate ct / tracking / label_preds, build the arrays of the distance step.
-        Returns None when the frame has no detection at all (the caller clears the tracks)."""
-        if len(results) == 0:
+    # ---- the phases of one step (reference: pub_tracker.py:55-210) -----------------------------------------------------
+    def _prepare(self, frame_dets, time_lag):
+        """Class filter + per-detection annotations (ct, tracking offset, class id) and the arrays of the distance step.
+        None for a frame without any detection: the caller then drops every track, as the reference does."""
+        if not frame_dets:
             return None
-        temp = []
-        for det in results:
-            if det["detection_name"] not in NUSCENES_TRACKING_NAMES:
-                continue
-            det["ct"] = np.array(det["translation"][:2])
-            det["tracking"] = np.array(det["velocity"][:2]) * -1 * time_lag
-            det["label_preds"] = NUSCENES_TRACKING_NAMES.index(det["detection_name"])
-            temp.append(det)
-        results = temp
-        if "tracking" in results[0]:  # IndexError on a frame without any tracking-class detection, like the reference
-            dets = np.array([det["ct"] + det["tracking"].astype(np.float32) for det in results], np.float32)
-        else:
-            dets = np.array([det["ct"] for det in results], np.float32)
-        item_cat = np.array([item["label_preds"] for item in results], np.int32)
-        track_cat = np.array([track["label_preds"] for track in self.tracks], np.int32)
-        max_diff = np.array([self.NUSCENE_CLS_VELOCITY_ERROR[box["detection_name"]] for box in results], np.float32)
-        tracks = np.array([pre_det["ct"] for pre_det in self.tracks], np.float32)
-        return results, dets, tracks, item_cat, track_cat, max_diff
+        kept = [d for d in frame_dets if d["detection_name"] in NUSCENES_TRACKING_NAMES]
+        for d in kept:
+            d["ct"] = np.array(d["translation"][:2])
+            d["tracking"] = np.array(d["velocity"][:2]) * -1 * time_lag
+            d["label_preds"] = NUSCENES_TRACKING_NAMES.index(d["detection_name"])
+        _ = kept[0]  # a frame with detections but none of a tracking class raises IndexError, like the reference
+        # predicted previous-frame centres: float32 offset added to the float64 centre, then the whole row to float32
+        det_xy = np.array([d["ct"] + d["tracking"].astype(np.float32) for d in kept], np.float32)
+        det_cls = np.array([d["label_preds"] for d in kept], np.int32)
+        gate = np.array([self.NUSCENE_CLS_VELOCITY_ERROR[d["detection_name"]] for d in kept], np.float32)
+        trk_xy = np.array([t["ct"] for t in self.tracks], np.float32)
+        trk_cls = np.array([t["label_preds"] for t in self.tracks], np.int32)
+        return kept, det_xy, trk_xy, det_cls, trk_cls, gate
 
-    def _finish(self, results, dets, tracks, dist, matched_indices):
-        """:118-210: unmatched bookkeeping, ids, ages, confidence refinement."""
-        unmatched_dets = [d for d in range(dets.shape[0]) if not (d in matched_indices[:, 0])]
-        unmatched_tracks = [d for d in range(tracks.shape[0]) if not (d in matched_indices[:, 1])]
-        if self.hungarian:
-            matches = []
-            for m in matched_indices:
-                if dist[m[0], m[1]] > 1e16:
-                    unmatched_dets.append(m[0])
-                else:
-                    matches.append(m)
-            matches = np.array(matches).reshape(-1, 2)
-        else:
-            matches = matched_indices
-        ret = []
-        for m in matches:
-            track = results[m[0]]
-            track["tracking_id"] = self.tracks[m[1]]["tracking_id"]
+    def _finish(self, dets, det_xy, trk_xy, dist, pairs):
+        """Bookkeeping after the assignment: ids, ages, `active` counters, confidence refinement, the newborn / dead
+        suppression rules, carrying unmatched tracks for up to max_age frames."""
+        n_det, n_trk = det_xy.shape[0], trk_xy.shape[0]
+        taken_d, taken_t = set(pairs[:, 0].tolist()), set(pairs[:, 1].tolist())
+        free_dets = [i for i in range(n_det) if i not in taken_d]
+        free_tracks = [j for j in range(n_trk) if j not in taken_t]
+        if self.hungarian:  # the solver pairs everything: pairs at the invalid cost are not matches
+            good = [p for p in pairs if not dist[p[0], p[1]] > 1e16]
+            free_dets += [p[0] for p in pairs if dist[p[0], p[1]] > 1e16]
+            pairs = np.array(good).reshape(-1, 2)
+        gate_of = self.NUSCENE_CLS_VELOCITY_ERROR
+        out = []
+        for i, j in pairs:
+            det, old = dets[i], self.tracks[j]
+            det["tracking_id"] = old["tracking_id"]
             if self.refine_confidence:
-                prev_track_conf = self.tracks[m[1]]["ref_detection_score"]
-                tp_prob = track["ref_detection_score"]
-                det_conf = track["detection_score"]
-                track["ref_detection_score"] = (tp_prob > self.alpha) * self.beta * det_conf + (1 - self.beta) * prev_track_conf
-            track["age"] = 1
-            track["active"] = self.tracks[m[1]]["active"] + 1
-            ret.append(track)
-        for i in unmatched_dets:
-            track = results[i]
-            if len(tracks) > 0:
-                if "newborn" not in track.keys() and (dist[i, :] <= self.NUSCENE_CLS_VELOCITY_ERROR[track["detection_name"]]).sum():
-                    continue
-            self.id_count += 1
-            track["tracking_id"] = self.id_count
-            track["ref_detection_score"] = track["detection_score"]
-            track["age"] = 1
-            track["active"] = 1
-            ret.append(track)
-        for i in unmatched_tracks:
-            track = self.tracks[i]
-            if "dead" in track.keys() and (dist[:, i] <= self.NUSCENE_CLS_VELOCITY_ERROR[track["detection_name"]]).sum():
+                det["ref_detection_score"] = ((det["ref_detection_score"] > self.alpha) * self.beta * det["detection_score"]
+                                              + (1 - self.beta) * old["ref_detection_score"])
+            det["age"] = 1
+            det["active"] = old["active"] + 1
+            out.append(det)
+        for i in free_dets:
+            det = dets[i]
+            # an unmatched detection that is not marked newborn but sits inside the gate of some track is dropped
+            if n_trk > 0 and "newborn" not in det and (dist[i, :] <= gate_of[det["detection_name"]]).sum():
                 continue
-            if track["age"] < self.max_age:
-                track["age"] += 1
-                track["active"] = 0
-                ct = track["ct"]
-                if "tracking" in track:
-                    offset = track["tracking"] * -1  # move forward
-                    track["ct"] = ct + offset
-                ret.append(track)
-        self.tracks = ret
-        return ret
+            self.id_count += 1
+            det.update(tracking_id=self.id_count, ref_detection_score=det["detection_score"], age=1, active=1)
+            out.append(det)
+        for j in free_tracks:
+            old = self.tracks[j]
+            if "dead" in old and (dist[:, j] <= gate_of[old["detection_name"]]).sum():
+                continue
+            if old["age"] < self.max_age:  # coast: keep the track, move its centre forward by its last offset
+                old["age"] += 1
+                old["active"] = 0
+                if "tracking" in old:
+                    old["ct"] = old["ct"] + old["tracking"] * -1
+                out.append(old)
+        self.tracks = out
+        return out
 
     def _host_assign(self, dist):
         from scipy.optimize import linear_sum_assignment

@@ -1,62 +1,64 @@
-"""Registry / build_from_cfg, mirroring det3d/utils/registry.py:6-78 and det3d/models/registry.py:3-14
-(same names, same argument meaning, same errors) so reference config dicts build this package's modules."""
+"""Name -> class registries and `build_from_cfg`, the contract of det3d/utils/registry.py:6-78 and
+det3d/models/registry.py:3-14: a config dict `{"type": "<registered name>" | <class>, **kwargs}` is turned into an
+instance, missing keyword arguments are filled from `default_args`.  Behaviour kept: `@REG.register_module` decorator,
+KeyError for duplicate or unknown names, TypeError for a non-class / a `type` that is neither str nor class, and the
+`_module_dict` / `module_dict` / `name` / `get` accessors that reference-side code (and INTEGRATION.md) uses."""
 import inspect
 
 
-class Registry(object):
+class Registry:
+    """A named table of classes."""
+
     def __init__(self, name):
-        self._name = name
-        self._module_dict = dict()
+        self._name = str(name)
+        self._module_dict = {}
+
+    name = property(lambda self: self._name)
+    module_dict = property(lambda self: self._module_dict)
 
     def __repr__(self):
-        return "{}(name={}, items={})".format(self.__class__.__name__, self._name, list(self._module_dict.keys()))
+        return "%s(name=%s, items=%s)" % (type(self).__name__, self._name, sorted(self._module_dict))
 
-    @property
-    def name(self):
-        return self._name
-
-    @property
-    def module_dict(self):
-        return self._module_dict
+    def __contains__(self, key):
+        return key in self._module_dict
 
     def get(self, key):
-        return self._module_dict.get(key, None)
-
-    def _register_module(self, module_class):
-        if not inspect.isclass(module_class):
-            raise TypeError("module must be a class, but got {}".format(type(module_class)))
-        module_name = module_class.__name__
-        if module_name in self._module_dict:
-            raise KeyError("{} is already registered in {}".format(module_name, self.name))
-        self._module_dict[module_name] = module_class
+        """Registered class or None."""
+        return self._module_dict.get(key)
 
     def register_module(self, cls):
-        self._register_module(cls)
+        """Class decorator: registers `cls` under its own __name__ and returns it unchanged."""
+        if not inspect.isclass(cls):
+            raise TypeError("module must be a class, but got %s" % type(cls))
+        key = cls.__name__
+        if key in self._module_dict:
+            raise KeyError("%s is already registered in %s" % (key, self._name))
+        self._module_dict[key] = cls
         return cls
 
 
+def _resolve(kind, registry):
+    if inspect.isclass(kind):
+        return kind
+    if not isinstance(kind, str):
+        raise TypeError("type must be a str or valid type, but got %s" % type(kind))
+    found = registry.get(kind)
+    if found is None:
+        raise KeyError("%s is not in the %s registry" % (kind, registry.name))
+    return found
+
+
 def build_from_cfg(cfg, registry, default_args=None):
-    """det3d/utils/registry.py:49-78: pop `type`, look the class up, fill defaults, call it."""
-    assert isinstance(cfg, dict) and "type" in cfg
-    assert isinstance(default_args, dict) or default_args is None
-    args = dict(cfg)
-    obj_type = args.pop("type")
-    if isinstance(obj_type, str):
-        obj_cls = registry.get(obj_type)
-        if obj_cls is None:
-            raise KeyError("{} is not in the {} registry".format(obj_type, registry.name))
-    elif inspect.isclass(obj_type):
-        obj_cls = obj_type
-    else:
-        raise TypeError("type must be a str or valid type, but got {}".format(type(obj_type)))
-    if default_args is not None:
-        for name, value in default_args.items():
-            args.setdefault(name, value)
-    return obj_cls(**args)
+    """Instantiate `cfg["type"]` (a registered name or a class) with the remaining keys; `default_args` only fills keys
+    the config does not set."""
+    if not (isinstance(cfg, dict) and "type" in cfg):
+        raise AssertionError("cfg must be a dict with a 'type' key")
+    if default_args is not None and not isinstance(default_args, dict):
+        raise AssertionError("default_args must be a dict or None")
+    kwargs = {k: v for k, v in cfg.items() if k != "type"}
+    for k, v in (default_args or {}).items():
+        kwargs.setdefault(k, v)
+    return _resolve(cfg["type"], registry)(**kwargs)
 
 
-READERS = Registry("reader")
-BACKBONES = Registry("backbone")
-NECKS = Registry("neck")
-TRACK = Registry("track")
-SECOND_STAGE = Registry("second_stage")
+READERS, BACKBONES, NECKS, TRACK, SECOND_STAGE = (Registry(n) for n in ("reader", "backbone", "neck", "track", "second_stage"))

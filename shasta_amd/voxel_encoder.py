@@ -1,8 +1,8 @@
-"""VoxelFeatureExtractorV3 (det3d/models/readers/voxel_encoder.py:9-28): per-voxel mean of the point slots.
+"""VoxelFeatureExtractorV3 (det3d/models/readers/voxel_encoder.py:9-28): the reader that averages the points of a voxel.
 
-On the HIP path the mean is produced by the voxeliser itself (shasta_voxelize_mean_f32); this module keeps the
-reference's reader interface for callers that already hold (voxels, num_points) tensors."""
-import torch
+On the HIP path the mean comes out of the voxeliser itself (`shasta_voxelize_mean_f32`, voxel_generator.generate_device);
+this module keeps the reference's reader interface - constructor keywords, `forward(features, num_voxels, coors)` - for
+callers that already hold zero-padded (V, max_points, C) voxel tensors and their point counts."""
 from torch import nn
 
 from .registry import READERS
@@ -12,10 +12,11 @@ from .registry import READERS
 class VoxelFeatureExtractorV3(nn.Module):
     def __init__(self, num_input_features=4, norm_cfg=None, name="VoxelFeatureExtractorV3"):
         super().__init__()
-        self.name = name
-        self.num_input_features = num_input_features
+        self.name, self.num_input_features = name, num_input_features
 
     def forward(self, features, num_voxels, coors=None):
-        assert self.num_input_features == features.shape[-1]
-        s = features[:, :, : self.num_input_features].sum(dim=1, keepdim=False)
-        return (s / num_voxels.type_as(features).view(-1, 1)).contiguous()
+        c = self.num_input_features
+        if features.shape[-1] != c:
+            raise AssertionError("expected %d point features, got %d" % (c, features.shape[-1]))
+        counts = num_voxels.to(features.dtype).reshape(-1, 1)  # padded slots are zero: the slot sum is the point sum
+        return (features[..., :c].sum(dim=1) / counts).contiguous()
