@@ -250,10 +250,12 @@ int shasta_nms_rotated_f32(const float* boxes_sorted, int num_boxes, float thres
  *  det_xy (S,Nmax,2) fp32 = ct + tracking of every detection, trk_xy (S,Mmax,2), det_cat / trk_cat int32 class ids,
  *  max_diff (S,Nmax) fp32 per-detection gate, n / m (S,) int32 valid counts (device), Mmax <= 4096
  *  dist (S,Nmax,Mmax) float64 or NULL (rows >= n, columns >= m are not written), match (S,Nmax) int32: track index or -1
+ *  row_any (S,Nmax) / col_any (S,Mmax) int32 or NULL: 1 when the row / column holds a pair inside the gate, i.e. the value
+ *  of `(dist[i, :] <= gate).sum() > 0` / `(dist[:, j] <= gate).sum() > 0` that pub_tracker.py:156,178 test
  * ------------------------------------------------------------------------------------------ */
 int shasta_center_greedy_f32(const float* det_xy, const float* trk_xy, const int32_t* det_cat, const int32_t* trk_cat,
                              const float* max_diff, const int32_t* n, const int32_t* m, int scenes, int Nmax, int Mmax,
-                             double* dist, int32_t* match, shasta_stream_t stream);
+                             double* dist, int32_t* match, int32_t* row_any, int32_t* col_any, shasta_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training path, backward helpers (the nn.Linear layers run on shasta_gemm_strided_f32; the first layer of each pair MLP

@@ -21,6 +21,8 @@ struct GreedyArgs {
     const int* m;          // (S,)
     double* dist;          // (S, Nmax, Mmax) or nullptr
     int* match;            // (S, Nmax): matched track index or -1
+    int* row_any;          // (S, Nmax) or nullptr: 1 when some track is inside the detection's gate (class + distance)
+    int* col_any;          // (S, Mmax) or nullptr: 1 when some detection is inside the gate of the track
     int Nmax, Mmax;
 };
 
@@ -46,13 +48,28 @@ __global__ __launch_bounds__(64) void center_greedy_kernel(GreedyArgs a) {
     int* match = a.match + (size_t)s * a.Nmax;
     for (int w = lane; w < GREEDY_MAX_M / 32; w += 64) taken[w] = 0u;
     for (int i = lane; i < a.Nmax; i += 64) match[i] = -1;
-    if (a.dist) {
-        double* D = a.dist + (size_t)s * a.Nmax * a.Mmax;
+    if (a.dist || a.row_any || a.col_any) {
+        // the flags are what the tracker's newborn / dead rules need from the matrix ((dist <= gate).sum() > 0 along a row
+        // or a column, pub_tracker.py:156,178): with them the N x M float64 matrix does not have to travel to the host
+        double* D = a.dist ? a.dist + (size_t)s * a.Nmax * a.Mmax : nullptr;
+        unsigned long long colbits = 0ull;  // bit k: column lane + 64 k has a valid pair
         for (int i = 0; i < N; ++i) {
             const float dx = dxy[2 * i], dy = dxy[2 * i + 1], mdi = md[i];
             const int dc = dcat[i];
-            for (int j = lane; j < M; j += 64) D[(size_t)i * a.Mmax + j] = pair_dist64(dx, dy, txy[2 * j], txy[2 * j + 1], mdi, dc, tcat[j]);
+            bool any = false;
+            for (int j = lane, k = 0; j < M; j += 64, ++k) {
+                const double v = pair_dist64(dx, dy, txy[2 * j], txy[2 * j + 1], mdi, dc, tcat[j]);
+                if (D) D[(size_t)i * a.Mmax + j] = v;
+                if (v < 1e16) {
+                    any = true;
+                    colbits |= 1ull << k;
+                }
+            }
+            const bool row_hit = __any(any);
+            if (a.row_any && lane == 0) a.row_any[(size_t)s * a.Nmax + i] = row_hit ? 1 : 0;
         }
+        if (a.col_any)
+            for (int j = lane, k = 0; j < M; j += 64, ++k) a.col_any[(size_t)s * a.Mmax + j] = (int)((colbits >> k) & 1ull);
     }
     __builtin_amdgcn_wave_barrier();
     if (M == 0) return;
@@ -94,11 +111,11 @@ using namespace shasta;
 
 extern "C" int shasta_center_greedy_f32(const float* det_xy, const float* trk_xy, const int32_t* det_cat, const int32_t* trk_cat,
                                         const float* max_diff, const int32_t* n, const int32_t* m, int scenes, int Nmax, int Mmax,
-                                        double* dist, int32_t* match, shasta_stream_t stream) {
+                                        double* dist, int32_t* match, int32_t* row_any, int32_t* col_any, shasta_stream_t stream) {
     SHASTA_REQUIRE(det_xy && trk_xy && det_cat && trk_cat && max_diff && n && m && match, "center_greedy: null pointer");
     SHASTA_REQUIRE(scenes >= 0 && Nmax >= 1 && Mmax >= 1 && Mmax <= GREEDY_MAX_M, "center_greedy: bad size (Mmax <= 4096)");
     if (scenes == 0) return SHASTA_OK;
-    GreedyArgs a{det_xy, trk_xy, det_cat, trk_cat, max_diff, n, m, dist, match, Nmax, Mmax};
+    GreedyArgs a{det_xy, trk_xy, det_cat, trk_cat, max_diff, n, m, dist, match, row_any, col_any, Nmax, Mmax};
     hipLaunchKernelGGL(center_greedy_kernel, dim3(scenes), dim3(64), 0, as_stream(stream), a);
     return check_launch("center_greedy");
 }

@@ -9,7 +9,7 @@ import os
 
 import torch
 
-ABI_VERSION = 2  # must equal shasta_abi_version() of the loaded library
+ABI_VERSION = 3  # must equal shasta_abi_version() of the loaded library
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libshasta_hip.so")
 _lib = None
 
@@ -71,7 +71,7 @@ SYMBOLS = {
     "shasta_bev_gather_bwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
     "shasta_nms_workspace_bytes": (_Z, [_I]),
     "shasta_nms_rotated_f32": (_I, [_P, _I, _F, _P, _Z, _P, _P, _P]),
-    "shasta_center_greedy_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "shasta_center_greedy_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "shasta_decode_flags_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "shasta_gemm_strided_f32": (_I, [_P, C.c_long, C.c_long, _P, C.c_long, C.c_long, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "shasta_gemm_nt_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -22,7 +22,10 @@ NUSCENE_CLS_VELOCITY_ERROR = {"car": 2, "truck": 2, "bus": 4, "trailer": 2, "ped
 
 def center_greedy_device(problems, device=None, want_dist=True):
     """problems: list of (dets (N,2) f32, tracks (M,2) f32, det_cat (N,) i32, trk_cat (M,) i32, max_diff (N,) f32) numpy
-    tuples with N, M >= 1.  Returns a list of (dist (N,M) float64 numpy or None, matched_indices (K,2) int32 numpy)."""
+    tuples with N, M >= 1.  Returns a list of (dist (N,M) float64 numpy or None, matched_indices (K,2) int32 numpy,
+    row_any (N,) bool, col_any (M,) bool); the two flag vectors say whether a detection / a track has any partner inside
+    its gate - all the tracker needs from the matrix unless it runs the Hungarian solver, so with want_dist=False the
+    float64 matrices never leave the device."""
     lib = hip.load()
     device = device or torch.device("cuda", torch.cuda.current_device())
     S = len(problems)
@@ -40,16 +43,18 @@ def center_greedy_device(problems, device=None, want_dist=True):
     dev = [torch.from_numpy(x).to(device) for x in (dxy, txy, dc, tc, md, n, m)]
     dist = torch.empty(S, Nmax, Mmax, dtype=torch.float64, device=device) if want_dist else None
     match = torch.empty(S, Nmax, dtype=torch.int32, device=device)
-    hip.check(lib.shasta_center_greedy_f32(*[hip.ptr(x) for x in dev], S, Nmax, Mmax, hip.ptr(dist), hip.ptr(match), hip.stream_ptr()),
-              "shasta_center_greedy_f32")
-    match_h = match.cpu().numpy()
+    row_any = torch.zeros(S, Nmax, dtype=torch.int32, device=device)
+    col_any = torch.zeros(S, Mmax, dtype=torch.int32, device=device)
+    hip.check(lib.shasta_center_greedy_f32(*[hip.ptr(x) for x in dev], S, Nmax, Mmax, hip.ptr(dist), hip.ptr(match), hip.ptr(row_any),
+                                           hip.ptr(col_any), hip.stream_ptr()), "shasta_center_greedy_f32")
+    match_h, row_h, col_h = match.cpu().numpy(), row_any.cpu().numpy() != 0, col_any.cpu().numpy() != 0
     dist_h = dist.cpu().numpy() if want_dist else None
     out = []
     for s in range(S):
         mi = match_h[s, :n[s]]
         rows = np.nonzero(mi >= 0)[0]
         pairs = np.stack([rows, mi[rows]], axis=1).astype(np.int32).reshape(-1, 2)
-        out.append((dist_h[s, :n[s], :m[s]].copy() if want_dist else None, pairs))
+        out.append((dist_h[s, :n[s], :m[s]].copy() if want_dist else None, pairs, row_h[s, :n[s]].copy(), col_h[s, :m[s]].copy()))
     return out
 
 
@@ -90,18 +95,22 @@ class PubTracker(object):
         trk_cls = np.array([t["label_preds"] for t in self.tracks], np.int32)
         return kept, det_xy, trk_xy, det_cls, trk_cls, gate
 
-    def _finish(self, dets, det_xy, trk_xy, dist, pairs):
+    def _finish(self, dets, det_xy, trk_xy, dist, pairs, det_near=None, trk_near=None):
         """Bookkeeping after the assignment: ids, ages, `active` counters, confidence refinement, the newborn / dead
         suppression rules, carrying unmatched tracks for up to max_age frames."""
         n_det, n_trk = det_xy.shape[0], trk_xy.shape[0]
         taken_d, taken_t = set(pairs[:, 0].tolist()), set(pairs[:, 1].tolist())
         free_dets = [i for i in range(n_det) if i not in taken_d]
         free_tracks = [j for j in range(n_trk) if j not in taken_t]
+        if det_near is None and dist is not None:  # flags of the newborn / dead rules straight from the matrix
+            det_near = np.array([(dist[i, :] <= self.NUSCENE_CLS_VELOCITY_ERROR[dets[i]["detection_name"]]).sum() > 0
+                                 for i in range(n_det)], bool)
+            trk_near = np.array([(dist[:, j] <= self.NUSCENE_CLS_VELOCITY_ERROR[self.tracks[j]["detection_name"]]).sum() > 0
+                                 for j in range(n_trk)], bool)
         if self.hungarian:  # the solver pairs everything: pairs at the invalid cost are not matches
             good = [p for p in pairs if not dist[p[0], p[1]] > 1e16]
             free_dets += [p[0] for p in pairs if dist[p[0], p[1]] > 1e16]
             pairs = np.array(good).reshape(-1, 2)
-        gate_of = self.NUSCENE_CLS_VELOCITY_ERROR
         out = []
         for i, j in pairs:
             det, old = dets[i], self.tracks[j]
@@ -115,14 +124,14 @@ class PubTracker(object):
         for i in free_dets:
             det = dets[i]
             # an unmatched detection that is not marked newborn but sits inside the gate of some track is dropped
-            if n_trk > 0 and "newborn" not in det and (dist[i, :] <= gate_of[det["detection_name"]]).sum():
+            if n_trk > 0 and "newborn" not in det and det_near[i]:
                 continue
             self.id_count += 1
             det.update(tracking_id=self.id_count, ref_detection_score=det["detection_score"], age=1, active=1)
             out.append(det)
         for j in free_tracks:
             old = self.tracks[j]
-            if "dead" in old and (dist[:, j] <= gate_of[old["detection_name"]]).sum():
+            if "dead" in old and trk_near[j]:
                 continue
             if old["age"] < self.max_age:  # coast: keep the track, move its centre forward by its last offset
                 old["age"] += 1
@@ -153,7 +162,8 @@ def step_batch(trackers, results_list, time_lags):
         if p is not None and len(p[2]) > 0:  # not the first frame of the scene
             where.append(k)
             problems.append((p[1], p[2], p[3], p[4], p[5]))
-    solved = dict(zip(where, center_greedy_device(problems))) if problems else {}
+    need_dist = any(trackers[k].hungarian for k in where)  # only the Hungarian solver needs the matrices on the host
+    solved = dict(zip(where, center_greedy_device(problems, want_dist=need_dist))) if problems else {}
     outs = []
     for k, trk in enumerate(trackers):
         p = prepared[k]
@@ -162,12 +172,13 @@ def step_batch(trackers, results_list, time_lags):
             outs.append([])
             continue
         results, dets, tracks = p[0], p[1], p[2]
+        det_near = trk_near = None
         if k in solved:
-            dist, matched = solved[k]
+            dist, matched, det_near, trk_near = solved[k]
             if trk.hungarian:
                 dist, matched = trk._host_assign(dist)
         else:
             assert len(trk.tracks) == 0
             dist, matched = None, np.array([], np.int32).reshape(-1, 2)
-        outs.append(trk._finish(results, dets, tracks, dist, matched))
+        outs.append(trk._finish(results, dets, tracks, dist, matched, det_near, trk_near))
     return outs

@@ -80,10 +80,11 @@ mm_ = torch.full((S,), m, dtype=torch.int32, device=dev)
 dist = torch.empty(S, n, m, dtype=torch.float64, device=dev)
 match = torch.empty(S, n, dtype=torch.int32, device=dev)
 us = timed(lambda: hip.check(lib.shasta_center_greedy_f32(hip.ptr(arrs[0]), hip.ptr(arrs[1]), hip.ptr(arrs[2]), hip.ptr(arrs[3]), hip.ptr(arrs[4]),
-                                                           hip.ptr(nn_), hip.ptr(mm_), S, n, m, hip.ptr(dist), hip.ptr(match), hip.stream_ptr()), "greedy"), reps=5)
+                                                           hip.ptr(nn_), hip.ptr(mm_), S, n, m, hip.ptr(dist), hip.ptr(match), None, None, hip.stream_ptr()), "greedy"), reps=5)
 print("%-34s %8.1f us  (%.1f us per scene)" % ("tracker assign, 150 scenes 300x300", us, us / S))
 import time  # noqa: E402
-t0 = time.perf_counter()
-center_greedy_device(probs)
-torch.cuda.synchronize()
-print("%-34s %8.1f us  end to end incl. host staging and D2H" % ("  same through center_greedy_device", (time.perf_counter() - t0) * 1e6))
+for want in (True, False):
+    t0 = time.perf_counter()
+    center_greedy_device(probs, want_dist=want)
+    torch.cuda.synchronize()
+    print("%-34s %8.1f us  end to end incl. host staging and D2H" % ("  center_greedy_device dist=%s" % want, (time.perf_counter() - t0) * 1e6))
