@@ -150,10 +150,14 @@ def _mlp(w, prefix, x):
 
 
 # row 3: shared_conv (shasta.py:42-47 applied :223-228): conv3x3+BN(eval)+ReLU -> NHWC
-def shared_conv_nhwc(w, bev_nchw, bn_eps=1e-5):
+def shared_conv_nhwc(w, bev_nchw, bn_eps=1e-5, batch_stats=False):
+    """batch_stats=True: BatchNorm as in train() mode (statistics of this batch; the running buffers are not updated here)."""
     y = TF.conv2d(bev_nchw, w["shared_conv.0.weight"], w["shared_conv.0.bias"], padding=1)
-    y = TF.batch_norm(y, w["shared_conv.1.running_mean"], w["shared_conv.1.running_var"],
-                      w["shared_conv.1.weight"], w["shared_conv.1.bias"], False, 0.0, bn_eps)
+    if batch_stats:
+        y = TF.batch_norm(y, None, None, w["shared_conv.1.weight"], w["shared_conv.1.bias"], True, 0.0, bn_eps)
+    else:
+        y = TF.batch_norm(y, w["shared_conv.1.running_mean"], w["shared_conv.1.running_var"],
+                          w["shared_conv.1.weight"], w["shared_conv.1.bias"], False, 0.0, bn_eps)
     return torch.relu(y).permute(0, 2, 3, 1).contiguous()
 
 
