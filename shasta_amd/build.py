@@ -17,6 +17,9 @@ SOURCES = ["abi.hip", "bev_gather.hip", "gemm_f32.hip", "anchor.hip", "anchor_mf
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fmaf(); products that the
 # reference rounds separately stay separately rounded (parity with the PyTorch fp32 forward).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-file additions.  pair.hip: keep the MFMA accumulators in architectural VGPRs (113 registers instead of 116 + 44 AGPRs:
+# 4 waves per SIMD become possible, and a layer's accumulators feed the next layer without v_accvgpr_read)
+EXTRA_FLAGS = {"pair.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc():
@@ -44,7 +47,7 @@ def build(force=False, verbose=True):
 
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))

@@ -668,8 +668,8 @@ struct A4 {
     static constexpr int NOB = a4_nob(F, L), KG = a4_kg(F, L), OFF = a4_offset(F, L), KIN = D.kin, BIAS = NOB * KG * 16;
 };
 
-template <int F>
-__global__ __launch_bounds__(256) void pair_mfma4_kernel(const float* __restrict__ packed, const float* __restrict__ UP,
+template <int F, int WPB>
+__global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __restrict__ packed, const float* __restrict__ UP,
                                                          const float* __restrict__ UC, const float* __restrict__ hand_prev,
                                                          const float* __restrict__ hand_det, const float* __restrict__ denom,
                                                          float* __restrict__ residual, int T, int D, int ld, int nf,
@@ -688,13 +688,13 @@ __global__ __launch_bounds__(256) void pair_mfma4_kernel(const float* __restrict
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(UC);
 #pragma unroll 4
-        for (int e = tid; e < 64 * (ET / 4); e += 256) {
+        for (int e = tid; e < 64 * (ET / 4); e += 64 * WPB) {
             const int r = e / (ET / 4), c = e - r * (ET / 4);
             *reinterpret_cast<f32x4*>(&s_uc[r * US + 4 * c]) = src[((size_t)b * D + min(d0 + r, D - 1)) * (ET / 4) + c];
         }
         const f32x4* asrc = reinterpret_cast<const f32x4*>(packed + P.a4);
 #pragma unroll 2
-        for (int e = tid; e < NA4 / 4; e += 256) reinterpret_cast<f32x4*>(s_a4)[e] = asrc[e];
+        for (int e = tid; e < NA4 / 4; e += 64 * WPB) reinterpret_cast<f32x4*>(s_a4)[e] = asrc[e];
     }
     float hd[12];
     {
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256) void pair_mfma4_kernel(const float* __restrict
     const unsigned abias_base = (unsigned)(unsigned long long)(s_a4 + (lane & 3));
     const f32x4 zero4 = {0, 0, 0, 0};
 
-    const int t_beg = (blockIdx.y * 4 + wid) * TW;
+    const int t_beg = (blockIdx.y * WPB + wid) * TW;
     const int t_end = min(T, t_beg + TW);
     for (int t = t_beg; t < t_end; ++t) {
         const cfloat* up = (const cfloat*)(UP + ((size_t)b * T + t) * ET);        // wave-uniform -> s_load
@@ -862,17 +862,24 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     static const bool use_mfma_chain = getenv("SHASTA_PAIR_MFMA") != nullptr;
     static const bool use_valu = getenv("SHASTA_PAIR_VALU") != nullptr;
     if (!use_mfma_chain && !use_valu) {
-        // default: lane = pair, 4x4x1 MFMA
+        // default: lane = pair, 4x4x1 MFMA.  WPB waves of a workgroup share one 64-detection UC tile and take different track
+        // ranges; 8 waves per workgroup (two workgroups per CU by LDS, 113 VGPRs in the VGPR MFMA form) give 4 waves per SIMD
+        // where 4-wave workgroups give 3 (43 KB of LDS each).
+        static const bool w4 = getenv("SHASTA_PAIR_W4") != nullptr;
+        const int wpb = w4 ? 4 : 8;
         int tw = 16;
-        while (tw > 2 && (long)B * cdiv(D, 64) * 4 * cdiv(T, 4 * tw) < 3072) tw >>= 1;
+        while (tw > 2 && (long)B * cdiv(D, 64) * wpb * cdiv(T, wpb * tw) < 4096) tw >>= 1;
         const size_t lds = ((size_t)64 * (d.ET + 4) + a4_total(F)) * sizeof(float);
-        dim3 grid(cdiv(D, 64), cdiv(T, 4 * tw), B);
+        dim3 grid(cdiv(D, 64), cdiv(T, wpb * tw), B);
+#define SHASTA_LAUNCH_PAIR4(FF, WW) \
+    hipLaunchKernelGGL((pair_mfma4_kernel<FF, WW>), grid, dim3(64 * WW), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw)
         switch (F) {
-            case 64: hipLaunchKernelGGL(pair_mfma4_kernel<64>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
-            case 256: hipLaunchKernelGGL(pair_mfma4_kernel<256>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
-            case 320: hipLaunchKernelGGL(pair_mfma4_kernel<320>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
+            case 64: if (w4) SHASTA_LAUNCH_PAIR4(64, 4); else SHASTA_LAUNCH_PAIR4(64, 8); break;
+            case 256: if (w4) SHASTA_LAUNCH_PAIR4(256, 4); else SHASTA_LAUNCH_PAIR4(256, 8); break;
+            case 320: if (w4) SHASTA_LAUNCH_PAIR4(320, 4); else SHASTA_LAUNCH_PAIR4(320, 8); break;
             default: set_error_msg("pair_residual: feat_dim must be 64, 256 or 320"); return SHASTA_E_ARG;
         }
+#undef SHASTA_LAUNCH_PAIR4
         return check_launch("pair_mfma4");
     }
     if (!use_mfma_chain) {
