@@ -294,7 +294,7 @@ def test_voxelize_vs_oracle_full_size(P, mp, mv, seed):
         assert np.array_equal(cell[:, ::-1], rc)
 
 
-@pytest.mark.parametrize("flag", ["SHASTA_PAIR_MFMA", "SHASTA_PAIR_VALU", "SHASTA_AFF_UNFUSED", "SHASTA_AFF_RG2", "SHASTA_L1_VALU"])
+@pytest.mark.parametrize("flag", ["SHASTA_PAIR_MFMA", "SHASTA_PAIR_VALU", "SHASTA_PAIR_W4", "SHASTA_AFF_UNFUSED", "SHASTA_AFF_RG2", "SHASTA_L1_VALU"])
 def test_alternative_kernel_variants_match_goldens(flag):
     """The selectable variants (16x16x4 MFMA chain / packed-VALU pair kernels, layer-by-layer aff, VALU batch kernels for
     the anchor stream) stay parity-green: rerun the golden tests in a subprocess with the variant's switch set."""
