@@ -291,6 +291,15 @@ int shasta_bev_gather_bwd_f32(const float* dfeat, int B, int H, int W, int C, co
                               int box_batch_stride, int num_point, float pc_x0, float pc_y0, float vs_x, float vs_y,
                               float out_stride, int row_stride, int batch_stride, float* dbev, shasta_stream_t stream);
 
+/* The two 1 GB streams of the anchor backward at small (world x) batch R <= 16 (K % 4 == 0, 16-byte aligned):
+ *   shasta_lowrank_outer_f32: dW (H, K) = G^T X, G (R, ldg >= H), X (R, ldx >= K)   -- torch autograd of nn.Linear weight
+ *   shasta_smallm_nn_f32:     Y (R rows, stride ldy) (+)= G W, W (H, K)             -- ... of its input
+ * fixed-order sums; shasta_smallm_nn_workspace_bytes(R, H, K) bytes of scratch for the second one. */
+int shasta_lowrank_outer_f32(const float* G, int ldg, const float* X, int ldx, int R, int H, int K, float* dW, shasta_stream_t stream);
+size_t shasta_smallm_nn_workspace_bytes(int R, int H, int K);
+int shasta_smallm_nn_f32(const float* G, int ldg, const float* W, int R, int H, int K, float* Y, long ldy, int accumulate, void* workspace,
+                         size_t workspace_bytes, shasta_stream_t stream);
+
 /* x *= alpha (gradient averaging over data-parallel ranks) */
 int shasta_scale_f32(float* x, long n, float alpha, shasta_stream_t stream);
 

@@ -344,6 +344,66 @@ __global__ void scale_kernel(float* __restrict__ x, long n, float alpha) {
     if (i < n) x[i] *= alpha;
 }
 
+// ---- the two big streams of the anchor backward at small batch ----------------------------------------------------------
+// dW1 = ghid^T x is a rank-R update of an (H, K) matrix (1 GB at N = 500) and dx = ghid W1 reads that matrix once; with R =
+// (world x) batch <= 16 both are pure HBM streams with R FMAs per element, which a 64 x 64-tile GEMM with a K = R
+// reduction serves at only ~2.7 TB/s.  One thread owns 4 consecutive columns (one 16-byte access per row).
+template <int RMAX>
+__global__ __launch_bounds__(256) void lowrank_outer_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
+                                                            int R, int H, int K, int rows_per_block, float* __restrict__ dW) {
+    const long k4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (k4 >= K) return;
+    f32x4 xv[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) xv[r] = r < R ? *reinterpret_cast<const f32x4*>(X + (size_t)r * ldx + k4) : f32x4{0, 0, 0, 0};
+    const int h0 = blockIdx.y * rows_per_block, h1 = min(H, h0 + rows_per_block);
+    for (int h = h0; h < h1; ++h) {
+        f32x4 o = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const float g = r < R ? G[(size_t)r * ldg + h] : 0.0f;  // wave-uniform: scalar load
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = fmaf(g, xv[r][c], o[c]);
+        }
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dW + (size_t)h * K + k4));
+    }
+}
+
+// part[chunk][r][k] = sum_{h in chunk} G[r][h] * W[h][k]
+template <int RMAX>
+__global__ __launch_bounds__(256) void smallm_nn_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ W, int R, int H,
+                                                        int K, int rows_per_chunk, float* __restrict__ part) {
+    const long k4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (k4 >= K) return;
+    f32x4 acc[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) acc[r] = f32x4{0, 0, 0, 0};
+    const int h0 = blockIdx.y * rows_per_chunk, h1 = min(H, h0 + rows_per_chunk);
+#pragma unroll 2
+    for (int h = h0; h < h1; ++h) {
+        const f32x4 wv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(W + (size_t)h * K + k4));
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const float g = r < R ? G[(size_t)r * ldg + h] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(g, wv[c], acc[r][c]);
+        }
+    }
+    for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.y * R + r) * K + k4) = acc[r];
+}
+
+__global__ __launch_bounds__(256) void smallm_finish_kernel(const float* __restrict__ part, int chunks, int R, int K, float* __restrict__ Y,
+                                                            long ldy, int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)R * K) return;
+    const int r = (int)(i / K);
+    const long k = i - (long)r * K;
+    float s = 0.0f;
+    for (int c = 0; c < chunks; ++c) s += part[((size_t)c * R + r) * K + k];
+    float* y = Y + (size_t)r * ldy + k;
+    *y = accumulate ? *y + s : s;
+}
+
 // gather backward: dBEV[b, y, x, :] += w * dfeat[b, n, pt*C : (pt+1)*C] for the four corners of every point (atomics)
 __global__ __launch_bounds__(256) void bev_gather_bwd_kernel(const float* __restrict__ dfeat, int H, int W, int C,
                                                              const float* __restrict__ boxes, int N, int box_stride,
@@ -538,4 +598,48 @@ extern "C" int shasta_scale_f32(float* x, long n, float alpha, shasta_stream_t s
     if (n == 0) return SHASTA_OK;
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, n, alpha);
     return check_launch("scale");
+}
+
+extern "C" int shasta_lowrank_outer_f32(const float* G, int ldg, const float* X, int ldx, int R, int H, int K, float* dW,
+                                        shasta_stream_t stream) {
+    SHASTA_REQUIRE(G && X && dW && R >= 1 && R <= 16 && H >= 0 && K >= 0, "lowrank_outer: bad argument (1 <= R <= 16)");
+    SHASTA_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)X | (uintptr_t)dW) & 15) == 0, "lowrank_outer: K, ldx multiples of 4, 16-byte aligned");
+    if (H == 0 || K == 0) return SHASTA_OK;
+    const int kblocks = cdiv(K / 4, 256);
+    const int rpb = std::max(1, std::min(64, cdiv(H, std::max(1, 2048 / kblocks))));  // >= ~2048 workgroups, <= 64 rows each
+    dim3 grid(kblocks, cdiv(H, rpb));
+    if (R <= 4) hipLaunchKernelGGL(lowrank_outer_kernel<4>, grid, dim3(256), 0, as_stream(stream), G, ldg, X, ldx, R, H, K, rpb, dW);
+    else if (R <= 8) hipLaunchKernelGGL(lowrank_outer_kernel<8>, grid, dim3(256), 0, as_stream(stream), G, ldg, X, ldx, R, H, K, rpb, dW);
+    else hipLaunchKernelGGL(lowrank_outer_kernel<16>, grid, dim3(256), 0, as_stream(stream), G, ldg, X, ldx, R, H, K, rpb, dW);
+    return check_launch("lowrank_outer");
+}
+
+extern "C" size_t shasta_smallm_nn_workspace_bytes(int R, int H, int K) {
+    const int kblocks = cdiv(std::max(K, 4) / 4, 256);
+    const int chunks = std::max(1, std::min(cdiv(std::max(H, 1), 64), cdiv(2048, kblocks)));
+    return (size_t)chunks * std::max(R, 1) * std::max(K, 4) * sizeof(float);
+}
+
+extern "C" int shasta_smallm_nn_f32(const float* G, int ldg, const float* W, int R, int H, int K, float* Y, long ldy, int accumulate,
+                                    void* workspace, size_t workspace_bytes, shasta_stream_t stream) {
+    SHASTA_REQUIRE(G && W && Y && workspace && R >= 1 && R <= 16 && H >= 1 && K >= 4, "smallm_nn: bad argument (1 <= R <= 16)");
+    SHASTA_REQUIRE(K % 4 == 0 && (((uintptr_t)W | (uintptr_t)workspace) & 15) == 0, "smallm_nn: K multiple of 4, 16-byte aligned");
+    if (workspace_bytes < shasta_smallm_nn_workspace_bytes(R, H, K)) {
+        set_error_msg("smallm_nn: workspace too small");
+        return SHASTA_E_WORKSPACE;
+    }
+    const int kblocks = cdiv(K / 4, 256);
+    int chunks = std::max(1, std::min(cdiv(H, 64), cdiv(2048, kblocks)));
+    const int rpc = cdiv(H, chunks);
+    chunks = cdiv(H, rpc);
+    float* part = static_cast<float*>(workspace);
+    dim3 grid(kblocks, chunks);
+    if (R <= 4) hipLaunchKernelGGL(smallm_nn_kernel<4>, grid, dim3(256), 0, as_stream(stream), G, ldg, W, R, H, K, rpc, part);
+    else if (R <= 8) hipLaunchKernelGGL(smallm_nn_kernel<8>, grid, dim3(256), 0, as_stream(stream), G, ldg, W, R, H, K, rpc, part);
+    else hipLaunchKernelGGL(smallm_nn_kernel<16>, grid, dim3(256), 0, as_stream(stream), G, ldg, W, R, H, K, rpc, part);
+    int rc = check_launch("smallm_nn");
+    if (rc) return rc;
+    hipLaunchKernelGGL(smallm_finish_kernel, dim3((unsigned)(((long)R * K + 255) / 256)), dim3(256), 0, as_stream(stream), part, chunks, R, K, Y,
+                       ldy, accumulate);
+    return check_launch("smallm_finish");
 }

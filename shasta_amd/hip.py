@@ -65,6 +65,9 @@ SYMBOLS = {
     "shasta_pair_hidden_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
     "shasta_pair_reduce_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "shasta_colsum_f32": (_I, [_P, _I, _I, _I, _P, _P, C.c_size_t, _P]),
+    "shasta_lowrank_outer_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),
+    "shasta_smallm_nn_workspace_bytes": (_Z, [_I, _I, _I]),
+    "shasta_smallm_nn_f32": (_I, [_P, _I, _P, _I, _I, _I, _P, C.c_long, _I, _P, _Z, _P]),
     "shasta_scale_f32": (_I, [_P, C.c_long, _F, _P]),
     "shasta_adam_step_f32": (_I, [_P, _P, _P, _P, C.c_long, _F, _F, _F, _F, _F, _I, _P]),
     "shasta_abs_f32": (_I, [_P, _P, _P, C.c_long, _I, _I, _I, _I, _P]),

@@ -28,6 +28,16 @@ def _gemm(lib, A, sa, W, sw, M, N, K, out, ldc=None, bias=None, act=0, mask=None
     return out
 
 
+def _outer(lib, G, ldg, X, ldx, R, H, K, dW):
+    """dW (H, K) = G[:R, :H]^T X[:R, :K]: the rank-R update of an anchor first-layer weight gradient.  Small R: a streaming
+    kernel (one pass over the 1 GB output); otherwise the MFMA GEMM."""
+    if R <= 16 and K % 4 == 0 and ldx % 4 == 0:
+        hip.check(lib.shasta_lowrank_outer_f32(hip.ptr_view(G), ldg, hip.ptr_view(X), ldx, R, H, K, hip.ptr(dW), hip.stream_ptr()),
+                  "shasta_lowrank_outer_f32")
+    else:
+        _gemm(lib, G, (1, ldg), X, (1, ldx), H, K, R, dW)
+
+
 def _colsum(lib, Y, ldy, M, N, out, ws):
     hip.check(lib.shasta_colsum_f32(hip.ptr(Y), ldy, M, N, hip.ptr(out), hip.ptr(ws), ws.numel() * 4 if ws is not None else 0,
                                     hip.stream_ptr()), "shasta_colsum_f32")
@@ -222,7 +232,7 @@ class _AffinityTrainFn(torch.autograd.Function):
                 ghid = torch.empty(B, H, device=dev)
                 _gemm(lib, gpre, (nout, 1), w2, (1, H), B, H, nout, ghid, mask=hid, ldmask=max(H, 1))
                 if gW1 is not None:
-                    _gemm(lib, ghid, (1, H), x, (1, sx_m), H, K, B, gW1)
+                    _outer(lib, ghid, H, x, sx_m, B, H, K, gW1)
                 _colsum(lib, ghid, H, B, H, gb1, ws)
                 gx = ghid
             return (gW1, gb1, gW2, gb2), gx, w1
@@ -245,7 +255,13 @@ class _AffinityTrainFn(torch.autograd.Function):
             ghids[i] = ghid
             if ghid is not None:  # dx = ghid W1 accumulated into the rows < N of the INPUT table's gradient
                 gin = dfeat if i < 2 else dprev_feat
-                _gemm(lib, ghid, (ghid.shape[1], 1), w1, (1, N * F), B, N * F, ghid.shape[1], gin, ldc=T * F, accum=True)
+                if B <= 16 and (N * F) % 4 == 0:  # small batch: stream the 1 GB matrix once (csrc/train.hip)
+                    nb = lib.shasta_smallm_nn_workspace_bytes(B, ghid.shape[1], N * F)
+                    sws = torch.empty((nb + 3) // 4, device=dev)
+                    hip.check(lib.shasta_smallm_nn_f32(hip.ptr(ghid), ghid.shape[1], hip.ptr(w1), B, ghid.shape[1], N * F, hip.ptr(gin), T * F, 1,
+                                                       hip.ptr(sws), nb, st()), "shasta_smallm_nn_f32")
+                else:
+                    _gemm(lib, ghid, (ghid.shape[1], 1), w1, (1, N * F), B, N * F, ghid.shape[1], gin, ldc=T * F, accum=True)
             # aug_dets[i]: input = boxes[:, :, :7] before back-projection (det for i<2, prev for i>=2), output anchor box row
             xb = (S["det_pre"] if i < 2 else S["prev"])[:, :, :7].contiguous()
             gbt = dprev_tab if i < 2 else ddet_tab
@@ -261,7 +277,7 @@ class _AffinityTrainFn(torch.autograd.Function):
             for i in range(4):
                 w1p = model.aug_shape[i][0].weight
                 gW1 = torch.empty_like(w1p)
-                _gemm(lib, gh_all[:, i * Hs_:], (1, 4 * Hs_), xs[0 if i < 2 else 1], (1, K), Hs_, K, world * B, gW1)
+                _outer(lib, gh_all[:, i * Hs_:], 4 * Hs_, xs[0 if i < 2 else 1], K, world * B, Hs_, K, gW1)
                 g = shape_grads[i]
                 shape_grads[i] = (gW1, g[1], g[2], g[3])
                 w1p._shasta_grad_is_global = True  # allreduce_gradients must not reduce it again

@@ -285,3 +285,30 @@ def test_low_rank_factor_exchange_path_equals_local_gradients():
         dist.destroy_process_group()
     for k in local:
         _close(k, glob[k], local[k], rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,H,K", [(1, 6, 384), (3, 48, 3072), (8, 450, 28800), (16, 33, 2048)])
+def test_lowrank_outer_and_smallm_nn(R, H, K):
+    """The two streaming kernels of the anchor backward against torch matmul (strided operands, accumulate)."""
+    from shasta_amd import hip
+    lib = hip.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(R * 1000 + H)
+    G = torch.randn(R, H + 5, device=dev)          # ldg > H
+    X = torch.randn(R, K + 64, device=dev)         # ldx > K
+    W = torch.randn(H, K, device=dev)
+    dW = torch.empty(H, K, device=dev)
+    hip.check(lib.shasta_lowrank_outer_f32(hip.ptr(G), H + 5, hip.ptr(X), K + 64, R, H, K, hip.ptr(dW), hip.stream_ptr()), "outer")
+    want = G[:, :H].double().t() @ X[:, :K].double()
+    assert float((dW.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    Y = torch.randn(R, K + 8, device=dev)
+    y0 = Y.clone()
+    nb = lib.shasta_smallm_nn_workspace_bytes(R, H, K)
+    ws = torch.empty((nb + 3) // 4, device=dev)
+    for acc in (1, 0):
+        hip.check(lib.shasta_smallm_nn_f32(hip.ptr(G), H + 5, hip.ptr(W), R, H, K, hip.ptr(Y), K + 8, acc, hip.ptr(ws), nb, hip.stream_ptr()), "nn")
+        want = G[:, :H].double() @ W.double() + (y0[:, :K].double() if acc else 0)
+        assert float((Y[:, :K].double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+        assert torch.equal(Y[:, K:], y0[:, K:])  # padding columns untouched
+        Y.copy_(y0)
