@@ -156,8 +156,22 @@ class Shasta(BaseTrack):
                 self.aff[0]]
         return [p for m in mods for p in (m.weight, m.bias)]
 
+    def _apply(self, fn, *a, **k):  # .to() / .cuda() / .float(): parameter storage moves -> drop pointer caches
+        self._wstruct = None
+        return super()._apply(fn, *a, **k)
+
     def _weights(self):
-        """shasta_weights struct over the live parameter storage (no copies)."""
+        """shasta_weights struct over the live parameter storage (no copies).  Cached: building it walks 64 tensors, which
+        is a visible part of a forward at small configurations; optimizer steps and load_state_dict update the storage in
+        place, moves go through _apply, and a re-assigned parameter is caught by the pointer check of two tensors."""
+        ws = getattr(self, "_wstruct", None)
+        if ws is not None and ws[1] == (self.aug_shape[0][0].weight.data_ptr(), self.aff[10].weight.data_ptr()):
+            return ws[0]
+        w = self._build_weights()
+        self._wstruct = (w, (self.aug_shape[0][0].weight.data_ptr(), self.aff[10].weight.data_ptr()))
+        return w
+
+    def _build_weights(self):
         def lin(m):
             for p in (m.weight, m.bias):
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
@@ -294,12 +308,6 @@ class Shasta(BaseTrack):
                                            matched=mat, det_tab=bufs["det_tab"], prev_tab=bufs["prev_tab"])
         return m1, m2
 
-    def capture_graph(self, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes):
-        """hipGraph of one forward over the CALLER'S tensors (bound by reference): refill them in place, then `.replay()`.
-        Small configurations are bound by the host side of the 13 launches, not by the GPU - the reference's shipped car
-        config (max_obj 90, batch 1): 0.21 ms per frame pair eager, 0.13 ms replayed; at N=500 there is nothing to gain."""
-        return GraphedForward(self, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes)
-
     def forward(self, example, train_mode=True, **kwargs):
         det = example["det_boxes"]
         prev = example["prev_det_boxes"]
@@ -324,43 +332,6 @@ class Shasta(BaseTrack):
         if not inplace:
             det[:, :, :2] = det_k[:, :, :2].to(det.dtype)  # keep the reference's in-place side effect
         return m1, m2, example
-
-
-class GraphedForward:
-    """A captured forward (Shasta.capture_graph).  `replay()` returns the static output tensors (matched1, matched2), which the
-    next replay overwrites; det_boxes[:, :, :2] is back-projected in place by every replay, exactly like an eager forward, so
-    the caller writes fresh boxes before each one.  When a small weight of the model was changed (re-packed) since the
-    capture, the graph is re-captured on the next replay."""
-
-    def __init__(self, model, bev, prev_bev, det, prev):
-        self.model, self.inputs = model, (bev, prev_bev, det, prev)
-        self._capture()
-
-    def _capture(self):
-        m = self.model
-        bev, prev_bev, det, prev = self.inputs
-        with torch.no_grad():
-            keep = det.clone()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):  # warm-up: lazy allocations (work buffers, weight packing) happen outside the capture
-                m.affinity_from_bev(bev, prev_bev, det, prev)
-                det.copy_(keep)
-            torch.cuda.current_stream().wait_stream(side)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.matched1, self.matched2 = m.affinity_from_bev(bev, prev_bev, det, prev)
-            det.copy_(keep)  # capturing does not execute: leave the caller's boxes as they were
-        self._packed_ptr = m._packed.data_ptr()
-
-    def replay(self):
-        m = self.model
-        if tuple((p.data_ptr(), p._version) for p in m._small_params()) != m._packed_key:  # a packed weight changed
-            m._ensure_packed(m._weights(), self.inputs[2].device)
-        if m._packed.data_ptr() != self._packed_ptr:
-            self._capture()
-        self.graph.replay()
-        return self.matched1, self.matched2
 
 
 def load_state_dict_permissive(module, state_dict, logger=None):

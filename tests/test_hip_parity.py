@@ -443,38 +443,3 @@ def test_device_decode_flags_match_host_decode():
         got = Dm.decode_frame_from_flags(pc[b], ps[b], df[b], ds[b], c2, p2, "tok", 0.5)
         assert got[1] == ref[1] and got[2] == ref[2], b
         assert got[0] == ref[0], b
-
-
-def test_capture_graph_equals_eager_and_tracks_weight_updates():
-    """Shasta.capture_graph: bitwise the eager result while the bound tensors are refilled in place, the in-place
-    back-projection happens on every replay, and a parameter update re-captures."""
-    import shasta_amd
-    dev = _dev()
-    torch.manual_seed(3)
-    m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
-                                         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54],
-                                                            voxel_size=[0.075, 0.075], out_stride=8),
-                                         max_obj=24, num_feats=3, num_point=5, in_channels=8)).eval().to(dev)
-    g = torch.Generator().manual_seed(11)
-
-    def inputs(B):
-        bev = torch.relu(torch.randn(B, 180, 180, 64, generator=g)).to(dev)
-        pbev = torch.relu(torch.randn(B, 180, 180, 64, generator=g)).to(dev)
-        return bev, pbev, O.synth_boxes(g, B, 24, None).to(dev), O.synth_boxes(g, B, 24, 20).to(dev)
-
-    with torch.no_grad():
-        sb, spb, sd, sp = inputs(2)
-        before = sd.clone()
-        gf = m.capture_graph(sb, spb, sd, sp)
-        assert torch.equal(sd, before)  # capturing leaves the caller's tensors alone
-        for rnd in range(4):
-            if rnd == 2:
-                m.fuse_det[0].weight.mul_(1.5)  # a packed weight changes -> re-captured on the next replay
-            bev, pbev, det, prev = inputs(2)
-            for dst, src in ((sb, bev), (spb, pbev), (sd, det), (sp, prev)):
-                dst.copy_(src)
-            g1, g2 = gf.replay()
-            d1 = det.clone()
-            e1, e2 = m.affinity_from_bev(bev, pbev, d1, prev)
-            assert torch.equal(e1, g1) and torch.equal(e2, g2) and torch.equal(d1, sd)
-            assert not torch.equal(sd[:, :, :2], det[:, :, :2])  # back-projected in place

@@ -44,14 +44,21 @@ for B in a.batch:
     graph = None
     with torch.no_grad():
         if a.graph:
-            graph = model.capture_graph(bev, pbev, det, prev)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                m1, m2 = step()
         for it in range(a.steps + 5):
             if it == 5:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             if graph is not None:
-                det.copy_(det0)
-                m1, m2 = graph.replay()
+                graph.replay()
             else:
                 m1, m2 = step()
         torch.cuda.synchronize()
