@@ -163,12 +163,15 @@ class Shasta(BaseTrack):
     def _weights(self):
         """shasta_weights struct over the live parameter storage (no copies).  Cached: building it walks 64 tensors, which
         is a visible part of a forward at small configurations; optimizer steps and load_state_dict update the storage in
-        place, moves go through _apply, and a re-assigned parameter is caught by the pointer check of two tensors."""
+        place, moves go through _apply, and a re-assigned parameter is caught by the pointer probe over one tensor per block."""
+        probe = tuple(t.data_ptr() for t in (self.aug_shape[0][0].weight, self.aug_shape[3][2].weight, self.aug_dets[0][0].weight,
+                                             self.fuse_shape[0].weight, self.fuse_det[0].weight, self.res_coeff[0].weight,
+                                             self.aff[0].weight, self.aff[10].weight))
         ws = getattr(self, "_wstruct", None)
-        if ws is not None and ws[1] == (self.aug_shape[0][0].weight.data_ptr(), self.aff[10].weight.data_ptr()):
+        if ws is not None and ws[1] == probe:
             return ws[0]
         w = self._build_weights()
-        self._wstruct = (w, (self.aug_shape[0][0].weight.data_ptr(), self.aff[10].weight.data_ptr()))
+        self._wstruct = (w, probe)
         return w
 
     def _build_weights(self):
