@@ -324,7 +324,7 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     a.part = part;
     if (ev0) (void)hipEventRecord(ev0, st);
     // B == 1: VALU weight-streaming GEMV (nothing to amortise; measured 6.5 TB/s).  B >= 2: the matrix-core kernel
-    // streams every weight once per 16 / 32 batch items (anchor_mfma.hip).  SHASTA_L1_VALU=1 forces the VALU kernels.
+    // streams every weight once per 16 / 32 / 64 batch items (anchor_mfma.hip).  SHASTA_L1_VALU=1 forces the VALU kernels.
     static const bool force_valu = getenv("SHASTA_L1_VALU") != nullptr;
     if (B == 1) launch_l1<1, R>(a, st);
     else if (!force_valu && K % 32 == 0) launch_anchor_l1_mfma(a.W, feat, prev_feat, part, H, K, B, a.x_batch_stride, &a.KS, st);

@@ -1,8 +1,9 @@
-// K3a: first aug_shape layer (det3d/models/tracker/shasta.py:54, applied :241-244) for batches of 2..32 frame-pairs:
+// K3a: first aug_shape layer (det3d/models/tracker/shasta.py:54, applied :241-244) for batches of 2 and more frame-pairs:
 //   part[ks][b][n] = sum_{k in chunk ks} W[n][k] * x[b][k]       W: 4 x (N*F/64, N*F) fp32, 4.1 GB at N=500,F=256
-// The weights are streamed from HBM exactly once per 32 batch items; the kernel is a weight-streaming skinny GEMM on the
-// matrix cores with the 32 weight rows of a wave as the A operand and up to 32 (or 16) batch items as the B operand:
+// The weights are streamed from HBM exactly once per pass of 16 / 32 / 64 batch items; the kernel is a weight-streaming skinny
+// GEMM on the matrix cores with the 32 weight rows of a wave as the A operand and the batch items as the B operand:
 //   v_mfma_f32_32x32x2_f32 (B in 17..32): 16 MFMA = 1024 SIMD cycles per 4 KB weight tile  -> 16 B/clk/CU consumable
+//   the same with two accumulators (B > 32, 64 rows per pass): 32 MFMA = 2048 cycles per tile -> 8 B/clk/CU: matrix-pipe bound
 //   v_mfma_f32_16x16x4_f32 (B <= 16)    : 16 MFMA =  512 SIMD cycles per 4 KB weight tile  -> 32 B/clk/CU consumable
 // against ~10 B/clk/CU that HBM delivers, so the kernel stays HBM-bound for every batch size it serves.
 // Data path: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip): each wave-instruction moves 8 rows x 128 B, i.e.
