@@ -5,7 +5,7 @@
 //   v_mfma_f32_32x32x2_f32 (B in 17..32): 16 MFMA = 1024 SIMD cycles per 4 KB weight tile  -> 16 B/clk/CU consumable
 //   the same with two accumulators (B > 32, 64 rows per pass): 32 MFMA = 2048 cycles per tile -> 8 B/clk/CU: matrix-pipe bound
 //   v_mfma_f32_16x16x4_f32 (B <= 16)    : 16 MFMA =  512 SIMD cycles per 4 KB weight tile  -> 32 B/clk/CU consumable
-// against ~10 B/clk/CU that HBM delivers, so the kernel stays HBM-bound for every batch size it serves.
+// against ~10 B/clk/CU that HBM delivers: HBM-bound up to 32 batch items per pass, matrix-pipe bound at 64.
 // Data path: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip): each wave-instruction moves 8 rows x 128 B, i.e.
 // whole 128-byte lines, into a lane-linear [32 rows][8 x 16 B] LDS image.  The 16-byte chunk c of row r is fetched into
 // chunk position c ^ ((r>>1)&7) (swizzle applied on the SOURCE address, the LDS destination of an LDS-DMA cannot be
