@@ -680,6 +680,11 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
     extern __shared__ __attribute__((aligned(16))) float s_dyn4[];
     float* s_uc = s_dyn4;              // [64][US]
     float* s_a4 = s_dyn4 + 64 * US;    // [NA4]
+    // UP rows (the per-track half of the first layers) of the next two tracks, per wave: [WPB][3 slots][256 floats].  They
+    // were scalar loads before; SMEM and LDS share lgkmcnt, so every s_load had to be waited for with lgkmcnt(0) before the
+    // next LDS result could be used - nine full scalar-memory latencies per track (measured: 25 % of the wave time parked).
+    // An LDS-DMA (counted on vmcnt) fetches row t+2 while row t is in use; the values are then read back as LDS broadcasts.
+    float* s_up = s_dyn4 + 64 * US + ((NA4 + 3) & ~3);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, d0 = blockIdx.x * 64;
@@ -715,9 +720,40 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
 
     const int t_beg = (blockIdx.y * WPB + wid) * TW;
     const int t_end = min(T, t_beg + TW);
+    float* my_up = s_up + wid * (3 * 256);
+    // lanes [0, ET/4): the UP row; the next 4 lanes: the 16-float hand row of the same track (lands right behind it); the
+    // remaining lanes repeat the last UP chunk (their LDS words are unused)
+    const bool hp_lane = lane >= ET / 4 && lane < ET / 4 + 4;
+    const int up_lane = 4 * min(lane, ET / 4 - 1), hp_off = 4 * (lane - ET / 4);
+    auto dma_up = [&](int row, int slot) {
+        const size_t r = (size_t)b * T + min(row, T - 1);
+        const float* src = hp_lane ? hand_prev + r * 16 + hp_off : UP + r * ET + up_lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(my_up + slot * 256), 16, 0, 0);
+    };
+    if (t_beg < t_end) {
+        dma_up(t_beg, 0);
+        dma_up(t_beg + 1, 1);
+    }
     for (int t = t_beg; t < t_end; ++t) {
-        const cfloat* up = (const cfloat*)(UP + ((size_t)b * T + t) * ET);        // wave-uniform -> s_load
-        const cfloat* hp = (const cfloat*)(hand_prev + ((size_t)b * T + t) * 16);
+        // rows t and t+1 were requested at least one whole iteration ago (or in the prologue): nothing younger is in flight
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dma_up(t + 2, (t - t_beg + 2) % 3);
+        unsigned upo = (unsigned)(unsigned long long)(my_up + ((t - t_beg) % 3) * 256);
+        asm volatile("" : "+v"(upo));
+        const lfloat* up = (const lfloat*)(unsigned long long)upo;
+        float hp[16];
+        {
+            const f32x4 h0 = *reinterpret_cast<const lf32x4*>(up + ET), h1 = *reinterpret_cast<const lf32x4*>(up + ET + 4),
+                        h2 = *reinterpret_cast<const lf32x4*>(up + ET + 8), h3 = *reinterpret_cast<const lf32x4*>(up + ET + 12);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                hp[k] = h0[k];
+                hp[4 + k] = h1[k];
+                hp[8 + k] = h2[k];
+                hp[12 + k] = h3[k];
+            }
+        }
         // the A table is loop invariant: an opaque copy of its address per track keeps the 128 ds_read_b128 inside the
         // loop instead of 512 hoisted registers
         unsigned ao = arow_base, bo = abias_base;
@@ -738,13 +774,14 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
 #pragma unroll
             for (int kg = 0; kg < AL::KG; ++kg) {
                 const f32x4 u = *reinterpret_cast<const f32x4*>(ucrow + seg + 4 * kg);
+                const f32x4 upv = *reinterpret_cast<const lf32x4*>(up + seg + 4 * kg);  // same address in every lane: LDS broadcast
                 f32x4 a4[AL::NOB];
 #pragma unroll
                 for (int ob = 0; ob < AL::NOB; ++ob) a4[ob] = *reinterpret_cast<const lf32x4*>(arow + AL::OFF + (ob * AL::KG + kg) * 16);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     if (4 * kg + kk < AL::KIN) {
-                        const float h = fmaxf(up[seg + 4 * kg + kk] + u[kk], 0.0f);
+                        const float h = fmaxf(upv[kk] + u[kk], 0.0f);
 #pragma unroll
                         for (int ob = 0; ob < AL::NOB; ++ob) acc[ob] = MFMA4(a4[ob][kk], h, acc[ob]);
                     }
@@ -869,10 +906,15 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
         const int wpb = w4 ? 4 : 8;
         int tw = 16;
         while (tw > 2 && (long)B * cdiv(D, 64) * wpb * cdiv(T, wpb * tw) < 4096) tw >>= 1;
-        const size_t lds = ((size_t)64 * (d.ET + 4) + a4_total(F)) * sizeof(float);
+        const size_t lds = ((size_t)64 * (d.ET + 4) + ((a4_total(F) + 3) & ~3) + (size_t)wpb * 3 * 256) * sizeof(float);
         dim3 grid(cdiv(D, 64), cdiv(T, wpb * tw), B);
-#define SHASTA_LAUNCH_PAIR4(FF, WW) \
-    hipLaunchKernelGGL((pair_mfma4_kernel<FF, WW>), grid, dim3(64 * WW), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw)
+#define SHASTA_LAUNCH_PAIR4(FF, WW)                                                                                                   \
+    do {                                                                                                                             \
+        if (lds > 64 * 1024)                                                                                                         \
+            (void)hipFuncSetAttribute((const void*)pair_mfma4_kernel<FF, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((pair_mfma4_kernel<FF, WW>), grid, dim3(64 * WW), lds, st, packed, UP, UC, hand_prev, hand_det, denom,    \
+                           residual, T, D, ld, nf, tw);                                                                              \
+    } while (0)
         switch (F) {
             case 64: if (w4) SHASTA_LAUNCH_PAIR4(64, 4); else SHASTA_LAUNCH_PAIR4(64, 8); break;
             case 256: if (w4) SHASTA_LAUNCH_PAIR4(256, 4); else SHASTA_LAUNCH_PAIR4(256, 8); break;

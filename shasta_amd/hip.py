@@ -10,7 +10,8 @@ import os
 import torch
 
 ABI_VERSION = 3  # must equal shasta_abi_version() of the loaded library
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libshasta_hip.so")
+# SHASTA_HIP_LIB: load another build of the same ABI (A/B timing of kernel variants on one box)
+_LIB_PATH = os.environ.get("SHASTA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libshasta_hip.so")
 _lib = None
 
 
