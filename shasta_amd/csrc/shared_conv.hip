@@ -159,15 +159,22 @@ __global__ __launch_bounds__(256) void shared_conv_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int CF_CK = 4;
 constexpr int CF_WT = CF_CK * 9 * 64;  // 2304 floats per chunk
-constexpr int CF_IN_PT = 18;           // staged input floats per thread (upper bound, W <= 256)
+constexpr int CF_IN_PT = 18;           // staged input floats per thread, upper bound (W <= 256)
 
+// IN_PT = staged input floats per thread for this map width (ceil(4 * rows * (W + 2) / 256)).
+// The f32 MFMA does not overlap VALU work, so the chunk loop is kept free of it: the halo / padding decisions are taken once
+// (clamped 32-bit offsets + a select per element instead of predicated loads), the loads use the scalar chunk base + a
+// per-lane offset, and the steady loop has no conditional around the accumulators (the last chunk is peeled; with the
+// condition inside, the register allocator moved all 32 accumulators through VGPRs every chunk).  Before: 233 VALU
+// instructions per 36 MFMAs.
+template <int IN_PT>
 __global__ __launch_bounds__(256) void shared_conv_flat_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
                                                                const float* __restrict__ packed, float* __restrict__ outa,
                                                                float* __restrict__ outb, int B, int Cin, int H, int W,
                                                                int rt_max) {
     extern __shared__ __attribute__((aligned(16))) float s_cf[];
     const int WT = W + 2;
-    const int in_cap = CF_CK * rt_max * WT;          // floats per input buffer
+    const int in_cap = 256 * IN_PT;                   // floats per input buffer (>= CF_CK * rt_max * WT)
     float* s_in0 = s_cf;
     float* s_in1 = s_cf + in_cap;
     float* s_w0 = s_cf + 2 * in_cap;
@@ -185,41 +192,41 @@ __global__ __launch_bounds__(256) void shared_conv_flat_kernel(const float* __re
     const int nchunk = Cin / CF_CK;
     const float* xin = x + (size_t)b * Cin * npix;
 
-    int in_off[CF_IN_PT];  // offset inside one 4-channel chunk of the input, -1 = zero (outside the image), -2 = unused slot
+    unsigned in_off[IN_PT];  // element offset inside one 4-channel chunk (clamped to 0 where the tile is outside the image)
+    bool in_ok[IN_PT];
 #pragma unroll
-    for (int j = 0; j < CF_IN_PT; ++j) {
+    for (int j = 0; j < IN_PT; ++j) {
         const int e = tid + 256 * j;
-        int off = -2;
+        int off = -1;
         if (e < CF_CK * plane) {
             const int c = e / plane, rem = e - c * plane;
             const int r = rem / WT, col = rem - r * WT;
             const int gy = y_first - 1 + r, gx = col - 1;
-            off = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? c * npix + gy * W + gx : -1;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) off = c * npix + gy * W + gx;
         }
-        in_off[j] = off;
+        in_ok[j] = off >= 0;
+        in_off[j] = (unsigned)max(off, 0);
     }
-    float rin[CF_IN_PT];
+    float rin[IN_PT];
     f32x4 rwt[3];
     auto load_chunk = [&](int ch) {
-        const float* xc = xin + (size_t)ch * CF_CK * npix;
+        const float* xc = xin + (size_t)ch * CF_CK * npix;  // wave-uniform
 #pragma unroll
-        for (int j = 0; j < CF_IN_PT; ++j) rin[j] = in_off[j] >= 0 ? xc[in_off[j]] : 0.0f;
-        const f32x4* wc = reinterpret_cast<const f32x4*>(packed + (size_t)ch * CF_WT);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int e = tid + 256 * j;
-            rwt[j] = e < CF_WT / 4 ? wc[e] : f32x4{0, 0, 0, 0};
+        for (int j = 0; j < IN_PT; ++j) {
+            const float v = xc[in_off[j]];  // always a valid address
+            rin[j] = in_ok[j] ? v : 0.0f;
         }
+        const f32x4* wc = reinterpret_cast<const f32x4*>(packed + (size_t)ch * CF_WT);
+        rwt[0] = wc[tid];
+        rwt[1] = wc[tid + 256];
+        rwt[2] = wc[min(tid, 63) + 512];
     };
     auto store_chunk = [&](float* si, float* sw) {
 #pragma unroll
-        for (int j = 0; j < CF_IN_PT; ++j)
-            if (in_off[j] != -2) si[tid + 256 * j] = rin[j];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int e = tid + 256 * j;
-            if (e < CF_WT / 4) reinterpret_cast<f32x4*>(sw)[e] = rwt[j];
-        }
+        for (int j = 0; j < IN_PT; ++j) si[tid + 256 * j] = rin[j];  // the buffer holds all 256 * IN_PT slots
+        reinterpret_cast<f32x4*>(sw)[tid] = rwt[0];
+        reinterpret_cast<f32x4*>(sw)[tid + 256] = rwt[1];
+        if (tid < 64) reinterpret_cast<f32x4*>(sw)[tid + 512] = rwt[2];
     };
 
     f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -230,14 +237,7 @@ __global__ __launch_bounds__(256) void shared_conv_flat_kernel(const float* __re
     // A: tile[c = c_lo + 2h][py - y_first + 1 + dy][px + 1 + dx] ; B: s_w[kp + 18h][32*nb + i]
     const int a_base = (2 * h) * plane + (py - y_first + 1) * WT + px + 1;
     const int b_base = (18 * h) * 64 + i;
-
-    load_chunk(0);
-    store_chunk(s_in0, s_w0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const float* si = (ch & 1) ? s_in1 : s_in0;
-        const float* sw = (ch & 1) ? s_w1 : s_w0;
-        if (ch + 1 < nchunk) load_chunk(ch + 1);
+    auto compute = [&](const float* si, const float* sw) {
         const float* ain = si + a_base;
         const float* bw = sw + b_base;
 #pragma unroll
@@ -248,10 +248,33 @@ __global__ __launch_bounds__(256) void shared_conv_flat_kernel(const float* __re
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
         }
-        if (ch + 1 < nchunk) {
-            store_chunk((ch & 1) ? s_in0 : s_in1, (ch & 1) ? s_w0 : s_w1);
-            __syncthreads();
-        }
+    };
+
+    load_chunk(0);
+    store_chunk(s_in0, s_w0);
+    __syncthreads();
+    // steady state: two chunks per trip so that the buffer roles are compile-time; every trip stages two more chunks
+    int ch = 0;
+#pragma unroll 1
+    for (; ch + 2 < nchunk; ch += 2) {
+        load_chunk(ch + 1);
+        compute(s_in0, s_w0);
+        store_chunk(s_in1, s_w1);
+        __syncthreads();
+        load_chunk(ch + 2);
+        compute(s_in1, s_w1);
+        store_chunk(s_in0, s_w0);
+        __syncthreads();
+    }
+    // tail: one or two chunks left, the first of them is in buffer 0
+    if (ch + 1 < nchunk) {
+        load_chunk(ch + 1);
+        compute(s_in0, s_w0);
+        store_chunk(s_in1, s_w1);
+        __syncthreads();
+        compute(s_in1, s_w1);
+    } else {
+        compute(s_in0, s_w0);
     }
     const float* par = packed + (size_t)Cin * 9 * 64;
     float* obase = out + (size_t)b * npix * 64;
@@ -306,11 +329,20 @@ extern "C" int shasta_shared_conv_f32(const float* x, const float* x_prev, int B
     if (B == 0) return SHASTA_OK;
     static const bool force_rect = getenv("SHASTA_CONV_RECT") != nullptr;
     const int rt_max = min(H, 128 / W + 2) + 2;
-    const size_t lds = ((size_t)2 * CF_CK * rt_max * (W + 2) + 2 * CF_WT) * sizeof(float);
-    if (!force_rect && W <= 256 && CF_CK * rt_max * (W + 2) <= 256 * CF_IN_PT && lds <= 64 * 1024) {
+    const int in_need = cdiv(CF_CK * rt_max * (W + 2), 256);  // staged input floats per thread
+    const int in_pt = in_need <= 8 ? 8 : in_need <= 12 ? 12 : in_need <= 14 ? 14 : in_need <= 16 ? 16 : in_need;  // template value
+    const size_t lds = ((size_t)2 * 256 * in_pt + 2 * CF_WT) * sizeof(float);
+    if (!force_rect && W <= 256 && in_pt <= CF_IN_PT && lds <= 64 * 1024) {
         dim3 grid(cdiv(H * W, 128), 1, x_prev ? 2 * B : B);
-        hipLaunchKernelGGL(shared_conv_flat_kernel, grid, dim3(256), lds, as_stream(stream), x, x_prev,
-                           static_cast<const float*>(packed), out, out_prev, B, in_channels, H, W, rt_max);
+        const float* pk = static_cast<const float*>(packed);
+#define SHASTA_CONV_FLAT(PT) \
+    hipLaunchKernelGGL(shared_conv_flat_kernel<PT>, grid, dim3(256), lds, as_stream(stream), x, x_prev, pk, out, out_prev, B, in_channels, H, W, rt_max)
+        if (in_pt == 8) SHASTA_CONV_FLAT(8);
+        else if (in_pt == 12) SHASTA_CONV_FLAT(12);
+        else if (in_pt == 14) SHASTA_CONV_FLAT(14);
+        else if (in_pt == 16) SHASTA_CONV_FLAT(16);
+        else SHASTA_CONV_FLAT(18);
+#undef SHASTA_CONV_FLAT
         return check_launch("shared_conv_flat");
     }
     dim3 grid(cdiv(W, CV_TC), cdiv(H, CV_TR), x_prev ? 2 * B : B);
