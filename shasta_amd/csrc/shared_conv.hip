@@ -330,7 +330,7 @@ extern "C" int shasta_shared_conv_f32(const float* x, const float* x_prev, int B
     static const bool force_rect = getenv("SHASTA_CONV_RECT") != nullptr;
     const int rt_max = min(H, 128 / W + 2) + 2;
     const int in_need = cdiv(CF_CK * rt_max * (W + 2), 256);  // staged input floats per thread
-    const int in_pt = in_need <= 8 ? 8 : in_need <= 12 ? 12 : in_need <= 14 ? 14 : in_need <= 16 ? 16 : in_need;  // template value
+    const int in_pt = in_need <= 8 ? 8 : in_need <= 12 ? 12 : in_need <= 14 ? 14 : in_need <= 16 ? 16 : in_need <= 18 ? 18 : 19;  // template value (19: does not fit)
     const size_t lds = ((size_t)2 * 256 * in_pt + 2 * CF_WT) * sizeof(float);
     if (!force_rect && W <= 256 && in_pt <= CF_IN_PT && lds <= 64 * 1024) {
         dim3 grid(cdiv(H * W, 128), 1, x_prev ? 2 * B : B);

@@ -94,7 +94,8 @@ def test_forward_with_shared_conv_on_device():
     np.testing.assert_allclose(m2.cpu().numpy(), z["m2"], rtol=0, atol=TOL)
 
 
-@pytest.mark.parametrize("B,cin,H,W", [(1, 512, 180, 180), (2, 8, 24, 24), (1, 16, 7, 45), (3, 64, 33, 70)])
+@pytest.mark.parametrize("B,cin,H,W", [(1, 512, 180, 180), (2, 8, 24, 24), (1, 16, 7, 45), (3, 64, 33, 70), (1, 8, 9, 200), (2, 8, 5, 240),
+                                        (1, 16, 6, 256), (1, 8, 4, 300)])
 def test_shared_conv_vs_oracle(B, cin, H, W):
     """K0 against the oracle (conv2d + eval batch_norm + relu -> NHWC); K = 9*Cin sequential fp32 accumulation differs from
     oneDNN's blocked order by ~1e-6 relative."""
