@@ -197,24 +197,33 @@ __global__ __launch_bounds__(64 * AFF_WAVES) void aff_fused_kernel(AffArgs a) {
     __syncthreads();
     aff_layer<false, 128, RG>(a.W[5], 128, a.bias[5], a.D, 128, ha, HS, xb, XS, a.Dp, lane, wid);
     __syncthreads();
-    // each wave: ROWS / AFF_WAVES rows: copy to `matched` (column softmax input) and row softmax for t < N
+    // each wave: ROWS / AFF_WAVES rows: copy to `matched` (column softmax input) and row softmax for t < N.  One exp per
+    // element (kept in the LDS row), one reciprocal per row: the f32 MFMAs of the other waves share the pipe with this.
     for (int pr = 0; pr < ROWS / AFF_WAVES; ++pr) {
         const int p = (ROWS / AFF_WAVES) * wid + pr, g = g0 + p;
         if (g >= a.M) break;
-        const float* x = xb + p * XS;
+        float* x = xb + p * XS;
         float* mo = a.matched + (size_t)g * a.ldm;
-        for (int d = lane; d < a.D; d += 64) mo[d] = x[d];
+        float mx = -INFINITY;
+        for (int d = lane; d < a.D; d += 64) {
+            const float v = x[d];
+            mo[d] = v;
+            mx = fmaxf(mx, v);
+        }
         const int b = g / a.T, t = g - b * a.T;
         if (t >= a.N) continue;
-        float mx = -INFINITY;
-        for (int d = lane; d < a.D; d += 64) mx = fmaxf(mx, x[d]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
         float s = 0.0f;
-        for (int d = lane; d < a.D; d += 64) s += expf(x[d] - mx);
+        for (int d = lane; d < a.D; d += 64) {
+            const float e = expf(x[d] - mx);
+            x[d] = e;  // lane d % 64 owns element d in every pass: no synchronisation needed
+            s += e;
+        }
         s = wave_sum(s);
+        const float inv = 1.0f / s;
         float* o = a.m1 + ((size_t)b * a.N + t) * a.D;
-        for (int d = lane; d < a.D; d += 64) o[d] = expf(x[d] - mx) / s;
+        for (int d = lane; d < a.D; d += 64) o[d] = x[d] * inv;
     }
 }
 
