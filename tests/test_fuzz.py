@@ -1,0 +1,123 @@
+"""Seeded random configurations of the whole path against the oracle: table sizes, feature counts, point counts, batch sizes,
+padding, map sizes, convolution shapes.  The fixed-shape tests cover the shipped configurations; this sweep is there for the
+seams between kernel variants (batch-size and width thresholds, partial tiles, odd sizes)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import shasta_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _model(N, nf, npnt, cin, seed, stride=8):
+    import shasta_amd
+    torch.manual_seed(seed)
+    return shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                            bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075],
+                                                               out_stride=stride),
+                                            max_obj=N, num_feats=nf, num_point=npnt, in_channels=cin)).eval()
+
+
+def _cases(n, seed):
+    rnd = random.Random(seed)
+    out = []
+    for k in range(n):
+        N = rnd.choice([1, 2, 3, 5, 7, 11, 16, 17, 23, 31, 32, 33, 47, 63, 64, 65, 70])
+        nf = rnd.randint(1, 7)
+        npnt = rnd.choice([1, 4, 5])
+        B = rnd.choice([1, 2, 3, 4, 5, 8, 9, 15, 16, 17, 31, 32, 33, 40, 64, 65])
+        if N * B > 1200:
+            B = max(1, 1200 // N)
+        n_real = rnd.choice([None, None, 0, max(0, N // 2), max(0, N - 1)])
+        hw = rnd.choice([24, 45, 90, 180])
+        out.append((N, nf, npnt, B, n_real, hw, 1000 + k))
+    return out
+
+
+@pytest.mark.parametrize("N,nf,npnt,B,n_real,hw,seed", _cases(28, 2024))
+def test_forward_random_configs_vs_oracle(N, nf, npnt, B, n_real, hw, seed):
+    dev = torch.device("cuda:0")
+    stride = 8 * 180 // hw  # the map always spans the same metric extent
+    m = _model(N, nf, npnt, 8, seed, stride)
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(seed)
+    bev = torch.relu(torch.randn(B, hw, hw, 64, generator=g))
+    pbev = torch.relu(torch.randn(B, hw, hw, 64, generator=g))
+    det, prev = O.synth_boxes(g, B, N, n_real), O.synth_boxes(g, B, N, n_real)
+    d_ref = det.clone()
+    r1, r2 = O.forward_from_bev(w, bev, pbev, d_ref, prev.clone(), nf, npnt, out_stride=stride)
+    m = m.to(dev)
+    d_dev = det.to(dev)
+    with torch.no_grad():
+        m1, m2 = m.affinity_from_bev(bev.to(dev), pbev.to(dev), d_dev, prev.to(dev))
+    assert bool(torch.isfinite(m1).all()) and bool(torch.isfinite(m2).all())
+    np.testing.assert_allclose(m1.cpu().numpy(), r1.numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(m2.cpu().numpy(), r2.numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(d_dev.cpu().numpy(), d_ref.numpy(), rtol=0, atol=1e-6)  # in-place back-projection
+
+
+def _conv_cases(n, seed):
+    rnd = random.Random(seed)
+    return [(rnd.choice([1, 2, 3]), rnd.choice([8, 16, 24, 40, 64]), rnd.randint(1, 40), rnd.choice([1, 2, 3, 7, 31, 32, 33, 64, 100, 127, 128, 129, 199,
+                                                                                                      255, 256, 257, 320]), 3000 + k) for k in range(n)]
+
+
+@pytest.mark.parametrize("B,cin,H,W,seed", _conv_cases(16, 77))
+def test_shared_conv_random_shapes_vs_oracle(B, cin, H, W, seed):
+    dev = torch.device("cuda:0")
+    m = _model(4, 7, 1, cin, seed)
+    with torch.no_grad():
+        m.shared_conv[1].running_mean.copy_(torch.randn(64) * 0.3)
+        m.shared_conv[1].running_var.copy_(torch.rand(64) + 0.5)
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(seed)
+    x, xp = torch.relu(torch.randn(B, cin, H, W, generator=g)), torch.relu(torch.randn(B, cin, H, W, generator=g))
+    ref, refp = O.shared_conv_nhwc(w, x), O.shared_conv_nhwc(w, xp)
+    m = m.to(dev)
+    with torch.no_grad():
+        got, gotp = m.shared_conv_nhwc(x.to(dev), xp.to(dev))
+    scale = max(1.0, float(ref.abs().max()))
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(gotp.cpu().numpy(), refp.numpy(), rtol=1e-4, atol=2e-5 * scale)
+
+
+def _grad_cases(n, seed):
+    rnd = random.Random(seed)
+    return [(rnd.choice([1, 3, 5, 9, 16, 21]), rnd.randint(1, 7), rnd.choice([1, 4, 5]), rnd.choice([1, 2, 5, 17]), 4000 + k) for k in range(n)]
+
+
+@pytest.mark.parametrize("N,nf,npnt,B,seed", _grad_cases(8, 9))
+def test_backward_random_configs_vs_oracle_autograd(N, nf, npnt, B, seed):
+    from shasta_amd import training
+    dev = torch.device("cuda:0")
+    m = _model(N, nf, npnt, 8, seed, 64)
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(seed)
+    a = torch.relu(torch.randn(B, 24, 24, 64, generator=g))
+    b = torch.relu(torch.randn(B, 24, 24, 64, generator=g))
+    det, prev = O.synth_boxes(g, B, N, None), O.synth_boxes(g, B, N, max(0, N - 2))
+    gt = (torch.rand(B, N + 2, N + 2, generator=g) < 0.2).float()
+    gt[:, 0, 0] = 1.0
+    wl = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.startswith("shared_conv")) for k, v in w.items()}
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    r1, r2 = O.forward_from_bev(wl, ar, br, det.clone(), prev.clone(), nf, npnt, out_stride=64, grad=True)
+    O.affinity_loss(r1, r2, gt).backward()
+    m = m.to(dev).train()
+    ad, bd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    m1, m2 = training.affinity_train(m, ad, bd, det.to(dev).contiguous(), prev.to(dev).contiguous())
+    training.affinity_loss(m1, m2, gt.to(dev)).backward()
+    named = dict(m.named_parameters())
+    for k, v in wl.items():
+        if v.grad is None or v.numel() == 0:  # max_obj < 5: the aug_dets hidden layer has width 0
+            continue
+        got, want = named[k].grad.double().cpu(), v.grad.double()
+        # identical anchor yaws (hidden width 0: anchor = bias) make d sqrt(0) = NaN in torch autograd - and here, at the same places
+        assert torch.equal(torch.isnan(got), torch.isnan(want)), k
+        got, want = torch.nan_to_num(got), torch.nan_to_num(want)
+        assert float((got - want).abs().max()) <= 3e-3 * max(float(want.abs().max()), 1e-7) + 1e-9, k
+    for got, want in ((ad.grad, ar.grad), (bd.grad, br.grad)):
+        assert float((got.double().cpu() - want.double()).abs().max()) <= 3e-3 * max(float(want.abs().max()), 1e-7) + 1e-9
