@@ -3,6 +3,8 @@
 //   matched1 = softmax(matched[:, :-2, :], dim=2)   (B, N, N+2): each previous detection over {dets, dead, FN}
 //   matched2 = softmax(matched[:, :, :-2], dim=1)   (B, N+2, N): each detection over {prev dets, newborn, FP}
 // The six layers are six launches of the generic matrix-core GEMM over the B*T rows (bias + ReLU fused).
+#include <algorithm>
+
 #include "common.hpp"
 #include "pair_layout.hpp"
 #include <stdlib.h>
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(64 * AFF_WAVES) void aff_fused_kernel(AffArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int XS = a.Dp + 4, HS = 132;
     float* xb = sm;                   // [ROWS][XS]  residual rows, later the matched rows
-    float* ha = sm + ROWS * XS;       // [ROWS][HS]
+    float* ha = sm + ROWS * max(XS, HS);  // [ROWS][HS]; the xb region must also hold hb ([ROWS][HS]) when D < 128
     // the second hidden buffer lives in xb: xb is dead between layer 0 (its last reader) and layer 5 (its next writer), which
     // is exactly the lifetime of hb (written by layers 1 and 3, read by layers 2 and 4)
     float* hb = xb;                   // [ROWS][HS]
@@ -259,11 +261,11 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
     // fit twice.  SHASTA_AFF_RG1 / SHASTA_AFF_RG2 force one form.
     static const bool rg1_forced = getenv("SHASTA_AFF_RG1") != nullptr;
     static const bool rg2_forced = getenv("SHASTA_AFF_RG2") != nullptr;
-    const size_t lds2 = (size_t)(32 * (Dp + 4) + 32 * 132) * sizeof(float);
+    const size_t lds2 = (size_t)(32 * std::max(Dp + 4, 132) + 32 * 132) * sizeof(float);
     int rg = (lds2 <= 80 * 1024 && M >= 32 * 512) ? 2 : 1;
     if (rg2_forced && lds2 <= 160 * 1024) rg = 2;
     if (rg1_forced) rg = 1;
-    const size_t lds = (size_t)(16 * rg * (Dp + 4) + 16 * rg * 132) * sizeof(float);
+    const size_t lds = (size_t)(16 * rg * std::max(Dp + 4, 132) + 16 * rg * 132) * sizeof(float);
     if (!unfused && lds <= 160 * 1024) {
         AffArgs fa;
         fa.W[0] = packed + P.aff0;  // zero padded (128, Dp)

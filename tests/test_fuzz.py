@@ -38,7 +38,10 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("N,nf,npnt,B,n_real,hw,seed", _cases(28, 2024))
+BIGGER = [(90, 3, 5, 17, 40, 180, 1), (100, 7, 4, 33, None, 90, 2), (130, 5, 1, 3, 100, 180, 3), (77, 2, 5, 65, 70, 45, 4), (129, 7, 4, 2, None, 180, 5)]
+
+
+@pytest.mark.parametrize("N,nf,npnt,B,n_real,hw,seed", _cases(28, 2024) + BIGGER)
 def test_forward_random_configs_vs_oracle(N, nf, npnt, B, n_real, hw, seed):
     dev = torch.device("cuda:0")
     stride = 8 * 180 // hw  # the map always spans the same metric extent
