@@ -38,7 +38,9 @@ def _cases(n, seed):
     return out
 
 
-BIGGER = [(90, 3, 5, 17, 40, 180, 1), (100, 7, 4, 33, None, 90, 2), (130, 5, 1, 3, 100, 180, 3), (77, 2, 5, 65, 70, 45, 4), (129, 7, 4, 2, None, 180, 5)]
+BIGGER = [(90, 3, 5, 17, 40, 180, 1), (100, 7, 4, 33, None, 90, 2), (130, 5, 1, 3, 100, 180, 3), (77, 2, 5, 65, 70, 45, 4), (129, 7, 4, 2, None, 180, 5),
+          (100, 3, 1, 165, 90, 45, 6), (126, 7, 1, 131, None, 24, 7), (50, 6, 4, 129, 10, 90, 8), (64, 1, 5, 70, None, 180, 9),
+          (200, 7, 1, 16, 150, 180, 10), (40, 4, 4, 48, 39, 45, 11)]
 
 
 @pytest.mark.parametrize("N,nf,npnt,B,n_real,hw,seed", _cases(28, 2024) + BIGGER)
