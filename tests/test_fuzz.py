@@ -126,3 +126,39 @@ def test_backward_random_configs_vs_oracle_autograd(N, nf, npnt, B, seed):
         assert float((got - want).abs().max()) <= 3e-3 * max(float(want.abs().max()), 1e-7) + 1e-9, k
     for got, want in ((ad.grad, ar.grad), (bd.grad, br.grad)):
         assert float((got.double().cpu() - want.double()).abs().max()) <= 3e-3 * max(float(want.abs().max()), 1e-7) + 1e-9
+
+
+def _vox_cases(n, seed):
+    rnd = random.Random(seed)
+    out = []
+    for k in range(n):
+        P = rnd.choice([1, 2, 63, 64, 65, 255, 1000, 4097, 20000, 65536])
+        ndim = rnd.choice([3, 4, 5, 6])
+        mp = rnd.choice([1, 2, 3, 10, 35])
+        mv = rnd.choice([1, 7, 100, 5000, 70000])
+        grid = rnd.choice(["nusc", "coarse", "tiny"])
+        out.append((P, ndim, mp, mv, grid, 5000 + k))
+    return out
+
+
+@pytest.mark.parametrize("P,ndim,mp,mv,grid,seed", _vox_cases(16, 31))
+def test_voxelizer_random_clouds_bit_exact_vs_c_oracle(P, ndim, mp, mv, grid, seed):
+    """Random point counts, point widths, capacities and grids (points outside the range, duplicates, many points per cell):
+    voxel order, contents, counts and coordinates bit-identical to the serial C restatement of the reference loop."""
+    from oracle import voxelize_oracle as VO
+    from shasta_amd.voxel_generator import points_to_voxel_device
+    dev = torch.device("cuda:0")
+    vs, rg = {"nusc": ([0.075, 0.075, 0.2], [-54, -54, -5, 54, 54, 3]), "coarse": ([0.5, 0.5, 8.0], [-20, -30, -5, 20, 30, 3]),
+              "tiny": ([1.0, 2.0, 4.0], [0, 0, 0, 4, 6, 4])}[grid]
+    vs, rg = np.array(vs, np.float32), np.array(rg, np.float32)
+    rng = np.random.default_rng(seed)
+    pts = rng.normal(0, 1, (P, ndim)).astype(np.float32)
+    span = (rg[3:] - rg[:3])
+    pts[:, :3] = (rg[:3] + span * rng.uniform(-0.1, 1.1, (P, 3))).astype(np.float32)  # ~1/4 of the points fall outside
+    if P > 10:
+        pts[: P // 7] = pts[P // 2: P // 2 + P // 7]  # exact duplicates
+    v, c, n, mean = points_to_voxel_device(torch.from_numpy(pts).to(dev), vs, rg, mp, mv, with_mean=True)
+    rv, rc, rn, rmean = VO.points_to_voxel(pts, vs, rg, mp, mv, with_mean=True)
+    assert v.shape[0] == rv.shape[0]
+    assert np.array_equal(c.cpu().numpy(), rc) and np.array_equal(n.cpu().numpy(), rn) and np.array_equal(v.cpu().numpy(), rv)
+    np.testing.assert_allclose(mean.cpu().numpy(), rmean, rtol=1e-6, atol=1e-6)
