@@ -162,3 +162,30 @@ def test_voxelizer_random_clouds_bit_exact_vs_c_oracle(P, ndim, mp, mv, grid, se
     assert v.shape[0] == rv.shape[0]
     assert np.array_equal(c.cpu().numpy(), rc) and np.array_equal(n.cpu().numpy(), rn) and np.array_equal(v.cpu().numpy(), rv)
     np.testing.assert_allclose(mean.cpu().numpy(), rmean, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("npnt,seed", [(1, 1), (4, 2), (5, 3)])
+def test_boxes_outside_the_map_follow_the_reference_clamping(npnt, seed):
+    """bilinear_interpolate_torch clamps the corner INDICES to the map but takes the weights from the clamped indices
+    (center_utils.py:92-121): boxes beyond the map edge (or far outside) must reproduce that, not be zeroed or rejected."""
+    dev = torch.device("cuda:0")
+    N, nf, B = 24, 7, 3
+    m = _model(N, nf, npnt, 8, seed)
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(seed)
+    bev = torch.relu(torch.randn(B, 180, 180, 64, generator=g))
+    pbev = torch.relu(torch.randn(B, 180, 180, 64, generator=g))
+    det, prev = O.synth_boxes(g, B, N, None), O.synth_boxes(g, B, N, None)
+    for t in (det, prev):
+        t[:, ::3, 0] = torch.empty(B, len(range(0, N, 3))).uniform_(-75, 75, generator=g)   # up to 21 m outside
+        t[:, 1::4, 1] = torch.empty(B, len(range(1, N, 4))).uniform_(-56, -53.5, generator=g)  # straddling the edge
+    r1, r2, im = O.forward_from_bev(w, bev, pbev, det.clone(), prev.clone(), nf, npnt, return_intermediates=True)
+    m = m.to(dev)
+    m.keep_intermediates = True
+    with torch.no_grad():
+        m1, m2 = m.affinity_from_bev(bev.to(dev), pbev.to(dev), det.to(dev), prev.to(dev))
+    feat = m.last_intermediates["feature"][:, :N].cpu()
+    scale = float(im["feature"].abs().max())
+    assert float((feat - im["feature"]).abs().max()) <= 2e-4 * max(1.0, scale)
+    np.testing.assert_allclose(m1.cpu().numpy(), r1.numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(m2.cpu().numpy(), r2.numpy(), rtol=0, atol=1e-4)
