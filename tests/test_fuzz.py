@@ -189,3 +189,32 @@ def test_boxes_outside_the_map_follow_the_reference_clamping(npnt, seed):
     assert float((feat - im["feature"]).abs().max()) <= 2e-4 * max(1.0, scale)
     np.testing.assert_allclose(m1.cpu().numpy(), r1.numpy(), rtol=0, atol=1e-4)
     np.testing.assert_allclose(m2.cpu().numpy(), r2.numpy(), rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("N,B,alpha,seed", [(1, 3, 0.5, 1), (63, 5, 0.05, 2), (64, 4, 0.02, 3), (65, 3, 0.3, 4), (130, 6, 0.01, 5), (500, 2, 0.004, 6)])
+def test_device_decode_decisions_random_sizes(N, B, alpha, seed):
+    """The batched decision kernel against the host restatement of the eval loop at table sizes around the 64-lane tiles and at
+    the headline size; peaked random rows / columns so that every branch (match, dead, FN, newborn, FP) occurs."""
+    import copy
+    from shasta_amd import decode as Dm
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    m1 = rng.dirichlet(np.full(N + 2, alpha), size=(B, N)).astype(np.float32)
+    m2 = np.swapaxes(rng.dirichlet(np.full(N + 2, alpha), size=(B, N)).astype(np.float32), 1, 2).copy()
+    n_prev, n_cur = rng.integers(0, N + 1, size=B), rng.integers(0, N + 1, size=B)
+    n_prev[0], n_cur[0] = N, N
+    pc, ps, df, ds = Dm.decode_flags_device(torch.from_numpy(m1).to(dev), torch.from_numpy(m2).to(dev), n_prev, n_cur)
+
+    def boxes(n, tag):
+        return [dict(sample_token=tag, translation=[float(i), float(-i), 0.5], velocity=[0.5 * i, -0.25 * i]) for i in range(n)]
+
+    events = 0
+    for b in range(B):
+        c1, p1 = boxes(int(n_cur[b]), "c"), boxes(int(n_prev[b]), "p")
+        c2, p2 = copy.deepcopy(c1), copy.deepcopy(p1)
+        ref = Dm.decode_frame(m1[b], m2[b], c1, p1, "tok", 0.5)
+        got = Dm.decode_frame_from_flags(pc[b], ps[b], df[b], ds[b], c2, p2, "tok", 0.5)
+        assert got[1] == ref[1] and got[2] == ref[2] and got[0] == ref[0], b
+        events += len(ref[1]) + sum(1 for a in ref[0] if a.get("FN") or a.get("newborn"))
+    if alpha <= 0.05 and N >= 63:
+        assert events > 0  # the peaked matrices do trigger the anchor branches
