@@ -218,3 +218,23 @@ def test_device_decode_decisions_random_sizes(N, B, alpha, seed):
         events += len(ref[1]) + sum(1 for a in ref[0] if a.get("FN") or a.get("newborn"))
     if alpha <= 0.05 and N >= 63:
         assert events > 0  # the peaked matrices do trigger the anchor branches
+
+
+@pytest.mark.parametrize("N,nf,B,n_real", [(600, 7, 2, None), (1000, 3, 1, 900), (2046, 7, 1, 1500)])
+def test_large_tables_up_to_the_documented_limit(N, nf, B, n_real):
+    """max_obj up to 2046 (the documented limit; F = 64 so that the anchor weights stay small): every kernel's size-dependent
+    choice (LDS footprints, column-softmax tiling, K splits) at its far end, against the oracle."""
+    dev = torch.device("cuda:0")
+    m = _model(N, nf, 1, 8, N)
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(N)
+    bev = torch.relu(torch.randn(B, 180, 180, 64, generator=g))
+    pbev = torch.relu(torch.randn(B, 180, 180, 64, generator=g))
+    det, prev = O.synth_boxes(g, B, N, n_real), O.synth_boxes(g, B, N, n_real)
+    r1, r2 = O.forward_from_bev(w, bev, pbev, det.clone(), prev.clone(), nf, 1)
+    m = m.to(dev)
+    with torch.no_grad():
+        m1, m2 = m.affinity_from_bev(bev.to(dev), pbev.to(dev), det.to(dev), prev.to(dev))
+    np.testing.assert_allclose(m1.cpu().numpy(), r1.numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(m2.cpu().numpy(), r2.numpy(), rtol=0, atol=TOL)
+    assert torch.equal(m1.argmax(-1).cpu(), r1.argmax(-1)) or float((torch.sort(r1, -1).values[..., -1] - torch.sort(r1, -1).values[..., -2]).min()) < 1e-6
