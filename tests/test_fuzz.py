@@ -95,7 +95,7 @@ def _grad_cases(n, seed):
     return [(rnd.choice([1, 3, 5, 9, 16, 21]), rnd.randint(1, 7), rnd.choice([1, 4, 5]), rnd.choice([1, 2, 5, 17]), 4000 + k) for k in range(n)]
 
 
-@pytest.mark.parametrize("N,nf,npnt,B,seed", _grad_cases(8, 9))
+@pytest.mark.parametrize("N,nf,npnt,B,seed", _grad_cases(8, 9) + [(100, 7, 4, 2, 4100), (130, 3, 5, 3, 4101), (64, 7, 1, 20, 4102)])
 def test_backward_random_configs_vs_oracle_autograd(N, nf, npnt, B, seed):
     from shasta_amd import training
     dev = torch.device("cuda:0")
