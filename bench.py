@@ -94,12 +94,12 @@ def main():
     det0, prev = boxes(), boxes()
     det = det0.clone()
 
-    evs = []
+    evs = []  # per step: (L1 start, L1 stop, pair start, pair stop)
     for _ in range(args.steps):
-        a, b_ = C.c_void_p(), C.c_void_p()
-        hip.check(lib.shasta_event_create(C.byref(a)), "event_create")
-        hip.check(lib.shasta_event_create(C.byref(b_)), "event_create")
-        evs.append((a, b_))
+        four = tuple(C.c_void_p() for _ in range(4))
+        for e in four:
+            hip.check(lib.shasta_event_create(C.byref(e)), "event_create")
+        evs.append(four)
 
     def step(ev=None):
         det.copy_(det0)  # forward back-projects det_boxes in place (shasta.py:270): restore the input
@@ -144,34 +144,50 @@ def main():
     assert bool(torch.isfinite(m1).all()) and abs(float(m1[0, 0].sum()) - 1.0) < 1e-4
 
     ms = C.c_float()
-    l1 = []
-    if graph is not None:  # the per-step events were not recorded under graph replay: time the dominant kernel separately
+    l1, pair = [], []
+    if graph is not None:  # the per-step events were not recorded under graph replay: time the two kernels separately
         with torch.no_grad():
             for i in range(args.steps):
                 step(evs[i])
         torch.cuda.synchronize()
-    for a, b_ in evs:
-        hip.check(lib.shasta_event_elapsed_ms(a, b_, C.byref(ms)), "event_elapsed")
+    for four in evs:
+        hip.check(lib.shasta_event_elapsed_ms(four[0], four[1], C.byref(ms)), "event_elapsed")
         l1.append(ms.value)
-        lib.shasta_event_destroy(a)
-        lib.shasta_event_destroy(b_)
-    l1_ms = sum(l1) / len(l1)
+        hip.check(lib.shasta_event_elapsed_ms(four[2], four[3], C.byref(ms)), "event_elapsed")
+        pair.append(ms.value)
+        for e in four:
+            lib.shasta_event_destroy(e)
+    l1_ms, pair_ms = sum(l1) / len(l1), sum(pair) / len(pair)
+    step_ms = elapsed / args.steps * 1e3
+    # Kernel 1: aug_shape first layer = the 4.1 GB fp32 weight stream.  HBM-bound by construction at every batch size the
+    # default build serves: B <= 32 on the f32 MFMA kernel (1024 matrix-pipe cycles per 4 KB tile against ~1300 of HBM),
+    # B > 32 on the bf16-piece kernel (768 / 1536 cycles per tile for 64 / 128 items per weight pass).  With
+    # SHASTA_L1_F32=1 and B > 32 the f32 MFMA kernel (2048 cycles per tile) is matrix-pipe bound instead.
     alg = l1_algorithmic_bytes(B)
     hbm_gbs = alg / (l1_ms * 1e-3) / 1e9
     K = N_OBJ * CH * NPOINT
     l1_flops = 2.0 * B * 4 * (K // 64) * K  # dense flops of the four first layers for B frame-pairs
-    mfma_tflops = l1_flops / (l1_ms * 1e-3) / 1e12
-    # One weight pass serves up to 32 frame-pairs at HBM speed (16 B/clk/CU of weights consumable by the 32x32x2 f32
-    # MFMAs vs ~10 B/clk/CU delivered); with 64 per pass the same stream needs 2x the MFMA work and is MFMA-bound.
-    if B <= 32:
-        roof = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS}
+    l1_tflops = l1_flops / (l1_ms * 1e-3) / 1e12
+    if B <= 32 or not os.environ.get("SHASTA_L1_F32"):
+        roof_l1 = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS}
     else:
-        roof = {"bound": "mfma", "achieved": mfma_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": mfma_tflops / MFMA_F32_PEAK_TFLOPS}
-    roof.update({"kernel": "anchor_l1_kernel (B=1) / anchor_l1_mfma_kernel (B>=2): aug_shape.*.0, 4 x 2000 x 128000 fp32 "
-                           "weight stream", "traffic": _pmc_traffic(B), "algorithmic_bytes_per_launch": alg,
-                 "algorithmic_flops_per_launch": l1_flops, "avg_launch_ms": l1_ms, "hbm_gbs": hbm_gbs,
-                 "mfma_tflops": mfma_tflops, "share_of_step": l1_ms / (elapsed / args.steps * 1e3)})
+        roof_l1 = {"bound": "mfma", "achieved": l1_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": l1_tflops / MFMA_F32_PEAK_TFLOPS}
+    roof_l1.update({"kernel": "anchor_l1_kernel (B=1) / anchor_l1_mfma_kernel (B<=32) / anchor_l1_split_kernel (B>32): "
+                              "aug_shape.*.0, 4 x 2000 x 128000 fp32 weight stream",
+                    "traffic": _pmc_traffic(B), "algorithmic_bytes_per_launch": alg, "algorithmic_flops_per_launch": l1_flops,
+                    "avg_launch_ms": l1_ms, "hbm_gbs": hbm_gbs, "fp32_equivalent_tflops": l1_tflops,
+                    "share_of_step": l1_ms / step_ms})
+    # Kernel 2: the pair kernel (layers 2-4 of fuse_shape / res_coeff / fuse_det for all (N+2)^2 pairs on the f32 matrix
+    # pipe): 1984 useful multiply-adds per pair; everything it reads is L2-resident.
+    pair_flops = 2.0 * 1984 * (N_OBJ + 2) ** 2 * B
+    pair_tflops = pair_flops / (pair_ms * 1e-3) / 1e12
+    roof_pair = {"bound": "mfma", "achieved": pair_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": pair_tflops / MFMA_F32_PEAK_TFLOPS, "traffic": _pmc_traffic(B, "pair"),
+                 "kernel": "pair_mfma4_kernel<256,8>: per-pair MLP tails + hand residual -> residual (B, 502, 502)",
+                 "algorithmic_flops_per_launch": pair_flops, "avg_launch_ms": pair_ms, "share_of_step": pair_ms / step_ms}
+    # `roofline` is the kernel with the longer average launch; the other one rides along as `roofline_second`
+    roof, second = (roof_l1, roof_pair) if l1_ms >= pair_ms else (roof_pair, roof_l1)
 
     out = {
         "metric": "affinity frame-pairs/sec at N=M=500, F=256",
@@ -187,6 +203,7 @@ def main():
                    "parallelism": "replica x%d (frame-parallel, no data-path collective)" % world,
                    "hip_graph": bool(args.graph)},
         "roofline": roof,
+        "roofline_second": second,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, args.cpu_sample)
@@ -196,13 +213,14 @@ def main():
         dist.destroy_process_group()
 
 
-def _pmc_traffic(B):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), corrected as
-    MI355X_MICROARCH.md prescribes (FETCH_SIZE doubled on gfx950); None when no profile for this batch size exists."""
+def _pmc_traffic(B, kernel="l1"):
+    """HBM bytes per launch of one of the two heaviest kernels from the committed rocprofv3 PMC passes (profiles/),
+    corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE doubled on gfx950); None when no profile for this batch size
+    exists."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get("batch_%d" % B)
+            return json.load(f).get(("batch_%d" if kernel == "l1" else "pair_batch_%d") % B)
     except (OSError, ValueError):
         return None
 

@@ -165,15 +165,18 @@ int shasta_affinity_forward_train_f32(const shasta_weights* w, const void* packe
                                       float* prev_tab, float* matched1, float* matched2, float* residual_out,
                                       float* shape_hidden_out, void* workspace, size_t workspace_bytes,
                                       shasta_stream_t stream);
-/* Measurement variant of the forward: identical work, plus hipEventRecord(ev_l1_start/stop) on `stream` around the
- * launch of the dominant kernel (the aug_shape first-layer weight stream, anchor_l1_kernel), so that bench.py can
- * read that kernel's duration live inside its timed region.  Events come from shasta_event_create (they are plain
- * hipEvent_t); shasta_event_elapsed_ms needs both events completed (synchronise the stream first). */
+/* Measurement variant of the forward: identical work, plus hipEventRecord on `stream` around the launches of the two
+ * kernels that carry the step - ev_l1_* around the aug_shape first-layer weight stream (anchor_l1_kernel /
+ * anchor_l1_mfma_kernel / anchor_l1_split_kernel), ev_pair_* around the pair kernel (pair_mfma4_kernel) - so that
+ * bench.py can read both durations live inside its timed region and report the roofline of whichever is the longer.
+ * Events come from shasta_event_create (they are plain hipEvent_t); shasta_event_elapsed_ms needs both events
+ * completed (synchronise the stream first). */
 int shasta_affinity_forward_timed_f32(const shasta_weights* w, const void* packed, int B, float* feat,
                                       float* prev_feat, float* det_boxes, const float* prev_det_boxes,
                                       int box_stride, float* det_tab, float* prev_tab, float* matched1,
                                       float* matched2, void* workspace, size_t workspace_bytes,
-                                      shasta_stream_t stream, void* ev_l1_start, void* ev_l1_stop);
+                                      shasta_stream_t stream, void* ev_l1_start, void* ev_l1_stop,
+                                      void* ev_pair_start, void* ev_pair_stop);
 int shasta_event_create(void** ev);
 int shasta_event_destroy(void* ev);
 int shasta_event_elapsed_ms(void* start, void* stop, float* h_ms);

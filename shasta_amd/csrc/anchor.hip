@@ -273,10 +273,17 @@ __global__ __launch_bounds__(256) void box_l2_tables_kernel(BoxL2Args a) {
     }
 }
 
+size_t anchor_split_workspace_bytes(int B, int K);
+bool anchor_split_serves(int B, int K, int x_batch_stride);
+void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, int B, int x_batch_stride, hipStream_t st);
+void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part, int H, int K, int B, int* ks_out,
+                            hipStream_t st);
+
+// [split-K partials, worst-case KS = 64][hidden (B, 4H)][bf16 activation image of anchor_split.hip, batches > 32 only]
 size_t anchor_shape_workspace_bytes(int B, int N, int F) {
     const int H = N * F / 64;
-    // worst-case KS is bounded by 64
-    return align_up((size_t)64 * B * 4 * H * sizeof(float), 256) + align_up((size_t)B * 4 * H * sizeof(float), 256);
+    return align_up((size_t)64 * B * 4 * H * sizeof(float), 256) + align_up((size_t)B * 4 * H * sizeof(float), 256) +
+           anchor_split_workspace_bytes(B, N * F);
 }
 
 int launch_anchor_l1_mfma(const float* const W[4], const float* feat, const float* prev_feat, float* part, int H, int K,
@@ -322,11 +329,18 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     float* part = static_cast<float*>(ws);
     float* hidden = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)64 * B * 4 * H * sizeof(float), 256));
     a.part = part;
-    if (ev0) (void)hipEventRecord(ev0, st);
-    // B == 1: VALU weight-streaming GEMV (nothing to amortise; measured 6.5 TB/s).  B >= 2: the matrix-core kernel
-    // streams every weight once per 16 / 32 / 64 batch items (anchor_mfma.hip).  SHASTA_L1_VALU=1 forces the VALU kernels.
+    // B == 1: VALU weight-streaming GEMV (nothing to amortise; measured 6.5 TB/s).  2 <= B <= 32: the f32 matrix-core kernel
+    // streams every weight once per 16 / 32 batch items at HBM speed (anchor_mfma.hip).  B > 32: the same fp32 arithmetic as
+    // exact bf16 piece products, 64 / 128 items per weight pass (anchor_split.hip); SHASTA_L1_F32=1 keeps the f32 MFMA
+    // kernel (64 items per pass, matrix-pipe bound), SHASTA_L1_VALU=1 forces the VALU kernels.
     static const bool force_valu = getenv("SHASTA_L1_VALU") != nullptr;
+    static const bool force_f32 = getenv("SHASTA_L1_F32") != nullptr;
+    void* xs = reinterpret_cast<char*>(hidden) + align_up((size_t)B * 4 * H * sizeof(float), 256);
+    const bool split = !force_valu && !force_f32 && anchor_split_serves(B, K, a.x_batch_stride);
+    if (split) launch_split_x(feat, prev_feat, xs, K, B, a.x_batch_stride, st);
+    if (ev0) (void)hipEventRecord(ev0, st);
     if (B == 1) launch_l1<1, R>(a, st);
+    else if (split) launch_anchor_l1_split(a.W, xs, part, H, K, B, &a.KS, st);
     else if (!force_valu && K % 32 == 0) launch_anchor_l1_mfma(a.W, feat, prev_feat, part, H, K, B, a.x_batch_stride, &a.KS, st);
     else if (B == 2) launch_l1<2, R>(a, st);
     else if (B <= 4) launch_l1<4, R>(a, st);

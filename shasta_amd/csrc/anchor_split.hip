@@ -1,0 +1,370 @@
+// K3b: first aug_shape layer (det3d/models/tracker/shasta.py:54, applied :241-244) for more than 32 frame-pairs per step:
+//   part[ks][b][n] = sum_{k in chunk ks} W[n][k] * x[b][k]       W: 4 x (N*F/64, N*F) fp32, 4.1 GB at N=500,F=256
+// The f32 MFMA kernel of anchor_mfma.hip is matrix-pipe bound from 64 batch rows per pass (2048 SIMD cycles per 4 KB weight
+// tile against ~1300 that HBM needs).  This kernel keeps fp32 ARITHMETIC but runs it on the bf16 matrix path, which is 16 x
+// faster per product: every fp32 operand is cut - exactly, by truncation - into three bf16 pieces
+//   a = a_hi + a_mid + a_lo      (8 + 8 + 8 significand bits; a_lo is exact because the remainder has at most 8 bits left)
+// and  w * x  is accumulated (in the fp32 accumulator of v_mfma_f32_32x32x16_bf16) as the six piece products of weight
+// 2^0 .. 2^-16:  w_lo x_hi + w_hi x_lo + w_mid x_mid + w_mid x_hi + w_hi x_mid + w_hi x_hi.
+// Each bf16 x bf16 product is exact in fp32; the three dropped products are below 2^-24 |w x|, i.e. below the rounding error
+// of the fp32 FMA they replace (tests/test_hip_parity.py compares both kernels with the float64 oracle: same error level).
+// Cost per 4 KB weight tile and 64 batch rows: 24 MFMA x 32 = 768 cycles instead of 2048 -> the kernel is HBM-bound again.
+//
+// Data path.  The weights stay fp32 in HBM (they are the reference's checkpoint tensors) and are streamed exactly once per
+// pass of 64 / 128 batch rows: LDS-DMA into a [32 rows][8 x 16 B] image per wave (source-side swizzle, see anchor_mfma.hip),
+// ds_read_b128 -> registers, cut into pieces on the VALU between the MFMAs (the bf16 MFMA leaves 24 of its 32 cycles to
+// other vector instructions; 16 weights per lane and tile = 88 instructions).  The activations are cut ONCE by
+// split_x_kernel into a bf16 image that is already in MFMA-fragment order (1 KB = one operand fragment of one wave), so the
+// x tile of a workgroup is a linear 12 / 24 KB copy and every fragment read is a conflict-free linear ds_read_b128.
+// The four waves of a workgroup (4 x 32 weight rows) share one x tile: x traffic from L2 is 0.75 x the weight bytes instead
+// of 2 x, and the ring is 5 (64 rows) or 4 (128 rows) slots deep = 64 / 48 KB of weights in flight per CU.
+// Sync: one s_barrier per tile.  Wave w waits (counted vmcnt) for its own share of tile t+1, then the barrier certifies
+// (a) every share of x tile t+1 has landed and (b) every wave has finished reading tile t out of its slot, which is then
+// refilled with tile t+NS.  Workgroups that share an x stream (same K chunk, same frame) sit on one XCD (blockIdx.x % 8).
+#include "common.hpp"
+
+// the LDS-DMA asm below names m0 in its clobber list on purpose (it writes it)
+#pragma clang diagnostic ignored "-Winline-asm"
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace shasta {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// a = h + m + l exactly, each with at most 8 significand bits (bf16-representable by truncation)
+__device__ __forceinline__ void split3(float a, float& h, float& m, float& l) {
+    h = __uint_as_float(__float_as_uint(a) & 0xffff0000u);
+    const float r = a - h;
+    m = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+    l = r - m;
+}
+// {bf16(even), bf16(odd)} of two floats whose low 16 bits are not needed
+__device__ __forceinline__ uint32_t pack_top(float even, float odd) {
+    return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u);
+}
+
+struct SplitXArgs {
+    const float* x[2];
+    uint32_t* xs;  // [2 frames][NBLK][KT][XT][2 k-steps][3 pieces][64 lanes][8 bf16]
+    int B, KT, NBLK, XT, x_batch_stride;
+};
+
+// grid (cdiv(KT, 8), NBLK * XT, 2): 32 batch rows x 256 k per block, transposed through LDS so that both the fp32 reads
+// (1 KB per row) and the fragment-order writes (1 KB per fragment) are whole lines.
+__global__ __launch_bounds__(256) void split_x_kernel(SplitXArgs a) {
+    __shared__ __attribute__((aligned(16))) float tile[32][264];
+    const int src = blockIdx.z, bblk = blockIdx.y / a.XT, u = blockIdx.y % a.XT;
+    const int kt0 = blockIdx.x * 8, nkt = min(8, a.KT - kt0);
+    const float* x = a.x[src];
+    const int brow0 = (bblk * a.XT + u) * 32;
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int r = i >> 6, c4 = i & 63, b = brow0 + r;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (b < a.B && (c4 >> 3) < nkt)
+            v = *reinterpret_cast<const f32x4*>(x + (size_t)b * a.x_batch_stride + (size_t)kt0 * 32 + c4 * 4);
+        *reinterpret_cast<f32x4*>(&tile[r][c4 * 4]) = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        const int lane = i & 63, s = (i >> 6) & 1, ktl = i >> 7;
+        if (ktl >= nkt) continue;
+        const int r = lane & 31, h = lane >> 5;
+        const float* p = &tile[r][ktl * 32 + 16 * s + 8 * h];
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        u32x4 hi, mid, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float h0, m0, l0, h1, m1, l1;
+            split3(v[2 * j], h0, m0, l0);
+            split3(v[2 * j + 1], h1, m1, l1);
+            hi[j] = pack_top(h0, h1);
+            mid[j] = pack_top(m0, m1);
+            lo[j] = pack_top(l0, l1);
+        }
+        const size_t frag0 = ((((size_t)src * a.NBLK + bblk) * a.KT + kt0 + ktl) * (6 * a.XT)) + (size_t)(u * 2 + s) * 3;
+        u32x4* o = reinterpret_cast<u32x4*>(a.xs) + frag0 * 64 + lane;
+        o[0] = hi;
+        o[64] = mid;
+        o[128] = lo;
+    }
+}
+
+struct AnchorSplitArgs {
+    const float* W[4];
+    const uint32_t* xs;
+    float* part;
+    int H, K, B, KS, Kc, KT, NBLK, groups_per_mlp;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm_split() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// XT = batch rows per pass / 32 (2 or 4); NS = ring slots
+template <int XT, int NS>
+__global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a) {
+    constexpr int XCH = 6 * XT;                  // 1 KB fragments of one x tile
+    constexpr int XPW = XCH / 4;                 // of which every wave fetches this many
+    static_assert(XCH % 4 == 0, "x fragments are dealt to four waves");
+    constexpr int SLOT = 4 * 1024 + XCH * 256;   // dwords per ring slot: 4 private W tiles + the shared x tile
+    constexpr int PER_TILE = 4 + XPW;            // vmcnt units a wave spends per tile
+    static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt is 6 bits");
+    constexpr int NM = 12 * XT;                  // MFMAs per tile
+    constexpr int ND = PER_TILE;                 // LDS-DMA instructions per tile and wave
+    constexpr int NR = 4 + XCH;                  // ds_read_b128 per tile and wave
+    constexpr int SG = (NM - 8) / 16;            // MFMA gaps between two weight elements being cut
+    static_assert(1 + NR < NM && 6 + 15 * SG < NM, "side work must fit the MFMA gaps of one tile");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    const int ncombo = 2 * a.KS;                 // (K chunk, frame) pairs: consecutive blocks -> consecutive XCDs
+    const int combo = blockIdx.x % ncombo, quad = blockIdx.x / ncombo;
+    const int ks = combo >> 1, src = combo & 1;
+    const int G2 = 2 * a.groups_per_mlp;         // 32-row groups over the two MLPs that read this frame
+    const bool active = quad * 4 + wid < G2;     // a spare wave repeats the last group (it still fetches x and joins barriers)
+    const int gg = min(quad * 4 + wid, G2 - 1);
+    const int mlp = 2 * src + gg / a.groups_per_mlp, r0 = (gg % a.groups_per_mlp) * 32;
+    const int bblk = blockIdx.y;
+    const int tpc = a.Kc >> 5;
+    const int kt_beg = ks * tpc, NT = min(a.KT, kt_beg + tpc) - kt_beg;
+
+    const float* wbase = mlp == 0 ? a.W[0] : mlp == 1 ? a.W[1] : mlp == 2 ? a.W[2] : a.W[3];
+    const char* wub = reinterpret_cast<const char*>(wbase + (size_t)r0 * a.K + (size_t)kt_beg * 32);
+    const char* xub = reinterpret_cast<const char*>(a.xs) + ((((size_t)src * a.NBLK + bblk) * a.KT + kt_beg) * XCH) * 1024;
+    uint32_t woff[4];
+    {
+        const int cpos = lane & 7, rl = lane >> 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 8 * j + rl;
+            const int c = cpos ^ ((r >> 1) & 7);
+            woff[j] = (uint32_t)(((min(r0 + r, a.H - 1) - r0) * a.K + 4 * c) * 4);
+        }
+    }
+    const uint32_t xoff = (uint32_t)(lane * 16 + wid * 1024);
+    const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) float*)lds);
+    // instruction idx of this wave for tile t (relative to kt_beg) into ring slot `slot`; no VALU: scalar base + 32-bit lane offset
+    auto dma = [&](int t, int slot, int idx) {
+        if (idx < 4) {
+            const char* base = wub + (size_t)t * 128;
+            const uint32_t dst = lds0 + (uint32_t)((slot * SLOT + wid * 1024 + idx * 256) * 4);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(woff[idx]), "s"(base), "s"(dst)
+                         : "memory", "m0");
+        } else {
+            const int i = idx - 4;
+            const char* base = xub + (size_t)t * (XCH * 1024) + (size_t)i * 4096;
+            const uint32_t dst = lds0 + (uint32_t)((slot * SLOT + 4096 + (wid + 4 * i) * 256) * 4);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(xoff), "s"(base), "s"(dst)
+                         : "memory", "m0");
+        }
+    };
+    auto issue = [&](int t, int slot) {
+#pragma unroll
+        for (int j = 0; j < ND; ++j) dma(t, slot, j);
+    };
+
+    struct Frag {
+        u32x4 A[2][3];      // weight pieces [k-step][piece]
+        u32x4 X[XT][2][3];  // activation pieces [32-row block][k-step][piece]
+    };
+    f32x4 raw[4];           // fp32 weights of the tile being cut: [2 * k-step + half]
+    const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
+    auto read_one = [&](int slot, Frag& f, int idx) {
+        const float* sl = lds + slot * SLOT;
+        if (idx < 4) {
+            const int s = idx >> 1, qq = idx & 1;
+            raw[idx] = *reinterpret_cast<const f32x4*>(sl + wid * 1024 + frow * 32 + (((4 * s + 2 * fh + qq) ^ fsw) * 4));
+        } else {
+            const int j = idx - 4;
+            f.X[j / 6][(j / 3) % 2][j % 3] = *reinterpret_cast<const u32x4*>(sl + 4096 + j * 256 + lane * 4);
+        }
+    };
+    // cut weight element e (0..15) of the tile in `raw`; the pair (e-1, e) is packed when e is odd
+    float ph = 0.0f, pm = 0.0f, pl = 0.0f;
+    auto cut_one = [&](Frag& f, int e) {
+        float h, m, l;
+        split3(raw[e >> 2][e & 3], h, m, l);
+        if ((e & 1) == 0) {
+            ph = h;
+            pm = m;
+            pl = l;
+        } else {
+            const int s = e >> 3, d = (e & 7) >> 1;
+            f.A[s][0][d] = pack_top(ph, h);
+            f.A[s][1][d] = pack_top(pm, m);
+            f.A[s][2][d] = pack_top(pl, l);
+        }
+    };
+
+    f32x16 acc[XT];
+#pragma unroll
+    for (int u = 0; u < XT; ++u) acc[u] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // piece products, small to large
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PX[6] = {0, 2, 1, 0, 1, 0};
+    auto mma_one = [&](const Frag& f, int i) {
+        const int s = i / (6 * XT), u = (i / 6) % XT, pr = i % 6;
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.A[s][PW[pr]]),
+                                                         __builtin_bit_cast(bf16x8, f.X[u][s][PX[pr]]), acc[u], 0, 0, 0);
+    };
+
+    // Prologue: fill the ring, take tile 0 into registers.
+    {
+        int s = 0;
+#pragma unroll 1
+        for (int t = 0; t < NS && t < NT; ++t, ++s) issue(t, s);
+    }
+    Frag fa, fb;
+    if (NT >= NS) wait_vm_split<PER_TILE*(NS - 1)>();
+    else wait_vm_split<0>();
+    __builtin_amdgcn_s_barrier();
+    if (NT > 0) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) read_one(0, fa, i);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cut_one(fa, e);
+    }
+    // One tile.  `cur` holds tile t in registers; slot sc (tile t's) is refilled with tile t+NS after the barrier; tile t+1
+    // is read out of slot sn and cut into `nxt`.  Everything that is not an MFMA sits between two MFMAs.
+    auto step = [&](const Frag& cur, Frag& nxt, int t, int sc, auto steady) {
+        constexpr bool STEADY = decltype(steady)::value;
+        const int sn = sc + 1 == NS ? 0 : sc + 1;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            mma_one(cur, i);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of tile t's slot have retired
+                if constexpr (STEADY) wait_vm_split<PER_TILE*(NS - 2)>();
+                else wait_vm_split<0>();
+                __builtin_amdgcn_s_barrier();
+                if constexpr (!STEADY) {
+                    if (t + NS < NT) issue(t + NS, sc);
+                }
+            }
+            if (i >= 1 && i - 1 < ND) {
+                if constexpr (STEADY) dma(t + NS, sc, i - 1);
+            }
+            if (i >= 1 && i - 1 < NR) read_one(sn, nxt, i - 1);
+            if (i >= 6 && (i - 6) % SG == 0 && (i - 6) / SG < 16) cut_one(nxt, (i - 6) / SG);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    int t = 0, sc = 0;
+    auto next = [&](int s) { return s + 1 == NS ? 0 : s + 1; };
+#pragma unroll 1
+    for (; t + NS + 1 < NT; t += 2) {
+        step(fa, fb, t, sc, std::true_type{});
+        sc = next(sc);
+        step(fb, fa, t + 1, sc, std::true_type{});
+        sc = next(sc);
+    }
+#pragma unroll 1
+    for (; t + 1 < NT; t += 2) {
+        step(fa, fb, t, sc, std::false_type{});
+        sc = next(sc);
+        step(fb, fa, t + 1, sc, std::false_type{});
+        sc = next(sc);
+    }
+    if (t < NT) step(fa, fb, t, sc, std::false_type{});
+
+    // D[i = weight row][j = batch row]
+    if (active) {
+#pragma unroll
+        for (int u = 0; u < XT; ++u) {
+            const int b = (bblk * XT + u) * 32 + frow;
+            if (b < a.B) {
+                float* o = a.part + ((size_t)ks * a.B + b) * (4 * a.H) + mlp * a.H;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (row < a.H) o[row] = acc[u][r];
+                }
+            }
+        }
+    }
+}
+
+static inline int split_xt(int B) { return B <= 64 ? 2 : 4; }
+static inline int split_nblk(int B) { return cdiv(B, 32 * split_xt(B)); }
+
+// bytes of the bf16 activation image (0 for batches the f32 kernels serve)
+size_t anchor_split_workspace_bytes(int B, int K) {
+    if (B <= 32 || K % 32 != 0) return 0;
+    return align_up((size_t)2 * split_nblk(B) * 32 * split_xt(B) * (size_t)K * 6, 256);
+}
+
+// true when anchor_l1_split_kernel serves this shape (otherwise the f32 kernels of anchor_mfma.hip / anchor.hip do)
+bool anchor_split_serves(int B, int K, int x_batch_stride) { return B > 32 && K % 32 == 0 && (x_batch_stride & 3) == 0; }
+
+// cut the activations of both frames into the bf16 fragment image `xs`
+void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, int B, int x_batch_stride, hipStream_t st) {
+    const int XT = split_xt(B), NBLK = split_nblk(B), KT = K / 32;
+    SplitXArgs sx;
+    sx.x[0] = feat;
+    sx.x[1] = prev_feat;
+    sx.xs = static_cast<uint32_t*>(xs);
+    sx.B = B;
+    sx.KT = KT;
+    sx.NBLK = NBLK;
+    sx.XT = XT;
+    sx.x_batch_stride = x_batch_stride;
+    hipLaunchKernelGGL(split_x_kernel, dim3(cdiv(KT, 8), NBLK * XT, 2), dim3(256), 0, st, sx);
+}
+
+void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part, int H, int K, int B, int* ks_out,
+                            hipStream_t st) {
+    const int XT = split_xt(B), NBLK = split_nblk(B), KT = K / 32;
+    AnchorSplitArgs a;
+    for (int i = 0; i < 4; ++i) a.W[i] = W[i];
+    a.xs = static_cast<const uint32_t*>(xs);
+    a.part = part;
+    a.H = H;
+    a.K = K;
+    a.B = B;
+    a.KT = KT;
+    a.NBLK = NBLK;
+    a.groups_per_mlp = cdiv(H, 32);
+    const int quads = cdiv(2 * a.groups_per_mlp, 4);  // workgroups per (K chunk, frame)
+    int ncu = 256;
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+        }
+    }
+    // one workgroup per CU (the ring takes the whole LDS): pick the K split that fills whole rounds of the CU array best
+    int ks = 1;
+    double best = -1.0;
+    for (int c = 1; c <= 64 && c * 16 <= KT; ++c) {
+        const int wgs = 2 * cdiv(KT, cdiv(KT, c)) * quads * NBLK;
+        const int rounds = cdiv(wgs, ncu);
+        const double eff = (double)wgs / ((double)rounds * ncu);
+        if (eff > best + 1e-9) {
+            best = eff;
+            ks = c;
+        }
+    }
+    const int tiles_per = cdiv(KT, ks);
+    a.Kc = tiles_per * 32;
+    a.KS = cdiv(KT, tiles_per);
+    *ks_out = a.KS;
+    auto launch = [&](auto kern, int ns, int xt) {
+        const size_t ldsb = (size_t)ns * (4 * 1024 + 6 * xt * 256) * sizeof(float);
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        hipLaunchKernelGGL(kern, dim3(2 * a.KS * quads, NBLK), dim3(256), ldsb, st, a);
+    };
+    static const bool ns4 = getenv("SHASTA_SPLIT_NS4") != nullptr;  // tuning probe: one ring slot less
+    if (XT == 2 && ns4) launch(anchor_l1_split_kernel<2, 4>, 4, 2);
+    else if (XT == 2) launch(anchor_l1_split_kernel<2, 5>, 5, 2);
+    else launch(anchor_l1_split_kernel<4, 4>, 4, 4);
+}
+
+}  // namespace shasta

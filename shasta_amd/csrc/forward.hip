@@ -14,7 +14,7 @@ int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* 
                  float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st);
 int pair_residual(const shasta_weights* w, const float* packed, int B, const float* feat, const float* prev_feat,
                   const float* det_tab, const float* prev_tab, float* residual, int ld, void* ws, size_t ws_bytes,
-                  hipStream_t st);
+                  hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 int aff_softmax(const shasta_weights* w, const float* packed, int B, const float* residual, int ld, float* m1,
                 float* m2, float* matched_out, void* ws, size_t ws_bytes, hipStream_t st);
 int pack_weights(const shasta_weights* w, float* packed, hipStream_t st);
@@ -121,7 +121,7 @@ extern "C" int shasta_pair_residual_f32(const shasta_weights* w, const void* pac
     SHASTA_REQUIRE(ld_residual >= w->max_obj + 2, "pair_residual: ld_residual < N+2");
     SHASTA_REQUIRE(((uintptr_t)feat | (uintptr_t)prev_feat | (uintptr_t)packed) % 16 == 0, "pair_residual: alignment");
     return pair_residual(w, static_cast<const float*>(packed), B, feat, prev_feat, det_tab, prev_tab, residual,
-                         ld_residual, workspace, workspace_bytes, as_stream(stream));
+                         ld_residual, workspace, workspace_bytes, as_stream(stream), nullptr, nullptr);
 }
 
 extern "C" int shasta_aff_softmax_f32(const shasta_weights* w, const void* packed, int B, const float* residual,
@@ -139,7 +139,7 @@ static int forward_impl(const shasta_weights* w, const void* packed, int B, floa
                         float* det_boxes, const float* prev_det_boxes, int box_stride, float* det_tab, float* prev_tab,
                         float* matched1, float* matched2, float* residual_out, float* matched_out, void* workspace,
                         size_t workspace_bytes, shasta_stream_t stream, hipEvent_t ev0, hipEvent_t ev1,
-                        float* shape_hidden_out = nullptr) {
+                        float* shape_hidden_out = nullptr, hipEvent_t ev_pair0 = nullptr, hipEvent_t ev_pair1 = nullptr) {
     int rc = check_weights(w);
     if (rc) return rc;
     SHASTA_REQUIRE(B >= 0 && packed && feat && prev_feat && det_boxes && prev_det_boxes && det_tab && prev_tab &&
@@ -172,7 +172,8 @@ static int forward_impl(const shasta_weights* w, const void* packed, int B, floa
     }
     if ((rc = anchor_boxes(w, B, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, static_cast<float*>(stage), st)))
         return rc;
-    if ((rc = pair_residual(w, pk, B, feat, prev_feat, det_tab, prev_tab, residual, Dp, stage, stage_bytes, st))) return rc;
+    if ((rc = pair_residual(w, pk, B, feat, prev_feat, det_tab, prev_tab, residual, Dp, stage, stage_bytes, st, ev_pair0, ev_pair1)))
+        return rc;
     if (residual_out) {
         hipError_t e = hipMemcpy2DAsync(residual_out, (size_t)T * sizeof(float), residual, (size_t)Dp * sizeof(float),
                                         (size_t)T * sizeof(float), (size_t)B * T, hipMemcpyDeviceToDevice, st);
@@ -208,11 +209,13 @@ extern "C" int shasta_affinity_forward_timed_f32(const shasta_weights* w, const 
                                                  float* prev_feat, float* det_boxes, const float* prev_det_boxes,
                                                  int box_stride, float* det_tab, float* prev_tab, float* matched1,
                                                  float* matched2, void* workspace, size_t workspace_bytes,
-                                                 shasta_stream_t stream, void* ev_l1_start, void* ev_l1_stop) {
-    SHASTA_REQUIRE(ev_l1_start && ev_l1_stop, "forward_timed: null event");
+                                                 shasta_stream_t stream, void* ev_l1_start, void* ev_l1_stop,
+                                                 void* ev_pair_start, void* ev_pair_stop) {
+    SHASTA_REQUIRE(ev_l1_start && ev_l1_stop && ev_pair_start && ev_pair_stop, "forward_timed: null event");
     return forward_impl(w, packed, B, feat, prev_feat, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, matched1,
                         matched2, nullptr, nullptr, workspace, workspace_bytes, stream,
-                        static_cast<hipEvent_t>(ev_l1_start), static_cast<hipEvent_t>(ev_l1_stop));
+                        static_cast<hipEvent_t>(ev_l1_start), static_cast<hipEvent_t>(ev_l1_stop), nullptr,
+                        static_cast<hipEvent_t>(ev_pair_start), static_cast<hipEvent_t>(ev_pair_stop));
 }
 
 extern "C" int shasta_event_create(void** ev) {

@@ -854,7 +854,7 @@ int launch_gemm_nt_dual(const float* A0, const float* W0, const float* bias0, fl
 
 int pair_residual(const shasta_weights* w, const float* packed, int B, const float* feat, const float* prev_feat,
                   const float* det_tab, const float* prev_tab, float* residual, int ld, void* ws, size_t ws_bytes,
-                  hipStream_t st) {
+                  hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const int N = w->max_obj, F = w->feat_dim, nf = w->num_feats, T = N + 2, D = N + 2;
     const PairDims d(F);
     const PackedLayout P(N, nf, F);
@@ -915,12 +915,14 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
         hipLaunchKernelGGL((pair_mfma4_kernel<FF, WW>), grid, dim3(64 * WW), lds, st, packed, UP, UC, hand_prev, hand_det, denom,    \
                            residual, T, D, ld, nf, tw);                                                                              \
     } while (0)
+        if (ev0) (void)hipEventRecord(ev0, st);  // bench.py: HIP events around the pair kernel alone
         switch (F) {
             case 64: if (w4) SHASTA_LAUNCH_PAIR4(64, 4); else SHASTA_LAUNCH_PAIR4(64, 8); break;
             case 256: if (w4) SHASTA_LAUNCH_PAIR4(256, 4); else SHASTA_LAUNCH_PAIR4(256, 8); break;
             case 320: if (w4) SHASTA_LAUNCH_PAIR4(320, 4); else SHASTA_LAUNCH_PAIR4(320, 8); break;
             default: set_error_msg("pair_residual: feat_dim must be 64, 256 or 320"); return SHASTA_E_ARG;
         }
+        if (ev1) (void)hipEventRecord(ev1, st);
 #undef SHASTA_LAUNCH_PAIR4
         return check_launch("pair_mfma4");
     }

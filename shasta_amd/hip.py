@@ -9,7 +9,7 @@ import os
 
 import torch
 
-ABI_VERSION = 3  # must equal shasta_abi_version() of the loaded library
+ABI_VERSION = 4  # must equal shasta_abi_version() of the loaded library
 # SHASTA_HIP_LIB: load another build of the same ABI (A/B timing of kernel variants on one box)
 _LIB_PATH = os.environ.get("SHASTA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libshasta_hip.so")
 _lib = None
@@ -50,7 +50,7 @@ SYMBOLS = {
     "shasta_forward_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "shasta_affinity_forward_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "shasta_affinity_forward_train_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
-    "shasta_affinity_forward_timed_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _P, _P]),
+    "shasta_affinity_forward_timed_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P]),
     "shasta_event_create": (_I, [C.POINTER(C.c_void_p)]),
     "shasta_event_destroy": (_I, [_P]),
     "shasta_event_elapsed_ms": (_I, [_P, _P, C.POINTER(C.c_float)]),

@@ -290,12 +290,12 @@ class Shasta(BaseTrack):
                 "shasta_affinity_forward_train_f32")
             for k in ("feat", "prev_feat", "det_tab", "prev_tab"):
                 _train_keep[k] = bufs[k].clone()
-        elif l1_events is not None:  # bench.py: hipEvents around the dominant kernel, same work otherwise
+        elif l1_events is not None:  # bench.py: hipEvents around the two heaviest kernels (L1 start/stop, pair start/stop)
             hip.check(lib.shasta_affinity_forward_timed_f32(
                 C.byref(w), hip.ptr(self._packed), B, hip.ptr(bufs["feat"]), hip.ptr(bufs["prev_feat"]),
                 hip.ptr(det_boxes), hip.ptr(prev_det_boxes), det_boxes.shape[2], hip.ptr(bufs["det_tab"]),
                 hip.ptr(bufs["prev_tab"]), hip.ptr(m1), hip.ptr(m2), hip.ptr(bufs["ws"]), bufs["ws_bytes"],
-                hip.stream_ptr(), l1_events[0], l1_events[1]), "shasta_affinity_forward_timed_f32")
+                hip.stream_ptr(), *l1_events[:4]), "shasta_affinity_forward_timed_f32")
         else:
             hip.check(lib.shasta_affinity_forward_f32(
                 C.byref(w), hip.ptr(self._packed), B, hip.ptr(bufs["feat"]), hip.ptr(bufs["prev_feat"]),
