@@ -27,6 +27,7 @@ N_OBJ, NF, NPOINT, CH = 500, 7, 4, 64  # N=M=500, F=256, nf=7
 HW = 180
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: dense f32-input MFMA peak (= f32 vector peak); no xf32 on gfx950
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (no sparsity)
 
 
 def l1_algorithmic_bytes(B):
@@ -43,7 +44,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="frame-pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="frame-pairs per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (no HIP-event roofline)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="frame-pairs timed on the host for cpu_baseline")
@@ -159,20 +160,27 @@ def main():
             lib.shasta_event_destroy(e)
     l1_ms, pair_ms = sum(l1) / len(l1), sum(pair) / len(pair)
     step_ms = elapsed / args.steps * 1e3
-    # Kernel 1: aug_shape first layer = the 4.1 GB fp32 weight stream.  HBM-bound by construction at every batch size the
-    # default build serves: B <= 32 on the f32 MFMA kernel (1024 matrix-pipe cycles per 4 KB tile against ~1300 of HBM),
-    # B > 32 on the bf16-piece kernel (768 / 1536 cycles per tile for 64 / 128 items per weight pass).  With
-    # SHASTA_L1_F32=1 and B > 32 the f32 MFMA kernel (2048 cycles per tile) is matrix-pipe bound instead.
+    # Kernel 1: aug_shape first layer = the 4.1 GB fp32 weight stream, read once per pass of up to 128 frame-pairs.
+    #   B <= 32: f32 MFMA kernel, 1024 matrix-pipe cycles per 4 KB weight tile against ~1300 of HBM        -> HBM-bound
+    #   B <= 64: bf16-piece kernel (each fp32 product = 6 exact bf16 piece products), 768 cycles per tile   -> HBM-bound
+    #   B  > 64: the same with 128 items per pass, 1536 cycles per tile -> bound by the bf16 matrix pipe; its peak for
+    #            fp32-equivalent flops is the dense bf16 peak / 6 piece products
+    #   SHASTA_L1_F32=1 and B > 32: f32 MFMA kernel, 64 items per pass, 2048 cycles per tile -> f32 matrix pipe
     alg = l1_algorithmic_bytes(B)
     hbm_gbs = alg / (l1_ms * 1e-3) / 1e9
     K = N_OBJ * CH * NPOINT
-    l1_flops = 2.0 * B * 4 * (K // 64) * K  # dense flops of the four first layers for B frame-pairs
+    l1_flops = 2.0 * B * 4 * (K // 64) * K  # dense fp32 flops of the four first layers for B frame-pairs
     l1_tflops = l1_flops / (l1_ms * 1e-3) / 1e12
-    if B <= 32 or not os.environ.get("SHASTA_L1_F32"):
+    f32_forced = bool(os.environ.get("SHASTA_L1_F32")) or bool(os.environ.get("SHASTA_L1_VALU"))
+    if B <= 32 or (B <= 64 and not f32_forced):
         roof_l1 = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS}
-    else:
+    elif f32_forced:
         roof_l1 = {"bound": "mfma", "achieved": l1_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": l1_tflops / MFMA_F32_PEAK_TFLOPS}
+    else:
+        peak = MFMA_BF16_PEAK_TFLOPS / 6.0
+        roof_l1 = {"bound": "mfma", "achieved": l1_tflops, "peak": peak, "unit": "TFLOP/s", "frac": l1_tflops / peak,
+                   "peak_note": "fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product"}
     roof_l1.update({"kernel": "anchor_l1_kernel (B=1) / anchor_l1_mfma_kernel (B<=32) / anchor_l1_split_kernel (B>32): "
                               "aug_shape.*.0, 4 x 2000 x 128000 fp32 weight stream",
                     "traffic": _pmc_traffic(B), "algorithmic_bytes_per_launch": alg, "algorithmic_flops_per_launch": l1_flops,

@@ -100,6 +100,10 @@ struct AnchorSplitArgs {
     int H, K, B, KS, Kc, KT, NBLK, groups_per_mlp;
 };
 
+#ifdef SHASTA_L1_STAMP  // diagnostic build only (tools/probes/l1_split_probe.hip): in-kernel clock and cycles per tile
+__device__ unsigned long long g_split_stamp[4096][3];
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vm_split() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -185,9 +189,15 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
             f.X[j / 6][(j / 3) % 2][j % 3] = *reinterpret_cast<const u32x4*>(sl + 4096 + j * 256 + lane * 4);
         }
     };
-    // cut weight element e (0..15) of the tile in `raw`; the pair (e-1, e) is packed when e is odd
+    // cut weight element e (0..15) of the tile in `raw`; the pair (e-1, e) is packed when e is odd.  (Packed-f32 subtractions,
+    // 9 instead of 11 VALU instructions per pair, measured the same: the kernel is not bound by VALU issue.)
     float ph = 0.0f, pm = 0.0f, pl = 0.0f;
     auto cut_one = [&](Frag& f, int e) {
+        const int s = e >> 3, d = (e & 7) >> 1;
+#ifdef SPLIT_EXP_NOCUT  // probe: no VALU work (results are wrong)
+        if (e & 1) f.A[s][0][d] = f.A[s][1][d] = f.A[s][2][d] = __float_as_uint(raw[e >> 2][e & 3]);
+        return;
+#endif
         float h, m, l;
         split3(raw[e >> 2][e & 3], h, m, l);
         if ((e & 1) == 0) {
@@ -195,7 +205,6 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
             pm = m;
             pl = l;
         } else {
-            const int s = e >> 3, d = (e & 7) >> 1;
             f.A[s][0][d] = pack_top(ph, h);
             f.A[s][1][d] = pack_top(pm, m);
             f.A[s][2][d] = pack_top(pl, l);
@@ -210,10 +219,16 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
     constexpr int PX[6] = {0, 2, 1, 0, 1, 0};
     auto mma_one = [&](const Frag& f, int i) {
         const int s = i / (6 * XT), u = (i / 6) % XT, pr = i % 6;
+#ifdef SPLIT_EXP_NOMFMA  // probe: data movement only
+        if (i % 6 != 0) return;
+#endif
         acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.A[s][PW[pr]]),
                                                          __builtin_bit_cast(bf16x8, f.X[u][s][PX[pr]]), acc[u], 0, 0, 0);
     };
 
+#ifdef SHASTA_L1_STAMP
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // Prologue: fill the ring, take tile 0 into registers.
     {
         int s = 0;
@@ -243,7 +258,9 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of tile t's slot have retired
                 if constexpr (STEADY) wait_vm_split<PER_TILE*(NS - 2)>();
                 else wait_vm_split<0>();
+#ifndef SPLIT_EXP_NOBAR  // probe: no workgroup coupling (results are wrong)
                 __builtin_amdgcn_s_barrier();
+#endif
                 if constexpr (!STEADY) {
                     if (t + NS < NT) issue(t + NS, sc);
                 }
@@ -274,6 +291,13 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
     }
     if (t < NT) step(fa, fb, t, sc, std::false_type{});
 
+#ifdef SHASTA_L1_STAMP
+    if (lane == 0 && wid == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+        g_split_stamp[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - st0;
+        g_split_stamp[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - sr0;
+        g_split_stamp[blockIdx.x][2] = (unsigned long long)NT;
+    }
+#endif
     // D[i = weight row][j = batch row]
     if (active) {
 #pragma unroll
@@ -361,9 +385,7 @@ void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         hipLaunchKernelGGL(kern, dim3(2 * a.KS * quads, NBLK), dim3(256), ldsb, st, a);
     };
-    static const bool ns4 = getenv("SHASTA_SPLIT_NS4") != nullptr;  // tuning probe: one ring slot less
-    if (XT == 2 && ns4) launch(anchor_l1_split_kernel<2, 4>, 4, 2);
-    else if (XT == 2) launch(anchor_l1_split_kernel<2, 5>, 5, 2);
+    if (XT == 2) launch(anchor_l1_split_kernel<2, 5>, 5, 2);  // 4 slots measure the same: the ring depth is not the limit
     else launch(anchor_l1_split_kernel<4, 4>, 4, 4);
 }
 

@@ -181,10 +181,11 @@ def test_gemm_nt_vs_torch(M, N, K, act):
 @pytest.mark.parametrize("name,B", [("tiny_4_7_5", 1), ("tiny_4_7_5", 3), ("tiny_4_7_5", 9), ("tiny_4_7_5", 20),
                                     ("tiny_4_7_5", 40), ("tiny_4_7_5", 70), ("small_32_7_4", 1), ("small_32_7_4", 3),
                                     ("small_32_7_4", 9), ("small_32_7_4", 17), ("small_32_7_4", 33),
-                                    ("car_90_3_5", 1), ("car_90_3_5", 3), ("car_90_3_5", 9)])
+                                    ("small_32_7_4", 64), ("small_32_7_4", 100), ("tiny_4_7_5", 128), ("tiny_4_7_5", 150),
+                                    ("car_90_3_5", 1), ("car_90_3_5", 3), ("car_90_3_5", 9), ("car_90_3_5", 48)])
 def test_batched_forward_vs_oracle(name, B):
-    """Batch sizes that exercise every variant of the anchor kernel (VALU B=1; MFMA 16 / 32 / 64 rows per pass, single
-    and multiple passes), against the CPU oracle."""
+    """Batch sizes that exercise every variant of the anchor kernel (VALU B=1; f32 MFMA 16 / 32 rows per pass; bf16-piece
+    MFMA 64 / 128 rows per pass, single and multiple passes, ragged last pass), against the CPU oracle."""
     dev = _dev()
     z, c, sums = load_golden(name)
     m = build_model(c)
@@ -295,10 +296,12 @@ def test_voxelize_vs_oracle_full_size(P, mp, mv, seed):
         assert np.array_equal(cell[:, ::-1], rc)
 
 
-@pytest.mark.parametrize("flag", ["SHASTA_PAIR_MFMA", "SHASTA_PAIR_VALU", "SHASTA_PAIR_W4", "SHASTA_AFF_UNFUSED", "SHASTA_AFF_RG2", "SHASTA_L1_VALU"])
+@pytest.mark.parametrize("flag", ["SHASTA_PAIR_MFMA", "SHASTA_PAIR_VALU", "SHASTA_PAIR_W4", "SHASTA_AFF_UNFUSED", "SHASTA_AFF_RG2", "SHASTA_L1_VALU",
+                                  "SHASTA_L1_F32"])
 def test_alternative_kernel_variants_match_goldens(flag):
     """The selectable variants (16x16x4 MFMA chain / packed-VALU pair kernels, layer-by-layer aff, VALU batch kernels for
-    the anchor stream) stay parity-green: rerun the golden tests in a subprocess with the variant's switch set."""
+    the anchor stream, f32 MFMA instead of bf16 pieces above 32 items) stay parity-green: rerun the golden tests in a
+    subprocess with the variant's switch set."""
     import os
     import subprocess
     import sys
@@ -308,6 +311,32 @@ def test_alternative_kernel_variants_match_goldens(flag):
                         "test_forward_matches_reference_golden or (test_batched_forward_vs_oracle and small)"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_bf16_piece_kernel_is_fp32_accurate():
+    """anchor_split.hip computes the fp32 products of the first aug_shape layer as six exact bf16 piece products.  Its
+    error against a float64 evaluation of relu(W x + b) must be at the level of the f32 MFMA kernel's own rounding error
+    (both are run on the same inputs, tools/l1_split_check.py; the environment switch is read once per process)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra_env):
+        env = dict(os.environ)
+        env.pop("SHASTA_L1_F32", None)
+        env.update(extra_env)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "l1_split_check.py"), "--max-obj", "120", "--batch", "48", "64",
+                            "128", "--steps", "2"], env=env, capture_output=True, text=True, cwd=root, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    pieces, f32 = run({}), run({"SHASTA_L1_F32": "1"})
+    assert len(pieces) == len(f32) == 3
+    for a, b in zip(pieces, f32):
+        assert not a["f32_forced"] and b["f32_forced"] and a["B"] == b["B"]
+        assert a["max_abs_err"] <= 2.0 * b["max_abs_err"] + 1e-9, (a, b)
+        assert a["max_abs_err"] < 2e-5 * max(1.0, a["ref_scale"])
 
 
 @pytest.mark.parametrize("N,nf,npnt,B,n_real", [(1, 7, 1, 2, None), (2, 3, 4, 18, 1), (5, 7, 5, 3, 0), (33, 1, 1, 2, 7),

@@ -50,13 +50,14 @@ def pmc(dirs, dst):
 
 if __name__ == "__main__":
     os.makedirs(P, exist_ok=True)
-    kernel_stats(os.path.join(G, SRC, "prof_default/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_default_b64.csv"))
+    kernel_stats(os.path.join(G, SRC, "prof_default/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_default_b128.csv"))
+    kernel_stats(os.path.join(G, SRC, "prof_b64/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_b64.csv"))
     kernel_stats(os.path.join(G, SRC, "prof_b1/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_b1.csv"))
     pmc([("b1_fetch", SRC + "/pmc_fetch_b1"), ("b1_write", SRC + "/pmc_write_b1"), ("b32_fetch", SRC + "/pmc_fetch_b32"),
          ("b32_write", SRC + "/pmc_write_b32"), ("b64_fetch", SRC + "/pmc_fetch_b64"), ("b64_write", SRC + "/pmc_write_b64"),
-         ("b64_mfma", SRC + "/pmc_mfma_b64"), ("pair_b64_sq", "pmc_pair3"), ("pair_b64_mfma", "pmc_pair4")],
+         ("b128_fetch", SRC + "/pmc_fetch_b128"), ("b128_write", SRC + "/pmc_write_b128"), ("b128_mfma", SRC + "/pmc_mfma_b128")],
         os.path.join(P, TAG + "_pmc_summary.csv"))
-    for b in ("default", "b1", "b32"):
+    for b in ("default", "b1", "b32", "b64", "b64_f32"):
         src = os.path.join(G, SRC, "bench_%s.json" % b)
         if os.path.exists(src):
             line = [l for l in open(src) if l.startswith("{")][-1]
@@ -64,12 +65,14 @@ if __name__ == "__main__":
     # HBM bytes per launch of the dominant kernel (bench.py: roofline.traffic), FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md)
     rows = list(csv.DictReader(open(os.path.join(P, TAG + "_pmc_summary.csv"))))
     traffic = {}
-    for b in (1, 32, 64):
-        f = [float(r["mean_value_per_launch"]) for r in rows if r["run"] == "b%d_fetch" % b and "anchor_l1" in r["kernel"] and r["counter"] == "FETCH_SIZE"]
-        w = [float(r["mean_value_per_launch"]) for r in rows if r["run"] == "b%d_write" % b and "anchor_l1" in r["kernel"] and r["counter"] == "WRITE_SIZE"]
-        if f and w:
-            traffic["batch_%d" % b] = int((2 * f[0] + w[0]) * 1024)
-    traffic["_note"] = ("HBM bytes per launch of anchor_l1(_mfma)_kernel = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc "
+    for b in (1, 32, 64, 128):
+        for key, kern in (("batch_%d", "anchor_l1"), ("pair_batch_%d", "pair_mfma4")):
+            f = [float(r["mean_value_per_launch"]) for r in rows if r["run"] == "b%d_fetch" % b and kern in r["kernel"] and r["counter"] == "FETCH_SIZE"]
+            w = [float(r["mean_value_per_launch"]) for r in rows if r["run"] == "b%d_write" % b and kern in r["kernel"] and r["counter"] == "WRITE_SIZE"]
+            if f and w:
+                traffic[key % b] = int((2 * f[0] + w[0]) * 1024)
+    traffic["_note"] = ("batch_B / pair_batch_B: HBM bytes per launch of anchor_l1*_kernel / pair_mfma4_kernel at B frame-pairs per step "
+                        "= (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc "
                         "passes (profiles/%s_pmc_summary.csv); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the "
                         "bytes of a wide coalesced stream)" % TAG)
     json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
