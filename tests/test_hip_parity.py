@@ -340,10 +340,11 @@ def test_bf16_piece_kernel_is_fp32_accurate():
 
 
 @pytest.mark.parametrize("N,nf,npnt,B,n_real", [(1, 7, 1, 2, None), (2, 3, 4, 18, 1), (5, 7, 5, 3, 0), (33, 1, 1, 2, 7),
-                                                 (64, 7, 4, 1, None)])
+                                                 (64, 7, 4, 1, None), (1, 7, 1, 40, None), (2, 3, 4, 70, 1), (5, 7, 5, 130, 0)])
 def test_edge_shapes_vs_oracle(N, nf, npnt, B, n_real):
     """Smallest tables (max_obj = 1, 2: the aug_dets hidden layer has width 0), every-row-padded inputs (n_real = 0),
-    nf = 1, and a max_obj that is an exact multiple of the 64-wide tiles."""
+    nf = 1, a max_obj that is an exact multiple of the 64-wide tiles, and the bf16-piece anchor kernel (B > 32) on weight
+    matrices with fewer K tiles than ring slots (max_obj 1: two tiles) and a single hidden row."""
     import shasta_amd
     dev = _dev()
     torch.manual_seed(N * 100 + nf)
