@@ -81,6 +81,56 @@ def test_forward_matches_reference_golden(name):
     print(name, "argmax rows equal %d/%d (undecided %d)" % (same.sum(), same.size, (~decided).sum()))
 
 
+def test_headline_size_batches_pin_every_anchor_kernel_on_the_reference_output():
+    """N=M=500, F=256 (BASELINE.json configs[1]) in batches: frame-pair 0 is the reference's golden frame, the others are
+    synthetic.  Frame-pairs are independent, so (a) frame 0 of a 130-batch (bf16-piece anchor kernel, two weight passes, the
+    second one ragged), of a 64-batch (one 64-item pass), of a 32-batch (f32 MFMA kernel) and of a 1-batch (VALU kernel) must all
+    reproduce the reference's golden output within 1e-4 with identical decided arg-max, and (b) every frame's result must not
+    depend on the batch it was computed in beyond fp32 summation order."""
+    dev = _dev()
+    z, c, m, bev, pbev, det, prev = _case("headline_500_7_4")
+    w_cpu = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        f0 = O.shared_conv_nhwc(w_cpu, bev).to(dev)
+        pf0 = O.shared_conv_nhwc(w_cpu, pbev).to(dev)
+    m = m.to(dev)
+    B, N, hw = 130, c["max_obj"], c["hw"]
+    g = torch.Generator(device=dev).manual_seed(77)
+    f = torch.relu(torch.randn(B, hw, hw, 64, device=dev, generator=g))
+    pf = torch.relu(torch.randn(B, hw, hw, 64, device=dev, generator=g))
+    f[0], pf[0] = f0[0], pf0[0]
+    gc = torch.Generator().manual_seed(78)
+    dets = O.synth_boxes(gc, B, N, None).to(dev)
+    prevs = O.synth_boxes(gc, B, N, None).to(dev)
+    dets[0], prevs[0] = det[0].to(dev), prev[0].to(dev)
+
+    def run(idx):
+        ex = dict(det_boxes=dets[idx].clone(), prev_det_boxes=prevs[idx].clone(), bev_feature=f[idx].contiguous(),
+                  prev_bev_feature=pf[idx].contiguous())
+        with torch.no_grad():
+            m1, m2, _ = m(ex, train_mode=False)
+        return m1.cpu().numpy(), m2.cpu().numpy()
+    full1, full2 = run(slice(0, B))
+    for lo, hi in ((0, 64), (0, 32), (0, 1), (129, 130), (64, 130)):
+        p1, p2 = run(slice(lo, hi))
+        np.testing.assert_allclose(p1, full1[lo:hi], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(p2, full2[lo:hi], rtol=0, atol=1e-5)
+        same, decided = row_argmax_agreement(p1, full1[lo:hi], 1e-5)
+        assert same[decided].all()
+        if lo == 0:  # the golden frame, through this batch's anchor kernel
+            np.testing.assert_allclose(p1[:1], z["m1"], rtol=0, atol=TOL)
+            np.testing.assert_allclose(p2[:1], z["m2"], rtol=0, atol=TOL)
+            same, decided = row_argmax_agreement(p1[:1], z["m1"], 1e-6)
+            assert same[decided].all(), "row argmax differs on a decided row"
+    np.testing.assert_allclose(full1[:1], z["m1"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(full2[:1], z["m2"], rtol=0, atol=TOL)
+    same, decided = row_argmax_agreement(full1[:1], z["m1"], 1e-6)
+    assert same[decided].all(), "row argmax differs on a decided row"
+    print("130-batch frame 0: max|m1-ref| %.3e  max|m2-ref| %.3e" % (np.abs(full1[:1] - z["m1"]).max(), np.abs(full2[:1] - z["m2"]).max()))
+    np.testing.assert_allclose(full1.sum(-1), 1.0, atol=1e-5)
+    np.testing.assert_allclose(full2.sum(1), 1.0, atol=1e-5)
+
+
 def test_forward_with_shared_conv_on_device():
     """Same as above for the tiny case but through extract_feat + shared_conv on the device (MIOpen conv)."""
     dev = _dev()
