@@ -851,6 +851,8 @@ int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float
                    int N, int K, int act, hipStream_t st);
 int launch_gemm_nt_dual(const float* A0, const float* W0, const float* bias0, float* C0, const float* A1, const float* W1,
                         const float* bias1, float* C1, int lda, int ldw, int ldc, int M, int N, int K, int act, hipStream_t st);
+int launch_gemm_nt_pieces(const float* A0, const float* W0, const float* bias0, float* C0, const float* A1, const float* W1,
+                          const float* bias1, float* C1, int lda, int ldw, int ldc, int M, int N, int K, int act, hipStream_t st);
 
 int pair_residual(const shasta_weights* w, const float* packed, int B, const float* feat, const float* prev_feat,
                   const float* det_tab, const float* prev_tab, float* residual, int ld, void* ws, size_t ws_bytes,
@@ -874,7 +876,15 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     base += align_up((size_t)B * T * 16 * sizeof(float), 256);
     float* denom = reinterpret_cast<float*>(base);
 
-    int rc = launch_gemm_nt_dual(prev_feat, packed + P.wemb_prev, nullptr, UP, feat, packed + P.wemb_cur, packed + P.bemb_cur, UC, F, F,
+    // row embeddings UP / UC: from 8192 table rows on the bf16-piece GEMM (gemm_pieces.hip: 128-row tiles, 1.35x the f32 MFMA
+    // kernel at 64 k rows), below that the 64-row f32 tiles fill the chip better.  SHASTA_GEMM_F32=1 keeps the f32 kernel.
+    static const bool gemm_f32 = getenv("SHASTA_GEMM_F32") != nullptr;
+    int rc;
+    if (B * T >= 8192 && !gemm_f32 && F % 4 == 0)
+        rc = launch_gemm_nt_pieces(prev_feat, packed + P.wemb_prev, nullptr, UP, feat, packed + P.wemb_cur, packed + P.bemb_cur, UC, F,
+                                   F, d.ET, B * T, P.E12, F, 0, st);
+    else
+        rc = launch_gemm_nt_dual(prev_feat, packed + P.wemb_prev, nullptr, UP, feat, packed + P.wemb_cur, packed + P.bemb_cur, UC, F, F,
                                  d.ET, B * T, P.E12, F, 0, st);
     if (rc) return rc;
     RowFinishArgs rf;

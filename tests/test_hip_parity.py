@@ -203,8 +203,10 @@ def test_bev_gather_vs_oracle(B, N, n_real, npnt, hw, stride):
 
 
 @pytest.mark.parametrize("M,N,K,act", [(502, 128, 502, 1), (1004, 96, 256, 0), (64, 502, 128, 0), (7, 5, 3, 2),
-                                       (4016, 64, 128, 1)])
-def test_gemm_nt_vs_torch(M, N, K, act):
+                                       (4016, 64, 128, 1), (300, 260, 70, 0), (129, 129, 33, 1)])
+@pytest.mark.parametrize("entry", ["shasta_gemm_nt_f32", "shasta_gemm_nt_pieces_f32"])
+def test_gemm_nt_vs_torch(M, N, K, act, entry):
+    """The f32 MFMA GEMM and the bf16-piece GEMM (six exact piece products per fp32 product) against float64."""
     from shasta_amd import hip
     dev = _dev()
     lib = hip.load()
@@ -221,8 +223,8 @@ def test_gemm_nt_vs_torch(M, N, K, act):
         Wp[:, :K] = Wt
         Cd = torch.full((M, N + 3), -7.0, device=dev)
         Ad, Wd, bd = A.to(dev), Wp.to(dev), bias.to(dev)  # keep the device copies alive across the launch
-        hip.check(lib.shasta_gemm_nt_f32(hip.ptr(Ad), lda, hip.ptr(Wd), ldw, hip.ptr(bd),
-                                         hip.ptr(Cd), N + 3, M, N, K, act, hip.stream_ptr()), "gemm")
+        hip.check(getattr(lib, entry)(hip.ptr(Ad), lda, hip.ptr(Wd), ldw, hip.ptr(bd),
+                                      hip.ptr(Cd), N + 3, M, N, K, act, hip.stream_ptr()), "gemm")
         out = Cd.cpu()
         np.testing.assert_allclose(out[:, :N].numpy(), ref.float().numpy(), rtol=2e-5, atol=2e-4)
         assert (out[:, N:] == -7.0).all()
@@ -347,7 +349,7 @@ def test_voxelize_vs_oracle_full_size(P, mp, mv, seed):
 
 
 @pytest.mark.parametrize("flag", ["SHASTA_PAIR_MFMA", "SHASTA_PAIR_VALU", "SHASTA_PAIR_W4", "SHASTA_AFF_UNFUSED", "SHASTA_AFF_RG2", "SHASTA_L1_VALU",
-                                  "SHASTA_L1_F32"])
+                                  "SHASTA_L1_F32", "SHASTA_GEMM_F32"])
 def test_alternative_kernel_variants_match_goldens(flag):
     """The selectable variants (16x16x4 MFMA chain / packed-VALU pair kernels, layer-by-layer aff, VALU batch kernels for
     the anchor stream, f32 MFMA instead of bf16 pieces above 32 items) stay parity-green: rerun the golden tests in a
