@@ -942,12 +942,14 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
         while (tw > 2 && (long)B * cdiv(D, 64) * 4 * cdiv(T, 4 * tw) < 4096) tw >>= 1;
         const size_t lds = (size_t)64 * (d.ET + 4) * sizeof(float);
         dim3 grid(cdiv(D, 64), cdiv(T, 4 * tw), B);
+        if (ev0) (void)hipEventRecord(ev0, st);
         switch (F) {
             case 64: hipLaunchKernelGGL(pair_valu_kernel<64>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
             case 256: hipLaunchKernelGGL(pair_valu_kernel<256>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
             case 320: hipLaunchKernelGGL(pair_valu_kernel<320>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
             default: set_error_msg("pair_residual: feat_dim must be 64, 256 or 320"); return SHASTA_E_ARG;
         }
+        if (ev1) (void)hipEventRecord(ev1, st);
         return check_launch("pair_valu");
     }
     // tracks per workgroup: the largest of 32/16/8 that still yields >= 2 waves per SIMD on 256 CUs
@@ -961,6 +963,7 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     dim3 grid(cdiv(D, 64), cdiv(T, tt), B);
     static const bool unroll2 = getenv("SHASTA_PAIR_UNROLL2") != nullptr;
     static const int stagger = getenv("SHASTA_PAIR_STAGGER") ? atoi(getenv("SHASTA_PAIR_STAGGER")) : 0;
+    if (ev0) (void)hipEventRecord(ev0, st);
     switch (F) {
         case 64:
             if (unroll2) hipLaunchKernelGGL((pair_mfma_kernel<64, 2>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt, stagger);
@@ -976,6 +979,7 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
             break;
         default: set_error_msg("pair_residual: feat_dim must be 64, 256 or 320"); return SHASTA_E_ARG;
     }
+    if (ev1) (void)hipEventRecord(ev1, st);
     return check_launch("pair_mfma");
 }
 
