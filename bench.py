@@ -209,7 +209,11 @@ def main():
                                "NHWC BEV features (SURVEY 8a rows 4-16)", "frame_pairs_per_step_per_gpu": B,
                    "max_obj": N_OBJ, "num_feats": NF, "num_point": NPOINT, "bev_hw": HW,
                    "parallelism": "replica x%d (frame-parallel, no data-path collective)" % world,
-                   "hip_graph": bool(args.graph)},
+                   "hip_graph": bool(args.graph),
+                   "arithmetic": "fp32 operands, fp32 accumulation throughout; above 32 frame-pairs per step the first aug_shape "
+                                 "layer (and from 8192 table rows the row-embedding GEMMs) form every fp32 product from six exact "
+                                 "bf16 piece products on the bf16 MFMA path (error below the fp32 FMA's rounding; SHASTA_L1_F32=1 / "
+                                 "SHASTA_GEMM_F32=1 select the f32 MFMA kernels)"},
         "roofline": roof,
         "roofline_second": second,
     }
