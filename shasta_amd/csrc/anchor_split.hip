@@ -1,4 +1,4 @@
-// K3b: first aug_shape layer (det3d/models/tracker/shasta.py:54, applied :241-244) for more than 32 frame-pairs per step:
+// K3a for more than 32 frame-pairs per step: first aug_shape layer (det3d/models/tracker/shasta.py:54, applied :241-244):
 //   part[ks][b][n] = sum_{k in chunk ks} W[n][k] * x[b][k]       W: 4 x (N*F/64, N*F) fp32, 4.1 GB at N=500,F=256
 // The f32 MFMA kernel of anchor_mfma.hip is matrix-pipe bound from 64 batch rows per pass (2048 SIMD cycles per 4 KB weight
 // tile against ~1300 that HBM needs).  This kernel keeps fp32 ARITHMETIC but runs it on the bf16 matrix path, which is 16 x

@@ -1,4 +1,4 @@
-"""First aug_shape layer (K3a / K3b): error of the kernel the library picks against a float64 evaluation of the same
+"""First aug_shape layer (K3a: VALU, f32 MFMA or bf16-piece kernel): error of the kernel the library picks against a float64 evaluation of the same
 relu(W x + b), and its duration.  Run once as is (bf16-piece kernel for batches > 32) and once with SHASTA_L1_F32=1 (f32 MFMA):
 the two error columns are what DESIGN.md section 4 quotes.
 usage: python tools/l1_split_check.py [--max-obj 500] [--points 4] [--batch 64 128] [--steps 20]"""
