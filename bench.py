@@ -31,12 +31,15 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (no sparsity)
 
 
 def l1_algorithmic_bytes(B):
-    """Dominant kernel = aug_shape first layer (anchor_l1*_kernel).  Algorithmic (minimum) HBM bytes of one launch:
-    every weight of the four (N*F/64, N*F) fp32 matrices once, the two (N*F) activation vectors of each of the B
-    batch items once, and one (4*N*F/64) partial vector per batch item written."""
+    """aug_shape first layer (anchor_l1*_kernel).  Algorithmic HBM bytes of one launch: every weight of the four
+    (N*F/64, N*F) fp32 matrices once per weight pass, the two (N*F) activation vectors of each of the B batch items
+    once, and one (4*N*F/64) partial vector per batch item written.  One weight pass serves up to
+    128 frame-pairs - from there the pass is bound by the matrix pipe, not by HBM, so larger batches take ceil(B/128)
+    passes by design."""
     K = N_OBJ * CH * NPOINT
     H = K // 64
-    return 4 * H * K * 4 + 2 * B * K * 4 + B * 4 * H * 4
+    passes = max(1, -(-B // 128))
+    return passes * 4 * H * K * 4 + 2 * B * K * 4 + B * 4 * H * 4
 
 
 def main():
@@ -44,7 +47,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="frame-pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="frame-pairs per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (no HIP-event roofline)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="frame-pairs timed on the host for cpu_baseline")

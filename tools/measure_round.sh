@@ -10,14 +10,16 @@ python3 $R/bench.py --batch 1 --no-cpu-baseline > $O/bench_b1.json 2> /dev/null
 python3 $R/bench.py --batch 32 --no-cpu-baseline > $O/bench_b32.json 2> /dev/null
 python3 $R/bench.py --batch 64 --no-cpu-baseline > $O/bench_b64.json 2> /dev/null
 SHASTA_L1_F32=1 python3 $R/bench.py --batch 64 --no-cpu-baseline > $O/bench_b64_f32.json 2> /dev/null
+python3 $R/bench.py --batch 128 --no-cpu-baseline > $O/bench_b128.json 2> /dev/null
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 $R/bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_torchrun.json 2> $O/bench_torchrun.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o d -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_default.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1 -o d -- python3 $R/bench.py --batch 1 --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_b1.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b64 -o d -- python3 $R/bench.py --batch 64 --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_b64.log 2>&1
-for b in 1 32 64 128; do
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b128 -o d -- python3 $R/bench.py --batch 128 --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_b128.log 2>&1
+for b in 1 32 64 128 512; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_b$b -o p -- python3 $R/bench.py --batch $b --steps 5 --warmup 2 --no-cpu-baseline > $O/pmc_fetch_b$b.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_b$b -o p -- python3 $R/bench.py --batch $b --steps 5 --warmup 2 --no-cpu-baseline > $O/pmc_write_b$b.log 2>&1
 done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_b128 -o p -- python3 $R/bench.py --batch 128 --steps 5 --warmup 2 --no-cpu-baseline > $O/pmc_mfma_b128.log 2>&1
-grep -h '^{' $O/bench_default.json $O/bench_b1.json $O/bench_b32.json $O/bench_b64.json $O/bench_b64_f32.json $O/bench_torchrun.json | cut -c1-400
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_b512 -o p -- python3 $R/bench.py --batch 512 --steps 5 --warmup 2 --no-cpu-baseline > $O/pmc_mfma_b512.log 2>&1
+grep -h '^{' $O/bench_default.json $O/bench_b1.json $O/bench_b32.json $O/bench_b64.json $O/bench_b64_f32.json $O/bench_b128.json $O/bench_torchrun.json | cut -c1-400
 ls $O

@@ -50,14 +50,16 @@ def pmc(dirs, dst):
 
 if __name__ == "__main__":
     os.makedirs(P, exist_ok=True)
-    kernel_stats(os.path.join(G, SRC, "prof_default/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_default_b128.csv"))
+    kernel_stats(os.path.join(G, SRC, "prof_default/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_default_b512.csv"))
+    kernel_stats(os.path.join(G, SRC, "prof_b128/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_b128.csv"))
     kernel_stats(os.path.join(G, SRC, "prof_b64/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_b64.csv"))
     kernel_stats(os.path.join(G, SRC, "prof_b1/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_b1.csv"))
     pmc([("b1_fetch", SRC + "/pmc_fetch_b1"), ("b1_write", SRC + "/pmc_write_b1"), ("b32_fetch", SRC + "/pmc_fetch_b32"),
          ("b32_write", SRC + "/pmc_write_b32"), ("b64_fetch", SRC + "/pmc_fetch_b64"), ("b64_write", SRC + "/pmc_write_b64"),
-         ("b128_fetch", SRC + "/pmc_fetch_b128"), ("b128_write", SRC + "/pmc_write_b128"), ("b128_mfma", SRC + "/pmc_mfma_b128")],
+         ("b128_fetch", SRC + "/pmc_fetch_b128"), ("b128_write", SRC + "/pmc_write_b128"), ("b512_fetch", SRC + "/pmc_fetch_b512"),
+         ("b512_write", SRC + "/pmc_write_b512"), ("b512_mfma", SRC + "/pmc_mfma_b512")],
         os.path.join(P, TAG + "_pmc_summary.csv"))
-    for b in ("default", "b1", "b32", "b64", "b64_f32"):
+    for b in ("default", "b1", "b32", "b64", "b64_f32", "b128"):
         src = os.path.join(G, SRC, "bench_%s.json" % b)
         if os.path.exists(src):
             line = [l for l in open(src) if l.startswith("{")][-1]
@@ -65,7 +67,7 @@ if __name__ == "__main__":
     # HBM bytes per launch of the dominant kernel (bench.py: roofline.traffic), FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md)
     rows = list(csv.DictReader(open(os.path.join(P, TAG + "_pmc_summary.csv"))))
     traffic = {}
-    for b in (1, 32, 64, 128):
+    for b in (1, 32, 64, 128, 512):
         for key, kern in (("batch_%d", "anchor_l1"), ("pair_batch_%d", "pair_mfma4")):
             f = [float(r["mean_value_per_launch"]) for r in rows if r["run"] == "b%d_fetch" % b and kern in r["kernel"] and r["counter"] == "FETCH_SIZE"]
             w = [float(r["mean_value_per_launch"]) for r in rows if r["run"] == "b%d_write" % b and kern in r["kernel"] and r["counter"] == "WRITE_SIZE"]
