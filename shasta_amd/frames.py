@@ -160,7 +160,8 @@ def collate_pairs(samples, device=None):
         prev_det_boxes=torch.from_numpy(np.stack([s["prev_det_boxes"] for s in samples]).astype(np.float32)),
         num_det_boxes=[s["num_det_boxes"] for s in samples], num_prev_det_boxes=[s["num_prev_det_boxes"] for s in samples],
         cls_det_boxes=[s["cls_det_boxes"] for s in samples], prev_cls_det_boxes=[s["prev_cls_det_boxes"] for s in samples],
-        metadata=[dict(token=s["token"]) for s in samples])
+        metadata=[dict(token=s["token"]) for s in samples],
+        prev_metadata=[dict(token=s["prev_token"]) for s in samples])  # decode.AffinityDecoder.add reads it (eval.py:118)
     if all("gt" in s for s in samples):
         batch["gt"] = torch.from_numpy(np.stack([s["gt"] for s in samples]).astype(np.float32))
     if device is not None:

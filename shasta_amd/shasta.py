@@ -110,6 +110,7 @@ class Shasta(BaseTrack):
         self._conv_key = None
         self._wstruct = None
         self._bufs = {}
+        self._graph_bufs = []
         self.keep_intermediates = False  # tests: also return residual / matched via self.last_intermediates
         self.last_intermediates = None
 
@@ -210,16 +211,28 @@ class Shasta(BaseTrack):
         self._packed_key = key
 
     def _work_buffers(self, B, device):
-        k = (B, str(device))
-        if k not in self._bufs:
+        """Feature / box tables and the stage workspace.  ONE set per device, sized for the largest batch seen so far and
+        sliced for smaller ones (the tables are batch-major, the C ABI only needs `workspace_bytes` >= its own figure), so a
+        sweep over batch sizes does not pin one full set per size in HBM.  A set that a hipGraph capture has recorded pointers
+        of is kept alive for the life of the module."""
+        k = str(device)
+        cur = self._bufs.get(k)
+        if cur is None or cur["B"] < B:
             lib = hip.load()
             N, F = self.max_obj, self.aug_shape_output
             ws = lib.shasta_forward_workspace_bytes(B, N, self.num_feats, F)
-            self._bufs[k] = dict(
-                feat=torch.empty(B, N + 2, F, device=device), prev_feat=torch.empty(B, N + 2, F, device=device),
+            if cur is not None and cur.get("captured"):
+                self._graph_bufs.append(cur)
+            cur = self._bufs[k] = dict(
+                B=B, feat=torch.empty(B, N + 2, F, device=device), prev_feat=torch.empty(B, N + 2, F, device=device),
                 det_tab=torch.empty(B, N + 2, 8, device=device), prev_tab=torch.empty(B, N + 2, 8, device=device),
                 ws=torch.empty((ws + 3) // 4, dtype=torch.float32, device=device), ws_bytes=ws)
-        return self._bufs[k]
+        if torch.cuda.is_current_stream_capturing():
+            cur["captured"] = True
+        if cur["B"] == B:
+            return cur
+        return dict(feat=cur["feat"][:B], prev_feat=cur["prev_feat"][:B], det_tab=cur["det_tab"][:B],
+                    prev_tab=cur["prev_tab"][:B], ws=cur["ws"], ws_bytes=cur["ws_bytes"])
 
     def shared_conv_nhwc(self, bev_map, prev_bev_map=None):
         """shasta.py:223-228: relu(bn(conv3x3(map))) -> NHWC for the current (and, in the same launch, the previous) neck
@@ -227,9 +240,18 @@ class Shasta(BaseTrack):
         statistics) only: in train() mode the module's own nn.Sequential is used so that batch statistics behave like
         the reference.  Returns one tensor, or a pair when prev_bev_map is given."""
         conv, bn = self.shared_conv[0], self.shared_conv[1]
-        if self.training or conv.in_channels % 8 != 0 or not bev_map.is_cuda:
-            outs = [self.shared_conv(t).permute(0, 2, 3, 1).contiguous() for t in (bev_map, prev_bev_map) if t is not None]
+        maps = [t for t in (bev_map, prev_bev_map) if t is not None]
+        if not all(t.is_cuda for t in maps):
+            raise hip.ShastaHipError("Shasta.shared_conv_nhwc needs device tensors; there is no CPU path")
+        needs_grad = torch.is_grad_enabled() and (any(t.requires_grad for t in maps) or
+                                                   any(p.requires_grad for p in self.shared_conv.parameters()))
+        if self.training or needs_grad:
+            # Training (train.py:193 keeps every BN in train() mode: batch statistics) and frozen-BN fine-tuning with autograd
+            # on are the reference's own differentiable nn.Sequential; the hand-written kernel is the inference operator.
+            outs = [self.shared_conv(t).permute(0, 2, 3, 1).contiguous() for t in maps]
             return outs[0] if prev_bev_map is None else tuple(outs)
+        if conv.in_channels % 8 != 0:  # the kernel's K chunks are 8 channels wide: zero-pad the channel axis (exact)
+            return self._shared_conv_padded(bev_map, prev_bev_map)
         lib = hip.load()
         tensors = [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
         key = tuple((t.data_ptr(), t._version) for t in tensors)
@@ -253,6 +275,37 @@ class Shasta(BaseTrack):
         hip.check(lib.shasta_shared_conv_f32(hip.ptr(x), hip.ptr(xp), B, Cin, H, W, hip.ptr(self._conv_packed), hip.ptr(out),
                                              hip.ptr(outp), hip.stream_ptr()), "shasta_shared_conv_f32")
         return out if prev_bev_map is None else (out, outp)
+
+    def _shared_conv_padded(self, bev_map, prev_bev_map):
+        """in_channels not a multiple of 8: run the same HIP kernel on zero-padded channels (zeros add exactly)."""
+        conv, bn = self.shared_conv[0], self.shared_conv[1]
+        lib = hip.load()
+        cin = conv.in_channels
+        cp = (cin + 7) // 8 * 8
+        dev = bev_map.device
+        tensors = [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = ("pad",) + tuple((t.data_ptr(), t._version) for t in tensors)
+        if self._conv_packed is None or self._conv_key != key or self._conv_packed.device != dev:
+            wpad = torch.zeros(conv.out_channels, cp, 3, 3, device=dev)
+            wpad[:, :cin] = conv.weight.detach()
+            nbytes = lib.shasta_shared_conv_packed_bytes(cp)
+            self._conv_packed = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            hip.check(lib.shasta_shared_conv_pack_f32(hip.ptr(wpad), *[hip.ptr(t.detach()) for t in tensors[1:]], float(bn.eps), cp,
+                                                      hip.ptr(self._conv_packed), nbytes, hip.stream_ptr()),
+                      "shasta_shared_conv_pack_f32")
+            self._conv_key = key
+        outs = []
+        for t in (bev_map, prev_bev_map):
+            if t is None:
+                continue
+            B, _, H, W = t.shape
+            x = torch.zeros(B, cp, H, W, device=dev)
+            x[:, :cin] = t.float()
+            out = torch.empty(B, H, W, conv.out_channels, device=dev)
+            hip.check(lib.shasta_shared_conv_f32(hip.ptr(x), None, B, cp, H, W, hip.ptr(self._conv_packed), hip.ptr(out), None,
+                                                 hip.stream_ptr()), "shasta_shared_conv_f32")
+            outs.append(out)
+        return outs[0] if prev_bev_map is None else tuple(outs)
 
     def affinity_from_bev(self, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes, l1_events=None, _train_keep=None):
         """Rows 4-16 of SURVEY.md 8(a) (shasta.py:231-325) on device.  bev maps (B,H,W,C) fp32 NHWC, boxes (B,N,>=10)
@@ -302,10 +355,11 @@ class Shasta(BaseTrack):
                 hip.ptr(det_boxes), hip.ptr(prev_det_boxes), det_boxes.shape[2], hip.ptr(bufs["det_tab"]),
                 hip.ptr(bufs["prev_tab"]), hip.ptr(m1), hip.ptr(m2), hip.ptr(res), hip.ptr(mat), hip.ptr(bufs["ws"]),
                 bufs["ws_bytes"], hip.stream_ptr()), "shasta_affinity_forward_f32")
-        self.newborn = bufs["prev_tab"][:, N:N + 1, :7]
-        self.fp = bufs["prev_tab"][:, N + 1:N + 2, :7]
-        self.dead_trk = bufs["det_tab"][:, N:N + 1, :7]
-        self.fn = bufs["det_tab"][:, N + 1:N + 2, :7]
+        # shasta.py:260-267 leaves the four anchor boxes on the module as fresh tensors: copy them out of the work buffers
+        # (two small copies), which the next forward overwrites
+        pa, da = bufs["prev_tab"][:, N:, :7].clone(), bufs["det_tab"][:, N:, :7].clone()
+        self.newborn, self.fp = pa[:, 0:1], pa[:, 1:2]
+        self.dead_trk, self.fn = da[:, 0:1], da[:, 1:2]
         if self.keep_intermediates:
             self.last_intermediates = dict(feature=bufs["feat"], prev_feature=bufs["prev_feat"], residual=res,
                                            matched=mat, det_tab=bufs["det_tab"], prev_tab=bufs["prev_tab"])

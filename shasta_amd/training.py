@@ -241,6 +241,10 @@ class _AffinityTrainFn(torch.autograd.Function):
         # N=500).  Instead of all-reducing 4 x 1 GB of gradients, the ranks exchange the FACTORS (all_gather of B x (4H + 2K)
         # floats per rank, ~1 MB per frame-pair) and every rank forms the averaged gradient with one GEMM over world*B rows.
         world, group = _exchange_world(model)
+        for p_ in (model.aug_shape[i][0].weight for i in range(4)):  # a stale flag from a step reduced some other way
+            p_._shasta_grad_is_global = False
+        if world > 1:
+            _check_equal_local_batch(B, world, group, dev)
         exchange = world > 1 or getattr(model, "_force_factor_exchange", False)  # the latter: single-rank test of the path
         shape_grads, box_grads, ghids = [None] * 4, [None] * 4, [None] * 4
         for i in range(4):
@@ -331,6 +335,19 @@ def _all_gather_rows(t, world, group=None):
     return out
 
 
+def _check_equal_local_batch(B, world, group, device):
+    """The factor exchange gathers equal-size chunks: every rank must bring the same number of frame-pairs (the reference's
+    DistributedGroupSampler pads the epoch so that it does, sampler.py:177-196).  A ragged last batch would hang or corrupt the
+    gather, so it is refused loudly."""
+    import torch.distributed as dist
+    sizes = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather(list(sizes.chunk(world)), torch.tensor([B], dtype=torch.int64, device=device), group=group)
+    sizes = sizes.tolist()
+    if any(s != B for s in sizes):
+        raise hip.ShastaHipError("low-rank gradient exchange needs the same local batch on every rank, got %s: pad the sampler "
+                                 "(shasta_amd.sampler.DistributedGroupSampler does) or set model.low_rank_grad_exchange = False" % sizes)
+
+
 def affinity_params(model):
     """Trainable parameters of rows 6-16 in the order the backward returns their gradients."""
     ps = []
@@ -396,6 +413,9 @@ class FusedAdam(torch.optim.Optimizer):
                 hip.check(lib.shasta_adam_step_f32(hip.ptr(p), hip.ptr(g), hip.ptr(st["exp_avg"]), hip.ptr(st["exp_avg_sq"]), p.numel(),
                                                    float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                    float(group["weight_decay"]), st["step"], hip.stream_ptr()), "shasta_adam_step_f32")
+                # the kernel wrote through the raw pointer: tell torch (Shasta._ensure_packed and the conv-weight cache key
+                # their packed copies on (data_ptr, _version); autograd's saved-tensor checks rely on it too)
+                torch.autograd.graph.increment_version(p)
         return loss
 
 

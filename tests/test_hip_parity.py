@@ -287,6 +287,63 @@ def test_forward_is_deterministic_and_repack_tracks_weights():
     assert not torch.equal(a1, a3)
 
 
+def test_anchor_boxes_are_fresh_tensors_and_work_buffers_are_bounded():
+    """shasta.py:260-267 leaves newborn / fp / dead_trk / fn on the module as tensors of that forward: a later forward (another
+    batch, same size) must not change them.  The work buffers are one set per device (largest batch), not one per batch size."""
+    dev = _dev()
+    z, c, m, bev, pbev, det, prev = _case("small_32_7_4")
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(5)
+    f = torch.relu(torch.randn(c["B"], 180, 180, 64, generator=g)).to(dev)
+    with torch.no_grad():
+        m.affinity_from_bev(f, f, det.clone().to(dev), prev.clone().to(dev))
+        kept = [t for t in (m.newborn, m.fp, m.dead_trk, m.fn)]
+        snap = [t.clone() for t in kept]
+        assert all(t.shape == (c["B"], 1, 7) for t in kept)
+        other = O.synth_boxes(torch.Generator().manual_seed(9), c["B"], c["max_obj"], None).to(dev)
+        m.affinity_from_bev(f, f, other.clone(), other.clone())
+        assert all(torch.equal(a, b) for a, b in zip(kept, snap))
+        assert not torch.equal(m.newborn, snap[0])
+        for B in (1, 2, 1):
+            m.affinity_from_bev(f[:B], f[:B], other[:B].clone(), other[:B].clone())
+    assert len(m._bufs) == 1 and next(iter(m._bufs.values()))["B"] == c["B"]
+
+
+def test_shared_conv_pads_odd_channel_counts_and_never_leaves_the_hip_kernel_in_inference():
+    """in_channels that is not a multiple of the kernel's 8-channel K chunk runs the SAME HIP kernel on zero-padded channels
+    (no MIOpen fallback); eval() with autograd on (frozen-BN fine-tuning) takes the differentiable module instead."""
+    import shasta_amd
+    dev = _dev()
+    torch.manual_seed(3)
+    m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54],
+                                                            voxel_size=[0.075, 0.075], out_stride=8),
+                                         max_obj=4, num_feats=7, num_point=5, in_channels=12)).eval()
+    with torch.no_grad():
+        m.shared_conv[1].running_mean.copy_(torch.randn(64) * 0.3)
+        m.shared_conv[1].running_var.copy_(torch.rand(64) + 0.5)
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    x, xp = torch.relu(torch.randn(2, 12, 9, 37, generator=g)), torch.relu(torch.randn(2, 12, 9, 37, generator=g))
+    ref, refp = O.shared_conv_nhwc(w, x), O.shared_conv_nhwc(w, xp)
+    m = m.to(dev)
+    called = []
+    m.shared_conv.register_forward_hook(lambda *a: called.append(1))
+    with torch.no_grad():
+        got, gotp = m.shared_conv_nhwc(x.to(dev), xp.to(dev))
+    assert not called, "inference must not run the torch conv"
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(ref.abs().max())))
+    np.testing.assert_allclose(gotp.cpu().numpy(), refp.numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(ref.abs().max())))
+    xg = x.to(dev).requires_grad_(True)
+    out = m.shared_conv_nhwc(xg)  # eval mode, grad enabled: differentiable path
+    assert called and out.requires_grad
+    out.sum().backward()
+    assert xg.grad is not None and m.shared_conv[0].weight.grad is not None
+    from shasta_amd import hip
+    with pytest.raises(hip.ShastaHipError):
+        m.shared_conv_nhwc(x)  # CPU tensor
+
+
 def test_cpu_tensors_fail_loudly():
     from shasta_amd import hip
     z, c, m, bev, pbev, det, prev = _case("tiny_4_7_5")

@@ -101,6 +101,40 @@ def test_training_step_reduces_loss_and_inference_sees_new_weights():
 
 
 @pytest.mark.gpu
+def test_fused_adam_steps_are_seen_by_the_next_forward():
+    """FusedAdam writes the parameters through raw pointers (shasta_adam_step_f32).  The packed copies of the pair-MLP / aff[0]
+    weights are keyed on torch's tensor versions, so the optimizer must bump them: after N fused steps both the training
+    forward and the inference forward must equal the oracle evaluated on the UPDATED state_dict."""
+    from shasta_amd import training
+    c, model, w, a, b, det, prev, gt = _case(12, 7, 4, 2, seed=11)
+    dev = torch.device("cuda:0")
+    model = model.to(dev).train()
+    params = training.affinity_params(model)
+    opt = training.FusedAdam(params, lr=5e-3)
+    ad, bd, gtd = a.to(dev), b.to(dev), gt.to(dev)
+    v0 = [p._version for p in params]
+    for _ in range(4):
+        opt.zero_grad()
+        m1, m2 = training.affinity_train(model, ad, bd, det.to(dev).contiguous(), prev.to(dev).contiguous())
+        training.affinity_loss(m1, m2, gtd).backward()
+        opt.step()
+    assert all(p._version > v for p, v in zip(params, v0))
+    w2 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    assert float((w2["fuse_shape.0.weight"] - w["fuse_shape.0.weight"]).abs().max()) > 1e-3  # the steps did move the weights
+    r1, r2 = O.forward_from_bev(w2, a, b, det.clone(), prev.clone(), c["nf"], c["np"], out_stride=c["stride"])
+    r1_old, _ = O.forward_from_bev(w, a, b, det.clone(), prev.clone(), c["nf"], c["np"], out_stride=c["stride"])
+    assert float((r1 - r1_old).abs().max()) > 1e-4  # ... enough that stale packed weights would be caught
+    t1, t2 = training.affinity_train(model, ad, bd, det.to(dev).contiguous(), prev.to(dev).contiguous())
+    np.testing.assert_allclose(t1.detach().cpu().numpy(), r1.numpy(), atol=1e-5)
+    np.testing.assert_allclose(t2.detach().cpu().numpy(), r2.numpy(), atol=1e-5)
+    model.eval()
+    with torch.no_grad():
+        e1, e2 = model.affinity_from_bev(ad, bd, det.to(dev).contiguous(), prev.to(dev).contiguous())
+    np.testing.assert_allclose(e1.cpu().numpy(), r1.numpy(), atol=1e-5)
+    np.testing.assert_allclose(e2.cpu().numpy(), r2.numpy(), atol=1e-5)
+
+
+@pytest.mark.gpu
 def test_model_forward_is_differentiable_like_the_reference_module():
     """model(example, train_mode=True) under autograd (det3d/torchie/apis/train_track.py:109-130 -> train.py:198-213):
     gradients reach the affinity parameters AND, through the NHWC maps, the torch shared_conv block."""
