@@ -25,6 +25,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import ref_import as R  # noqa: E402
 from oracle import shasta_oracle as O  # noqa: E402  (only for the shared synthetic-input generator)
+from tests.helpers import PROBE_IDX, sharpen_state_dict  # noqa: E402
 
 # n_real None = all rows real; `store` = keep weights and BEV inputs inside the npz (tiny only)
 CONFIGS = [
@@ -33,7 +34,16 @@ CONFIGS = [
     dict(name="small_32_7_4", max_obj=32, nf=7, np=4, B=2, n_real=None),   # BASELINE config 1 (F=256)
     dict(name="small_32_3_5_pad", max_obj=32, nf=3, np=5, B=1, n_real=20),  # zero-padded rows, nf=3
     dict(name="car_90_3_5", max_obj=90, nf=3, np=5, B=1, n_real=40),        # shipped car config, padded
-    dict(name="headline_500_7_4", max_obj=500, nf=7, np=4, B=1, n_real=None, inter=False),  # N=M=500
+    # the other shipped class configs (configs/nusc/truck.py / trailer: 60, bicycle / motorcycle: 50, bus: 20; nf=3, np=5), padded
+    dict(name="truck_60_3_5", max_obj=60, nf=3, np=5, B=2, n_real=23),
+    dict(name="bicycle_50_3_5", max_obj=50, nf=3, np=5, B=2, n_real=17),
+    dict(name="bus_20_3_5", max_obj=20, nf=3, np=5, B=3, n_real=6),
+    # "sharpened" seeded weights (tests/helpers.py sharpen_state_dict): peaked outputs, arg-max asserted on every row / column
+    dict(name="sharp_90_3_5", max_obj=90, nf=3, np=5, B=2, n_real=None, sharp=(4.0, 2.0)),
+    dict(name="sharp_90_3_5_pad", max_obj=90, nf=3, np=5, B=1, n_real=40, sharp=(2.5, 1.0)),
+    # N=M=500 (BASELINE metric size): intermediates as probe rows / columns + float64 checksums of every row and column
+    dict(name="headline_500_7_4", max_obj=500, nf=7, np=4, B=1, n_real=None, inter="probe"),
+    dict(name="sharp_500_7_4", max_obj=500, nf=7, np=4, B=1, n_real=None, inter="probe", sharp=(5.0, 2.0)),
 ]
 
 
@@ -43,9 +53,11 @@ def checksums(sd):
 
 
 def run_forward_config(name, max_obj, nf, np_, B, n_real, cin=512, hw=180, stride=8, store=False,
-                       inter=True, seed=0):
+                       inter=True, seed=0, sharp=None):
     torch.manual_seed(seed)
     m = R.build_ref_model(max_obj, nf, np_, in_channels=cin, out_stride=stride)
+    if sharp is not None:
+        sharpen_state_dict(m.state_dict(), *sharp)  # in place on the reference model's parameters
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     bev, pbev, det, prev = O.synth_case(B, max_obj, n_real, cin, hw, hw, seed)
     det_in = det.clone()
@@ -72,13 +84,27 @@ def run_forward_config(name, max_obj, nf, np_, B, n_real, cin=512, hw=180, strid
     step = max(1, hw // 4)
     arrays["bev_probe"] = out["bev_feature"][:, ::step, ::step, :].numpy()
     arrays["prev_bev_probe"] = prev_bev_nhwc[:, ::step, ::step, :].numpy()
+    if sharp is not None:
+        arrays["sharp"] = np.array(sharp, np.float64)
     if inter:
         arrays.update(
-            feature=feats[0].numpy(), prev_feature=feats[1].numpy(),
-            geom=np.stack([torch.abs(g).numpy() for g in geoms]),  # newborn, fp, dead, fn: (4,B,F)
-            newborn=m.newborn.numpy(), fp=m.fp.numpy(), dead_trk=m.dead_trk.numpy(), fn=m.fn.numpy(),
-            residual=grab["residual"].numpy(), matched=grab["matched"].numpy(),
+            geom=np.stack([torch.abs(g).numpy() for g in geoms]),  # newborn, fp, dead, fn: (4,B,F)  (shasta.py:241-244)
+            newborn=m.newborn.numpy(), fp=m.fp.numpy(), dead_trk=m.dead_trk.numpy(), fn=m.fn.numpy(),  # shasta.py:260-267
         )
+    if inter == "probe":  # N=500: probe rows / columns in full, float64 checksums of every row and column
+        idx = [i for i in PROBE_IDX if i < max_obj]
+        for k, t in (("feature", feats[0]), ("prev_feature", feats[1])):
+            arrays[k + "_rows"] = t[:, idx].numpy()
+            arrays[k + "_rowsum"] = t.double().sum(-1).numpy()
+        for k in ("residual", "matched"):   # shasta.py:319 / :323
+            t = grab[k]
+            arrays[k + "_rows"] = t[:, PROBE_IDX].numpy()
+            arrays[k + "_cols"] = t[:, :, PROBE_IDX].numpy()
+            arrays[k + "_rowabs"] = t.double().abs().sum(-1).numpy()
+            arrays[k + "_colabs"] = t.double().abs().sum(-2).numpy()
+    elif inter:
+        arrays.update(feature=feats[0].numpy(), prev_feature=feats[1].numpy(),
+                      residual=grab["residual"].numpy(), matched=grab["matched"].numpy())
     if store:
         arrays["bev_in"] = bev.numpy()
         arrays["prev_bev_in"] = pbev.numpy()
@@ -195,8 +221,11 @@ def _js(o):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["forward", "voxel", "tracker"]
-    if "forward" in which:
+    only = [w[5:] for w in which if w.startswith("only=")]
+    if "forward" in which or only:
         for c in CONFIGS:
+            if only and c["name"] not in only:
+                continue
             c = dict(c)
             run_forward_config(c.pop("name"), c.pop("max_obj"), c.pop("nf"), c.pop("np"), c.pop("B"),
                                c.pop("n_real"), **c)

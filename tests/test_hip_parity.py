@@ -1,7 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI) against the golden vectors from the reference and against
-the CPU oracle on the same seeded inputs.  Tolerances: 1e-4 absolute on the affinity matrices (BASELINE.json
-north_star: 'within 1e-4 fp32'), measured errors are ~1e-7; row/column argmax identical wherever the reference's own
-top-2 margin exceeds 1e-6."""
+the CPU oracle on the same seeded inputs.  Against the reference's goldens (tests/helpers.py): matched1 / matched2 within 1e-6
+(default init, values ~1/N; BASELINE.json north_star allows 1e-4) or 1e-4 (sharpened weights, probabilities up to 1), arg-max
+of every row / column for the sharpened goldens, and the intermediates geom / anchor boxes / residual / matched within 1e-5
+relative - at every size including N=M=500.  Against the oracle on random inputs: TOL."""
 import ctypes as C
 
 import numpy as np
@@ -9,7 +10,8 @@ import pytest
 import torch
 
 from oracle import shasta_oracle as O
-from tests.helpers import FORWARD_CASES, build_model, check_weight_sums, golden_weights, load_golden, row_argmax_agreement
+from tests.helpers import (FORWARD_CASES, build_model, check_intermediates, check_outputs, check_weight_sums, golden_weights, load_golden,
+                           row_argmax_agreement)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -54,46 +56,39 @@ def test_forward_matches_reference_golden(name):
         m1, m2, out = m(ex, train_mode=False)
     torch.cuda.synchronize()
     assert out is ex
-    np.testing.assert_allclose(ex["det_boxes"].cpu().numpy(), z["det_boxes_out"], rtol=0, atol=1e-5)
-    im = m.last_intermediates
-    N = c["max_obj"]
-    if "feature" in z.files:
-        np.testing.assert_allclose(im["feature"][:, :N].cpu().numpy(), z["feature"], rtol=0, atol=2e-4)
-        np.testing.assert_allclose(im["prev_feature"][:, :N].cpu().numpy(), z["prev_feature"], rtol=0, atol=2e-4)
-        g = np.stack([im["prev_feature"][:, N].cpu().numpy(), im["prev_feature"][:, N + 1].cpu().numpy(),
-                      im["feature"][:, N].cpu().numpy(), im["feature"][:, N + 1].cpu().numpy()])
-        np.testing.assert_allclose(g, z["geom"], rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(m.newborn.cpu().numpy(), z["newborn"], rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(m.fp.cpu().numpy(), z["fp"], rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(m.dead_trk.cpu().numpy(), z["dead_trk"], rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(m.fn.cpu().numpy(), z["fn"], rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(im["residual"].cpu().numpy(), z["residual"], rtol=1e-4, atol=1e-4)
-        np.testing.assert_allclose(im["matched"].cpu().numpy(), z["matched"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ex["det_boxes"].cpu().numpy(), z["det_boxes_out"], rtol=0, atol=1e-6)
     a1, a2 = m1.cpu().numpy(), m2.cpu().numpy()
     assert a1.shape == z["m1"].shape and a2.shape == z["m2"].shape
-    np.testing.assert_allclose(a1, z["m1"], rtol=0, atol=TOL)
-    np.testing.assert_allclose(a2, z["m2"], rtol=0, atol=TOL)
-    print(name, "max|m1-ref| %.3e  max|m2-ref| %.3e" % (np.abs(a1 - z["m1"]).max(), np.abs(a2 - z["m2"]).max()))
-    same, decided = row_argmax_agreement(a1, z["m1"], 1e-6)
-    assert same[decided].all(), "row argmax differs on a decided row"
-    same2, decided2 = row_argmax_agreement(np.swapaxes(a2, 1, 2), np.swapaxes(z["m2"], 1, 2), 1e-6)
-    assert same2[decided2].all(), "column argmax differs on a decided column"
-    print(name, "argmax rows equal %d/%d (undecided %d)" % (same.sum(), same.size, (~decided).sum()))
+    worst = check_intermediates(z, _tables(m))
+    e1, e2 = check_outputs(z, a1, a2)
+    print(name, "max|m1-ref| %.3e  max|m2-ref| %.3e; worst error / bound per pinned tensor: %s" %
+          (e1, e2, ", ".join("%s %.2f" % kv for kv in worst.items())))
+    for k, t in (("newborn", m.newborn), ("fp", m.fp), ("dead_trk", m.dead_trk), ("fn", m.fn)):  # the module attributes
+        np.testing.assert_allclose(t.cpu().numpy(), z[k], rtol=1e-5, atol=1e-5 * float(np.abs(z[k]).max()))
 
 
-def test_headline_size_batches_pin_every_anchor_kernel_on_the_reference_output():
+def _tables(m):
+    return {k: v.cpu().numpy() for k, v in m.last_intermediates.items()}
+
+
+@pytest.mark.parametrize("name", ["headline_500_7_4", "sharp_500_7_4"])
+def test_headline_size_batches_pin_every_anchor_kernel_on_the_reference_output(name):
     """N=M=500, F=256 (BASELINE.json configs[1]) in batches: frame-pair 0 is the reference's golden frame, the others are
     synthetic.  Frame-pairs are independent, so (a) frame 0 of a 130-batch (bf16-piece anchor kernel, two weight passes, the
-    second one ragged), of a 64-batch (one 64-item pass), of a 32-batch (f32 MFMA kernel) and of a 1-batch (VALU kernel) must all
-    reproduce the reference's golden output within 1e-4 with identical decided arg-max, and (b) every frame's result must not
-    depend on the batch it was computed in beyond fp32 summation order."""
+    second one ragged), of a 64-batch (one 64-item pass), of a 32-batch (f32 MFMA kernel) and of a 1-batch (VALU kernel) must
+    each reproduce the reference: geom = the aug_shape anchors (K = 128 000 first layer, shasta.py:241-244), the aug_dets anchor
+    boxes, the residual and matched probes / checksums within 1e-5 relative, matched1 / matched2 within 1e-6 (1e-4 and the
+    arg-max of every row and column with the sharpened weights); and (b) every frame's result must not depend on the batch it was
+    computed in beyond fp32 summation order."""
     dev = _dev()
-    z, c, m, bev, pbev, det, prev = _case("headline_500_7_4")
+    z, c, m, bev, pbev, det, prev = _case(name)
     w_cpu = {k: v.detach().clone() for k, v in m.state_dict().items()}
     with torch.no_grad():
         f0 = O.shared_conv_nhwc(w_cpu, bev).to(dev)
         pf0 = O.shared_conv_nhwc(w_cpu, pbev).to(dev)
+    del w_cpu
     m = m.to(dev)
+    m.keep_intermediates = True
     B, N, hw = 130, c["max_obj"], c["hw"]
     g = torch.Generator(device=dev).manual_seed(77)
     f = torch.relu(torch.randn(B, hw, hw, 64, device=dev, generator=g))
@@ -103,30 +98,32 @@ def test_headline_size_batches_pin_every_anchor_kernel_on_the_reference_output()
     dets = O.synth_boxes(gc, B, N, None).to(dev)
     prevs = O.synth_boxes(gc, B, N, None).to(dev)
     dets[0], prevs[0] = det[0].to(dev), prev[0].to(dev)
+    sharp = c["sharp"] is not None
+    batch_tol = 1e-4 if sharp else 1e-6
 
     def run(idx):
         ex = dict(det_boxes=dets[idx].clone(), prev_det_boxes=prevs[idx].clone(), bev_feature=f[idx].contiguous(),
                   prev_bev_feature=pf[idx].contiguous())
         with torch.no_grad():
             m1, m2, _ = m(ex, train_mode=False)
-        return m1.cpu().numpy(), m2.cpu().numpy()
-    full1, full2 = run(slice(0, B))
+        tabs = {k: v[:1].cpu().numpy() for k, v in m.last_intermediates.items()}
+        return m1.cpu().numpy(), m2.cpu().numpy(), tabs
+    full1, full2, full_t = run(slice(0, B))
+    runs = {(0, B): (full1, full2, full_t)}
     for lo, hi in ((0, 64), (0, 32), (0, 1), (129, 130), (64, 130)):
-        p1, p2 = run(slice(lo, hi))
-        np.testing.assert_allclose(p1, full1[lo:hi], rtol=0, atol=1e-5)
-        np.testing.assert_allclose(p2, full2[lo:hi], rtol=0, atol=1e-5)
-        same, decided = row_argmax_agreement(p1, full1[lo:hi], 1e-5)
-        assert same[decided].all()
-        if lo == 0:  # the golden frame, through this batch's anchor kernel
-            np.testing.assert_allclose(p1[:1], z["m1"], rtol=0, atol=TOL)
-            np.testing.assert_allclose(p2[:1], z["m2"], rtol=0, atol=TOL)
-            same, decided = row_argmax_agreement(p1[:1], z["m1"], 1e-6)
-            assert same[decided].all(), "row argmax differs on a decided row"
-    np.testing.assert_allclose(full1[:1], z["m1"], rtol=0, atol=TOL)
-    np.testing.assert_allclose(full2[:1], z["m2"], rtol=0, atol=TOL)
-    same, decided = row_argmax_agreement(full1[:1], z["m1"], 1e-6)
-    assert same[decided].all(), "row argmax differs on a decided row"
-    print("130-batch frame 0: max|m1-ref| %.3e  max|m2-ref| %.3e" % (np.abs(full1[:1] - z["m1"]).max(), np.abs(full2[:1] - z["m2"]).max()))
+        p1, p2, tabs = run(slice(lo, hi))
+        runs[(lo, hi)] = (p1, p2, tabs)
+        np.testing.assert_allclose(p1, full1[lo:hi], rtol=0, atol=batch_tol)
+        np.testing.assert_allclose(p2, full2[lo:hi], rtol=0, atol=batch_tol)
+        if sharp:
+            assert np.array_equal(p1.argmax(-1), full1[lo:hi].argmax(-1)) and np.array_equal(p2.argmax(1), full2[lo:hi].argmax(1))
+    for (lo, hi), (p1, p2, tabs) in runs.items():
+        if lo != 0:
+            continue  # the golden frame, through this batch size's anchor kernel
+        worst = check_intermediates(z, tabs)
+        e1, e2 = check_outputs(z, p1[:1], p2[:1])
+        print("%s in a %d-batch: max|m1-ref| %.3e max|m2-ref| %.3e; error / bound: %s" %
+              (name, hi, e1, e2, ", ".join("%s %.2f" % kv for kv in worst.items())))
     np.testing.assert_allclose(full1.sum(-1), 1.0, atol=1e-5)
     np.testing.assert_allclose(full2.sum(1), 1.0, atol=1e-5)
 
