@@ -5,7 +5,9 @@
  * `nn.Module.forward` of det3d/models/tracker/shasta.py and the ATen ops below it.  This header
  * is the C boundary a maintainer binds instead (ctypes / pybind / cgo alike): plain pointers and
  * sizes, no torch types, every call asynchronous on the caller's `hipStream_t`, no allocation
- * inside, no globals, `int` status (0 = ok, <0 = SHASTA_E_*), never exit()/abort().
+ * inside, no globals and no environment switches (kernel choices that change arithmetic are per-call
+ * `options` bits of shasta_weights), `int` status (0 = ok, <0 = SHASTA_E_*), never exit()/abort().
+ * The shared library exports exactly the functions declared here (built with -fvisibility=hidden).
  * All pointers are DEVICE pointers unless a parameter name starts with `h_`.
  * All arithmetic is fp32 (the reference runs apex O0 = fp32, tools/nusc_shasta/train.py:149).
  *
@@ -20,6 +22,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#pragma GCC visibility push(default)
 
 typedef void* shasta_stream_t; /* a hipStream_t; NULL = the null stream */
 
@@ -64,6 +68,13 @@ int shasta_voxelize_mean_f32(const float* points, int num_points, int ndim, cons
                              int32_t* coors, int32_t* num_points_per_voxel, float* mean,
                              int32_t* num_voxels, int32_t* cell_map, void* workspace,
                              size_t workspace_bytes, shasta_stream_t stream);
+
+/* The reader alone, for callers that already hold voxelised input (det3d/models/readers/voxel_encoder.py:18-28 as called from
+ * Shasta.extract_feat, det3d/models/tracker/shasta.py:178-179): out (V, num_features) = sum over the max_points slots of
+ * voxels (V, max_points, ndim)[..., :num_features] / num_points.  num_points_f32: (V,) fp32 - example_to_device
+ * (det3d/torchie/apis/train_track.py:60) has already cast the counts to float, as in the reference. */
+int shasta_voxel_mean_f32(const float* voxels, const float* num_points_f32, int num_voxels, int max_points, int ndim,
+                          int num_features, float* out, shasta_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K2  BEV bilinear gather at box centre / edge mid-points
@@ -111,10 +122,18 @@ typedef struct shasta_linear {
     const float* bias;   /* (out,) */
 } shasta_linear;
 
+/* shasta_weights.options: every bit keeps fp32 operands and fp32 accumulation; they select HOW the fp32 products are formed.
+ * Default (0): above 32 frame-pairs per call the aug_shape first layer, and from 8192 table rows the row-embedding GEMMs of the
+ * pair stage, form each fp32 product from six exact bf16 piece products on the bf16 matrix path (anchor_split.hip,
+ * gemm_pieces.hip; error at the level of the fp32 FMA's own rounding). */
+#define SHASTA_OPT_F32_WEIGHT_STREAM 1 /* aug_shape first layer on v_mfma_f32_32x32x2_f32 for every batch size */
+#define SHASTA_OPT_F32_EMBED_GEMM 2    /* row-embedding GEMMs on v_mfma_f32_32x32x2_f32 for every row count */
+
 typedef struct shasta_weights {
     int max_obj;   /* N */
     int num_feats; /* nf: 1..7 */
     int feat_dim;  /* F = share_conv_channel * num_point; supported: 64, 256, 320 */
+    int options;   /* SHASTA_OPT_* bits, 0 = default */
     shasta_linear aug_shape[4][2]; /* aug_shape.{i}.{0,2}: (N*F/64, N*F), (F, N*F/64) */
     shasta_linear aug_dets[4][2];  /* aug_dets.{i}.{0,2}:  (7N/32, 7N), (7, 7N/32)     */
     shasta_linear fuse_shape[4];   /* fuse_shape.{0,2,4,6}: 2F->F/8->F/16->F/32->1      */
@@ -315,6 +334,8 @@ int shasta_scale_f32(float* x, long n, float alpha, shasta_stream_t stream);
  * weight decay folded into the gradient, bias correction with `step` (1-based), no amsgrad).  16-byte aligned pointers. */
 int shasta_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                          float beta2, float eps, float weight_decay, int step, shasta_stream_t stream);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,8 @@ SOURCES = ["abi.hip", "bev_gather.hip", "gemm_f32.hip", "gemm_pieces.hip", "anch
            "voxelize.hip", "shared_conv.hip", "iou3d.hip", "decode.hip", "train.hip", "track.hip", "nms.hip"]
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fmaf(); products that the
 # reference rounds separately stay separately rounded (parity with the PyTorch fp32 forward).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -fvisibility=hidden: the .so exports exactly the extern "C" functions include/shasta_hip.h declares (its visibility pragma)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # per-file additions.  pair.hip: keep the MFMA accumulators in architectural VGPRs (113 registers instead of 116 + 44 AGPRs:
 # 4 waves per SIMD become possible, and a layer's accumulators feed the next layer without v_accvgpr_read)
 # gemm_pieces.hip: same switch - with AGPR accumulators the allocator moved all 64 of them through VGPRs in every K slice
@@ -34,7 +35,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h"))]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h", ".map"))]
     deps.append(os.path.join(os.path.dirname(CSRC), "..", "include", "shasta_hip.h"))
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
@@ -58,7 +59,7 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(cc, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)

@@ -7,32 +7,10 @@
 
 #include "common.hpp"
 #include "pair_layout.hpp"
-#include <stdlib.h>
 
 namespace shasta {
 
-int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
-                   int N, int K, int act, hipStream_t st);
-
 // one wave per (b, t < N): softmax over the D entries of the row
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ matched, float* __restrict__ m1,
-                                                           int B, int N, int T, int D, int ld) {
-    const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= B * N) return;
-    const int b = item / N, t = item % N;
-    const float* x = matched + ((size_t)b * T + t) * ld;
-    float mx = -INFINITY;
-    for (int d = lane; d < D; d += 64) mx = fmaxf(mx, x[d]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    float s = 0.0f;
-    for (int d = lane; d < D; d += 64) s += expf(x[d] - mx);
-    s = wave_sum(s);
-    float* o = m1 + ((size_t)b * N + t) * D;
-    for (int d = lane; d < D; d += 64) o[d] = expf(x[d] - mx) / s;
-}
-
 // block = 64 detections x 16 track groups (1024 threads): softmax over the T rows of each column d < N.  A wave reads
 // 64 consecutive columns of one row (256 B, coalesced) and keeps its <= MAXR rows of the column in registers (one pass
 // over memory); max and sum are combined across the 16 groups in a fixed order.  MAXR = ceil(T / 16) <= 128.
@@ -231,7 +209,7 @@ __global__ __launch_bounds__(64 * AFF_WAVES) void aff_fused_kernel(AffArgs a) {
 
 size_t aff_workspace_bytes(int B, int N) {
     const int T = N + 2, Dp = (T + 3) / 4 * 4;
-    return 2 * align_up((size_t)B * T * 128 * sizeof(float), 256) + align_up((size_t)B * T * Dp * sizeof(float), 256);
+    return align_up((size_t)B * T * Dp * sizeof(float), 256);  // matched (B, T, Dp) between the row MLP and the column softmax
 }
 
 int aff_softmax(const shasta_weights* w, const float* packed, int B, const float* residual, int ld, float* m1,
@@ -244,29 +222,22 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
     }
     if (B == 0) return SHASTA_OK;
     char* base = static_cast<char*>(ws);
-    float* h0 = reinterpret_cast<float*>(base);
-    base += align_up((size_t)B * T * 128 * sizeof(float), 256);
-    float* h1 = reinterpret_cast<float*>(base);
-    base += align_up((size_t)B * T * 128 * sizeof(float), 256);
     float* matched = reinterpret_cast<float*>(base);
     const int M = B * T;
     int rc;
-    (void)h0;
-    (void)h1;
-    static const bool unfused = getenv("SHASTA_AFF_UNFUSED") != nullptr;
     // 32 rows per workgroup (RG = 2) halve the L2 -> register weight traffic per row, the limiter of this kernel (29 % matrix-
     // pipe utilisation at 16 rows).  With the second hidden buffer aliased into xb two such workgroups fit one CU (80 KB each
     // at N = 500); measured at B = 64: 187 us against 230 us for 16 rows.  16 rows stay the choice when there are too few
     // rows to give every CU two workgroups (small batches: parallelism matters more than traffic) or when 32 rows do not
-    // fit twice.  SHASTA_AFF_RG1 / SHASTA_AFF_RG2 force one form.
-    static const bool rg1_forced = getenv("SHASTA_AFF_RG1") != nullptr;
-    static const bool rg2_forced = getenv("SHASTA_AFF_RG2") != nullptr;
+    // fit twice.
     const size_t lds2 = (size_t)(32 * std::max(Dp + 4, 132) + 32 * 132) * sizeof(float);
-    int rg = (lds2 <= 80 * 1024 && M >= 32 * 512) ? 2 : 1;
-    if (rg2_forced && lds2 <= 160 * 1024) rg = 2;
-    if (rg1_forced) rg = 1;
+    const int rg = (lds2 <= 80 * 1024 && M >= 32 * 512) ? 2 : 1;
     const size_t lds = (size_t)(16 * rg * std::max(Dp + 4, 132) + 16 * rg * 132) * sizeof(float);
-    if (!unfused && lds <= 160 * 1024) {
+    if (lds > 160 * 1024) {  // max_obj <= 2046 (check_weights) keeps 16 rows within 140 KB
+        set_error_msg("aff_softmax: max_obj too large for the on-chip row tile");
+        return SHASTA_E_ARG;
+    }
+    {
         AffArgs fa;
         fa.W[0] = packed + P.aff0;  // zero padded (128, Dp)
         fa.bias[0] = w->aff[0].bias;
@@ -292,21 +263,6 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
             hipLaunchKernelGGL(aff_fused_kernel<1>, dim3(cdiv(M, 16)), dim3(64 * AFF_WAVES), lds, st, fa);
         }
         if ((rc = check_launch("aff_fused"))) return rc;
-    } else {
-        // layer-by-layer path: six launches of the generic GEMM + a row softmax kernel
-        // aff.0 uses the zero-padded copy when the caller's residual rows are Dp-strided (16-byte aligned rows)
-        if (ld % 4 == 0)
-            rc = launch_gemm_nt(residual, ld, packed + P.aff0, Dp, w->aff[0].bias, h0, 128, M, 128, D, 1, st);
-        else
-            rc = launch_gemm_nt(residual, ld, w->aff[0].weight, D, w->aff[0].bias, h0, 128, M, 128, D, 1, st);
-        if (rc) return rc;
-        if ((rc = launch_gemm_nt(h0, 128, w->aff[1].weight, 128, w->aff[1].bias, h1, 128, M, 64, 128, 1, st))) return rc;
-        if ((rc = launch_gemm_nt(h1, 128, w->aff[2].weight, 64, w->aff[2].bias, h0, 128, M, 32, 64, 1, st))) return rc;
-        if ((rc = launch_gemm_nt(h0, 128, w->aff[3].weight, 32, w->aff[3].bias, h1, 128, M, 64, 32, 1, st))) return rc;
-        if ((rc = launch_gemm_nt(h1, 128, w->aff[4].weight, 64, w->aff[4].bias, h0, 128, M, 128, 64, 1, st))) return rc;
-        if ((rc = launch_gemm_nt(h0, 128, w->aff[5].weight, 128, w->aff[5].bias, matched, Dp, M, D, 128, 0, st))) return rc;
-        hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(B * N, 4)), dim3(256), 0, st, matched, m1, B, N, T, D, Dp);
-        if ((rc = check_launch("softmax_rows"))) return rc;
     }
     if (T <= 512) hipLaunchKernelGGL(softmax_cols_kernel<32>, dim3(cdiv(N, 64), B), dim3(1024), 0, st, matched, m2, N, T, Dp);
     else if (T <= 1024) hipLaunchKernelGGL(softmax_cols_kernel<64>, dim3(cdiv(N, 64), B), dim3(1024), 0, st, matched, m2, N, T, Dp);

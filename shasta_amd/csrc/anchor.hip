@@ -14,7 +14,6 @@
 // concurrently, and the split-K partials are summed in a fixed order afterwards (no float atomics -> bitwise
 // reproducible).
 #include "common.hpp"
-#include <stdlib.h>
 
 namespace shasta {
 
@@ -329,22 +328,18 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     float* part = static_cast<float*>(ws);
     float* hidden = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)64 * B * 4 * H * sizeof(float), 256));
     a.part = part;
-    // B == 1: VALU weight-streaming GEMV (nothing to amortise; measured 6.5 TB/s).  2 <= B <= 32: the f32 matrix-core kernel
+    // B == 1: VALU weight-streaming GEMV (nothing to amortise; measured 6.8 TB/s).  2 <= B <= 32: the f32 matrix-core kernel
     // streams every weight once per 16 / 32 batch items at HBM speed (anchor_mfma.hip).  B > 32: the same fp32 arithmetic as
-    // exact bf16 piece products, 64 / 128 items per weight pass (anchor_split.hip); SHASTA_L1_F32=1 keeps the f32 MFMA
-    // kernel (64 items per pass, matrix-pipe bound), SHASTA_L1_VALU=1 forces the VALU kernels.
-    static const bool force_valu = getenv("SHASTA_L1_VALU") != nullptr;
-    static const bool force_f32 = getenv("SHASTA_L1_F32") != nullptr;
+    // exact bf16 piece products, 64 / 128 items per weight pass (anchor_split.hip); with SHASTA_OPT_F32_WEIGHT_STREAM in
+    // w->options the f32 MFMA kernel serves every B >= 2 (64 items per pass, matrix-pipe bound).  K = N*F is a multiple of 64.
+    const bool force_f32 = (w->options & SHASTA_OPT_F32_WEIGHT_STREAM) != 0;
     void* xs = reinterpret_cast<char*>(hidden) + align_up((size_t)B * 4 * H * sizeof(float), 256);
-    const bool split = !force_valu && !force_f32 && anchor_split_serves(B, K, a.x_batch_stride);
+    const bool split = !force_f32 && anchor_split_serves(B, K, a.x_batch_stride);
     if (split) launch_split_x(feat, prev_feat, xs, K, B, a.x_batch_stride, st);
     if (ev0) (void)hipEventRecord(ev0, st);
     if (B == 1) launch_l1<1, R>(a, st);
     else if (split) launch_anchor_l1_split(a.W, xs, part, H, K, B, &a.KS, st);
-    else if (!force_valu && K % 32 == 0) launch_anchor_l1_mfma(a.W, feat, prev_feat, part, H, K, B, a.x_batch_stride, &a.KS, st);
-    else if (B == 2) launch_l1<2, R>(a, st);
-    else if (B <= 4) launch_l1<4, R>(a, st);
-    else launch_l1<8, R>(a, st);
+    else launch_anchor_l1_mfma(a.W, feat, prev_feat, part, H, K, B, a.x_batch_stride, &a.KS, st);
     if (ev1) (void)hipEventRecord(ev1, st);
     int rc = check_launch("anchor_l1");
     if (rc) return rc;

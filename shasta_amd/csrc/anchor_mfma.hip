@@ -23,7 +23,6 @@
 
 // the LDS-DMA asm below names m0 in its clobber list on purpose (it writes it)
 #pragma clang diagnostic ignored "-Winline-asm"
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -317,9 +316,8 @@ int launch_anchor_l1_mfma(const float* const W[4], const float* feat, const floa
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(cdiv(G * a.KS, 4), cdiv(B, xr)), dim3(256), lds, st, a);
     };
-    static const bool no64 = getenv("SHASTA_L1_NO64") != nullptr;
     if (B <= 16) launch(anchor_l1_mfma_kernel<0, 6>, 6, 16);
-    else if (B <= 32 || no64) launch(anchor_l1_mfma_kernel<1, 4>, 4, 32);
+    else if (B <= 32) launch(anchor_l1_mfma_kernel<1, 4>, 4, 32);
     else launch(anchor_l1_mfma_kernel<2, 3>, 3, 64);
     return 0;
 }

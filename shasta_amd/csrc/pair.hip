@@ -9,11 +9,11 @@
 //   row_finish          per table row: box columns of res_coeff.0 / fuse_det.0, log-dims, cos/sin
 //   col_norm            column L2 norm over tracks (F.normalize, dim=1) of the squared box distances
 //                       (the dim / rot terms and the normalised distance are evaluated inside pair_mfma)
-//   pair_mfma<F>        per 16 pairs: h1 = relu(UP[t]+UC[d]) then 44 (F=256) v_mfma_f32_16x16x4_f32 -> residual
+//   pair_mfma4<F, WPB>  lane = pair: h1 = relu(UP[t]+UC[d]), layers 2-4 on v_mfma_f32_4x4x1_16B_f32 -> residual
+// (Two other formulations - a 16x16x4 accumulator-chained MFMA kernel and a packed-VALU kernel with SGPR weights - measured
+// within 4 % of this one and were removed from the product library after round 1; they are in the history of this file.)
 #include "common.hpp"
 #include "pair_layout.hpp"
-#include <stdlib.h>
-#include <type_traits>
 
 namespace shasta {
 
@@ -39,69 +39,12 @@ __device__ __forceinline__ void layer_src(const PackArgs& a, int l, const float*
     }
 }
 
-// feature held by output row i of block bo (or -1)
-__device__ __forceinline__ int row_feature(const LayerDesc& L, int bo, int i) {
-    const int c = blk_count(L.hout, bo);
-    const int fl = L.final_ ? i : (i >> 2) + 4 * (i & 3);
-    return fl < c ? 16 * bo + fl : -1;
-}
-
-// input feature multiplied at k-step s by lanes with k-slot kq (or -1)
-__device__ __forceinline__ int step_input(const LayerDesc& L, int s, int kq) {
-    if (!L.chained) return kq * (L.kin / 4) + s;
-    int bi = 0, r = s;
-    while (true) {
-        const int c = blk_count(L.kin, bi);
-        const int st = (c + 3) / 4;
-        if (r < st) {
-            const int fl = kq + 4 * r;
-            return fl < c ? 16 * bi + fl : -1;
-        }
-        r -= st;
-        ++bi;
-    }
-}
-
 __global__ void pack_pair_weights_kernel(PackArgs a) {
     const PackedLayout P(a.N, a.nf, a.F);
     const PairDims d(a.F);
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nth = gridDim.x * blockDim.x;
     const int F = a.F, nf = a.nf;
-    // MFMA A-operand fragments
-    for (int l = 0; l < L_COUNT; ++l) {
-        const LayerDesc L = layer_desc(F, l);
-        const float *W, *b;
-        int ldw;
-        layer_src(a, l, W, b, ldw);
-        const int steps = L.steps(), nb = nblk(L.hout);
-        float* fo = a.out + P.frags + (size_t)frag_offset(F, l) * 64;
-        for (int e = tid; e < nb * steps * 64; e += nth) {
-            const int lane = e & 63, s = (e >> 6) % steps, bo = (e >> 6) / steps;
-            const int f = row_feature(L, bo, lane & 15), k = step_input(L, s, lane >> 4);
-            fo[e] = (f >= 0 && k >= 0) ? W[(size_t)f * ldw + k] : 0.0f;
-        }
-        // bias as the initial accumulator: lane (kq = lane>>4) register r holds output row 4*kq + r
-        float* bo_ = a.out + P.biasf + (size_t)bias_offset(F, l) * 256;
-        for (int e = tid; e < nb * 256; e += nth) {
-            const int r = e & 3, lane = (e >> 2) & 63, bo = e >> 8;
-            const int f = row_feature(L, bo, 4 * (lane >> 4) + r);
-            bo_[e] = f >= 0 ? b[f] : 0.0f;
-        }
-    }
-    // transposed, padded copies for the VALU pair kernel: Wt[k][HP] then bias[HP]
-    for (int l = 0; l < L_COUNT; ++l) {
-        const LayerDesc L = layer_desc(F, l);
-        const float *W, *b;
-        int ldw;
-        layer_src(a, l, W, b, ldw);
-        const int HP = vw_hp(F, l);
-        float* o = a.out + P.vw + vw_offset(F, l);
-        for (int e = tid; e < (L.kin + 1) * HP; e += nth) {
-            const int k = e / HP, j = e % HP;
-            o[e] = j < L.hout ? (k < L.kin ? W[(size_t)j * ldw + k] : b[j]) : 0.0f;
-        }
-    }
     // 4x4x1 A operands: [ob][kg][i][kk], then bias [ob][i]
     for (int l = 0; l < L_COUNT; ++l) {
         const LayerDesc L = layer_desc(F, l);
@@ -253,401 +196,6 @@ __global__ __launch_bounds__(256) void col_norm_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < 16; ++i) tot += red[dl][i];  // fixed order
         denom[(size_t)b * D + d] = fmaxf(sqrtf(tot), 1e-12f);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// pair_mfma
-// ------------------------------------------------------------------------------------------------------------
-// tracks per workgroup: a runtime argument (8..64).  Larger values amortise the per-workgroup prologue (weight
-// fragments, detection-side embeddings, bias fragments) over more pairs; smaller ones give B=1 enough workgroups.
-
-template <int F, int L>
-struct Frags {
-    static constexpr LayerDesc D = layer_desc(F, L);
-    static constexpr int NB = nblk(D.hout), ST = D.steps();
-    float w[NB][ST];
-    __device__ __forceinline__ void load(const float* packed_frags, int lane) {
-#pragma unroll
-        for (int bo = 0; bo < NB; ++bo)
-#pragma unroll
-            for (int s = 0; s < ST; ++s) w[bo][s] = packed_frags[(size_t)(frag_offset(F, L) + bo * ST + s) * 64 + lane];
-    }
-};
-
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
-template <int F, int UNROLL>
-__global__ __launch_bounds__(256) void pair_mfma_kernel(const float* __restrict__ packed, const float* __restrict__ UP,
-                                                        const float* __restrict__ UC, const float* __restrict__ hand_prev,
-                                                        const float* __restrict__ hand_det, const float* __restrict__ denom,
-                                                        float* __restrict__ residual, int T, int D, int ld, int nf,
-                                                        int TT, int stagger) {
-    constexpr PairDims dm(F);
-    constexpr int H1 = dm.H1, R1 = dm.R1, ET = dm.ET;
-    constexpr int S_FS = H1 / 4, S_RC = R1 / 4, S_FD = 8;
-    constexpr int NBIAS = total_bias_blocks(F);
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    __shared__ __attribute__((aligned(16))) float s_bias[NBIAS * 256];
-    __shared__ float s_hd[64 * 17];
-    float* s_up = s_dyn;                // [TT][ET]
-    float* s_dist = s_up + TT * ET;     // [TT][64]
-    float* s_hp = s_dist + TT * 64;     // [TT][16], followed by 256 floats of scratch
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int p = lane & 15, kq = lane >> 4;
-    const int b = blockIdx.z, t0 = blockIdx.y * TT, dblk = blockIdx.x * 64;
-    const int d = dblk + wid * 16 + p;
-    const int dc = min(d, D - 1);
-    const PackedLayout P(0, 0, F);  // only the fragment/bias offsets are used here (independent of N, nf)
-
-    // stage UP rows of this workgroup's tracks, the bias fragments and the dist tile
-    const int nt = min(TT, T - t0);
-    {
-        // ET is a multiple of 4 and the tables are 16-byte aligned: stage with float4, several loads in flight
-        const f32x4* src = reinterpret_cast<const f32x4*>(UP + ((size_t)b * T + t0) * ET);
-        f32x4* dst = reinterpret_cast<f32x4*>(s_up);
-#pragma unroll 4
-        for (int e = tid; e < nt * (ET / 4); e += 256) dst[e] = src[e];
-        const f32x4* bsrc = reinterpret_cast<const f32x4*>(packed + P.biasf);
-        f32x4* bdst = reinterpret_cast<f32x4*>(s_bias);
-#pragma unroll
-        for (int e = tid; e < NBIAS * 64; e += 256) bdst[e] = bsrc[e];
-    }
-#pragma unroll 4
-    for (int e = tid; e < TT * 16; e += 256) s_hp[e] = hand_prev[((size_t)b * T + min(t0 + (e >> 4), T - 1)) * 16 + (e & 15)];
-#pragma unroll
-    for (int e = tid; e < 64 * 16; e += 256) {
-        const int dd = e >> 4, c = e & 15;
-        // slot 7 of a detection row (unused padding in the hand table) carries the column norm of shasta.py:279
-        s_hd[dd * 17 + c] = c == 7 ? denom[(size_t)b * D + min(dblk + dd, D - 1)]
-                                   : hand_det[((size_t)b * D + min(dblk + dd, D - 1)) * 16 + c];
-    }
-
-    Frags<F, L_FS2> w_fs2; Frags<F, L_FS3> w_fs3; Frags<F, L_FS4> w_fs4;
-    Frags<F, L_RC2> w_rc2; Frags<F, L_RC3> w_rc3;
-    Frags<F, L_FD2> w_fd2; Frags<F, L_FD3> w_fd3;
-    const float* pf = packed + P.frags;
-    w_fs2.load(pf, lane); w_fs3.load(pf, lane); w_fs4.load(pf, lane);
-    w_rc2.load(pf, lane); w_rc3.load(pf, lane);
-    w_fd2.load(pf, lane); w_fd3.load(pf, lane);
-
-    // this lane's slice of the detection-side embedding: k = kq*S + s
-    float uc_fs[S_FS], uc_rc[S_RC], uc_fd[S_FD];
-    {
-        const float* u = UC + ((size_t)b * D + dc) * ET;
-#pragma unroll
-        for (int s = 0; s < S_FS; ++s) uc_fs[s] = u[kq * S_FS + s];
-#pragma unroll
-        for (int s = 0; s < S_RC; ++s) uc_rc[s] = u[H1 + kq * S_RC + s];
-#pragma unroll
-        for (int s = 0; s < S_FD; ++s) uc_fd[s] = u[H1 + R1 + kq * S_FD + s];
-    }
-    __syncthreads();
-    // hand-designed residual (shasta.py:277-283) for the TT x 64 pairs of this workgroup, 4 pairs per thread
-    for (int e = tid; e < TT * 64; e += 256) {
-        const int tt = e >> 6, dd = e & 63;
-        const float* hp = s_hp + tt * 16;
-        const float* hd = s_hd + dd * 17;
-        float d2 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 7; ++k)
-            if (k < nf) {
-                const float df = hp[k] - hd[k];
-                d2 += df * df;
-            }
-        float r = d2 / hd[7];
-        const float dim = (fabsf(hp[8] - hd[8]) + fabsf(hp[9] - hd[9])) + fabsf(hp[10] - hd[10]);
-        const float dcs = hp[11] - hd[11], dsn = hp[12] - hd[12];
-        s_dist[e] = (r + dim) + sqrtf(dcs * dcs + dsn * dsn);
-    }
-    __syncthreads();
-
-    auto bias = [&](int l, int bo) -> f32x4 {
-        return *reinterpret_cast<const f32x4*>(&s_bias[(bias_offset(F, l) + bo) * 256 + lane * 4]);
-    };
-    auto relu4 = [](f32x4 v) -> f32x4 {
-        v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
-        return v;
-    };
-
-    // One step = the 16 pairs (track t0+tt) x (this wave's 16 detections).  No branch inside: the result goes to the
-    // LDS tile (lanes kq != 0 write to a scratch slot), so two steps can be interleaved by the scheduler (UNROLL = 2)
-    // and the tile leaves the workgroup as whole 256-byte rows after the loop.
-    auto step = [&](int tt) {
-        const float* up = s_up + tt * ET;
-        // ---- layer 1 (factorised): h1 = relu(UP[t] + UC[d]) ----
-        float h_fs[S_FS], h_rc[S_RC], h_fd[S_FD];
-#pragma unroll
-        for (int s = 0; s < S_FS; ++s) h_fs[s] = fmaxf(up[kq * S_FS + s] + uc_fs[s], 0.0f);
-#pragma unroll
-        for (int s = 0; s < S_RC; ++s) h_rc[s] = fmaxf(up[H1 + kq * S_RC + s] + uc_rc[s], 0.0f);
-#pragma unroll
-        for (int s = 0; s < S_FD; ++s) h_fd[s] = fmaxf(up[H1 + R1 + kq * S_FD + s] + uc_fd[s], 0.0f);
-
-        // ---- layer 2 of the three MLPs (independent accumulators, interleaved) ----
-        constexpr int NB_FS2 = Frags<F, L_FS2>::NB, NB_RC2 = Frags<F, L_RC2>::NB;
-        f32x4 a_fs2[NB_FS2], a_rc2[NB_RC2], a_fd2;
-#pragma unroll
-        for (int bo = 0; bo < NB_FS2; ++bo) a_fs2[bo] = bias(L_FS2, bo);
-#pragma unroll
-        for (int bo = 0; bo < NB_RC2; ++bo) a_rc2[bo] = bias(L_RC2, bo);
-        a_fd2 = bias(L_FD2, 0);
-        constexpr int SMAX = S_RC > S_FS ? (S_RC > S_FD ? S_RC : S_FD) : (S_FS > S_FD ? S_FS : S_FD);
-#pragma unroll
-        for (int s = 0; s < SMAX; ++s) {
-            if (s < S_RC) {
-#pragma unroll
-                for (int bo = 0; bo < NB_RC2; ++bo) a_rc2[bo] = MFMA16(w_rc2.w[bo][s], h_rc[s], a_rc2[bo]);
-            }
-            if (s < S_FS) {
-#pragma unroll
-                for (int bo = 0; bo < NB_FS2; ++bo) a_fs2[bo] = MFMA16(w_fs2.w[bo][s], h_fs[s], a_fs2[bo]);
-            }
-            if (s < S_FD) a_fd2 = MFMA16(w_fd2.w[0][s], h_fd[s], a_fd2);
-        }
-#pragma unroll
-        for (int bo = 0; bo < NB_FS2; ++bo) a_fs2[bo] = relu4(a_fs2[bo]);
-#pragma unroll
-        for (int bo = 0; bo < NB_RC2; ++bo) a_rc2[bo] = relu4(a_rc2[bo]);
-        a_fd2 = relu4(a_fd2);
-
-        // ---- layer 3: inputs are the layer-2 accumulators, register r of block bi = k-step ----
-        f32x4 a_fs3 = bias(L_FS3, 0), a_rc3 = bias(L_RC3, 0), a_fd3 = bias(L_FD3, 0);
-        {
-            int st = 0;
-#pragma unroll
-            for (int bi = 0; bi < NB_FS2; ++bi)
-#pragma unroll
-                for (int r = 0; r < (blk_count(dm.H2, bi) + 3) / 4; ++r) a_fs3 = MFMA16(w_fs3.w[0][st++], a_fs2[bi][r], a_fs3);
-            st = 0;
-#pragma unroll
-            for (int bi = 0; bi < NB_RC2; ++bi)
-#pragma unroll
-                for (int r = 0; r < (blk_count(dm.R2, bi) + 3) / 4; ++r) a_rc3 = MFMA16(w_rc3.w[0][st++], a_rc2[bi][r], a_rc3);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) a_fd3 = MFMA16(w_fd3.w[0][r], a_fd2[r], a_fd3);
-        }
-        a_fs3 = relu4(a_fs3);
-        // ---- layer 4 of fuse_shape ----
-        f32x4 a_fs4 = bias(L_FS4, 0);
-#pragma unroll
-        for (int r = 0; r < (dm.H3 + 3) / 4; ++r) a_fs4 = MFMA16(w_fs4.w[0][r], a_fs3[r], a_fs4);
-
-        // ---- combine (shasta.py:316-319): alpha, beta, omega = res_coeff outputs 0,1,2 (valid in the kq == 0 lanes) ----
-        const float alpha = a_rc3[0], beta = a_rc3[1], omega = a_rc3[2];
-        const float fused = a_fd3[0], shape = a_fs4[0];
-        const int slot = tt * 64 + wid * 16 + p;
-        const float dst = s_dist[slot];
-        const float r = (alpha * fused + beta * dst) + omega * shape;
-        s_dist[kq == 0 ? slot : TT * 64 + TT * 16 + lane + 64 * wid] = r;  // scratch behind s_hp for the other lanes
-    };
-    // de-synchronise the waves that share a SIMD's matrix pipe (same program, same phase otherwise)
-    for (int z = 0; z < stagger * (int)(blockIdx.y & 3); ++z) __builtin_amdgcn_s_sleep(8);
-    if constexpr (UNROLL == 2) {
-        int tt = 0;
-        for (; tt + 1 < nt; tt += 2) {
-            step(tt);
-            step(tt + 1);
-        }
-        if (tt < nt) step(tt);
-    } else {
-        for (int tt = 0; tt < nt; ++tt) step(tt);
-    }
-    __syncthreads();
-    for (int e = tid; e < nt * 64; e += 256) {
-        const int tt = e >> 6, dd = dblk + (e & 63);
-        if (dd < D) residual[((size_t)b * T + t0 + tt) * ld + dd] = s_dist[e];
-    }
-    (void)d;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// pair_valu: the same math with one lane per pair and the weights as scalar operands.
-// Measured on MI355X (profiles/README.md): f32-input MFMA runs at exactly the f32 VALU rate (64 FLOP/clk/SIMD) and does
-// not co-execute with VALU work (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so for these small layers the 16x16 tile padding of
-// the MFMA chain (44 MFMAs = 2816 MAC slots per pair for 1984 useful MACs) plus its ~115 VALU instructions per 16 pairs
-// cost 139 SIMD-cycles per pair.  Here every v_fmac_f32 does 64 useful MACs: lane = detection d (64 per wave), the
-// wave walks the tracks t; UP[t] and all weights are wave-uniform -> SGPR operands fed by s_load_dwordx4..x16 from the
-// transposed/padded weight block; the detection-side embeddings UC[d] come from an LDS tile shared by the 4 waves.
-//   per 64 pairs: 1984 FMA + 256 (add, relu of layer 1) + ~150 (bias, relu, hand residual, combine) VALU instructions.
-// Summation order per output: bias, then k ascending (a k-ordered fmaf chain, like the MFMA form).
-// ------------------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(4))) float cfloat;  // constant address space: uniform loads become s_load_dword*
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// acc[j] = fma(w[j], h, acc[j]) for one weight row, two outputs per instruction: plain v_fma_f32 issues at half the f32
-// rate of the SIMD (4 cycles per wave64 instruction); v_pk_fma_f32 does two FMAs per lane in the same 4 cycles.
-template <int HP>
-__device__ __forceinline__ void pk_fma_row(const float (&w)[HP], float h, float* acc) {
-    const f32x2 h2 = {h, h};
-#pragma unroll
-    for (int j = 0; j < HP; j += 2) {
-        const f32x2 w2 = {w[j], w[j + 1]};
-        f32x2 a2 = {acc[j], acc[j + 1]};
-        a2 = __builtin_elementwise_fma(w2, h2, a2);
-        acc[j] = a2[0];
-        acc[j + 1] = a2[1];
-    }
-}
-
-template <int F, int L>
-struct VW {
-    static constexpr LayerDesc D = layer_desc(F, L);
-    static constexpr int HP = vw_hp(F, L), OFF = vw_offset(F, L), KIN = D.kin, HOUT = D.hout;
-};
-
-template <int F>
-__global__ __launch_bounds__(256) void pair_valu_kernel(const float* __restrict__ packed, const float* __restrict__ UP,
-                                                        const float* __restrict__ UC, const float* __restrict__ hand_prev,
-                                                        const float* __restrict__ hand_det, const float* __restrict__ denom,
-                                                        float* __restrict__ residual, int T, int D, int ld, int nf,
-                                                        int TW) {
-    constexpr PairDims dm(F);
-    constexpr int H1 = dm.H1, R1 = dm.R1, ET = dm.ET, US = ET + 4;  // LDS row stride: +4 floats spreads the banks
-    extern __shared__ __attribute__((aligned(16))) float s_uc[];     // [64][US]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, d0 = blockIdx.x * 64;
-    const int d = d0 + lane, dcl = min(d, D - 1);
-    const PackedLayout P(0, 0, F);
-    const float* __restrict__ vw = packed + P.vw;
-
-    // stage the 64 detection-side embedding rows
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(UC);
-#pragma unroll 4
-        for (int e = tid; e < 64 * (ET / 4); e += 256) {
-            const int r = e / (ET / 4), c = e - r * (ET / 4);
-            const f32x4 v = src[((size_t)b * D + min(d0 + r, D - 1)) * (ET / 4) + c];
-            *reinterpret_cast<f32x4*>(&s_uc[r * US + 4 * c]) = v;
-        }
-    }
-    // this lane's detection: hand features and column norm
-    float hd[13];
-    {
-        const f32x4* h = reinterpret_cast<const f32x4*>(hand_det + ((size_t)b * D + dcl) * 16);
-        const f32x4 a = h[0], c = h[1], e = h[2], g = h[3];
-        hd[0] = a[0]; hd[1] = a[1]; hd[2] = a[2]; hd[3] = a[3]; hd[4] = c[0]; hd[5] = c[1]; hd[6] = c[2];
-        hd[7] = e[0]; hd[8] = e[1]; hd[9] = e[2]; hd[10] = e[3]; hd[11] = g[0]; hd[12] = 0.0f;
-    }
-    const float dnm = denom[(size_t)b * D + dcl];
-    __syncthreads();
-    const float* ucrow = s_uc + lane * US;
-
-    const int t_beg = (blockIdx.y * 4 + wid) * TW;
-    const int t_end = min(T, t_beg + TW);
-    for (int t = t_beg; t < t_end; ++t) {
-        // wave-uniform, read-only in this kernel: constant address space -> s_load
-        const cfloat* up = (const cfloat*)(UP + ((size_t)b * T + t) * ET);
-        const cfloat* hp = (const cfloat*)(hand_prev + ((size_t)b * T + t) * 16);
-        // The weights are loop invariant: without this the compiler hoists all ~2000 scalar loads out of the track loop
-        // and spills them.  An opaque copy of the base pointer per iteration keeps the s_loads next to their uses.
-        unsigned long long wbits = (unsigned long long)vw;
-        asm volatile("" : "+s"(wbits));
-        const cfloat* vwt = (const cfloat*)wbits;
-
-        // ---- one MLP branch: layer 1 (factorised) feeding layer 2 -------------------------------------------
-        // Scalar loads from the constant address space carry no ordering, so the compiler would float all ~130
-        // s_load_dwordx16 of an iteration to its top and spill ~2000 SGPRs.  Each weight row is therefore addressed
-        // through a pointer that passes an empty asm together with acc[0]: the row for input k+1 can only be requested
-        // once the FMAs of input k-1 have been issued -> one row of prefetch, <= 2*HP weights live in SGPRs.
-        auto tie = [&](const cfloat* w, float* a, auto hp_tag) -> const cfloat* {
-            constexpr int HP = decltype(hp_tag)::value;
-            unsigned long long bits = (unsigned long long)w;
-            // every accumulator pair of the group passes the asm: none of the group's FMAs can be postponed past it.
-            // Pairs are passed as 64-bit operands so that they stay in the aligned register pairs v_pk_fma_f32 needs.
-            f32x2* p = reinterpret_cast<f32x2*>(a);
-            if constexpr (HP == 4)
-                asm volatile("" : "+s"(bits), "+v"(p[0]), "+v"(p[1]));
-            else if constexpr (HP == 8)
-                asm volatile("" : "+s"(bits), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));
-            else if constexpr (HP == 12)
-                asm volatile("" : "+s"(bits), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]));
-            else if constexpr (HP == 16)
-                asm volatile("" : "+s"(bits), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
-            else {
-                static_assert(HP == 20, "unsupported padded width");
-                asm volatile("" : "+s"(bits), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]),
-                             "+v"(p[8]), "+v"(p[9]));
-            }
-            return (const cfloat*)bits;
-        };
-        auto layer12 = [&](auto tag, int seg, float* acc) {
-            using W2 = decltype(tag);
-            const cfloat* w = vwt + W2::OFF;
-            float wc[W2::HP], wn[W2::HP];
-#pragma unroll
-            for (int j = 0; j < W2::HP; ++j) acc[j] = w[W2::KIN * W2::HP + j];  // bias row
-#pragma unroll
-            for (int j = 0; j < W2::HP; ++j) wc[j] = w[j];
-#pragma unroll
-            for (int k = 0; k < W2::KIN; k += 4) {
-                const f32x4 u = *reinterpret_cast<const f32x4*>(ucrow + seg + k);
-                float upv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) upv[q] = up[seg + k + q];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (k + q + 1 < W2::KIN) {
-                        const cfloat* wr = tie(w, acc, std::integral_constant<int, W2::HP>{}) + (k + q + 1) * W2::HP;
-#pragma unroll
-                        for (int j = 0; j < W2::HP; ++j) wn[j] = wr[j];
-                    }
-                    const float h = fmaxf(upv[q] + u[q], 0.0f);
-                    pk_fma_row<W2::HP>(wc, h, acc);
-#pragma unroll
-                    for (int j = 0; j < W2::HP; ++j) wc[j] = wn[j];
-                }
-            }
-        };
-        auto layer = [&](auto tag, const float* in, float* acc) {  // acc = bias + W . relu(in)
-            using WL = decltype(tag);
-            const cfloat* w = vwt + WL::OFF;
-            float wc[WL::HP], wn[WL::HP];
-#pragma unroll
-            for (int j = 0; j < WL::HP; ++j) acc[j] = w[WL::KIN * WL::HP + j];
-#pragma unroll
-            for (int j = 0; j < WL::HP; ++j) wc[j] = w[j];
-#pragma unroll
-            for (int k = 0; k < WL::KIN; ++k) {
-                if (k + 1 < WL::KIN) {
-                    const cfloat* wr = tie(w, acc, std::integral_constant<int, WL::HP>{}) + (k + 1) * WL::HP;
-#pragma unroll
-                    for (int j = 0; j < WL::HP; ++j) wn[j] = wr[j];
-                }
-                const float h = fmaxf(in[k], 0.0f);
-                pk_fma_row<WL::HP>(wc, h, acc);
-#pragma unroll
-                for (int j = 0; j < WL::HP; ++j) wc[j] = wn[j];
-            }
-        };
-        alignas(8) float a_rc2[VW<F, L_RC2>::HP], a_rc3[VW<F, L_RC3>::HP];
-        layer12(VW<F, L_RC2>{}, H1, a_rc2);
-        layer(VW<F, L_RC3>{}, a_rc2, a_rc3);
-        alignas(8) float a_fs2[VW<F, L_FS2>::HP], a_fs3[VW<F, L_FS3>::HP], a_fs4[VW<F, L_FS4>::HP];
-        layer12(VW<F, L_FS2>{}, 0, a_fs2);
-        layer(VW<F, L_FS3>{}, a_fs2, a_fs3);
-        layer(VW<F, L_FS4>{}, a_fs3, a_fs4);
-        alignas(8) float a_fd2[VW<F, L_FD2>::HP], a_fd3[VW<F, L_FD3>::HP];
-        layer12(VW<F, L_FD2>{}, H1 + R1, a_fd2);
-        layer(VW<F, L_FD3>{}, a_fd2, a_fd3);
-
-        // ---- hand-designed residual (shasta.py:277-283) ----
-        float d2 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 7; ++k)
-            if (k < nf) {
-                const float df = hp[k] - hd[k];
-                d2 += df * df;
-            }
-        float r = d2 / dnm;
-        const float dim = (fabsf(hp[8] - hd[7]) + fabsf(hp[9] - hd[8])) + fabsf(hp[10] - hd[9]);
-        const float dcs = hp[11] - hd[10], dsn = hp[12] - hd[11];
-        const float dist = (r + dim) + sqrtf(dcs * dcs + dsn * dsn);
-        // ---- combine (shasta.py:316-319) ----
-        const float res = (a_rc3[0] * a_fd3[0] + a_rc3[1] * dist) + a_rc3[2] * a_fs4[0];
-        if (d < D) residual[((size_t)b * T + t) * ld + d] = res;
     }
 }
 
@@ -877,8 +425,8 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     float* denom = reinterpret_cast<float*>(base);
 
     // row embeddings UP / UC: from 8192 table rows on the bf16-piece GEMM (gemm_pieces.hip: 128-row tiles, 1.35x the f32 MFMA
-    // kernel at 64 k rows), below that the 64-row f32 tiles fill the chip better.  SHASTA_GEMM_F32=1 keeps the f32 kernel.
-    static const bool gemm_f32 = getenv("SHASTA_GEMM_F32") != nullptr;
+    // kernel at 64 k rows), below that the 64-row f32 tiles fill the chip better.  SHASTA_OPT_F32_EMBED_GEMM keeps the f32 kernel.
+    const bool gemm_f32 = (w->options & SHASTA_OPT_F32_EMBED_GEMM) != 0;
     int rc;
     if (B * T >= 8192 && !gemm_f32 && F % 4 == 0)
         rc = launch_gemm_nt_pieces(prev_feat, packed + P.wemb_prev, nullptr, UP, feat, packed + P.wemb_cur, packed + P.bemb_cur, UC, F,
@@ -906,81 +454,30 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     hipLaunchKernelGGL(col_norm_kernel, dim3(cdiv(D, 16), B), dim3(256), 0, st, hand_prev, hand_det, denom, T, D, nf);
     rc = check_launch("col_norm");
     if (rc) return rc;
-    static const bool use_mfma_chain = getenv("SHASTA_PAIR_MFMA") != nullptr;
-    static const bool use_valu = getenv("SHASTA_PAIR_VALU") != nullptr;
-    if (!use_mfma_chain && !use_valu) {
-        // default: lane = pair, 4x4x1 MFMA.  WPB waves of a workgroup share one 64-detection UC tile and take different track
-        // ranges; 8 waves per workgroup (two workgroups per CU by LDS, 113 VGPRs in the VGPR MFMA form) give 4 waves per SIMD
-        // where 4-wave workgroups give 3 (43 KB of LDS each).
-        static const bool w4 = getenv("SHASTA_PAIR_W4") != nullptr;
-        const int wpb = w4 ? 4 : 8;
-        int tw = 16;
-        while (tw > 2 && (long)B * cdiv(D, 64) * wpb * cdiv(T, wpb * tw) < 4096) tw >>= 1;
-        const size_t lds = ((size_t)64 * (d.ET + 4) + ((a4_total(F) + 3) & ~3) + (size_t)wpb * 3 * 256) * sizeof(float);
-        dim3 grid(cdiv(D, 64), cdiv(T, wpb * tw), B);
-#define SHASTA_LAUNCH_PAIR4(FF, WW)                                                                                                   \
-    do {                                                                                                                             \
-        if (lds > 64 * 1024)                                                                                                         \
-            (void)hipFuncSetAttribute((const void*)pair_mfma4_kernel<FF, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((pair_mfma4_kernel<FF, WW>), grid, dim3(64 * WW), lds, st, packed, UP, UC, hand_prev, hand_det, denom,    \
-                           residual, T, D, ld, nf, tw);                                                                              \
+    // lane = pair, 4x4x1 MFMA.  The 8 waves of a workgroup share one 64-detection UC tile and take different track ranges
+    // (two workgroups per CU by LDS, 113 VGPRs in the VGPR MFMA form: 4 waves per SIMD).
+    constexpr int wpb = 8;
+    int tw = 16;
+    while (tw > 2 && (long)B * cdiv(D, 64) * wpb * cdiv(T, wpb * tw) < 4096) tw >>= 1;
+    const size_t lds = ((size_t)64 * (d.ET + 4) + ((a4_total(F) + 3) & ~3) + (size_t)wpb * 3 * 256) * sizeof(float);
+    dim3 grid(cdiv(D, 64), cdiv(T, wpb * tw), B);
+#define SHASTA_LAUNCH_PAIR4(FF)                                                                                                        \
+    do {                                                                                                                              \
+        if (lds > 64 * 1024)                                                                                                          \
+            (void)hipFuncSetAttribute((const void*)pair_mfma4_kernel<FF, wpb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((pair_mfma4_kernel<FF, wpb>), grid, dim3(64 * wpb), lds, st, packed, UP, UC, hand_prev, hand_det, denom,   \
+                           residual, T, D, ld, nf, tw);                                                                               \
     } while (0)
-        if (ev0) (void)hipEventRecord(ev0, st);  // bench.py: HIP events around the pair kernel alone
-        switch (F) {
-            case 64: if (w4) SHASTA_LAUNCH_PAIR4(64, 4); else SHASTA_LAUNCH_PAIR4(64, 8); break;
-            case 256: if (w4) SHASTA_LAUNCH_PAIR4(256, 4); else SHASTA_LAUNCH_PAIR4(256, 8); break;
-            case 320: if (w4) SHASTA_LAUNCH_PAIR4(320, 4); else SHASTA_LAUNCH_PAIR4(320, 8); break;
-            default: set_error_msg("pair_residual: feat_dim must be 64, 256 or 320"); return SHASTA_E_ARG;
-        }
-        if (ev1) (void)hipEventRecord(ev1, st);
-#undef SHASTA_LAUNCH_PAIR4
-        return check_launch("pair_mfma4");
-    }
-    if (!use_mfma_chain) {
-        // tracks per wave: enough workgroups for >= 4 waves per SIMD when the batch allows it
-        int tw = 16;
-        while (tw > 2 && (long)B * cdiv(D, 64) * 4 * cdiv(T, 4 * tw) < 4096) tw >>= 1;
-        const size_t lds = (size_t)64 * (d.ET + 4) * sizeof(float);
-        dim3 grid(cdiv(D, 64), cdiv(T, 4 * tw), B);
-        if (ev0) (void)hipEventRecord(ev0, st);
-        switch (F) {
-            case 64: hipLaunchKernelGGL(pair_valu_kernel<64>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
-            case 256: hipLaunchKernelGGL(pair_valu_kernel<256>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
-            case 320: hipLaunchKernelGGL(pair_valu_kernel<320>, grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tw); break;
-            default: set_error_msg("pair_residual: feat_dim must be 64, 256 or 320"); return SHASTA_E_ARG;
-        }
-        if (ev1) (void)hipEventRecord(ev1, st);
-        return check_launch("pair_valu");
-    }
-    // tracks per workgroup: the largest of 32/16/8 that still yields >= 2 waves per SIMD on 256 CUs
-    int tt = 32;  // measured: 8..32 tie once the chip is full, 64 loses occupancy to its LDS footprint
-    while (tt > 8 && (long)B * cdiv(D, 64) * 4 * cdiv(T, tt) < 2048) tt >>= 1;
-    if (const char* e = getenv("SHASTA_PAIR_TT")) {  // tuning override
-        const int v = atoi(e);
-        if (v == 8 || v == 16 || v == 32 || v == 64) tt = v;
-    }
-    const size_t lds = ((size_t)tt * (d.ET + 64 + 16) + 256) * sizeof(float);
-    dim3 grid(cdiv(D, 64), cdiv(T, tt), B);
-    static const bool unroll2 = getenv("SHASTA_PAIR_UNROLL2") != nullptr;
-    static const int stagger = getenv("SHASTA_PAIR_STAGGER") ? atoi(getenv("SHASTA_PAIR_STAGGER")) : 0;
-    if (ev0) (void)hipEventRecord(ev0, st);
+    if (ev0) (void)hipEventRecord(ev0, st);  // bench.py: HIP events around the pair kernel alone
     switch (F) {
-        case 64:
-            if (unroll2) hipLaunchKernelGGL((pair_mfma_kernel<64, 2>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt, stagger);
-            else hipLaunchKernelGGL((pair_mfma_kernel<64, 1>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt, stagger);
-            break;
-        case 256:
-            if (unroll2) hipLaunchKernelGGL((pair_mfma_kernel<256, 2>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt, stagger);
-            else hipLaunchKernelGGL((pair_mfma_kernel<256, 1>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt, stagger);
-            break;
-        case 320:
-            if (unroll2) hipLaunchKernelGGL((pair_mfma_kernel<320, 2>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt, stagger);
-            else hipLaunchKernelGGL((pair_mfma_kernel<320, 1>), grid, dim3(256), lds, st, packed, UP, UC, hand_prev, hand_det, denom, residual, T, D, ld, nf, tt, stagger);
-            break;
+        case 64: SHASTA_LAUNCH_PAIR4(64); break;
+        case 256: SHASTA_LAUNCH_PAIR4(256); break;
+        case 320: SHASTA_LAUNCH_PAIR4(320); break;
         default: set_error_msg("pair_residual: feat_dim must be 64, 256 or 320"); return SHASTA_E_ARG;
     }
     if (ev1) (void)hipEventRecord(ev1, st);
-    return check_launch("pair_mfma");
+#undef SHASTA_LAUNCH_PAIR4
+    return check_launch("pair_mfma4");
 }
 
 int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {

@@ -8,14 +8,8 @@
 // generic GEMM; the pair kernel only adds them, applies ReLU and runs the remaining small layers on the matrix
 // cores.  The (B, T*D, 2F) pair tensor of the reference (516 MB at N=500) is never materialised.
 //
-// Later layers run as  out^T[feat][pair] = W[feat][k] . h^T[k][pair]  with v_mfma_f32_16x16x4_f32:
-//   A operand = weight fragment (lane l: row i = l&15, k-slot kq = l>>4), B operand = activations of pair l&15,
-//   D: lane (pair = l&15, kq = l>>4) register r holds output row 4*kq + r.
-// Output feature f of a 16-row block is stored in row 4*(f%4) + f/4, so that lane kq register r holds feature
-// kq + 4r: the accumulator registers of one layer are then, unmoved, the B operands of the next layer's k-steps
-// (step r covers features 4r..4r+3), and a block with c valid features needs only ceil(c/4) steps.
-// The last layer of each MLP uses identity rows (feature f in row f) so its outputs sit in registers 0..2 of the
-// kq == 0 lanes.
+// Later layers run with one LANE per pair on v_mfma_f32_4x4x1_16B_f32 (pair.hip): the four result registers of a lane are
+// four output features of its own pair, so a layer's accumulators are, unmoved, the next layer's inputs.
 #pragma once
 
 namespace shasta {
@@ -25,10 +19,6 @@ namespace shasta {
 #else
 #define SH_HD
 #endif
-
-SH_HD constexpr int nblk(int h) { return (h + 15) / 16; }
-SH_HD constexpr int blk_count(int h, int b) { return (h - 16 * b) < 16 ? (h - 16 * b) : 16; }
-SH_HD constexpr int chained_steps(int hprev) { return (hprev / 16) * 4 + ((hprev % 16) + 3) / 4; }
 
 struct PairDims {
     int F, H1, H2, H3, R1, R2, ET;
@@ -40,49 +30,20 @@ struct PairDims {
 enum { L_FS2 = 0, L_FS3, L_FS4, L_RC2, L_RC3, L_FD2, L_FD3, L_COUNT };
 
 struct LayerDesc {
-    int hout;     // output features
-    int kin;      // input features
-    int chained;  // 0: input built by VALU (k = kq*S + s), 1: input = previous layer's accumulators
-    int final_;   // identity output rows
-    SH_HD constexpr int steps() const { return chained ? chained_steps(kin) : kin / 4; }
-    SH_HD constexpr int frags() const { return nblk(hout) * steps(); }
+    int hout;  // output features
+    int kin;   // input features
 };
 
 SH_HD constexpr LayerDesc layer_desc(int F, int l) {
     const PairDims d(F);
-    return l == L_FS2   ? LayerDesc{d.H2, d.H1, 0, 0}
-           : l == L_FS3 ? LayerDesc{d.H3, d.H2, 1, 0}
-           : l == L_FS4 ? LayerDesc{1, d.H3, 1, 1}
-           : l == L_RC2 ? LayerDesc{d.R2, d.R1, 0, 0}
-           : l == L_RC3 ? LayerDesc{3, d.R2, 1, 1}
-           : l == L_FD2 ? LayerDesc{8, 32, 0, 0}
-                        : LayerDesc{1, 8, 1, 1};
+    return l == L_FS2   ? LayerDesc{d.H2, d.H1}
+           : l == L_FS3 ? LayerDesc{d.H3, d.H2}
+           : l == L_FS4 ? LayerDesc{1, d.H3}
+           : l == L_RC2 ? LayerDesc{d.R2, d.R1}
+           : l == L_RC3 ? LayerDesc{3, d.R2}
+           : l == L_FD2 ? LayerDesc{8, 32}
+                        : LayerDesc{1, 8};
 }
-
-// offset (in 64-float fragments) of layer l's first weight fragment / first bias fragment group
-SH_HD constexpr int frag_offset(int F, int l) {
-    int o = 0;
-    for (int i = 0; i < l; ++i) o += layer_desc(F, i).frags();
-    return o;
-}
-SH_HD constexpr int total_frags(int F) { return frag_offset(F, L_COUNT); }
-SH_HD constexpr int bias_offset(int F, int l) {  // in units of 256 floats ([64 lanes][4 regs])
-    int o = 0;
-    for (int i = 0; i < l; ++i) o += nblk(layer_desc(F, i).hout);
-    return o;
-}
-SH_HD constexpr int total_bias_blocks(int F) { return bias_offset(F, L_COUNT); }
-
-// VALU formulation (pair_valu_kernel): layer l is stored transposed and padded, Wt[kin][HP] followed by bias[HP],
-// HP = hout rounded up to 4, so that the HP weights that multiply one input feature are one aligned scalar load.
-SH_HD constexpr int vw_hp(int F, int l) { return (layer_desc(F, l).hout + 3) / 4 * 4; }
-SH_HD constexpr int vw_size(int F, int l) { return (layer_desc(F, l).kin + 1) * vw_hp(F, l); }
-SH_HD constexpr int vw_offset(int F, int l) {
-    int o = 0;
-    for (int i = 0; i < l; ++i) o += vw_size(F, i);
-    return o;
-}
-SH_HD constexpr int vw_total(int F) { return (vw_offset(F, L_COUNT) + 3) / 4 * 4; }
 
 // 4x4x1 formulation (pair_mfma4_kernel): layer l as A operands of v_mfma_f32_4x4x1_16B_f32.  Per output block ob (4
 // features) and k-group kg (4 inputs): 16 floats [i][kk] = W[4*ob + i][4*kg + kk] (zero padded); after all blocks, the
@@ -100,7 +61,7 @@ SH_HD constexpr int a4_total(int F) { return a4_offset(F, L_COUNT); }
 // Packed buffer sections (float offsets).  Dp = padded aff width (multiple of 4).
 struct PackedLayout {
     int F, nf, N, D, Dp, E12, ET;
-    size_t frags, biasf, vw, a4, wemb_prev, wemb_cur, bemb_cur, wbox_prev, wbox_cur, bbox_cur, aff0, total;
+    size_t a4, wemb_prev, wemb_cur, bemb_cur, wbox_prev, wbox_cur, bbox_cur, aff0, total;
     SH_HD PackedLayout(int max_obj, int num_feats, int f) {
         const PairDims d(f);
         F = f;
@@ -111,10 +72,7 @@ struct PackedLayout {
         E12 = d.H1 + d.R1;
         ET = d.ET;
         size_t o = 0;
-        frags = o;      o += (size_t)total_frags(f) * 64;
-        biasf = o;      o += (size_t)total_bias_blocks(f) * 256;
-        vw = o;         o += (size_t)vw_total(f);      // transposed / padded layers 2-4 for the VALU pair kernel
-        a4 = o;         o += (size_t)a4_total(f);      // 4x4x1 MFMA A operands of layers 2-4
+        a4 = o;         o += (size_t)((a4_total(f) + 3) / 4 * 4);  // 4x4x1 MFMA A operands of layers 2-4
         wemb_prev = o;  o += (size_t)E12 * f;          // [E12][F]   fuse_shape.0 / res_coeff.0, prev feature cols
         wemb_cur = o;   o += (size_t)E12 * f;          // [E12][F]   ... cur feature cols
         bemb_cur = o;   o += (size_t)((E12 + 3) / 4 * 4);  // [E12]  fuse_shape.0.bias | res_coeff.0.bias

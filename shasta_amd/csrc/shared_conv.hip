@@ -13,7 +13,6 @@
 // in the epilogue exactly as PyTorch's eval kernel does: y = (acc + bias) * alpha + beta', alpha = gamma / sqrt(var + eps),
 // beta' = beta - mean * alpha.
 #include "common.hpp"
-#include <stdlib.h>
 
 namespace shasta {
 
@@ -327,12 +326,11 @@ extern "C" int shasta_shared_conv_f32(const float* x, const float* x_prev, int B
     SHASTA_REQUIRE((uintptr_t)packed % 16 == 0, "shared_conv: packed buffer must be 16-byte aligned");
     SHASTA_REQUIRE((long)in_channels * H * W < (1L << 31), "shared_conv: one image exceeds 2^31 elements");
     if (B == 0) return SHASTA_OK;
-    static const bool force_rect = getenv("SHASTA_CONV_RECT") != nullptr;
     const int rt_max = min(H, 128 / W + 2) + 2;
     const int in_need = cdiv(CF_CK * rt_max * (W + 2), 256);  // staged input floats per thread
     const int in_pt = in_need <= 8 ? 8 : in_need <= 12 ? 12 : in_need <= 14 ? 14 : in_need <= 16 ? 16 : in_need <= 18 ? 18 : 19;  // template value (19: does not fit)
     const size_t lds = ((size_t)2 * 256 * in_pt + 2 * CF_WT) * sizeof(float);
-    if (!force_rect && W <= 256 && in_pt <= CF_IN_PT && lds <= 64 * 1024) {
+    if (W <= 256 && in_pt <= CF_IN_PT && lds <= 64 * 1024) {
         dim3 grid(cdiv(H * W, 128), 1, x_prev ? 2 * B : B);
         const float* pk = static_cast<const float*>(packed);
 #define SHASTA_CONV_FLAT(PT) \

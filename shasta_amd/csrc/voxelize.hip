@@ -193,6 +193,18 @@ __global__ void vox_finalize_kernel(const int* __restrict__ slot_idx, const int*
     }
 }
 
+// VoxelFeatureExtractorV3.forward on already voxelised input: one thread per (voxel, channel), slots summed in order
+__global__ void voxel_mean_kernel(const float* __restrict__ voxels, const float* __restrict__ counts, int V, int max_points,
+                                  int ndim, int c_used, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)V * c_used) return;
+    const int v = (int)(i / c_used), c = (int)(i % c_used);
+    const float* src = voxels + (size_t)v * max_points * ndim + c;
+    float s = 0.0f;
+    for (int r = 0; r < max_points; ++r) s += src[(size_t)r * ndim];  // padded slots are zero (voxel_encoder.py:24)
+    out[i] = s / counts[v];
+}
+
 struct VoxWs {
     size_t keys, pvid, vidp, bsum, slots, total;
     VoxWs(int P, int max_voxels, int max_points) {
@@ -294,4 +306,15 @@ extern "C" int shasta_voxelize_mean_f32(const float* points, int P, int ndim, co
     hipLaunchKernelGGL(vox_finalize_kernel, dim3(cdiv(max_voxels, 256)), dim3(256), 0, st, slots, num_voxels, max_points,
                        ndim, voxels, num_points_per_voxel, mean);
     return check_launch("vox_finalize");
+}
+
+extern "C" int shasta_voxel_mean_f32(const float* voxels, const float* num_points_f32, int num_voxels, int max_points, int ndim,
+                                     int num_features, float* out, shasta_stream_t stream) {
+    SHASTA_REQUIRE(num_voxels >= 0 && max_points > 0 && ndim > 0 && num_features > 0 && num_features <= ndim, "voxel_mean: bad size");
+    if (num_voxels == 0) return SHASTA_OK;
+    SHASTA_REQUIRE(voxels && num_points_f32 && out, "voxel_mean: null pointer");
+    const long total = (long)num_voxels * num_features;
+    hipLaunchKernelGGL(voxel_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), voxels, num_points_f32,
+                       num_voxels, max_points, ndim, num_features, out);
+    return check_launch("voxel_mean");
 }

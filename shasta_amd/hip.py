@@ -9,7 +9,7 @@ import os
 
 import torch
 
-ABI_VERSION = 5  # must equal shasta_abi_version() of the loaded library
+ABI_VERSION = 6  # must equal shasta_abi_version() of the loaded library
 # SHASTA_HIP_LIB: load another build of the same ABI (A/B timing of kernel variants on one box)
 _LIB_PATH = os.environ.get("SHASTA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libshasta_hip.so")
 _lib = None
@@ -19,12 +19,16 @@ class ShastaHipError(RuntimeError):
     pass
 
 
+OPT_F32_WEIGHT_STREAM = 1  # include/shasta_hip.h SHASTA_OPT_*
+OPT_F32_EMBED_GEMM = 2
+
+
 class Linear(C.Structure):
     _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p)]
 
 
 class Weights(C.Structure):
-    _fields_ = [("max_obj", C.c_int), ("num_feats", C.c_int), ("feat_dim", C.c_int),
+    _fields_ = [("max_obj", C.c_int), ("num_feats", C.c_int), ("feat_dim", C.c_int), ("options", C.c_int),
                 ("aug_shape", (Linear * 2) * 4), ("aug_dets", (Linear * 2) * 4),
                 ("fuse_shape", Linear * 4), ("fuse_det", Linear * 3), ("res_coeff", Linear * 3),
                 ("aff", Linear * 6)]
@@ -41,6 +45,7 @@ SYMBOLS = {
     "shasta_voxelize_cell_map_init": (_I, [_P, _Z, _P]),
     "shasta_voxelize_workspace_bytes": (_Z, [_I, _I, _I]),
     "shasta_voxelize_mean_f32": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "shasta_voxel_mean_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "shasta_bev_gather_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P, _I, _I, _P]),
     "shasta_shared_conv_packed_bytes": (_Z, [_I]),
     "shasta_shared_conv_pack_f32": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _P, _Z, _P]),

@@ -111,6 +111,10 @@ class Shasta(BaseTrack):
         self._wstruct = None
         self._bufs = {}
         self._graph_bufs = []
+        # "pieces" (default): above 32 frame-pairs per call the aug_shape first layer and, from 8192 table rows, the
+        # row-embedding GEMMs form their fp32 products from exact bf16 pieces on the bf16 matrix path; "f32": the f32 MFMA
+        # kernels everywhere (shasta_weights.options, include/shasta_hip.h).  Both are fp32 operands / fp32 accumulation.
+        self.arithmetic = "pieces"
         self.keep_intermediates = False  # tests: also return residual / matched via self.last_intermediates
         self.last_intermediates = None
 
@@ -167,7 +171,7 @@ class Shasta(BaseTrack):
         place, moves go through _apply, and a re-assigned parameter is caught by the pointer probe over one tensor per block."""
         probe = tuple(t.data_ptr() for t in (self.aug_shape[0][0].weight, self.aug_shape[3][2].weight, self.aug_dets[0][0].weight,
                                              self.fuse_shape[0].weight, self.fuse_det[0].weight, self.res_coeff[0].weight,
-                                             self.aff[0].weight, self.aff[10].weight))
+                                             self.aff[0].weight, self.aff[10].weight)) + (self.arithmetic,)
         ws = getattr(self, "_wstruct", None)
         if ws is not None and ws[1] == probe:
             return ws[0]
@@ -185,6 +189,9 @@ class Shasta(BaseTrack):
 
         w = hip.Weights()
         w.max_obj, w.num_feats, w.feat_dim = self.max_obj, self.num_feats, self.aug_shape_output
+        if self.arithmetic not in ("pieces", "f32"):
+            raise ValueError("Shasta.arithmetic must be 'pieces' or 'f32'")
+        w.options = (hip.OPT_F32_WEIGHT_STREAM | hip.OPT_F32_EMBED_GEMM) if self.arithmetic == "f32" else 0
         for i in range(4):
             w.aug_shape[i][0], w.aug_shape[i][1] = lin(self.aug_shape[i][0]), lin(self.aug_shape[i][2])
             w.aug_dets[i][0], w.aug_dets[i][1] = lin(self.aug_dets[i][0]), lin(self.aug_dets[i][2])

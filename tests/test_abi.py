@@ -21,8 +21,24 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "library does not export " + n
         assert n in hip.SYMBOLS, "ctypes binding missing for " + n
-    assert lib.shasta_abi_version() == hip.ABI_VERSION == 5
+    assert lib.shasta_abi_version() == hip.ABI_VERSION == 6
     assert b"gfx950" in lib.shasta_build_info()
+
+
+def test_library_exports_exactly_the_declared_abi_and_reads_no_environment():
+    """-fvisibility=hidden + the linker version script: the dynamic symbol table holds the declared C functions and nothing else
+    (no kernel handles, no C++ helpers); kernel choices are per-call `options` bits, not getenv switches."""
+    import subprocess
+    from shasta_amd import hip
+    out = subprocess.run(["nm", "-D", "--defined-only", hip.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert exported == _declared()
+    und = subprocess.run(["nm", "-D", "--undefined-only", hip.lib_path()], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    csrc = os.path.join(ROOT, "shasta_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".hpp")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
 
 
 def test_size_queries_do_not_need_a_gpu():

@@ -402,46 +402,60 @@ def test_voxelize_vs_oracle_full_size(P, mp, mv, seed):
         assert np.array_equal(cell[:, ::-1], rc)
 
 
-@pytest.mark.parametrize("flag", ["SHASTA_PAIR_MFMA", "SHASTA_PAIR_VALU", "SHASTA_PAIR_W4", "SHASTA_AFF_UNFUSED", "SHASTA_AFF_RG2", "SHASTA_L1_VALU",
-                                  "SHASTA_L1_F32", "SHASTA_GEMM_F32"])
-def test_alternative_kernel_variants_match_goldens(flag):
-    """The selectable variants (16x16x4 MFMA chain / packed-VALU pair kernels, layer-by-layer aff, VALU batch kernels for
-    the anchor stream, f32 MFMA instead of bf16 pieces above 32 items) stay parity-green: rerun the golden tests in a
-    subprocess with the variant's switch set."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ)
-    env[flag] = "1"
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
-                        "test_forward_matches_reference_golden or (test_batched_forward_vs_oracle and small)"],
-                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+@pytest.mark.parametrize("name,B", [("small_32_7_4", 40), ("small_32_7_4", 100), ("car_90_3_5", 48), ("sharp_90_3_5", 70), ("truck_60_3_5", 150)])
+def test_f32_arithmetic_option_matches_oracle_and_pieces(name, B):
+    """Shasta.arithmetic = "f32" (shasta_weights.options: f32 MFMA kernels for the weight stream and the row-embedding GEMMs at
+    every batch size) against the oracle, and against the default bf16-piece arithmetic on the same inputs: both are fp32
+    products with fp32 accumulation, so they agree to summation-order noise."""
+    dev = _dev()
+    z, c, sums = load_golden(name)
+    m = build_model(c)
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(21 + B)
+    hw = c["hw"]
+    bev = torch.relu(torch.randn(B, hw, hw, 64, generator=g))
+    pbev = torch.relu(torch.randn(B, hw, hw, 64, generator=g))
+    det = O.synth_boxes(g, B, c["max_obj"], c["n_real"])
+    prev = O.synth_boxes(g, B, c["max_obj"], c["n_real"])
+    r1, r2, im = O.forward_from_bev(w, bev, pbev, det.clone(), prev.clone(), c["nf"], c["np"], out_stride=c["stride"],
+                                    return_intermediates=True)
+    m = m.to(dev)
+    m.keep_intermediates = True
+    outs = {}
+    for mode in ("pieces", "f32"):
+        m.arithmetic = mode
+        ex = dict(det_boxes=det.clone().to(dev), prev_det_boxes=prev.to(dev), bev_feature=bev.to(dev), prev_bev_feature=pbev.to(dev))
+        with torch.no_grad():
+            m1, m2, _ = m(ex, train_mode=False)
+        outs[mode] = (m1.cpu().numpy(), m2.cpu().numpy(), m.last_intermediates["residual"].cpu().numpy())
+        tol = 1e-4 if c["sharp"] else 1e-6
+        np.testing.assert_allclose(outs[mode][0], r1.numpy(), rtol=0, atol=tol)
+        np.testing.assert_allclose(outs[mode][1], r2.numpy(), rtol=0, atol=tol)
+        ref = im["residual"].numpy()
+        np.testing.assert_allclose(outs[mode][2], ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
+    assert not np.array_equal(outs["pieces"][2], outs["f32"][2])  # two different kernels did run
 
 
 def test_bf16_piece_kernel_is_fp32_accurate():
     """anchor_split.hip computes the fp32 products of the first aug_shape layer as six exact bf16 piece products.  Its
     error against a float64 evaluation of relu(W x + b) must be at the level of the f32 MFMA kernel's own rounding error
-    (both are run on the same inputs, tools/l1_split_check.py; the environment switch is read once per process)."""
+    (both are run on the same inputs, tools/l1_split_check.py)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-    def run(extra_env):
-        env = dict(os.environ)
-        env.pop("SHASTA_L1_F32", None)
-        env.update(extra_env)
+    def run(extra):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "l1_split_check.py"), "--max-obj", "120", "--batch", "48", "64",
-                            "128", "--steps", "2"], env=env, capture_output=True, text=True, cwd=root, timeout=600)
+                            "128", "--steps", "2"] + extra, capture_output=True, text=True, cwd=root, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         return [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    pieces, f32 = run({}), run({"SHASTA_L1_F32": "1"})
+    pieces, f32 = run([]), run(["--f32"])
     assert len(pieces) == len(f32) == 3
     for a, b in zip(pieces, f32):
         assert not a["f32_forced"] and b["f32_forced"] and a["B"] == b["B"]
-        assert a["max_abs_err"] <= 2.0 * b["max_abs_err"] + 1e-9, (a, b)
+        assert a["max_abs_err"] <= 1.5 * b["max_abs_err"] + 1e-9, (a, b)
         assert a["max_abs_err"] < 2e-5 * max(1.0, a["ref_scale"])
 
 

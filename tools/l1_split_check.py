@@ -1,7 +1,7 @@
 """First aug_shape layer (K3a: VALU, f32 MFMA or bf16-piece kernel): error of the kernel the library picks against a float64 evaluation of the same
-relu(W x + b), and its duration.  Run once as is (bf16-piece kernel for batches > 32) and once with SHASTA_L1_F32=1 (f32 MFMA):
+relu(W x + b), and its duration.  Run once as is (bf16-piece kernel for batches > 32) and once with --f32 (Shasta.arithmetic = "f32": f32 MFMA):
 the two error columns are what DESIGN.md section 4 quotes.
-usage: python tools/l1_split_check.py [--max-obj 500] [--points 4] [--batch 64 128] [--steps 20]"""
+usage: python tools/l1_split_check.py [--max-obj 500] [--points 4] [--batch 64 128] [--steps 20] [--f32]"""
 import argparse
 import json
 import os
@@ -18,6 +18,7 @@ ap.add_argument("--feats", type=int, default=7)
 ap.add_argument("--points", type=int, default=4)
 ap.add_argument("--batch", type=int, nargs="+", default=[64, 128])
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--f32", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -25,6 +26,8 @@ with torch.device(dev):
     model = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
                                              bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
                                              max_obj=a.max_obj, num_feats=a.feats, num_point=a.points)).eval()
+if a.f32:
+    model.arithmetic = "f32"
 N = a.max_obj
 K = model.aug_shape_input
 for B in a.batch:
@@ -63,5 +66,5 @@ for B in a.batch:
         t1.record()
         torch.cuda.synchronize()
         ms = t0.elapsed_time(t1) / a.steps
-    print(json.dumps(dict(B=B, max_obj=N, K=K, f32_forced=bool(os.environ.get("SHASTA_L1_F32")), max_abs_err=err, ref_scale=scale,
+    print(json.dumps(dict(B=B, max_obj=N, K=K, f32_forced=bool(a.f32), max_abs_err=err, ref_scale=scale,
                           ms_per_step=round(ms, 4), frame_pairs_per_s=round(B / ms * 1e3, 1))), flush=True)
