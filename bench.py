@@ -10,12 +10,16 @@ the elapsed time.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the definition of every field).
+`python bench.py --gpus N` with N > 1 and no launcher environment starts its own N ranks (fresh child processes, one per
+GPU, started before this process touches the GPU; rank 0's JSON line is the output).  Rank 0 prints ONE JSON line (see
+DESIGN.md "Measurement" for the definition of every field).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,16 +34,46 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: dense f32-input MFMA peak (= f32 vec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (no sparsity)
 
 
+# Algorithmic work per frame-pair at N=M=500, F=256, nf=7; P = (N+2)^2 = 252 004 pairs
+PAIRS = (N_OBJ + 2) ** 2
+DENSE_PAIR_MACS = 17032 + 712 + 34736   # fuse_shape + fuse_det + res_coeff per pair in the reference's dense formulation
+USEFUL_PAIR_MACS = 1984                 # layers 2-4 of the three pair MLPs (the first layers are factorised over table rows)
+EXECUTED_PAIR_MACS = 2108               # the same with every layer width rounded up to the 4-wide MFMA block
+DENSE_GFLOP_PER_PAIR = 28.65            # whole forward, dense formulation: 26.45 pair MLPs + 2.05 anchors + 0.15 aff
+
+
 def l1_algorithmic_bytes(B):
-    """aug_shape first layer (anchor_l1*_kernel).  Algorithmic HBM bytes of one launch: every weight of the four
-    (N*F/64, N*F) fp32 matrices once per weight pass, the two (N*F) activation vectors of each of the B batch items
-    once, and one (4*N*F/64) partial vector per batch item written.  One weight pass serves up to
-    128 frame-pairs - from there the pass is bound by the matrix pipe, not by HBM, so larger batches take ceil(B/128)
-    passes by design."""
+    """aug_shape first layer (anchor_l1*_kernel).  ALGORITHMIC HBM bytes of one launch over B frame-pairs: every weight of the
+    four (N*F/64, N*F) fp32 matrices ONCE (4.096 GB, whatever the batch), the two (N*F) activation vectors of each batch item
+    once, one (4*N*F/64) partial vector per batch item written.  (The kernel makes ceil(B/128) weight passes above 128
+    frame-pairs per launch; those re-reads are executed traffic, not algorithmic - reported as `weight_passes_executed`.)"""
     K = N_OBJ * CH * NPOINT
     H = K // 64
-    passes = max(1, -(-B // 128))
-    return passes * 4 * H * K * 4 + 2 * B * K * 4 + B * 4 * H * 4
+    return 4 * H * K * 4 + 2 * B * K * 4 + B * 4 * H * 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` typed as is: start N fresh children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would), before this process has made any GPU call; rank 0's stdout (the JSON line) is passed through."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main():
@@ -51,7 +85,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (no HIP-event roofline)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="frame-pairs timed on the host for cpu_baseline")
+    ap.add_argument("--arithmetic", choices=["pieces", "f32"], default="pieces",
+                    help="Shasta.arithmetic: fp32 products from exact bf16 pieces above 32 frame-pairs per step (default) or f32 MFMA kernels only")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / reduction plumbing only, on the CPU with gloo (no GPU, no forward): for the CPU test suite")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -65,12 +105,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=dev)
-    assert args.gpus == world, "--gpus must equal the number of launched ranks"
+    assert args.gpus == world, "--gpus must equal the number of launched ranks (WORLD_SIZE)"
 
     lib = hip.load()
     B = args.batch
@@ -80,6 +122,7 @@ def main():
             type="Shasta", reader=None, backbone=None, neck=None,
             bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
             max_obj=N_OBJ, num_feats=NF, num_point=NPOINT)).eval()
+    model.arithmetic = args.arithmetic
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     bev = torch.relu(torch.randn(B, HW, HW, CH, device=dev, generator=g))
     pbev = torch.relu(torch.randn(B, HW, HW, CH, device=dev, generator=g))
@@ -146,6 +189,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert bool(torch.isfinite(m1).all()) and abs(float(m1[0, 0].sum()) - 1.0) < 1e-4
+    # self-check of the operating point: three frame-pairs of the timed batch recomputed one at a time (batch 1 runs the VALU
+    # weight-stream kernel and the small-batch tiles of every other stage) must reproduce the batched result
+    selfcheck = 0.0
+    with torch.no_grad():
+        for i in sorted({0, B // 2, B - 1}):
+            s1, s2 = model.affinity_from_bev(bev[i:i + 1], pbev[i:i + 1], det0[i:i + 1].clone(), prev[i:i + 1])
+            selfcheck = max(selfcheck, float((s1 - m1[i:i + 1]).abs().max()), float((s2 - m2[i:i + 1]).abs().max()))
+    assert selfcheck <= 1e-6, "self-check failed: batched and one-at-a-time results differ by %.3e" % selfcheck
 
     ms = C.c_float()
     l1, pair = [], []
@@ -163,40 +214,49 @@ def main():
             lib.shasta_event_destroy(e)
     l1_ms, pair_ms = sum(l1) / len(l1), sum(pair) / len(pair)
     step_ms = elapsed / args.steps * 1e3
-    # Kernel 1: aug_shape first layer = the 4.1 GB fp32 weight stream, read once per pass of up to 128 frame-pairs.
+    # Kernel 1: aug_shape first layer = the 4.1 GB fp32 weight stream.
     #   B <= 32: f32 MFMA kernel, 1024 matrix-pipe cycles per 4 KB weight tile against ~1300 of HBM        -> HBM-bound
     #   B <= 64: bf16-piece kernel (each fp32 product = 6 exact bf16 piece products), 768 cycles per tile   -> HBM-bound
-    #   B  > 64: the same with 128 items per pass, 1536 cycles per tile -> bound by the bf16 matrix pipe; its peak for
-    #            fp32-equivalent flops is the dense bf16 peak / 6 piece products
-    #   SHASTA_L1_F32=1 and B > 32: f32 MFMA kernel, 64 items per pass, 2048 cycles per tile -> f32 matrix pipe
+    #   B  > 64: the same with 128 items per weight pass, 1536 cycles per tile -> bound by the bf16 matrix pipe: priced as
+    #            EXECUTED bf16 flops (6 piece products per fp32 product) against the dense bf16 MFMA peak
+    #   --arithmetic f32 and B > 32: f32 MFMA kernel, 64 items per pass, 2048 cycles per tile -> f32 matrix pipe
     alg = l1_algorithmic_bytes(B)
     hbm_gbs = alg / (l1_ms * 1e-3) / 1e9
     K = N_OBJ * CH * NPOINT
-    l1_flops = 2.0 * B * 4 * (K // 64) * K  # dense fp32 flops of the four first layers for B frame-pairs
+    l1_flops = 2.0 * B * 4 * (K // 64) * K  # dense fp32 flops of the four first layers for B frame-pairs (algorithmic = executed)
     l1_tflops = l1_flops / (l1_ms * 1e-3) / 1e12
-    f32_forced = bool(os.environ.get("SHASTA_L1_F32")) or bool(os.environ.get("SHASTA_L1_VALU"))
+    f32_forced = args.arithmetic == "f32"
+    passes = 1 if B <= 32 else (-(-B // 64) if f32_forced else (1 if B <= 64 else -(-B // 128)))
     if B <= 32 or (B <= 64 and not f32_forced):
         roof_l1 = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS}
     elif f32_forced:
         roof_l1 = {"bound": "mfma", "achieved": l1_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                   "frac": l1_tflops / MFMA_F32_PEAK_TFLOPS}
+                   "frac": l1_tflops / MFMA_F32_PEAK_TFLOPS, "mfma_dtype": "f32"}
     else:
-        peak = MFMA_BF16_PEAK_TFLOPS / 6.0
-        roof_l1 = {"bound": "mfma", "achieved": l1_tflops, "peak": peak, "unit": "TFLOP/s", "frac": l1_tflops / peak,
-                   "peak_note": "fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product"}
+        roof_l1 = {"bound": "mfma", "achieved": 6.0 * l1_tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": 6.0 * l1_tflops / MFMA_BF16_PEAK_TFLOPS, "mfma_dtype": "bf16",
+                   "note": "executed bf16 MFMA flops = 6 exact piece products per fp32 product, against the dense bf16 peak"}
     roof_l1.update({"kernel": "anchor_l1_kernel (B=1) / anchor_l1_mfma_kernel (B<=32) / anchor_l1_split_kernel (B>32): "
                               "aug_shape.*.0, 4 x 2000 x 128000 fp32 weight stream",
-                    "traffic": _pmc_traffic(B), "algorithmic_bytes_per_launch": alg, "algorithmic_flops_per_launch": l1_flops,
-                    "avg_launch_ms": l1_ms, "hbm_gbs": hbm_gbs, "fp32_equivalent_tflops": l1_tflops,
+                    "traffic": _pmc_traffic(B), "algorithmic_bytes_per_launch": alg, "weight_passes_executed": passes,
+                    "executed_weight_bytes_per_launch": passes * 4 * (K // 64) * K * 4,
+                    "algorithmic_flops_per_launch": l1_flops, "executed_flops_per_launch": l1_flops if (B <= 32 or f32_forced) else 6.0 * l1_flops,
+                    "avg_launch_ms": l1_ms, "algorithmic_hbm_gbs": hbm_gbs, "fp32_tflops": l1_tflops,
                     "share_of_step": l1_ms / step_ms})
-    # Kernel 2: the pair kernel (layers 2-4 of fuse_shape / res_coeff / fuse_det for all (N+2)^2 pairs on the f32 matrix
-    # pipe): 1984 useful multiply-adds per pair; everything it reads is L2-resident.
-    pair_flops = 2.0 * 1984 * (N_OBJ + 2) ** 2 * B
-    pair_tflops = pair_flops / (pair_ms * 1e-3) / 1e12
+    # Kernel 2: the pair kernel = layers 2-4 of fuse_shape / res_coeff / fuse_det for all (N+2)^2 pairs on the f32 matrix pipe.
+    # Three flop counts per launch: `dense` = the reference's formulation of the three pair MLPs (first layers
+    # on the concatenated pair tensor), `useful` = what is left for the pair kernel once the first layers are factorised over
+    # the table rows (their GEMMs run in gemm_nt_*), `executed` = useful with every width rounded up to the MFMA block.
+    # `achieved` prices the USEFUL flops against the f32 MFMA peak.
+    pair_useful = 2.0 * USEFUL_PAIR_MACS * PAIRS * B
+    pair_tflops = pair_useful / (pair_ms * 1e-3) / 1e12
     roof_pair = {"bound": "mfma", "achieved": pair_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": pair_tflops / MFMA_F32_PEAK_TFLOPS, "traffic": _pmc_traffic(B, "pair"),
+                 "frac": pair_tflops / MFMA_F32_PEAK_TFLOPS, "mfma_dtype": "f32", "traffic": _pmc_traffic(B, "pair"),
                  "kernel": "pair_mfma4_kernel<256,8>: per-pair MLP tails + hand residual -> residual (B, 502, 502)",
-                 "algorithmic_flops_per_launch": pair_flops, "avg_launch_ms": pair_ms, "share_of_step": pair_ms / step_ms}
+                 "useful_flops_per_launch": pair_useful, "executed_flops_per_launch": 2.0 * EXECUTED_PAIR_MACS * PAIRS * B,
+                 "dense_algorithmic_flops_per_launch": 2.0 * DENSE_PAIR_MACS * PAIRS * B,
+                 "dense_equivalent_tflops": 2.0 * DENSE_PAIR_MACS * PAIRS * B / (pair_ms * 1e-3) / 1e12,
+                 "avg_launch_ms": pair_ms, "share_of_step": pair_ms / step_ms}
     # `roofline` is the kernel with the longer average launch; the other one rides along as `roofline_second`
     roof, second = (roof_l1, roof_pair) if l1_ms >= pair_ms else (roof_pair, roof_l1)
 
@@ -213,10 +273,13 @@ def main():
                    "max_obj": N_OBJ, "num_feats": NF, "num_point": NPOINT, "bev_hw": HW,
                    "parallelism": "replica x%d (frame-parallel, no data-path collective)" % world,
                    "hip_graph": bool(args.graph),
-                   "arithmetic": "fp32 operands, fp32 accumulation throughout; above 32 frame-pairs per step the first aug_shape "
-                                 "layer (and from 8192 table rows the row-embedding GEMMs) form every fp32 product from six exact "
-                                 "bf16 piece products on the bf16 MFMA path (error below the fp32 FMA's rounding; SHASTA_L1_F32=1 / "
-                                 "SHASTA_GEMM_F32=1 select the f32 MFMA kernels)"},
+                   "arithmetic": ("fp32 operands, fp32 accumulation throughout; above 32 frame-pairs per step the first aug_shape "
+                                  "layer (and from 8192 table rows the row-embedding GEMMs) form every fp32 product from six exact "
+                                  "bf16 piece products on the bf16 MFMA path (error at the level of the fp32 FMA's own rounding; "
+                                  "--arithmetic f32 selects the f32 MFMA kernels)") if args.arithmetic == "pieces" else
+                                 "fp32 operands, fp32 accumulation throughout, f32 MFMA kernels only (--arithmetic f32)"},
+        "dense_equivalent_tflops": DENSE_GFLOP_PER_PAIR * 1e9 * world * B * args.steps / elapsed / 1e12,
+        "selfcheck_max_abs": selfcheck,
         "roofline": roof,
         "roofline_second": second,
     }
@@ -271,9 +334,30 @@ def cpu_baseline(model, sample):
         O.forward_from_bev(w, bev, pbev, det.clone(), prev, NF, NPOINT)
     dt = time.perf_counter() - t0
     torch.set_num_threads(all_threads)
-    return {"value": sample / dt, "unit": "frame-pairs/s", "cores": best_n, "kind": "port",
-            "sample": "%d frame-pairs at N=M=500,F=256, batch 1, torch-CPU fp32 oracle, %.1f s; best of {8,16,32,64,%d} "
-                      "threads = %d" % (sample, dt, all_threads, best_n)}
+    host = os.cpu_count() or all_threads
+    return {"value": sample / dt, "unit": "frame-pairs/s", "cores": host, "threads": best_n, "kind": "port",
+            "sample": "%d frame-pairs at N=M=500,F=256, batch 1, torch-CPU fp32 oracle, %.1f s on a host with %d logical CPUs; the "
+                      "fastest of {8,16,32,64,%d} torch threads was used: %d" % (sample, dt, host, all_threads, best_n)}
+
+
+def dry_run(args, rank, world):
+    """CPU plumbing check of the multi-rank launch (no GPU, no forward): rendezvous over gloo, the barrier and the MAX
+    reduction over ranks that bracket the timed region, and the rank-0 JSON line with `value` null."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    assert int(t.item()) == world and args.gpus == world
+    if rank == 0:
+        print(json.dumps({"metric": "affinity frame-pairs/sec at N=M=500, F=256", "value": None, "unit": "frame-pairs/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "max_over_ranks": t.item()}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

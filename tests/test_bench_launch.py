@@ -1,0 +1,44 @@
+"""bench.py's multi-rank launch contract on the CPU (gloo, --dry-run: rendezvous, barrier, MAX over ranks, one JSON line from
+rank 0 - no GPU and no forward): typed as `python bench.py --gpus N` (self-launch of N fresh children) and under
+`python -m torch.distributed.run` as the driver starts it."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _json_lines(out):
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_gpus_2_typed_as_is_starts_its_own_ranks():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["max_over_ranks"] == 2.0 and lines[0]["steps"] == 3
+
+
+def test_bench_under_torch_distributed_run():
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["dry_run"] is True
+
+
+def test_bench_rank_count_mismatch_fails():
+    env = dict(_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=120, env=env, cwd=ROOT)
+    assert r.returncode != 0

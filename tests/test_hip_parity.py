@@ -128,6 +128,56 @@ def test_headline_size_batches_pin_every_anchor_kernel_on_the_reference_output(n
     np.testing.assert_allclose(full2.sum(1), 1.0, atol=1e-5)
 
 
+def test_benchmark_operating_point_n500_b512():
+    """The configuration bench.py publishes: N=M=500, F=256, 512 frame-pairs per step (four weight passes of the bf16-piece
+    kernel, pair / aff grids 512 x the single-frame ones).  Frame 0 is the reference's golden frame: its intermediates and
+    outputs must match the reference; frames 0, 255 and 511 recomputed one at a time (batch-1 kernels) must match the batch."""
+    dev = _dev()
+    z, c, m, bev, pbev, det, prev = _case("headline_500_7_4")
+    w_cpu = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        f0 = O.shared_conv_nhwc(w_cpu, bev).to(dev)
+        pf0 = O.shared_conv_nhwc(w_cpu, pbev).to(dev)
+    del w_cpu
+    m = m.to(dev)
+    m.keep_intermediates = True
+    B, N, hw = 512, c["max_obj"], c["hw"]
+    g = torch.Generator(device=dev).manual_seed(177)
+    f = torch.relu(torch.randn(B, hw, hw, 64, device=dev, generator=g))
+    pf = torch.relu(torch.randn(B, hw, hw, 64, device=dev, generator=g))
+    f[0], pf[0] = f0[0], pf0[0]
+
+    def boxes():
+        b = torch.zeros(B, N, 11, device=dev)
+        b[..., 0:2] = torch.rand(B, N, 2, device=dev, generator=g) * 100 - 50
+        b[..., 2] = torch.randn(B, N, device=dev, generator=g)
+        b[..., 3:6] = torch.rand(B, N, 3, device=dev, generator=g) * 4 + 0.5
+        b[..., 6] = (torch.rand(B, N, device=dev, generator=g) * 2 - 1) * 3.14159265
+        b[..., 7:9] = torch.randn(B, N, 2, device=dev, generator=g)
+        b[..., 9] = 0.5
+        return b
+    dets, prevs = boxes(), boxes()
+    dets[0], prevs[0] = det[0].to(dev), prev[0].to(dev)
+    with torch.no_grad():
+        m1, m2 = m.affinity_from_bev(f, pf, dets.clone(), prevs)
+        tabs = {k: v[:1].cpu().numpy() for k, v in m.last_intermediates.items()}
+        worst = check_intermediates(z, tabs)
+        e1, e2 = check_outputs(z, m1[:1].cpu().numpy(), m2[:1].cpu().numpy())
+        print("golden frame inside the 512-batch: max|m1-ref| %.3e max|m2-ref| %.3e; error / bound: %s" %
+              (e1, e2, ", ".join("%s %.2f" % kv for kv in worst.items())))
+        res512 = m.last_intermediates["residual"]
+        for i in (0, 255, 511):
+            keep = res512[i].clone()
+            s1, s2 = m.affinity_from_bev(f[i:i + 1], pf[i:i + 1], dets[i:i + 1].clone(), prevs[i:i + 1])
+            np.testing.assert_allclose(s1.cpu().numpy(), m1[i:i + 1].cpu().numpy(), rtol=0, atol=1e-6)
+            np.testing.assert_allclose(s2.cpu().numpy(), m2[i:i + 1].cpu().numpy(), rtol=0, atol=1e-6)
+            r1 = m.last_intermediates["residual"][0].cpu().numpy()
+            np.testing.assert_allclose(keep.cpu().numpy(), r1, rtol=1e-5, atol=1e-5 * float(np.abs(r1).max()))
+    assert bool(torch.isfinite(m1).all()) and bool(torch.isfinite(m2).all())
+    np.testing.assert_allclose(m1.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
+    np.testing.assert_allclose(m2.sum(1).cpu().numpy(), 1.0, atol=1e-5)
+
+
 def test_forward_with_shared_conv_on_device():
     """Same as above for the tiny case but through extract_feat + shared_conv on the device (MIOpen conv)."""
     dev = _dev()
