@@ -217,6 +217,20 @@ __global__ __launch_bounds__(256) void box_l1_small_kernel(BoxL1Args a) {
         a.hid[((size_t)b * 4 + mlp) * a.HD + u] = fmaxf(((part[0] + part[1]) + (part[2] + part[3])) + a.bias[mlp][u], 0.0f);
 }
 
+// Batches >= 16: the four first layers as GEMMs.  Their input - the 7-vectors of the boxes BEFORE back-projection, flattened -
+// is strided (7 of box_stride floats per row) in the caller's tensors: pack it once into (2, B, ldx) rows, ldx = ceil4(7N),
+// zero tail (x7[0] = current boxes: newborn / fp, x7[1] = previous boxes: dead_trk / fn).
+__global__ __launch_bounds__(256) void box_pack7_kernel(const float* __restrict__ det, const float* __restrict__ prev, float* __restrict__ x7,
+                                                        int B, int N, int box_stride, int ldx) {
+    const int b = blockIdx.y, which = blockIdx.z;
+    const float* src = (which ? prev : det) + (size_t)b * N * box_stride;
+    float* dst = x7 + ((size_t)which * B + b) * ldx;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < ldx; k += gridDim.x * 256) {
+        const int n = k / 7, c = k - 7 * n;
+        dst[k] = k < 7 * N ? src[(size_t)n * box_stride + c] : 0.0f;
+    }
+}
+
 struct BoxL2Args {
     const float* W[4];  // aug_dets.i.2.weight (7, HD)
     const float* bias[4];
@@ -287,6 +301,8 @@ size_t anchor_shape_workspace_bytes(int B, int N, int F) {
 
 int launch_anchor_l1_mfma(const float* const W[4], const float* feat, const float* prev_feat, float* part, int H, int K,
                           int B, int x_batch_stride, int* ks_out, hipStream_t st);
+int launch_gemm_nt_quad(const float* const A[4], const float* const W[4], const float* const bias[4], float* const C[4], int lda,
+                        int ldw, int ldc, int M, int N, int K, int act, hipStream_t st);
 
 template <int BT, int R>
 static void launch_l1(const AnchorL1Args& a, hipStream_t st) {
@@ -361,6 +377,21 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     l2.F = F;
     l2.N = N;
     l2.B = B;
+    if (B >= 16) {
+        // a plain GEMM per MLP from here on: (B, H) x (F, H)^T on the matrix cores, |.| and the table row as the epilogue's
+        // target (row N + (i & 1) of prev_feat for newborn / fp, of feat for dead_trk / fn; leading dimension = one batch item)
+        const float* A[4];
+        const float* W2[4];
+        const float* b2[4];
+        float* C[4];
+        for (int i = 0; i < 4; ++i) {
+            A[i] = hidden + (size_t)i * H;
+            W2[i] = l2.W[i];
+            b2[i] = l2.bias[i];
+            C[i] = ((i < 2) ? prev_feat : feat) + (size_t)(N + (i & 1)) * F;
+        }
+        return launch_gemm_nt_quad(A, W2, b2, C, 4 * H, H, (N + 2) * F, B, F, H, 2, st);
+    }
     // small batches: no duplicated activation loads (BT = batch items that share one weight row read)
     if (B == 1) hipLaunchKernelGGL(anchor_l2_kernel<1>, dim3(cdiv(B * 4 * F, 4)), dim3(256), 0, st, l2);
     else if (B == 2) hipLaunchKernelGGL(anchor_l2_kernel<2>, dim3(cdiv(cdiv(B, 2) * 4 * F, 4)), dim3(256), 0, st, l2);
@@ -369,7 +400,10 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     return check_launch("anchor_l2");
 }
 
-size_t anchor_boxes_workspace_bytes(int B, int N) { return align_up((size_t)B * 4 * max(1, 7 * N / 32) * sizeof(float), 256); }
+// [hidden (B, 4, HD)][packed box rows (2, B, ceil4(7N)) for the GEMM form]
+size_t anchor_boxes_workspace_bytes(int B, int N) {
+    return align_up((size_t)B * 4 * max(1, 7 * N / 32) * sizeof(float), 256) + align_up((size_t)2 * B * ((7 * N + 3) / 4 * 4) * sizeof(float), 256);
+}
 
 int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes, int box_stride,
                  float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st) {
@@ -388,7 +422,23 @@ int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* 
         a.N = N;
         a.B = B;
         a.box_stride = box_stride;
-        if (B <= 4) hipLaunchKernelGGL(box_l1_small_kernel, dim3(B * 4 * HD), dim3(256), 0, st, a);
+        if (B >= 16) {
+            const int ldx = (7 * N + 3) / 4 * 4;
+            float* x7 = reinterpret_cast<float*>(reinterpret_cast<char*>(hid_ws) + align_up((size_t)B * 4 * HD * sizeof(float), 256));
+            hipLaunchKernelGGL(box_pack7_kernel, dim3(cdiv(ldx, 256), B, 2), dim3(256), 0, st, det_boxes, prev_det_boxes, x7, B, N, box_stride, ldx);
+            int rc = check_launch("box_pack7");
+            if (rc) return rc;
+            const float* A[4] = {x7, x7, x7 + (size_t)B * ldx, x7 + (size_t)B * ldx};
+            const float* W1[4];
+            const float* b1[4];
+            float* C[4];
+            for (int i = 0; i < 4; ++i) {
+                W1[i] = a.W[i];
+                b1[i] = a.bias[i];
+                C[i] = hid_ws + (size_t)i * HD;  // hid (B, 4, HD): MLP i at column block i, leading dimension 4 HD
+            }
+            if ((rc = launch_gemm_nt_quad(A, W1, b1, C, ldx, 7 * N, 4 * HD, B, HD, 7 * N, 1, st))) return rc;
+        } else if (B <= 4) hipLaunchKernelGGL(box_l1_small_kernel, dim3(B * 4 * HD), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(box_l1_kernel, dim3(cdiv(cdiv(B, 4) * 4 * cdiv(HD, 4), 4)), dim3(256), 0, st, a);
         int rc = check_launch("box_l1");
         if (rc) return rc;

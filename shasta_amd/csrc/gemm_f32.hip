@@ -126,6 +126,41 @@ int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float
     return check_launch("gemm_nt_f32");
 }
 
+// up to four independent problems of one shape in one launch (blockIdx.z picks the problem): the second layers of the four
+// aug_shape / first layers of the four aug_dets anchor MLPs at batch >= 16 (anchor.hip)
+struct GemmNtQuad {
+    const float* A[4];
+    const float* W[4];
+    const float* bias[4];
+    float* C[4];
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemm_nt_f32_quad_kernel(GemmNtQuad p, int lda, int ldw, int ldc, int M, int N, int K, int act) {
+    __shared__ float As[BM * LDS_LD];
+    __shared__ float Ws[BN * LDS_LD];
+    const int z = blockIdx.z;
+    gemm_nt_tile<VEC>(As, Ws, p.A[z], lda, p.W[z], ldw, p.bias[z], p.C[z], ldc, M, N, K, act);
+}
+
+int launch_gemm_nt_quad(const float* const A[4], const float* const W[4], const float* const bias[4], float* const C[4], int lda,
+                        int ldw, int ldc, int M, int N, int K, int act, hipStream_t st) {
+    if (M == 0 || N == 0) return SHASTA_OK;
+    GemmNtQuad p;
+    bool vec = (lda % 4 == 0) && (ldw % 4 == 0);
+    for (int i = 0; i < 4; ++i) {
+        p.A[i] = A[i];
+        p.W[i] = W[i];
+        p.bias[i] = bias[i];
+        p.C[i] = C[i];
+        vec = vec && (((uintptr_t)A[i] | (uintptr_t)W[i]) % 16 == 0);
+    }
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), 4);
+    if (vec) hipLaunchKernelGGL(gemm_nt_f32_quad_kernel<true>, grid, dim3(256), 0, st, p, lda, ldw, ldc, M, N, K, act);
+    else hipLaunchKernelGGL(gemm_nt_f32_quad_kernel<false>, grid, dim3(256), 0, st, p, lda, ldw, ldc, M, N, K, act);
+    return check_launch("gemm_nt_f32_quad");
+}
+
 // C0 = A0 W0^T (+bias0), C1 = A1 W1^T (+bias1), same shapes and leading dimensions; falls back to two launches when the
 // vector-load preconditions do not hold
 int launch_gemm_nt_dual(const float* A0, const float* W0, const float* bias0, float* C0, const float* A1, const float* W1,

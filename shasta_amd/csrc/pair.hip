@@ -6,9 +6,9 @@
 // Kernels (per forward):
 //   pack_pair_weights   once per weight load: fragments + factorised first-layer matrices
 //   [gemm_nt_f32 x2]    UP = prev_feat . Wemb_prev^T ; UC = feat . Wemb_cur^T + b          (matrix cores)
-//   row_finish          per table row: box columns of res_coeff.0 / fuse_det.0, log-dims, cos/sin
-//   col_norm            column L2 norm over tracks (F.normalize, dim=1) of the squared box distances
-//                       (the dim / rot terms and the normalised distance are evaluated inside pair_mfma)
+//   row_prep            per table row: box columns of res_coeff.0 / fuse_det.0, log-dims, cos/sin; per column: the L2 norm
+//                       over tracks (F.normalize, dim=1) of the squared box distances (the dim / rot terms and the
+//                       normalised distance are evaluated inside the pair kernel)
 //   pair_mfma4<F, WPB>  lane = pair: h1 = relu(UP[t]+UC[d]), layers 2-4 on v_mfma_f32_4x4x1_16B_f32 -> residual
 // (Two other formulations - a 16x16x4 accumulator-chained MFMA kernel and a packed-VALU kernel with SGPR weights - measured
 // within 4 % of this one and were removed from the product library after round 1; they are in the history of this file.)
@@ -107,80 +107,115 @@ __global__ void pack_pair_weights_kernel(PackArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// row_finish: one wave per table row (prev rows then cur rows of each batch item)
-//   E[row][H1 + j]       += Wbox[j][:nf] . box[:nf]                 (res_coeff.0 box columns)
-//   E[row][H1 + R1 + j]   = Wbox[R1 + j][:nf] . box[:nf] (+ bias)   (fuse_det.0)
-//   hand[row] = [box7, 0, log(w+eps), log(l+eps), log(h+eps), cos(yaw), sin(yaw), 0, 0, 0]
+// row_prep: everything the pair kernel needs per table row or per column besides the GEMM part of the row embeddings, in ONE
+// launch of three block roles.
+//  blocks [0, nrow): 32 table rows of one side each (first half: prev rows, second half: cur rows), 32 threads per row, one
+//   float4 of outputs per thread:
+//   threads 0 .. (R1+32)/4-1:  E[row][H1 + j]       += Wbox[j][:nf] . box[:nf]                 (res_coeff.0 box columns)
+//                              E[row][H1 + R1 + j]   = Wbox[R1 + j][:nf] . box[:nf] (+ bias)   (fuse_det.0)
+//  blocks [nrow, nrow + nhand): one thread per table row:
+//                              hand[row] = [box7, 0, log(w+eps), log(l+eps), log(h+eps), cos(yaw), sin(yaw), 0, 0, 0]
+//  the remaining blocks: col_norm (shasta.py:278-279): d2[t][d] = sum_{k<nf} (prev_k - det_k)^2,
+//   denom[d] = max(||d2[:, d]||_2, 1e-12) (F.normalize acts along dim=1 = tracks); 16 detections x 16 track groups per block,
+//   read straight from the (B, T, 8) box tables (4 tracks in flight per thread, fixed-order reduction).
 // ------------------------------------------------------------------------------------------------------------
-struct RowFinishArgs {
+struct RowPrepArgs {
     const float* packed;
     const float* tab[2];  // [0] prev_tab, [1] det_tab   (B, T, 8)
     float* emb[2];        // [0] UP, [1] UC             (B, T, ET)
     float* hand[2];       // (B, T, 16)
-    int B, T, N, nf, F;
+    float* denom;         // (B, D)
+    int B, T, N, nf, F, nrow_blocks, nhand_blocks, dblocks;
 };
 
-__global__ __launch_bounds__(256) void row_finish_kernel(RowFinishArgs a) {
-    const PackedLayout P(a.N, a.nf, a.F);
-    const PairDims d(a.F);
-    const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= 2 * a.B * a.T) return;
-    const int which = item / (a.B * a.T), row = item % (a.B * a.T);
-    const float* box = a.tab[which] + (size_t)row * 8;
-    float* e = a.emb[which] + (size_t)row * d.ET;
-    const float* wb = a.packed + (which ? P.wbox_cur : P.wbox_prev);
-    float bx[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) bx[c] = box[c];
-    for (int j = lane; j < d.R1 + 32; j += 64) {
-        float s = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 7; ++c) s = fmaf(wb[j * 8 + c], bx[c], s);  // columns >= nf are packed as 0
-        if (j < d.R1) {
-            e[d.H1 + j] += s;
-        } else {
-            if (which) s += a.packed[P.bbox_cur + (j - d.R1)];
-            e[d.H1 + j] = s;
-        }
-    }
-    if (lane < 16) {
-        float v = 0.0f;
-        if (lane < 7) v = bx[lane];
-        else if (lane >= 8 && lane < 11) v = logf(bx[3 + lane - 8] + 1e-10f);
-        else if (lane == 11) v = cosf(bx[6]);
-        else if (lane == 12) v = sinf(bx[6]);
-        a.hand[which][(size_t)row * 16 + lane] = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// col_norm (shasta.py:278-279): d2[t][d] = sum_{k<nf} (prev_k - det_k)^2 ; denom[d] = max(||d2[:, d]||_2, 1e-12)
-// (F.normalize acts along dim=1 = tracks).  block = 16 detections x 16 track groups; the previous boxes are read as
-// one float4 pair per track (first 8 floats of the 16-float hand row), 4 tracks in flight per thread.
-// ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void col_norm_kernel(const float* __restrict__ hand_prev,
-                                                       const float* __restrict__ hand_det, float* __restrict__ denom,
-                                                       int T, int D, int nf) {
+__global__ __launch_bounds__(256) void row_prep_kernel(RowPrepArgs a) {
     __shared__ float red[16][17];
-    const int b = blockIdx.y, dl = threadIdx.x & 15, tg = threadIdx.x >> 4;
-    const int d = blockIdx.x * 16 + dl;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < a.nrow_blocks) {
+        // 32 table rows per block (4 rounds of 8 rows x 32 threads).  The (R1+32) x 8 box-column weights of this side are staged
+        // through LDS TRANSPOSED, wT[c][j]: a thread then reads its 4 consecutive outputs of column c as one conflict-free
+        // float4 (straight from the packed [j][8] table the 24 active lanes of a row hit 24 different cache lines per load).
+        __shared__ __attribute__((aligned(16))) float wT[7 * 104];
+        const PackedLayout P(a.N, a.nf, a.F);
+        const PairDims d(a.F);
+        const int J = d.R1 + 32;  // <= 104, a multiple of 4 for every supported F
+        // a block never straddles the two sides: nrow_blocks = 2 * ceil(B*T / 32), block i < half handles prev rows
+        const int half = a.nrow_blocks / 2;
+        const int which = (int)blockIdx.x >= half;
+        const int side_row0 = (blockIdx.x - which * half) * 32;
+        {
+            const float* wb = a.packed + (which ? P.wbox_cur : P.wbox_prev);
+            for (int e = tid; e < J * 8; e += 256) {
+                const int j = e >> 3, c = e & 7;
+                if (c < 7) wT[c * 104 + j] = wb[e];
+            }
+        }
+        __syncthreads();
+        const int q = tid & 31, nq = J / 4;
+        for (int it = 0; it < 4; ++it) {
+            const int row = side_row0 + it * 8 + (tid >> 5);
+            if (row >= a.B * a.T || q >= nq) continue;
+            const f32x4* bp = reinterpret_cast<const f32x4*>(a.tab[which] + (size_t)row * 8);
+            const f32x4 b0 = bp[0], b1 = bp[1];
+            const float bx[7] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2]};
+            f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};  // columns >= nf are packed as 0; k-ordered fmaf chain per output
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wT[c * 104 + 4 * q]);
+                s[0] = fmaf(w4[0], bx[c], s[0]); s[1] = fmaf(w4[1], bx[c], s[1]);
+                s[2] = fmaf(w4[2], bx[c], s[2]); s[3] = fmaf(w4[3], bx[c], s[3]);
+            }
+            f32x4* e = reinterpret_cast<f32x4*>(a.emb[which] + (size_t)row * d.ET + d.H1 + 4 * q);
+            const int j = 4 * q;
+            if (j < d.R1) {
+                f32x4 v = *e;
+                v[0] += s[0]; v[1] += s[1]; v[2] += s[2]; v[3] += s[3];
+                *e = v;
+            } else {
+                if (which) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(a.packed + P.bbox_cur + (j - d.R1));
+                    s[0] += bb[0]; s[1] += bb[1]; s[2] += bb[2]; s[3] += bb[3];
+                }
+                *e = s;
+            }
+        }
+        return;
+    }
+    if ((int)blockIdx.x < a.nrow_blocks + a.nhand_blocks) {
+        // hand rows, one THREAD per table row: the five transcendentals are long instruction sequences, so they run with all 64
+        // lanes of a wave busy (a wave per row spent its time here with 2-4 active lanes)
+        const int item = (blockIdx.x - a.nrow_blocks) * 256 + tid;
+        if (item >= 2 * a.B * a.T) return;
+        const int which = item / (a.B * a.T), row = item % (a.B * a.T);
+        const f32x4* bp = reinterpret_cast<const f32x4*>(a.tab[which] + (size_t)row * 8);
+        const f32x4 b0 = bp[0], b1 = bp[1];
+        f32x4* h = reinterpret_cast<f32x4*>(a.hand[which] + (size_t)row * 16);
+        h[0] = b0;
+        h[1] = f32x4{b1[0], b1[1], b1[2], 0.0f};
+        h[2] = f32x4{logf(b0[3] + 1e-10f), logf(b1[0] + 1e-10f), logf(b1[1] + 1e-10f), cosf(b1[2])};
+        h[3] = f32x4{sinf(b1[2]), 0.0f, 0.0f, 0.0f};
+        return;
+    }
+    // ---- column norms ----
+    const int T = a.T, D = a.T, nf = a.nf;
+    const int cb = blockIdx.x - a.nrow_blocks - a.nhand_blocks;
+    const int b = cb / a.dblocks, dl = tid & 15, tg = tid >> 4;
+    const int dd = (cb % a.dblocks) * 16 + dl;
     float db[8];
     {
-        const f32x4* h = reinterpret_cast<const f32x4*>(hand_det + ((size_t)b * D + min(d, D - 1)) * 16);
-        const f32x4 a = h[0], c = h[1];
-        db[0] = a[0]; db[1] = a[1]; db[2] = a[2]; db[3] = a[3]; db[4] = c[0]; db[5] = c[1]; db[6] = c[2]; db[7] = 0.0f;
+        const f32x4* h = reinterpret_cast<const f32x4*>(a.tab[1] + ((size_t)b * D + min(dd, D - 1)) * 8);
+        const f32x4 x = h[0], c = h[1];
+        db[0] = x[0]; db[1] = x[1]; db[2] = x[2]; db[3] = x[3]; db[4] = c[0]; db[5] = c[1]; db[6] = c[2]; db[7] = 0.0f;
     }
-    // columns >= nf do not take part: zero both sides
-    float mask[7];
+    float mask[7];  // columns >= nf do not take part: zero both sides
 #pragma unroll
     for (int k = 0; k < 7; ++k) mask[k] = k < nf ? 1.0f : 0.0f;
-    const f32x4* hp = reinterpret_cast<const f32x4*>(hand_prev + (size_t)b * T * 16);
+    const f32x4* hp = reinterpret_cast<const f32x4*>(a.tab[0] + (size_t)b * T * 8);
     float ssq = 0.0f;
 #pragma unroll 4
     for (int t = tg; t < T; t += 16) {
-        const f32x4 a = hp[(size_t)t * 4], c = hp[(size_t)t * 4 + 1];
-        const float p[7] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2]};
+        const f32x4 x = hp[(size_t)t * 2], c = hp[(size_t)t * 2 + 1];
+        const float p[7] = {x[0], x[1], x[2], x[3], c[0], c[1], c[2]};
         float d2 = 0.0f;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
@@ -191,11 +226,11 @@ __global__ __launch_bounds__(256) void col_norm_kernel(const float* __restrict__
     }
     red[dl][tg] = ssq;
     __syncthreads();
-    if (tg == 0 && d < D) {
+    if (tg == 0 && dd < D) {
         float tot = 0.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) tot += red[dl][i];  // fixed order
-        denom[(size_t)b * D + d] = fmaxf(sqrtf(tot), 1e-12f);
+        a.denom[(size_t)b * D + dd] = fmaxf(sqrtf(tot), 1e-12f);
     }
 }
 
@@ -435,24 +470,25 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
         rc = launch_gemm_nt_dual(prev_feat, packed + P.wemb_prev, nullptr, UP, feat, packed + P.wemb_cur, packed + P.bemb_cur, UC, F, F,
                                  d.ET, B * T, P.E12, F, 0, st);
     if (rc) return rc;
-    RowFinishArgs rf;
-    rf.packed = packed;
-    rf.tab[0] = prev_tab;
-    rf.tab[1] = det_tab;
-    rf.emb[0] = UP;
-    rf.emb[1] = UC;
-    rf.hand[0] = hand_prev;
-    rf.hand[1] = hand_det;
-    rf.B = B;
-    rf.T = T;
-    rf.N = N;
-    rf.nf = nf;
-    rf.F = F;
-    hipLaunchKernelGGL(row_finish_kernel, dim3(cdiv(2 * B * T, 4)), dim3(256), 0, st, rf);
-    rc = check_launch("row_finish");
-    if (rc) return rc;
-    hipLaunchKernelGGL(col_norm_kernel, dim3(cdiv(D, 16), B), dim3(256), 0, st, hand_prev, hand_det, denom, T, D, nf);
-    rc = check_launch("col_norm");
+    RowPrepArgs rp;
+    rp.packed = packed;
+    rp.tab[0] = prev_tab;
+    rp.tab[1] = det_tab;
+    rp.emb[0] = UP;
+    rp.emb[1] = UC;
+    rp.hand[0] = hand_prev;
+    rp.hand[1] = hand_det;
+    rp.denom = denom;
+    rp.B = B;
+    rp.T = T;
+    rp.N = N;
+    rp.nf = nf;
+    rp.F = F;
+    rp.nrow_blocks = 2 * cdiv(B * T, 32);
+    rp.nhand_blocks = cdiv(2 * B * T, 256);
+    rp.dblocks = cdiv(D, 16);
+    hipLaunchKernelGGL(row_prep_kernel, dim3(rp.nrow_blocks + rp.nhand_blocks + rp.dblocks * B), dim3(256), 0, st, rp);
+    rc = check_launch("row_prep");
     if (rc) return rc;
     // lane = pair, 4x4x1 MFMA.  The 8 waves of a workgroup share one 64-detection UC tile and take different track ranges
     // (two workgroups per CU by LDS, 113 VGPRs in the VGPR MFMA form: 4 waves per SIMD).

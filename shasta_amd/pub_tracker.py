@@ -182,3 +182,148 @@ def step_batch(trackers, results_list, time_lags):
             dist, matched = None, np.array([], np.int32).reshape(-1, 2)
         outs.append(trk._finish(results, dets, tracks, dist, matched, det_near, trk_near))
     return outs
+
+
+# per-class confidence-refinement parameters of the merged tracker (pub_tracker_merged.py:34-42)
+TRK_REF = {
+    "bicycle": {"alpha": 0.5, "beta": 0.4, "ref": True},
+    "bus": {"alpha": 0.5, "beta": 0.7, "ref": True},
+    "car": {"alpha": 0.5, "beta": 0.5, "ref": True},
+    "motorcycle": {"alpha": 0.5, "beta": 0.5, "ref": True},
+    "pedestrian": {"alpha": 0.5, "beta": 0.5, "ref": True},
+    "trailer": {"alpha": 0.5, "beta": 0.4, "ref": True},
+    "truck": {"alpha": 0.5, "beta": 0.5, "ref": True},
+}
+
+
+class PubTrackerMerged(object):
+    """tools/nusc_shasta/pub_tracker_merged.py:57-225, the tracker `pub_test.py` runs over the merged seven-class detections
+    (official_val.sh): one association per tracking class and frame, per-class confidence refinement (TRK_REF), unmatched
+    tracks coast with a decayed score.  Same `reset()` / `step_centertrack(results, time_lag)` contract; the (up to seven)
+    class problems of a frame - of many scenes with `step_batch_merged` - are ONE launch of the centre-distance / greedy kernel."""
+
+    def __init__(self, hungarian=False, max_age=0, verbose=False):
+        self.hungarian = hungarian
+        self.max_age = max_age
+        self.NUSCENE_CLS_VELOCITY_ERROR = NUSCENE_CLS_VELOCITY_ERROR
+        self.trk_ref = TRK_REF
+        if verbose:
+            print("Use hungarian: {}".format(hungarian))
+            print(self.NUSCENE_CLS_VELOCITY_ERROR)
+        self.reset()
+
+    def reset(self):
+        self.id_count = 0
+        self.tracks = []
+
+    def _prepare(self, results, time_lag):
+        """Per class: (class name, detections, tracks of that class, arrays of the distance step or None)."""
+        per_class = []
+        for name in NUSCENES_TRACKING_NAMES:
+            dets = [d for d in results if d["detection_name"] == name]
+            for d in dets:
+                d["ct"] = np.array(d["translation"][:2])
+                d["tracking"] = np.array(d["velocity"][:2]) * -1 * time_lag
+                d["label_preds"] = NUSCENES_TRACKING_NAMES.index(d["detection_name"])
+            if len(dets) == 0:  # pub_tracker_merged.py:101-102: nothing of this class in the frame -> its tracks are dropped
+                continue
+            tracks = [t for t in self.tracks if t["detection_name"] == name]
+            det_xy = np.array([d["ct"] + d["tracking"].astype(np.float32) for d in dets], np.float32)
+            det_cls = np.array([d["label_preds"] for d in dets], np.int32)
+            gate = np.array([self.NUSCENE_CLS_VELOCITY_ERROR[d["detection_name"]] for d in dets], np.float32)
+            trk_xy = np.array([t["ct"] for t in tracks], np.float32)
+            trk_cls = np.array([t["label_preds"] for t in tracks], np.int32)
+            per_class.append((name, dets, tracks, det_xy, trk_xy, det_cls, trk_cls, gate))
+        return per_class
+
+    def _finish_class(self, name, dets, tracks, dist, pairs, det_near, trk_near, ret):
+        n_det, n_trk = len(dets), len(tracks)
+        taken_d, taken_t = set(pairs[:, 0].tolist()), set(pairs[:, 1].tolist())
+        free_dets = [i for i in range(n_det) if i not in taken_d]
+        free_tracks = [j for j in range(n_trk) if j not in taken_t]
+        if det_near is None and dist is not None:
+            gate = self.NUSCENE_CLS_VELOCITY_ERROR[name]
+            det_near = np.array([(dist[i, :] <= gate).sum() > 0 for i in range(n_det)], bool)
+            trk_near = np.array([(dist[:, j] <= gate).sum() > 0 for j in range(n_trk)], bool)
+        if self.hungarian:
+            good = [p for p in pairs if not dist[p[0], p[1]] > 1e16]
+            free_dets += [p[0] for p in pairs if dist[p[0], p[1]] > 1e16]
+            pairs = np.array(good).reshape(-1, 2)
+        ref = self.trk_ref[name]
+        for i, j in pairs:
+            det, old = dets[i], tracks[j]
+            det["tracking_id"] = old["tracking_id"]
+            if ref["ref"]:
+                det["ref_detection_score"] = ((det["ref_detection_score"] > ref["alpha"]) * ref["beta"] * det["detection_score"]
+                                              + (1 - ref["beta"]) * old["ref_detection_score"])
+            else:
+                det["ref_detection_score"] = det["detection_score"]
+            det["age"] = 1
+            det["active"] = old["active"] + 1
+            ret.append(det)
+        for i in free_dets:
+            det = dets[i]
+            if n_trk > 0 and "newborn" not in det and det_near[i]:
+                continue
+            self.id_count += 1
+            det["tracking_id"] = self.id_count
+            det["ref_detection_score"] = ref["beta"] * det["detection_score"] if ref["ref"] else det["detection_score"]
+            det["age"] = 1
+            det["active"] = 1
+            ret.append(det)
+        for j in free_tracks:
+            old = tracks[j]
+            if "dead" in old and trk_near[j]:
+                continue
+            if old["age"] < self.max_age:
+                old["age"] += 1
+                old["active"] = 0
+                if ref["ref"]:
+                    old["ref_detection_score"] = (1 - ref["beta"]) * old["ref_detection_score"]
+                if "tracking" in old:
+                    old["ct"] = old["ct"] + old["tracking"] * -1
+                ret.append(old)
+
+    def _host_assign(self, dist):
+        return PubTracker._host_assign(self, dist)
+
+    def step_centertrack(self, results, time_lag):
+        return step_batch_merged([self], [results], [time_lag])[0]
+
+
+def step_batch_merged(trackers, results_list, time_lags):
+    """One merged-tracker step for many independent scenes: every (scene, class) association is a problem of ONE launch."""
+    prepared, problems, where = [], [], []
+    for k, (trk, results, lag) in enumerate(zip(trackers, results_list, time_lags)):
+        if len(results) == 0:
+            prepared.append(None)
+            continue
+        per_class = trk._prepare(results, lag)
+        prepared.append(per_class)
+        for c, p in enumerate(per_class):
+            if len(p[4]) > 0:
+                where.append((k, c))
+                problems.append((p[3], p[4], p[5], p[6], p[7]))
+    need_dist = any(trackers[k].hungarian for k, _ in where)
+    solved = dict(zip(where, center_greedy_device(problems, want_dist=need_dist))) if problems else {}
+    outs = []
+    for k, trk in enumerate(trackers):
+        per_class = prepared[k]
+        if per_class is None:
+            trk.tracks = []
+            outs.append([])
+            continue
+        ret = []
+        for c, (name, dets, tracks, det_xy, trk_xy, _, _, _) in enumerate(per_class):
+            det_near = trk_near = None
+            if (k, c) in solved:
+                dist, matched, det_near, trk_near = solved[(k, c)]
+                if trk.hungarian:
+                    dist, matched = trk._host_assign(dist)
+            else:
+                assert len(tracks) == 0
+                dist, matched = None, np.array([], np.int32).reshape(-1, 2)
+            trk._finish_class(name, dets, tracks, dist, matched, det_near, trk_near, ret)
+        trk.tracks = ret
+        outs.append(ret)
+    return outs

@@ -82,8 +82,24 @@ def main():
         out["expected"].append(per_case)
     import gzip
     path = os.path.join(HERE, "pub_tracker_golden.json.gz")
+    if "merged" not in sys.argv[1:]:
+        with gzip.open(path, "wt", compresslevel=9) as f:
+            json.dump(out, f)
+        print("wrote", path, os.path.getsize(path), "bytes")
+    # the merged (all-class) tracker of pub_test.py: tools/nusc_shasta/pub_tracker_merged.py, same scenes
+    from pub_tracker_merged import PubTrackerMerged
+    merged_cases = [dict(hungarian=False, max_age=0), dict(hungarian=False, max_age=3), dict(hungarian=True, max_age=2)]
+    mout = dict(cases=merged_cases, expected=[])
+    for case in merged_cases:
+        per_case = []
+        for frames in scenes:
+            with contextlib.redirect_stdout(io.StringIO()):
+                trk = PubTrackerMerged(**case)
+            per_case.append([snapshot(trk.step_centertrack(dets, 0.5)) for dets in copy.deepcopy(frames)])
+        mout["expected"].append(per_case)
+    path = os.path.join(HERE, "pub_tracker_merged_golden.json.gz")
     with gzip.open(path, "wt", compresslevel=9) as f:
-        json.dump(out, f)
+        json.dump(mout, f)
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
