@@ -124,6 +124,34 @@ class AffinityDecoder:
         self.results[token] = annos
         return annos
 
+    def add_batch(self, matched1, matched2, processed_batch, on_device=True):
+        """Every frame pair of a batch (any number of frames x classes).  on_device: the per-row / per-column decisions of the
+        whole batch come from ONE launch of the decode kernel and one device->host copy per decision array; otherwise the
+        matrices are copied to the host once and the restated reference loop runs per frame."""
+        B = matched1.shape[0]
+        cls_all, prev_all = processed_batch["cls_det_boxes"], processed_batch["prev_cls_det_boxes"]
+        lags = processed_batch["prev_det_boxes"][:, 0, 9].detach().float().cpu().numpy()
+        if on_device:
+            pc, ps, df, ds = decode_flags_device(matched1, matched2, [len(p) for p in prev_all], [len(c) for c in cls_all])
+        else:
+            m1h, m2h = matched1.detach().cpu().numpy(), matched2.detach().cpu().numpy()
+        for b in range(B):
+            token = processed_batch["metadata"][b]["token"]
+            self.dead_tracker.setdefault(token, {"dead_idx": [], "keep_idx": []})
+            cls, prev_cls = cls_all[b], prev_all[b]
+            time_lag = float(lags[b]) if len(prev_cls) else 0.0
+            if on_device:
+                annos, dead_prev, keep = decode_frame_from_flags(pc[b], ps[b], df[b], ds[b], cls, prev_cls, token, time_lag)
+            else:
+                annos, dead_prev, keep = decode_frame(m1h[b], m2h[b], cls, prev_cls, token, time_lag)
+            if len(prev_cls):
+                prev_token = processed_batch["prev_metadata"][b]["token"]
+                self.dead_tracker.setdefault(prev_token, {"dead_idx": [], "keep_idx": []})
+                self.dead_tracker[prev_token]["dead_idx"].extend(dead_prev)
+            if len(cls):
+                self.dead_tracker[token]["keep_idx"] = keep
+            self.results[token] = annos
+
     def finalize(self):
         for token, annos in self.results.items():
             info = self.dead_tracker[token]

@@ -161,7 +161,9 @@ def collate_pairs(samples, device=None):
         num_det_boxes=[s["num_det_boxes"] for s in samples], num_prev_det_boxes=[s["num_prev_det_boxes"] for s in samples],
         cls_det_boxes=[s["cls_det_boxes"] for s in samples], prev_cls_det_boxes=[s["prev_cls_det_boxes"] for s in samples],
         metadata=[dict(token=s["token"]) for s in samples],
-        prev_metadata=[dict(token=s["prev_token"]) for s in samples])  # decode.AffinityDecoder.add reads it (eval.py:118)
+        # decode.AffinityDecoder.add reads it (eval.py:118); a frame without predecessor carries its own token there, because
+        # the reference then runs the current frame's LiDAR a second time as "previous" data (nuscenes.py:399-406)
+        prev_metadata=[dict(token=s["prev_token"] or s["token"]) for s in samples])
     if all("gt" in s for s in samples):
         batch["gt"] = torch.from_numpy(np.stack([s["gt"] for s in samples]).astype(np.float32))
     if device is not None:

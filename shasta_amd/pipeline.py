@@ -1,0 +1,167 @@
+"""The inference chain of BASELINE configs 2-4 as one runnable whole (the reference spreads it over three CLIs,
+official_val.sh):
+
+  tools/nusc_shasta/eval.py:90-193        per class: dataset -> batch -> track_batch_processor -> decode loop -> cp_<split>.json
+  tools/nusc_shasta/merge_results.py:37-59  the seven per-class files merged per sample token            -> merged_cp_<split>.json
+  tools/nusc_shasta/pub_test.py:88-162     merged detections -> PubTrackerMerged per scene                  -> tracking_result.json
+
+Here: `FramePairs` (the dataset's detection side) -> `collate_pairs` (any number of frames in one batch: the reference runs
+batch_size=1) -> `Shasta.forward` through `track_batch_processor` -> device decode decisions -> `AffinityDecoder`; scenes are
+sharded over the ranks (one process per GPU, replica.shard_scenes) and only the decoded per-token lists travel to rank 0
+(replica.gather_decoded, no collective in the forward); the tracker advances ALL scenes of the split in lock step, one launch of
+the centre-distance / greedy kernel per frame index.  The spconv backbone and the neck are out of scope (SURVEY.md section 2 rows
+10-11): `bev` is any callable token -> (H, W, C) NHWC feature map after shared_conv (`scenes.TokenBev` for the synthetic split).
+"""
+import copy
+import json
+import os
+
+import torch
+
+from . import builder, decode, frames, replica
+from .pub_tracker import NUSCENES_TRACKING_NAMES, PubTracker, PubTrackerMerged, step_batch, step_batch_merged
+from .train_track import track_batch_processor
+
+# configs/nusc/<class>.py:26-29,66-71: table size per class; every shipped config has num_feats=3, num_point=5 (F=320)
+CLASS_CONFIGS = {"bicycle": 50, "bus": 20, "car": 90, "motorcycle": 50, "pedestrian": 90, "trailer": 60, "truck": 60}
+META = {"use_camera": False, "use_lidar": True, "use_radar": False, "use_map": False, "use_external": False}
+
+
+def class_model_cfg(name, num_feats=3, num_point=5):
+    """The `model = dict(type="Shasta", ...)` block of configs/nusc/<class>.py without the out-of-scope reader / backbone / neck."""
+    return dict(type="Shasta", reader=None, backbone=None, neck=None,
+                bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
+                max_obj=CLASS_CONFIGS[name], num_feats=num_feats, num_point=num_point)
+
+
+def build_class_model(name, device, checkpoint=None, seed=0, **kw):
+    """tools/nusc_shasta/eval.py:80-88: build from the class config, load the checkpoint when there is one (random init
+    under `seed` otherwise: the shipped *.pth files are external downloads)."""
+    torch.manual_seed(seed)
+    model = builder.build_simp_track(class_model_cfg(name, **kw)).eval()
+    if checkpoint is not None:
+        from .shasta import load_state_dict_permissive
+        sd = torch.load(checkpoint, map_location="cpu")
+        load_state_dict_permissive(model, sd.get("state_dict", sd) if isinstance(sd, dict) else sd)
+    return model.to(device)
+
+
+def eval_class(model, name, paths, tokens, bev, device, known_tokens=None, batch_pairs=32, decode_on_device=True, forward=None):
+    """eval.py:96-181 for one class over `tokens` (in time order inside every scene).  Returns the AffinityDecoder (not finalized:
+    the `dead` post-pass needs the whole split, replica.gather_decoded / finalize do it).  `forward`: replaces the device model
+    call - the tests pass the CPU oracle here to obtain the reference-side result of the same chain."""
+    ds = frames.FramePairs(paths["det_path"], paths["cls_info_path"], paths["frame_info_path"], det_type=[name],
+                           max_objects=CLASS_CONFIGS[name], test_mode=True)
+    known = set(ds.frame_info.keys()) if known_tokens is None else set(known_tokens)
+    dec = decode.AffinityDecoder()
+    for i in range(0, len(tokens), batch_pairs):
+        samples = [ds.load(t, known_tokens=known) for t in tokens[i:i + batch_pairs]]
+        batch = frames.collate_pairs(samples)
+        batch["bev_feature"] = torch.stack([bev(s["token"]) for s in samples])
+        batch["prev_bev_feature"] = torch.stack([bev(s["prev_token"] or s["token"]) for s in samples])  # nuscenes.py:399-406
+        if forward is not None:
+            m1, m2, example = forward(batch)
+            dec.add_batch(m1, m2, example, on_device=False)
+            continue
+        with torch.no_grad():
+            m1, m2, example = track_batch_processor(model, batch, train_mode=False, local_rank=device.index or 0)
+        dec.add_batch(m1, m2, example, on_device=decode_on_device)
+    return dec
+
+
+def merge_results(per_class):
+    """merge_results.py:37-59: per sample token, the class lists concatenated in NUSCENES_TRACKING_NAMES order."""
+    out = {"meta": dict(META), "results": {}}
+    for name in NUSCENES_TRACKING_NAMES:
+        if name not in per_class:
+            continue
+        for token, annos in per_class[name]["results"].items():
+            out["results"].setdefault(token, []).extend(annos)
+    return out
+
+
+def run_tracking(predictions, frames_meta, max_age=4, hungarian=False, merged=True, refine_confidence=False, alpha=0.5, beta=0.5,
+                 tracker_factory=None, batch_step=None):
+    """pub_test.py:88-162 (merged=True, PubTrackerMerged, tracking_score = ref_detection_score) or eval.py:226-300
+    (merged=False, PubTracker).  The reference walks the frames of all scenes in file order with one tracker that is reset at
+    every scene start; scenes are independent, so here every scene has its own tracker and all scenes advance together, one
+    kernel launch per frame index."""
+    scenes = []
+    for fr in frames_meta:
+        if fr["first"]:
+            scenes.append([])
+        scenes[-1].append(fr)
+    if tracker_factory is None:
+        tracker_factory = (lambda: PubTrackerMerged(max_age=max_age, hungarian=hungarian)) if merged else \
+            (lambda: PubTracker(max_age=max_age, hungarian=hungarian, refine_confidence=refine_confidence, alpha=alpha, beta=beta))
+        batch_step = step_batch_merged if merged else step_batch
+    trackers = [tracker_factory() for _ in scenes]
+    last = [None] * len(scenes)
+    annos = {"results": {}, "meta": dict(META)}
+    for fi in range(max(len(s) for s in scenes) if scenes else 0):
+        live = [k for k, s in enumerate(scenes) if fi < len(s)]
+        lags, preds = [], []
+        for k in live:
+            fr = scenes[k][fi]
+            if fr["first"]:
+                last[k] = fr["timestamp"]
+            lags.append(fr["timestamp"] - last[k])
+            last[k] = fr["timestamp"]
+            preds.append(predictions[fr["token"]])
+        if batch_step is not None:
+            outs = batch_step([trackers[k] for k in live], preds, lags)
+        else:
+            outs = [trackers[k].step_centertrack(p, lag) for k, p, lag in zip(live, preds, lags)]
+        for k, out in zip(live, outs):
+            token = scenes[k][fi]["token"]
+            rows = []
+            for item in out:
+                if item["active"] == 0:
+                    continue
+                row = {"sample_token": token, "translation": item["translation"], "size": item["size"], "rotation": item["rotation"],
+                       "velocity": item["velocity"], "tracking_id": str(item["tracking_id"]), "tracking_name": item["detection_name"],
+                       "tracking_score": item["ref_detection_score"] if (merged or refine_confidence) else item["detection_score"]}
+                if not merged:
+                    row["attribute_name"] = item["attribute_name"]
+                rows.append(row)
+            annos["results"][token] = rows
+    return annos
+
+
+def run_split(models, paths, scenes, bev, device, work_dir=None, split="val", max_age=4, batch_pairs=32, decode_on_device=True,
+              rank=0, world=1, group=None, forward_override=None, tracker_on_device=True):
+    """Configs 2-4 end to end.  models: {class name: Shasta on `device`}; scenes: [(scene name, [tokens])] of the WHOLE split.
+    Scenes are sharded over `world` ranks; rank 0 returns (per-class cp dicts, merged dict, tracking dict) and, with work_dir,
+    writes <class>/cp_<split>.json, merged_cp_<split>.json and tracking_result.json like the reference CLIs; other ranks
+    return None.  forward_override ({class name: callable(batch) -> (m1, m2, example)}) and tracker_on_device=False exist for the
+    CPU tests of the sharding / gather / merge logic (gloo, no GPU in the build container); the product path leaves them alone."""
+    mine = set(replica.shard_scenes([(n, len(t)) for n, t in scenes], rank, world))
+    tokens = [t for n, toks in scenes if n in mine for t in toks]
+    all_tokens = [t for _, toks in scenes for t in toks]
+    per_class = {}
+    for name in NUSCENES_TRACKING_NAMES:
+        if name not in models:
+            continue
+        dec = eval_class(models[name], name, paths, tokens, bev, device, known_tokens=all_tokens, batch_pairs=batch_pairs,
+                         decode_on_device=decode_on_device, forward=None if forward_override is None else forward_override[name])
+        per_class[name] = replica.gather_decoded(dec, dst=0, group=group)
+    if rank != 0:
+        return None
+    merged = merge_results(per_class)
+    with open(paths["frames_meta_path"]) as f:
+        meta = json.load(f)["frames"]
+    if tracker_on_device:
+        tracking = run_tracking(copy.deepcopy(merged["results"]), meta, max_age=max_age)
+    else:
+        tracking = None
+    if work_dir is not None:
+        for name, cp in per_class.items():
+            os.makedirs(os.path.join(work_dir, name), exist_ok=True)
+            with open(os.path.join(work_dir, name, "cp_%s.json" % split), "w") as f:
+                json.dump(cp, f)
+        with open(os.path.join(work_dir, "merged_cp_%s.json" % split), "w") as f:
+            json.dump(merged, f)
+        if tracking is not None:
+            with open(os.path.join(work_dir, "tracking_result.json"), "w") as f:
+                json.dump(tracking, f)
+    return per_class, merged, tracking
