@@ -174,8 +174,11 @@ def test_split_pipeline_on_device_matches_the_reference_style_chain(tmp_path):
     _same_tracking(got_trk, want_trk)
     assert os.path.exists(tmp_path / "work" / "tracking_result.json") and os.path.exists(tmp_path / "work" / "merged_cp_val.json")
     # host decode (one copy of the matrices per batch, the restated loop) gives the same lists as the device decisions
-    host_pc, host_merged, _ = pipeline.run_split(models, paths, sc, scenes.TokenBev(), dev, batch_pairs=3, decode_on_device=False)
-    _same_cp(host_merged, got_merged, tol=1e-5)
+    host_pc, host_merged, _ = pipeline.run_split(models, paths, sc, scenes.TokenBev(), dev, batch_pairs=8, decode_on_device=False)
+    _same_cp(host_merged, got_merged, tol=1e-7)
+    # and the result does not depend on how the frame pairs are batched beyond fp32 summation order
+    b3_pc, b3_merged, _ = pipeline.run_split(models, paths, sc, scenes.TokenBev(), dev, batch_pairs=3)
+    _same_cp(b3_merged, got_merged, tol=1e-4)
 
 
 @pytest.mark.gpu

@@ -59,3 +59,94 @@ def test_allreduce_gradients_two_ranks():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _train_worker(rank, world, port, q):
+    """One data-parallel training step on half of the batch: SyncBN for shared_conv.1, the reference's loss per rank, gradient
+    averaging (training.allreduce_gradients).  The affinity part is the CPU oracle's autograd (the HIP backward needs a GPU;
+    its equality with this autograd is what tests/test_training*.py establish on the device)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from shasta_amd.sync_bn import convert_syncbn_model
+    from shasta_amd.training import allreduce_gradients
+    model, bev, pbev, det, prev, gt = _ddp_case()
+    convert_syncbn_model(model)
+    model.train()
+    sl = slice(rank * 2, rank * 2 + 2)
+    loss = _oracle_loss(model, bev[sl], pbev[sl], det[sl], prev[sl], gt[sl])
+    loss.backward()
+    params = [p for p in model.parameters() if p.grad is not None]
+    allreduce_gradients(params)
+    out = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    out["__running_mean"] = model.shared_conv[1].running_mean.clone()
+    out["__running_var"] = model.shared_conv[1].running_var.clone()
+    q.put((rank, {k: v.numpy() for k, v in out.items()}))
+    dist.destroy_process_group()
+
+
+def _ddp_case():
+    import shasta_amd
+    from oracle import shasta_oracle as O
+    torch.manual_seed(4)
+    model = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                             bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075],
+                                                                out_stride=8), max_obj=6, num_feats=3, num_point=4, in_channels=8))
+    bev, pbev, det, prev = O.synth_case(4, 6, 5, 8, 24, 24, 11)
+    span = 24 * 8 * 0.075
+    for t in (det, prev):
+        t[:, :, 0] = (t[:, :, 0] % (span * 0.8)) - 54 + 0.1 * span
+        t[:, :, 1] = (t[:, :, 1] % (span * 0.8)) - 54 + 0.1 * span
+    g = torch.Generator().manual_seed(5)
+    gt = (torch.rand(4, 8, 8, generator=g) < 0.2).float()
+    gt[:, 0, 0] = 1.0
+    gt[:2, 1, 1] = 1.0  # different normalisers on the two ranks
+    return model, bev, pbev, det, prev, gt
+
+
+def _oracle_loss(model, bev, pbev, det, prev, gt):
+    from oracle import shasta_oracle as O
+    w = dict(model.named_parameters())
+    w.update(dict(model.named_buffers()))
+    a = model.shared_conv(bev).permute(0, 2, 3, 1).contiguous()   # the module itself: plain or synchronised BatchNorm
+    b = model.shared_conv(pbev).permute(0, 2, 3, 1).contiguous()
+    m1, m2 = O.forward_from_bev(w, a, b, det.clone(), prev.clone(), 3, 4, grad=True)
+    return O.affinity_loss(m1, m2, gt)
+
+
+def test_two_rank_train_step_equals_the_single_process_step():
+    """BASELINE config 5's shape on 2 gloo ranks: 2 x (B/2) with SyncBN + averaged gradients == what apex SyncBN + DDP compute,
+    i.e. the gradient of the MEAN of the per-rank losses with BatchNorm statistics of the whole batch; running statistics too."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    model, bev, pbev, det, prev, gt = _ddp_case()
+    model.train()
+    # single process: both halves through ONE BatchNorm call each (statistics of all 4 maps), mean of the two per-rank losses
+    from oracle import shasta_oracle as O
+    w = dict(model.named_parameters())
+    w.update(dict(model.named_buffers()))
+    a = model.shared_conv(bev).permute(0, 2, 3, 1).contiguous()
+    b = model.shared_conv(pbev).permute(0, 2, 3, 1).contiguous()
+    loss = 0
+    for r in range(2):
+        sl = slice(2 * r, 2 * r + 2)
+        m1, m2 = O.forward_from_bev(w, a[sl], b[sl], det[sl].clone(), prev[sl].clone(), 3, 4, grad=True)
+        loss = loss + O.affinity_loss(m1, m2, gt[sl]) / 2
+    loss.backward()
+    want = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(want) <= set(res[0]) and len(want) > 60
+    for n, g in want.items():
+        for r in range(2):
+            scale = max(float(g.abs().max()), 1e-8)
+            assert float((torch.from_numpy(res[r][n]) - g).abs().max()) <= 2e-4 * scale + 1e-7, (n, r)
+    # note: the two BatchNorm calls per step (current and previous map) each update the running statistics, like the reference
+    for k, ref in (("__running_mean", model.shared_conv[1].running_mean), ("__running_var", model.shared_conv[1].running_var)):
+        assert torch.allclose(torch.from_numpy(res[0][k]), ref, rtol=1e-4, atol=1e-6), k
+        assert torch.equal(torch.from_numpy(res[0][k]), torch.from_numpy(res[1][k]))
