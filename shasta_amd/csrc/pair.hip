@@ -350,7 +350,9 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
 #pragma unroll
             for (int ob = 0; ob < AL::NOB; ++ob) acc[ob] = MFMA4(abias[AL::OFF + AL::BIAS + ob * 4], 1.0f, zero4);
         };
-        // layer 1 (factorised) feeding layer 2
+        // layer 1 (factorised) feeding layer 2.  (Forming UP[t] + UC[d] on the matrix pipe - one 4x4x1 MFMA with B = 1.0 and
+        // C = the UC float4 per 4 features instead of 4 v_add - was measured in round 2: 7.15 - 7.27 ms against 6.31 - 6.51 ms
+        // for this form on the same box, 512 frame-pairs per launch; the adds stay on the VALU.)
         auto layer12 = [&](auto tag, int seg, f32x4* acc) {
             using AL = decltype(tag);
             init(tag, acc);
