@@ -124,10 +124,11 @@ typedef struct shasta_linear {
 
 /* shasta_weights.options: every bit keeps fp32 operands and fp32 accumulation; they select HOW the fp32 products are formed.
  * Default (0): above 32 frame-pairs per call the aug_shape first layer, and from 8192 table rows the row-embedding GEMMs of the
- * pair stage, form each fp32 product from six exact bf16 piece products on the bf16 matrix path (anchor_split.hip,
- * gemm_pieces.hip; error at the level of the fp32 FMA's own rounding). */
+ * pair stage and the six aff layers, form each fp32 product from six exact bf16 piece products on the bf16 matrix path
+ * (anchor_split.hip, gemm_pieces.hip, aff_pieces.hip; error at the level of the fp32 FMA's own rounding). */
 #define SHASTA_OPT_F32_WEIGHT_STREAM 1 /* aug_shape first layer on v_mfma_f32_32x32x2_f32 for every batch size */
 #define SHASTA_OPT_F32_EMBED_GEMM 2    /* row-embedding GEMMs on v_mfma_f32_32x32x2_f32 for every row count */
+#define SHASTA_OPT_F32_AFF 4           /* the six aff layers on v_mfma_f32_16x16x4_f32 for every row count */
 
 typedef struct shasta_weights {
     int max_obj;   /* N */

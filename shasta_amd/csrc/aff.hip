@@ -212,6 +212,11 @@ size_t aff_workspace_bytes(int B, int N) {
     return align_up((size_t)B * T * Dp * sizeof(float), 256);  // matched (B, T, Dp) between the row MLP and the column softmax
 }
 
+size_t aff_pieces_lds_bytes(int Dp);
+bool aff_pieces_serves(int D);
+int launch_aff_pieces(const shasta_weights* w, const float* packed_pieces, const float* residual, int ld, float* matched, int ldm,
+                      float* m1, int M, hipStream_t st);
+
 int aff_softmax(const shasta_weights* w, const float* packed, int B, const float* residual, int ld, float* m1,
                 float* m2, float* matched_out, void* ws, size_t ws_bytes, hipStream_t st) {
     const int N = w->max_obj, T = N + 2, D = N + 2, Dp = (T + 3) / 4 * 4;
@@ -233,11 +238,17 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
     const size_t lds2 = (size_t)(32 * std::max(Dp + 4, 132) + 32 * 132) * sizeof(float);
     const int rg = (lds2 <= 80 * 1024 && M >= 32 * 512) ? 2 : 1;
     const size_t lds = (size_t)(16 * rg * std::max(Dp + 4, 132) + 16 * rg * 132) * sizeof(float);
-    if (lds > 160 * 1024) {  // max_obj <= 2046 (check_weights) keeps 16 rows within 140 KB
+    // From 8192 residual rows up the six layers run as exact bf16 piece products (aff_pieces.hip: 2.7 x fewer matrix cycles per
+    // fp32 product) for tables up to 512 columns whose rows are 16-byte aligned; SHASTA_OPT_F32_AFF keeps the f32
+    // kernel.  Small batches stay on the f32 kernel (16-row workgroups: more parallelism, less latency).
+    const bool pieces = M >= 8192 && !(w->options & SHASTA_OPT_F32_AFF) && aff_pieces_serves(D) && ld % 4 == 0 &&
+                        (uintptr_t)residual % 16 == 0;
+    if (pieces) {
+        if ((rc = launch_aff_pieces(w, packed + P.affp, residual, ld, matched, Dp, m1, M, st))) return rc;
+    } else if (lds > 160 * 1024) {  // max_obj <= 2046 (check_weights) keeps 16 rows within 140 KB
         set_error_msg("aff_softmax: max_obj too large for the on-chip row tile");
         return SHASTA_E_ARG;
-    }
-    {
+    } else {
         AffArgs fa;
         fa.W[0] = packed + P.aff0;  // zero padded (128, Dp)
         fa.bias[0] = w->aff[0].bias;

@@ -518,6 +518,8 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     return check_launch("pair_mfma4");
 }
 
+int aff_pieces_pack(const shasta_weights* w, float* out, hipStream_t st);
+
 int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {
     PackArgs a;
     for (int i = 0; i < 4; ++i) a.fs[i] = w->fuse_shape[i];
@@ -529,7 +531,9 @@ int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {
     a.nf = w->num_feats;
     a.F = w->feat_dim;
     hipLaunchKernelGGL(pack_pair_weights_kernel, dim3(256), dim3(256), 0, st, a);
-    return check_launch("pack_pair_weights");
+    int rc = check_launch("pack_pair_weights");
+    if (rc) return rc;
+    return aff_pieces_pack(w, packed + PackedLayout(w->max_obj, w->num_feats, w->feat_dim).affp, st);
 }
 
 }  // namespace shasta

@@ -58,10 +58,26 @@ SH_HD constexpr int a4_offset(int F, int l) {
 }
 SH_HD constexpr int a4_total(int F) { return a4_offset(F, L_COUNT); }
 
+// aff layers as bf16 piece fragments (aff_pieces.hip): k steps (16 wide) and feature blocks (32 wide) of the six layers for a
+// table of D = N + 2 columns; one fragment = [64 lanes][16 B] = 256 dwords, three pieces per (feature block, k step)
+SH_HD constexpr int ap_ksteps(int layer, int D) {
+    return layer == 0 ? (D + 15) / 16 : layer == 1 ? 8 : layer == 2 ? 4 : layer == 3 ? 2 : layer == 4 ? 4 : 8;
+}
+SH_HD constexpr int ap_fblocks(int layer, int D) {
+    return layer == 0 ? 4 : layer == 1 ? 2 : layer == 2 ? 1 : layer == 3 ? 2 : layer == 4 ? 4 : (D + 31) / 32;
+}
+SH_HD constexpr int ap_kin(int layer, int D) { return layer == 0 ? D : layer == 1 ? 128 : layer == 2 ? 64 : layer == 3 ? 32 : layer == 4 ? 64 : 128; }
+SH_HD constexpr int ap_out(int layer, int D) { return layer == 0 ? 128 : layer == 1 ? 64 : layer == 2 ? 32 : layer == 3 ? 64 : layer == 4 ? 128 : D; }
+SH_HD constexpr size_t ap_layer_offset(int layer, int D) {  // in fragments
+    size_t o = 0;
+    for (int l = 0; l < layer; ++l) o += (size_t)ap_fblocks(l, D) * ap_ksteps(l, D) * 3;
+    return o;
+}
+
 // Packed buffer sections (float offsets).  Dp = padded aff width (multiple of 4).
 struct PackedLayout {
     int F, nf, N, D, Dp, E12, ET;
-    size_t a4, wemb_prev, wemb_cur, bemb_cur, wbox_prev, wbox_cur, bbox_cur, aff0, total;
+    size_t a4, wemb_prev, wemb_cur, bemb_cur, wbox_prev, wbox_cur, bbox_cur, aff0, affp, total;
     SH_HD PackedLayout(int max_obj, int num_feats, int f) {
         const PairDims d(f);
         F = f;
@@ -80,6 +96,7 @@ struct PackedLayout {
         wbox_cur = o;   o += (size_t)(d.R1 + 32) * 8;  // [R1+32][8] ... cur box cols
         bbox_cur = o;   o += (size_t)32;               // [32]       fuse_det.0.bias
         aff0 = o;       o += (size_t)128 * Dp;         // aff.0.weight zero padded to (128, Dp)
+        affp = o;       o += ap_layer_offset(6, D) * 256;  // the six aff layers as bf16 piece fragments (aff_pieces.hip)
         total = o;
     }
 };

@@ -191,7 +191,7 @@ class Shasta(BaseTrack):
         w.max_obj, w.num_feats, w.feat_dim = self.max_obj, self.num_feats, self.aug_shape_output
         if self.arithmetic not in ("pieces", "f32"):
             raise ValueError("Shasta.arithmetic must be 'pieces' or 'f32'")
-        w.options = (hip.OPT_F32_WEIGHT_STREAM | hip.OPT_F32_EMBED_GEMM) if self.arithmetic == "f32" else 0
+        w.options = (hip.OPT_F32_WEIGHT_STREAM | hip.OPT_F32_EMBED_GEMM | hip.OPT_F32_AFF) if self.arithmetic == "f32" else 0
         for i in range(4):
             w.aug_shape[i][0], w.aug_shape[i][1] = lin(self.aug_shape[i][0]), lin(self.aug_shape[i][2])
             w.aug_dets[i][0], w.aug_dets[i][1] = lin(self.aug_dets[i][0]), lin(self.aug_dets[i][2])

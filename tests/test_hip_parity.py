@@ -116,8 +116,11 @@ def test_headline_size_batches_pin_every_anchor_kernel_on_the_reference_output(n
         runs[(lo, hi)] = (p1, p2, tabs)
         np.testing.assert_allclose(p1, full1[lo:hi], rtol=0, atol=batch_tol)
         np.testing.assert_allclose(p2, full2[lo:hi], rtol=0, atol=batch_tol)
-        if sharp:
-            assert np.array_equal(p1.argmax(-1), full1[lo:hi].argmax(-1)) and np.array_equal(p2.argmax(1), full2[lo:hi].argmax(1))
+        if sharp:  # the synthetic frames may hold near-ties: arg-max must agree wherever the top-2 margin exceeds the tolerance
+            same, decided = row_argmax_agreement(p1, full1[lo:hi], 4 * batch_tol)
+            assert same[decided].all() and decided.mean() > 0.99
+            same, decided = row_argmax_agreement(np.swapaxes(p2, 1, 2), np.swapaxes(full2[lo:hi], 1, 2), 4 * batch_tol)
+            assert same[decided].all() and decided.mean() > 0.99
     for (lo, hi), (p1, p2, tabs) in runs.items():
         if lo != 0:
             continue  # the golden frame, through this batch size's anchor kernel
@@ -282,10 +285,13 @@ def test_gemm_nt_vs_torch(M, N, K, act, entry):
                                     ("tiny_4_7_5", 40), ("tiny_4_7_5", 70), ("small_32_7_4", 1), ("small_32_7_4", 3),
                                     ("small_32_7_4", 9), ("small_32_7_4", 17), ("small_32_7_4", 33),
                                     ("small_32_7_4", 64), ("small_32_7_4", 100), ("tiny_4_7_5", 128), ("tiny_4_7_5", 150),
-                                    ("car_90_3_5", 1), ("car_90_3_5", 3), ("car_90_3_5", 9), ("car_90_3_5", 48)])
+                                    ("car_90_3_5", 1), ("car_90_3_5", 3), ("car_90_3_5", 9), ("car_90_3_5", 48),
+                                    ("car_90_3_5", 100), ("bus_20_3_5", 400), ("sharp_90_3_5_pad", 96)])
 def test_batched_forward_vs_oracle(name, B):
     """Batch sizes that exercise every variant of the anchor kernel (VALU B=1; f32 MFMA 16 / 32 rows per pass; bf16-piece
-    MFMA 64 / 128 rows per pass, single and multiple passes, ragged last pass), against the CPU oracle."""
+    MFMA 64 / 128 rows per pass, single and multiple passes, ragged last pass) and both aff kernels (f32 fused below 8192
+    residual rows, bf16 pieces from there: the last three cases, incl. a ragged last 32-row workgroup and sharpened weights),
+    against the CPU oracle."""
     dev = _dev()
     z, c, sums = load_golden(name)
     m = build_model(c)
@@ -306,8 +312,11 @@ def test_batched_forward_vs_oracle(name, B):
         m1, m2, _ = m(ex, train_mode=False)
     np.testing.assert_allclose(ex["det_boxes"].cpu().numpy(), det_o.numpy(), rtol=0, atol=1e-5)
     np.testing.assert_allclose(m.last_intermediates["residual"].cpu().numpy(), im["residual"].numpy(), rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(m1.cpu().numpy(), r1.numpy(), rtol=0, atol=TOL)
-    np.testing.assert_allclose(m2.cpu().numpy(), r2.numpy(), rtol=0, atol=TOL)
+    ref_mat = im["matched"].numpy()
+    np.testing.assert_allclose(m.last_intermediates["matched"].cpu().numpy(), ref_mat, rtol=1e-5, atol=2e-5 * float(np.abs(ref_mat).max()))
+    tol = 2e-3 if c["sharp"] else 1e-6  # tests/helpers.py M_ATOL / M_ATOL_SHARP
+    np.testing.assert_allclose(m1.cpu().numpy(), r1.numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(m2.cpu().numpy(), r2.numpy(), rtol=0, atol=tol)
     # softmax properties: rows of m1 and columns of m2 sum to one
     np.testing.assert_allclose(m1.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
     np.testing.assert_allclose(m2.sum(1).cpu().numpy(), 1.0, atol=1e-5)
