@@ -85,8 +85,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (no HIP-event roofline)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="frame-pairs timed on the host for cpu_baseline")
-    ap.add_argument("--arithmetic", choices=["pieces", "f32"], default="pieces",
-                    help="Shasta.arithmetic: fp32 products from exact bf16 pieces above 32 frame-pairs per step (default) or f32 MFMA kernels only")
+    ap.add_argument("--arithmetic", choices=["f16x2", "pieces", "f32"], default="f16x2",
+                    help="Shasta.arithmetic: how fp32 products are formed on the matrix cores above the batch thresholds: two fp16 pieces for "
+                         "the weight stream + three bf16 pieces elsewhere (default), three bf16 pieces everywhere, or f32 MFMA kernels only")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only, on the CPU with gloo (no GPU, no forward): for the CPU test suite")
     args = ap.parse_args()
@@ -216,31 +217,42 @@ def main():
     step_ms = elapsed / args.steps * 1e3
     # Kernel 1: aug_shape first layer = the 4.1 GB fp32 weight stream.
     #   B <= 32: f32 MFMA kernel, 1024 matrix-pipe cycles per 4 KB weight tile against ~1300 of HBM        -> HBM-bound
-    #   B <= 64: bf16-piece kernel (each fp32 product = 6 exact bf16 piece products), 768 cycles per tile   -> HBM-bound
-    #   B  > 64: the same with 128 items per weight pass, 1536 cycles per tile -> bound by the bf16 matrix pipe: priced as
-    #            EXECUTED bf16 flops (6 piece products per fp32 product) against the dense bf16 MFMA peak
+    #   pieces: B <= 64: bf16-piece kernel (each fp32 product = 6 exact bf16 piece products), 768 cycles per tile   -> HBM-bound
+    #           B  > 64: the same with 128 items per weight pass, 1536 cycles per tile -> bound by the bf16 matrix pipe: priced as
+    #                    EXECUTED bf16 flops (6 piece products per fp32 product) against the dense bf16 MFMA peak
+    #   f16x2 (default): 3 fp16 piece products: 128 items per pass (768 cycles per tile, HBM-bound) up to 128 frame-pairs, 256 items
+    #                    per pass (1536 cycles) above: EXECUTED f16 flops (3 per fp32 product) against the dense f16 MFMA peak
     #   --arithmetic f32 and B > 32: f32 MFMA kernel, 64 items per pass, 2048 cycles per tile -> f32 matrix pipe
     alg = l1_algorithmic_bytes(B)
     hbm_gbs = alg / (l1_ms * 1e-3) / 1e9
     K = N_OBJ * CH * NPOINT
     l1_flops = 2.0 * B * 4 * (K // 64) * K  # dense fp32 flops of the four first layers for B frame-pairs (algorithmic = executed)
     l1_tflops = l1_flops / (l1_ms * 1e-3) / 1e12
-    f32_forced = args.arithmetic == "f32"
-    passes = 1 if B <= 32 else (-(-B // 64) if f32_forced else (1 if B <= 64 else -(-B // 128)))
-    if B <= 32 or (B <= 64 and not f32_forced):
+    f32_forced, f16x2 = args.arithmetic == "f32", args.arithmetic == "f16x2"
+    if B <= 32:
+        passes, nprod = 1, 1
+    elif f32_forced:
+        passes, nprod = -(-B // 64), 1
+    elif f16x2:  # 128 items per weight pass up to 128 frame-pairs, 256 above; three fp16 piece products per fp32 product
+        passes, nprod = (1 if B <= 128 else -(-B // 256)), 3
+    else:        # 64 / 128 items per pass; six bf16 piece products
+        passes, nprod = (1 if B <= 64 else -(-B // 128)), 6
+    hbm_bound = B <= 32 or (not f32_forced and (B <= 128 if f16x2 else B <= 64))  # <= 768 matrix cycles per 4 KB weight tile
+    if hbm_bound:
         roof_l1 = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS}
     elif f32_forced:
         roof_l1 = {"bound": "mfma", "achieved": l1_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": l1_tflops / MFMA_F32_PEAK_TFLOPS, "mfma_dtype": "f32"}
     else:
-        roof_l1 = {"bound": "mfma", "achieved": 6.0 * l1_tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                   "frac": 6.0 * l1_tflops / MFMA_BF16_PEAK_TFLOPS, "mfma_dtype": "bf16",
-                   "note": "executed bf16 MFMA flops = 6 exact piece products per fp32 product, against the dense bf16 peak"}
+        roof_l1 = {"bound": "mfma", "achieved": nprod * l1_tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": nprod * l1_tflops / MFMA_BF16_PEAK_TFLOPS, "mfma_dtype": "f16" if f16x2 else "bf16",
+                   "note": "executed %s MFMA flops = %d piece products per fp32 product, against the dense bf16 / f16 peak"
+                           % ("f16" if f16x2 else "bf16", nprod)}
     roof_l1.update({"kernel": "anchor_l1_kernel (B=1) / anchor_l1_mfma_kernel (B<=32) / anchor_l1_split_kernel (B>32): "
                               "aug_shape.*.0, 4 x 2000 x 128000 fp32 weight stream",
                     "traffic": _pmc_traffic(B), "algorithmic_bytes_per_launch": alg, "weight_passes_executed": passes,
                     "executed_weight_bytes_per_launch": passes * 4 * (K // 64) * K * 4,
-                    "algorithmic_flops_per_launch": l1_flops, "executed_flops_per_launch": l1_flops if (B <= 32 or f32_forced) else 6.0 * l1_flops,
+                    "algorithmic_flops_per_launch": l1_flops, "executed_flops_per_launch": nprod * l1_flops,
                     "avg_launch_ms": l1_ms, "algorithmic_hbm_gbs": hbm_gbs, "fp32_tflops": l1_tflops,
                     "share_of_step": l1_ms / step_ms})
     # Kernel 2: the pair kernel = layers 2-4 of fuse_shape / res_coeff / fuse_det for all (N+2)^2 pairs on the f32 matrix pipe.
@@ -273,11 +285,15 @@ def main():
                    "max_obj": N_OBJ, "num_feats": NF, "num_point": NPOINT, "bev_hw": HW,
                    "parallelism": "replica x%d (frame-parallel, no data-path collective)" % world,
                    "hip_graph": bool(args.graph),
-                   "arithmetic": ("fp32 operands, fp32 accumulation throughout; above 32 frame-pairs per step the first aug_shape "
-                                  "layer (and from 8192 table rows the row-embedding GEMMs) form every fp32 product from six exact "
-                                  "bf16 piece products on the bf16 MFMA path (error at the level of the fp32 FMA's own rounding; "
-                                  "--arithmetic f32 selects the f32 MFMA kernels)") if args.arithmetic == "pieces" else
-                                 "fp32 operands, fp32 accumulation throughout, f32 MFMA kernels only (--arithmetic f32)"},
+                   "arithmetic": {"f16x2": "fp32 operands in HBM, fp32 accumulation throughout; above 32 frame-pairs per step the first "
+                                           "aug_shape layer forms every fp32 product from three products of two range-scaled fp16 pieces per "
+                                           "operand (round to nearest; measured max error vs float64 5.5e-6, f32 MFMA kernel 7.0e-6); from "
+                                           "8192 table rows the row-embedding GEMMs and the aff layers use six products of three exact bf16 "
+                                           "pieces (--arithmetic pieces / f32 select the other forms)",
+                                  "pieces": "fp32 operands, fp32 accumulation throughout; above 32 frame-pairs per step the first aug_shape "
+                                            "layer, and from 8192 table rows the row-embedding GEMMs and the aff layers, form every fp32 product "
+                                            "from six exact bf16 piece products on the bf16 MFMA path",
+                                  "f32": "fp32 operands, fp32 accumulation throughout, f32 MFMA kernels only"}[args.arithmetic]},
         "dense_equivalent_tflops": DENSE_GFLOP_PER_PAIR * 1e9 * world * B * args.steps / elapsed / 1e12,
         "selfcheck_max_abs": selfcheck,
         "roofline": roof,

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void anchor_l1_kernel(AnchorL1Args a) {
 // hidden[b][r] = relu(bias1[r] + sum_ks part[ks][b][r]),  r over the 4H concatenated hidden units
 __global__ void anchor_hidden_kernel(const float* __restrict__ part, const float* b0, const float* b1,
                                      const float* b2, const float* b3, float* __restrict__ hidden, int H, int B,
-                                     int KS) {
+                                     int KS, const int* xexp, const int* wexp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = B * 4 * H;
     if (i >= total) return;
@@ -88,6 +88,8 @@ __global__ void anchor_hidden_kernel(const float* __restrict__ part, const float
     const float* bias = mlp == 0 ? b0 : mlp == 1 ? b1 : mlp == 2 ? b2 : b3;
     float s = part[i];
     for (int ks = 1; ks < KS; ++ks) s += part[(size_t)ks * total + i];
+    // two-piece fp16 form of the weight stream: undo the row scalings 2^e_b (activations of batch row b) and 2^e_r (weight row), exactly
+    if (xexp) s = __builtin_ldexpf(s, -(xexp[(mlp >> 1) * B + i / (4 * H)] + wexp[r]));
     hidden[i] = fmaxf(s + bias[j], 0.0f);
 }
 
@@ -288,15 +290,18 @@ __global__ __launch_bounds__(256) void box_l2_tables_kernel(BoxL2Args a) {
 
 size_t anchor_split_workspace_bytes(int B, int K);
 bool anchor_split_serves(int B, int K, int x_batch_stride);
-void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, int B, int x_batch_stride, hipStream_t st);
-void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part, int H, int K, int B, int* ks_out,
-                            hipStream_t st);
+void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, int B, int x_batch_stride, int np, const int* xexp,
+                    hipStream_t st);
+void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part, int H, int K, int B, int* ks_out, int np,
+                            const int* wexp, hipStream_t st);
+void launch_x_exponents(const float* feat, const float* prev_feat, int K, int B, int x_batch_stride, int* xexp, hipStream_t st);
+void launch_w_exponents(const float* const W[4], int H, int K, int* wexp, hipStream_t st);
 
 // [split-K partials, worst-case KS = 64][hidden (B, 4H)][bf16 activation image of anchor_split.hip, batches > 32 only]
 size_t anchor_shape_workspace_bytes(int B, int N, int F) {
     const int H = N * F / 64;
     return align_up((size_t)64 * B * 4 * H * sizeof(float), 256) + align_up((size_t)B * 4 * H * sizeof(float), 256) +
-           anchor_split_workspace_bytes(B, N * F);
+           anchor_split_workspace_bytes(B, N * F) + align_up((size_t)2 * B * sizeof(int), 256) + align_up((size_t)4 * H * sizeof(int), 256);
 }
 
 int launch_anchor_l1_mfma(const float* const W[4], const float* feat, const float* prev_feat, float* part, int H, int K,
@@ -318,7 +323,7 @@ const float* anchor_shape_hidden(const void* ws, int B, int N, int F) {
 }
 
 int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes,
-                 hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+                 hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const int* wexp) {
     const int N = w->max_obj, F = w->feat_dim;
     const int K = N * F, H = K / 64;
     if (ws_bytes < anchor_shape_workspace_bytes(B, N, F)) {
@@ -351,10 +356,21 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     const bool force_f32 = (w->options & SHASTA_OPT_F32_WEIGHT_STREAM) != 0;
     void* xs = reinterpret_cast<char*>(hidden) + align_up((size_t)B * 4 * H * sizeof(float), 256);
     const bool split = !force_f32 && anchor_split_serves(B, K, a.x_batch_stride);
-    if (split) launch_split_x(feat, prev_feat, xs, K, B, a.x_batch_stride, st);
+    const bool f16x2 = split && (w->options & SHASTA_OPT_F16X2_WEIGHT_STREAM) != 0;
+    const int np = f16x2 ? 2 : 3;
+    int* xexp = reinterpret_cast<int*>(static_cast<char*>(xs) + anchor_split_workspace_bytes(B, K));
+    if (f16x2) {
+        if (!wexp) {  // stage entry point without a packed buffer: one extra pass over the weights into the workspace
+            int* we = reinterpret_cast<int*>(reinterpret_cast<char*>(xexp) + align_up((size_t)2 * B * sizeof(int), 256));
+            launch_w_exponents(a.W, H, K, we, st);
+            wexp = we;
+        }
+        launch_x_exponents(feat, prev_feat, K, B, a.x_batch_stride, xexp, st);
+    }
+    if (split) launch_split_x(feat, prev_feat, xs, K, B, a.x_batch_stride, np, xexp, st);
     if (ev0) (void)hipEventRecord(ev0, st);
     if (B == 1) launch_l1<1, R>(a, st);
-    else if (split) launch_anchor_l1_split(a.W, xs, part, H, K, B, &a.KS, st);
+    else if (split) launch_anchor_l1_split(a.W, xs, part, H, K, B, &a.KS, np, wexp, st);
     else launch_anchor_l1_mfma(a.W, feat, prev_feat, part, H, K, B, a.x_batch_stride, &a.KS, st);
     if (ev1) (void)hipEventRecord(ev1, st);
     int rc = check_launch("anchor_l1");
@@ -362,7 +378,7 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     const int total = B * 4 * H;
     hipLaunchKernelGGL(anchor_hidden_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, part,
                        w->aug_shape[0][0].bias, w->aug_shape[1][0].bias, w->aug_shape[2][0].bias,
-                       w->aug_shape[3][0].bias, hidden, H, B, a.KS);
+                       w->aug_shape[3][0].bias, hidden, H, B, a.KS, f16x2 ? xexp : nullptr, wexp);
     rc = check_launch("anchor_hidden");
     if (rc) return rc;
     AnchorL2Args l2;

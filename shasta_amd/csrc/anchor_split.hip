@@ -32,6 +32,8 @@
 namespace shasta {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // a = h + m + l exactly, each with at most 8 significand bits (bf16-representable by truncation)
@@ -46,10 +48,79 @@ __device__ __forceinline__ uint32_t pack_top(float even, float odd) {
     return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u);
 }
 
+// exponent e with max * 2^e in (2^13, 2^14]: the scaled values use fp16's normal range with room below 65504
+__device__ __forceinline__ int range_exponent(float mx) {
+    if (!(mx > 0.0f) || !(mx < INFINITY)) return 0;
+    int ex;
+    (void)frexpf(mx, &ex);  // mx = m 2^ex, m in [0.5, 1)
+    return max(-60, min(60, 14 - ex));
+}
+
+// one workgroup per (row, source): e = range_exponent(max |row|) over `len` floats (16-byte aligned rows, len % 4 == 0)
+struct RowExpArgs {
+    const float* base[4];
+    long stride;     // floats between consecutive rows of one source
+    int rows, len;   // rows per source, floats per row
+    int* out;        // [source][rows]
+};
+__global__ __launch_bounds__(256) void row_exponent_kernel(RowExpArgs a) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, src = blockIdx.y;
+    const f32x4* p = reinterpret_cast<const f32x4*>(a.base[src] + (size_t)row * a.stride);
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < a.len / 4; i += 256) {
+        const f32x4 v = __builtin_nontemporal_load(p + i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) a.out[src * a.rows + row] = range_exponent(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+// exponents of the batch rows of both feature tables (frame 0: feat, frame 1: prev_feat): x_exp[2][B]
+void launch_x_exponents(const float* feat, const float* prev_feat, int K, int B, int x_batch_stride, int* xexp, hipStream_t st) {
+    RowExpArgs r;
+    r.base[0] = feat;
+    r.base[1] = prev_feat;
+    r.base[2] = r.base[3] = nullptr;
+    r.stride = x_batch_stride;
+    r.rows = B;
+    r.len = K;
+    r.out = xexp;
+    hipLaunchKernelGGL(row_exponent_kernel, dim3(B, 2), dim3(256), 0, st, r);
+}
+// exponents of the 4 x H weight rows of the aug_shape first layers (pack time): w_exp[4][H]
+void launch_w_exponents(const float* const W[4], int H, int K, int* wexp, hipStream_t st) {
+    RowExpArgs r;
+    for (int i = 0; i < 4; ++i) r.base[i] = W[i];
+    r.stride = K;
+    r.rows = H;
+    r.len = K;
+    r.out = wexp;
+    hipLaunchKernelGGL(row_exponent_kernel, dim3(H, 4), dim3(256), 0, st, r);
+}
+
+// Two-piece fp16 form (NP = 2): a * 2^e = h + l + err with h = fp16(a 2^e) and l = fp16(a 2^e - h), both rounded to nearest:
+// |err| <= 2^-24 |a 2^e|, half an ulp of the fp32 value itself.  2^e is an exact power of two - one per batch row of the
+// activations, one per weight row - that puts the row's largest magnitude into (2^13, 2^14] (range_exponent); the result row /
+// column is scaled back by 2^-(e_b + e_m) in anchor_hidden_kernel, exactly.  w * x is then the THREE products w_l x_h + w_h x_l + w_h x_h (each exact in the fp32 accumulator of
+// v_mfma_f32_32x32x16_f16; the dropped w_l x_l is below 2^-24 |w x|), half the matrix work of the six bf16 piece products.
+__device__ __forceinline__ void split2h(float a, _Float16& h, _Float16& l) {
+    h = (_Float16)a;
+    l = (_Float16)(a - (float)h);
+}
+__device__ __forceinline__ uint32_t pack_h2(_Float16 even, _Float16 odd) {
+    const f16x2 v = {even, odd};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
 struct SplitXArgs {
     const float* x[2];
-    uint32_t* xs;  // [2 frames][NBLK][KT][XT][2 k-steps][3 pieces][64 lanes][8 bf16]
-    int B, KT, NBLK, XT, x_batch_stride;
+    uint32_t* xs;  // [2 frames][NBLK][KT][XT][2 k-steps][NP pieces][64 lanes][8 bf16 / fp16]
+    int B, KT, NBLK, XT, x_batch_stride, NP;
+    const int* xexp;  // NP = 2: [2 frames][B] exponents e: batch row b of frame f is cut as x * 2^e (row_exponent_kernel)
 };
 
 // grid (cdiv(KT, 8), NBLK * XT, 2): 32 batch rows x 256 k per block, transposed through LDS so that both the fp32 reads
@@ -75,6 +146,23 @@ __global__ __launch_bounds__(256) void split_x_kernel(SplitXArgs a) {
         const float* p = &tile[r][ktl * 32 + 16 * s + 8 * h];
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
         const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (a.NP == 2) {
+            const int e = a.xexp[src * a.B + min(brow0 + r, a.B - 1)];
+            u32x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 h0, l0, h1, l1;
+                split2h(__builtin_ldexpf(v[2 * j], e), h0, l0);
+                split2h(__builtin_ldexpf(v[2 * j + 1], e), h1, l1);
+                hi[j] = pack_h2(h0, h1);
+                lo[j] = pack_h2(l0, l1);
+            }
+            const size_t frag0 = ((((size_t)src * a.NBLK + bblk) * a.KT + kt0 + ktl) * (4 * a.XT)) + (size_t)(u * 2 + s) * 2;
+            u32x4* o = reinterpret_cast<u32x4*>(a.xs) + frag0 * 64 + lane;
+            o[0] = hi;
+            o[64] = lo;
+            continue;
+        }
         u32x4 hi, mid, lo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -98,6 +186,7 @@ struct AnchorSplitArgs {
     const uint32_t* xs;
     float* part;
     int H, K, B, KS, Kc, KT, NBLK, groups_per_mlp;
+    const int* wexp;  // NP = 2: [4][H] exponents of the weight rows (launch_w_exponents, pack time)
 };
 
 #ifdef SHASTA_L1_STAMP  // diagnostic build only (tools/probes/l1_split_probe.hip): in-kernel clock and cycles per tile
@@ -109,16 +198,17 @@ __device__ __forceinline__ void wait_vm_split() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// XT = batch rows per pass / 32 (2 or 4); NS = ring slots
-template <int XT, int NS>
+// XT = batch rows per pass / 32 (2, 4 or 8); NS = ring slots; NP = pieces per operand: 3 (bf16, six products) or 2 (fp16, three)
+template <int XT, int NS, int NP>
 __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a) {
-    constexpr int XCH = 6 * XT;                  // 1 KB fragments of one x tile
+    constexpr int NPROD = NP == 3 ? 6 : 3;
+    constexpr int XCH = 2 * NP * XT;             // 1 KB fragments of one x tile
     constexpr int XPW = XCH / 4;                 // of which every wave fetches this many
     static_assert(XCH % 4 == 0, "x fragments are dealt to four waves");
     constexpr int SLOT = 4 * 1024 + XCH * 256;   // dwords per ring slot: 4 private W tiles + the shared x tile
     constexpr int PER_TILE = 4 + XPW;            // vmcnt units a wave spends per tile
     static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt is 6 bits");
-    constexpr int NM = 12 * XT;                  // MFMAs per tile
+    constexpr int NM = 2 * NPROD * XT;           // MFMAs per tile
     constexpr int ND = PER_TILE;                 // LDS-DMA instructions per tile and wave
     constexpr int NR = 4 + XCH;                  // ds_read_b128 per tile and wave
     constexpr int SG = (NM - 8) / 16;            // MFMA gaps between two weight elements being cut
@@ -174,8 +264,8 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
     };
 
     struct Frag {
-        u32x4 A[2][3];      // weight pieces [k-step][piece]
-        u32x4 X[XT][2][3];  // activation pieces [32-row block][k-step][piece]
+        u32x4 A[2][NP];      // weight pieces [k-step][piece]
+        u32x4 X[XT][2][NP];  // activation pieces [32-row block][k-step][piece]
     };
     f32x4 raw[4];           // fp32 weights of the tile being cut: [2 * k-step + half]
     const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
@@ -186,28 +276,39 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
             raw[idx] = *reinterpret_cast<const f32x4*>(sl + wid * 1024 + frow * 32 + (((4 * s + 2 * fh + qq) ^ fsw) * 4));
         } else {
             const int j = idx - 4;
-            f.X[j / 6][(j / 3) % 2][j % 3] = *reinterpret_cast<const u32x4*>(sl + 4096 + j * 256 + lane * 4);
+            f.X[j / (2 * NP)][(j / NP) % 2][j % NP] = *reinterpret_cast<const u32x4*>(sl + 4096 + j * 256 + lane * 4);
         }
     };
     // cut weight element e (0..15) of the tile in `raw`; the pair (e-1, e) is packed when e is odd.  (Packed-f32 subtractions,
     // 9 instead of 11 VALU instructions per pair, measured the same: the kernel is not bound by VALU issue.)
     float ph = 0.0f, pm = 0.0f, pl = 0.0f;
+    _Float16 qh = 0, ql = 0;
+    int wex = 0;  // exponent of this lane's weight row
+    if constexpr (NP == 2) wex = a.wexp[mlp * a.H + min(r0 + frow, a.H - 1)];
     auto cut_one = [&](Frag& f, int e) {
         const int s = e >> 3, d = (e & 7) >> 1;
-#ifdef SPLIT_EXP_NOCUT  // probe: no VALU work (results are wrong)
-        if (e & 1) f.A[s][0][d] = f.A[s][1][d] = f.A[s][2][d] = __float_as_uint(raw[e >> 2][e & 3]);
-        return;
-#endif
-        float h, m, l;
-        split3(raw[e >> 2][e & 3], h, m, l);
-        if ((e & 1) == 0) {
-            ph = h;
-            pm = m;
-            pl = l;
+        if constexpr (NP == 2) {
+            _Float16 h, l;
+            split2h(__builtin_ldexpf(raw[e >> 2][e & 3], wex), h, l);
+            if ((e & 1) == 0) {
+                qh = h;
+                ql = l;
+            } else {
+                f.A[s][0][d] = pack_h2(qh, h);
+                f.A[s][1][d] = pack_h2(ql, l);
+            }
         } else {
-            f.A[s][0][d] = pack_top(ph, h);
-            f.A[s][1][d] = pack_top(pm, m);
-            f.A[s][2][d] = pack_top(pl, l);
+            float h, m, l;
+            split3(raw[e >> 2][e & 3], h, m, l);
+            if ((e & 1) == 0) {
+                ph = h;
+                pm = m;
+                pl = l;
+            } else {
+                f.A[s][0][d] = pack_top(ph, h);
+                f.A[s][1][d] = pack_top(pm, m);
+                f.A[s][NP - 1][d] = pack_top(pl, l);
+            }
         }
     };
 
@@ -215,15 +316,19 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
 #pragma unroll
     for (int u = 0; u < XT; ++u) acc[u] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // piece products, small to large
-    constexpr int PW[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int PX[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PW2[3] = {1, 0, 0};
+    constexpr int PX[6] = {0, 2, 1, 0, 1, 0}, PX2[3] = {0, 1, 0};
     auto mma_one = [&](const Frag& f, int i) {
-        const int s = i / (6 * XT), u = (i / 6) % XT, pr = i % 6;
+        const int s = i / (NPROD * XT), u = (i / NPROD) % XT, pr = i % NPROD;
 #ifdef SPLIT_EXP_NOMFMA  // probe: data movement only
-        if (i % 6 != 0) return;
+        if (i % NPROD != 0) return;
 #endif
-        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.A[s][PW[pr]]),
-                                                         __builtin_bit_cast(bf16x8, f.X[u][s][PX[pr]]), acc[u], 0, 0, 0);
+        if constexpr (NP == 3)
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.A[s][PW[pr]]),
+                                                             __builtin_bit_cast(bf16x8, f.X[u][s][PX[pr]]), acc[u], 0, 0, 0);
+        else
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.A[s][PW2[pr]]),
+                                                            __builtin_bit_cast(f16x8, f.X[u][s][PX2[pr]]), acc[u], 0, 0, 0);
     };
 
 #ifdef SHASTA_L1_STAMP
@@ -315,21 +420,25 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
     }
 }
 
-static inline int split_xt(int B) { return B <= 64 ? 2 : 4; }
-static inline int split_nblk(int B) { return cdiv(B, 32 * split_xt(B)); }
+// np = pieces per operand: 3 = bf16 (six products), 2 = fp16 (three products, SHASTA_OPT_F16X2_WEIGHT_STREAM)
+static inline int split_xt(int B, int np) { return np == 2 ? (B > 128 ? 8 : 4) : (B <= 64 ? 2 : 4); }
+static inline int split_nblk(int B, int np) { return cdiv(B, 32 * split_xt(B, np)); }
 
-// bytes of the bf16 activation image (0 for batches the f32 kernels serve)
+// bytes of the piece image of the activations (0 for batches the f32 kernels serve): sized for the larger of the two forms
 size_t anchor_split_workspace_bytes(int B, int K) {
     if (B <= 32 || K % 32 != 0) return 0;
-    return align_up((size_t)2 * split_nblk(B) * 32 * split_xt(B) * (size_t)K * 6, 256);
+    const size_t b3 = (size_t)2 * split_nblk(B, 3) * 32 * split_xt(B, 3) * (size_t)K * 6;
+    const size_t b2 = (size_t)2 * split_nblk(B, 2) * 32 * split_xt(B, 2) * (size_t)K * 4;
+    return align_up(b3 > b2 ? b3 : b2, 256);
 }
 
 // true when anchor_l1_split_kernel serves this shape (otherwise the f32 kernels of anchor_mfma.hip / anchor.hip do)
 bool anchor_split_serves(int B, int K, int x_batch_stride) { return B > 32 && K % 32 == 0 && (x_batch_stride & 3) == 0; }
 
 // cut the activations of both frames into the bf16 fragment image `xs`
-void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, int B, int x_batch_stride, hipStream_t st) {
-    const int XT = split_xt(B), NBLK = split_nblk(B), KT = K / 32;
+void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, int B, int x_batch_stride, int np, const int* xexp,
+                    hipStream_t st) {
+    const int XT = split_xt(B, np), NBLK = split_nblk(B, np), KT = K / 32;
     SplitXArgs sx;
     sx.x[0] = feat;
     sx.x[1] = prev_feat;
@@ -339,12 +448,14 @@ void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, 
     sx.NBLK = NBLK;
     sx.XT = XT;
     sx.x_batch_stride = x_batch_stride;
+    sx.NP = np;
+    sx.xexp = xexp;
     hipLaunchKernelGGL(split_x_kernel, dim3(cdiv(KT, 8), NBLK * XT, 2), dim3(256), 0, st, sx);
 }
 
-void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part, int H, int K, int B, int* ks_out,
-                            hipStream_t st) {
-    const int XT = split_xt(B), NBLK = split_nblk(B), KT = K / 32;
+void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part, int H, int K, int B, int* ks_out, int np,
+                            const int* wexp, hipStream_t st) {
+    const int XT = split_xt(B, np), NBLK = split_nblk(B, np), KT = K / 32;
     AnchorSplitArgs a;
     for (int i = 0; i < 4; ++i) a.W[i] = W[i];
     a.xs = static_cast<const uint32_t*>(xs);
@@ -355,6 +466,7 @@ void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part
     a.KT = KT;
     a.NBLK = NBLK;
     a.groups_per_mlp = cdiv(H, 32);
+    a.wexp = wexp;
     const int quads = cdiv(2 * a.groups_per_mlp, 4);  // workgroups per (K chunk, frame)
     int ncu = 256;
     {
@@ -365,9 +477,13 @@ void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part
         }
     }
     // one workgroup per CU (the ring takes the whole LDS): pick the K split that fills whole rounds of the CU array best
-    int ks = 1;
+    // ... among splits of at least 4 chunks (when K allows): an fp32 accumulator then sums at most K/4 products, which keeps the
+    // accumulation rounding at the level of the 64-row f32 kernel's (measured against float64 at 512 frame-pairs per launch:
+    // 2.9e-5 with one 128 000-term chain per accumulator, 7e-6 ... 1.2e-5 with chains of 32 000)
+    const int cmin = KT >= 64 ? 4 : 1;
+    int ks = cmin;
     double best = -1.0;
-    for (int c = 1; c <= 64 && c * 16 <= KT; ++c) {
+    for (int c = cmin; c <= 64 && c * 16 <= KT; ++c) {
         const int wgs = 2 * cdiv(KT, cdiv(KT, c)) * quads * NBLK;
         const int rounds = cdiv(wgs, ncu);
         const double eff = (double)wgs / ((double)rounds * ncu);
@@ -381,12 +497,15 @@ void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part
     a.KS = cdiv(KT, tiles_per);
     *ks_out = a.KS;
     auto launch = [&](auto kern, int ns, int xt) {
-        const size_t ldsb = (size_t)ns * (4 * 1024 + 6 * xt * 256) * sizeof(float);
+        const size_t ldsb = (size_t)ns * (4 * 1024 + 2 * np * xt * 256) * sizeof(float);
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         hipLaunchKernelGGL(kern, dim3(2 * a.KS * quads, NBLK), dim3(256), ldsb, st, a);
     };
-    if (XT == 2) launch(anchor_l1_split_kernel<2, 5>, 5, 2);  // 4 slots measure the same: the ring depth is not the limit
-    else launch(anchor_l1_split_kernel<4, 4>, 4, 4);
+    if (np == 2) {
+        if (XT == 4) launch(anchor_l1_split_kernel<4, 4, 2>, 4, 4);
+        else launch(anchor_l1_split_kernel<8, 3, 2>, 3, 8);
+    } else if (XT == 2) launch(anchor_l1_split_kernel<2, 5, 3>, 5, 2);  // 4 slots measure the same: the ring depth is not the limit
+    else launch(anchor_l1_split_kernel<4, 4, 3>, 4, 4);
 }
 
 }  // namespace shasta

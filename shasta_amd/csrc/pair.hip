@@ -519,6 +519,7 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
 }
 
 int aff_pieces_pack(const shasta_weights* w, float* out, hipStream_t st);
+void launch_w_exponents(const float* const W[4], int H, int K, int* wexp, hipStream_t st);
 
 int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {
     PackArgs a;
@@ -533,7 +534,16 @@ int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {
     hipLaunchKernelGGL(pack_pair_weights_kernel, dim3(256), dim3(256), 0, st, a);
     int rc = check_launch("pack_pair_weights");
     if (rc) return rc;
-    return aff_pieces_pack(w, packed + PackedLayout(w->max_obj, w->num_feats, w->feat_dim).affp, st);
+    const PackedLayout P(w->max_obj, w->num_feats, w->feat_dim);
+    if ((rc = aff_pieces_pack(w, packed + P.affp, st))) return rc;
+    if (w->options & SHASTA_OPT_F16X2_WEIGHT_STREAM) {  // one pass over the four first-layer matrices (4.1 GB at N=500, F=256)
+        const float* W[4];
+        for (int i = 0; i < 4; ++i) W[i] = w->aug_shape[i][0].weight;
+        const int K = w->max_obj * w->feat_dim, H = K / 64;
+        if (H > 0) launch_w_exponents(W, H, K, reinterpret_cast<int*>(packed + P.l1wexp), st);
+        rc = check_launch("w_exponents");
+    }
+    return rc;
 }
 
 }  // namespace shasta

@@ -22,6 +22,7 @@ class ShastaHipError(RuntimeError):
 OPT_F32_WEIGHT_STREAM = 1  # include/shasta_hip.h SHASTA_OPT_*
 OPT_F32_EMBED_GEMM = 2
 OPT_F32_AFF = 4
+OPT_F16X2_WEIGHT_STREAM = 8
 
 
 class Linear(C.Structure):

@@ -111,10 +111,14 @@ class Shasta(BaseTrack):
         self._wstruct = None
         self._bufs = {}
         self._graph_bufs = []
-        # "pieces" (default): above 32 frame-pairs per call the aug_shape first layer and, from 8192 table rows, the
-        # row-embedding GEMMs form their fp32 products from exact bf16 pieces on the bf16 matrix path; "f32": the f32 MFMA
-        # kernels everywhere (shasta_weights.options, include/shasta_hip.h).  Both are fp32 operands / fp32 accumulation.
-        self.arithmetic = "pieces"
+        # How fp32 products are formed on the matrix cores (shasta_weights.options, include/shasta_hip.h); fp32 operands in HBM and
+        # fp32 accumulation in every mode:
+        #   "f16x2" (default): as "pieces", but the aug_shape first layer (the 4.1 GB weight stream) cuts every operand into TWO
+        #            fp16 pieces, rounded to nearest and range-scaled per row, and forms three products per fp32 product;
+        #   "pieces": above 32 frame-pairs per call the aug_shape first layer and, from 8192 table rows, the row-embedding GEMMs
+        #            and the aff layers use three exact bf16 pieces per operand, six products per fp32 product;
+        #   "f32":   the f32 MFMA kernels everywhere.
+        self.arithmetic = "f16x2"
         self.keep_intermediates = False  # tests: also return residual / matched via self.last_intermediates
         self.last_intermediates = None
 
@@ -189,9 +193,10 @@ class Shasta(BaseTrack):
 
         w = hip.Weights()
         w.max_obj, w.num_feats, w.feat_dim = self.max_obj, self.num_feats, self.aug_shape_output
-        if self.arithmetic not in ("pieces", "f32"):
-            raise ValueError("Shasta.arithmetic must be 'pieces' or 'f32'")
-        w.options = (hip.OPT_F32_WEIGHT_STREAM | hip.OPT_F32_EMBED_GEMM | hip.OPT_F32_AFF) if self.arithmetic == "f32" else 0
+        if self.arithmetic not in ("pieces", "f32", "f16x2"):
+            raise ValueError("Shasta.arithmetic must be 'pieces', 'f32' or 'f16x2'")
+        w.options = {"pieces": 0, "f32": hip.OPT_F32_WEIGHT_STREAM | hip.OPT_F32_EMBED_GEMM | hip.OPT_F32_AFF,
+                     "f16x2": hip.OPT_F16X2_WEIGHT_STREAM}[self.arithmetic]
         for i in range(4):
             w.aug_shape[i][0], w.aug_shape[i][1] = lin(self.aug_shape[i][0]), lin(self.aug_shape[i][2])
             w.aug_dets[i][0], w.aug_dets[i][1] = lin(self.aug_dets[i][0]), lin(self.aug_dets[i][2])
@@ -205,7 +210,9 @@ class Shasta(BaseTrack):
         return w
 
     def _ensure_packed(self, w, device):
-        key = tuple((p.data_ptr(), p._version) for p in self._small_params())
+        key = tuple((p.data_ptr(), p._version) for p in self._small_params()) + (self.arithmetic,)
+        if self.arithmetic == "f16x2":  # the packed buffer then also holds the range exponents of the first-layer weight rows
+            key += tuple((self.aug_shape[i][0].weight.data_ptr(), self.aug_shape[i][0].weight._version) for i in range(4))
         if self._packed is not None and self._packed_key == key and self._packed.device == device:
             return
         lib = hip.load()

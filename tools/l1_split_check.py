@@ -19,6 +19,7 @@ ap.add_argument("--points", type=int, default=4)
 ap.add_argument("--batch", type=int, nargs="+", default=[64, 128])
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--f32", action="store_true")
+ap.add_argument("--arithmetic", choices=["pieces", "f32", "f16x2"], default=None)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -28,6 +29,8 @@ with torch.device(dev):
                                              max_obj=a.max_obj, num_feats=a.feats, num_point=a.points)).eval()
 if a.f32:
     model.arithmetic = "f32"
+if a.arithmetic:
+    model.arithmetic = a.arithmetic
 N = a.max_obj
 K = model.aug_shape_input
 for B in a.batch:
@@ -66,5 +69,5 @@ for B in a.batch:
         t1.record()
         torch.cuda.synchronize()
         ms = t0.elapsed_time(t1) / a.steps
-    print(json.dumps(dict(B=B, max_obj=N, K=K, f32_forced=bool(a.f32), max_abs_err=err, ref_scale=scale,
+    print(json.dumps(dict(B=B, max_obj=N, K=K, f32_forced=bool(a.f32 or a.arithmetic == "f32"), arithmetic=model.arithmetic, max_abs_err=err, ref_scale=scale,
                           ms_per_step=round(ms, 4), frame_pairs_per_s=round(B / ms * 1e3, 1))), flush=True)
