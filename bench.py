@@ -220,15 +220,16 @@ def main():
     #   pieces: B <= 64: bf16-piece kernel (each fp32 product = 6 exact bf16 piece products), 768 cycles per tile   -> HBM-bound
     #           B  > 64: the same with 128 items per weight pass, 1536 cycles per tile -> bound by the bf16 matrix pipe: priced as
     #                    EXECUTED bf16 flops (6 piece products per fp32 product) against the dense bf16 MFMA peak
-    #   f16x2 (default): 3 fp16 piece products: 128 items per pass (768 cycles per tile, HBM-bound) up to 128 frame-pairs, 256 items
-    #                    per pass (1536 cycles) above: EXECUTED f16 flops (3 per fp32 product) against the dense f16 MFMA peak
+    #   f16x2 (default): as pieces up to 64 frame-pairs; above, 3 fp16 piece products: 128 items per pass (768 cycles per tile,
+    #                    HBM-bound) up to 128 frame-pairs, 256 items per pass (1536 cycles) above: EXECUTED f16 flops (3 per fp32
+    #                    product) against the dense f16 MFMA peak
     #   --arithmetic f32 and B > 32: f32 MFMA kernel, 64 items per pass, 2048 cycles per tile -> f32 matrix pipe
     alg = l1_algorithmic_bytes(B)
     hbm_gbs = alg / (l1_ms * 1e-3) / 1e9
     K = N_OBJ * CH * NPOINT
     l1_flops = 2.0 * B * 4 * (K // 64) * K  # dense fp32 flops of the four first layers for B frame-pairs (algorithmic = executed)
     l1_tflops = l1_flops / (l1_ms * 1e-3) / 1e12
-    f32_forced, f16x2 = args.arithmetic == "f32", args.arithmetic == "f16x2"
+    f32_forced, f16x2 = args.arithmetic == "f32", args.arithmetic == "f16x2" and B > 64  # up to 64 frame-pairs the bf16-piece kernel serves
     if B <= 32:
         passes, nprod = 1, 1
     elif f32_forced:

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void anchor_l1_kernel(AnchorL1Args a) {
 // hidden[b][r] = relu(bias1[r] + sum_ks part[ks][b][r]),  r over the 4H concatenated hidden units
 __global__ void anchor_hidden_kernel(const float* __restrict__ part, const float* b0, const float* b1,
                                      const float* b2, const float* b3, float* __restrict__ hidden, int H, int B,
-                                     int KS, const int* xexp, const int* wexp) {
+                                     int KS, const unsigned* xmax, const unsigned* wmax) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = B * 4 * H;
     if (i >= total) return;
@@ -89,7 +89,7 @@ __global__ void anchor_hidden_kernel(const float* __restrict__ part, const float
     float s = part[i];
     for (int ks = 1; ks < KS; ++ks) s += part[(size_t)ks * total + i];
     // two-piece fp16 form of the weight stream: undo the row scalings 2^e_b (activations of batch row b) and 2^e_r (weight row), exactly
-    if (xexp) s = __builtin_ldexpf(s, -(xexp[(mlp >> 1) * B + i / (4 * H)] + wexp[r]));
+    if (xmax) s = __builtin_ldexpf(s, -(range_exponent_bits(xmax[(mlp >> 1) * B + i / (4 * H)]) + range_exponent_bits(wmax[r])));
     hidden[i] = fmaxf(s + bias[j], 0.0f);
 }
 
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void box_l1_small_kernel(BoxL1Args a) {
         a.hid[((size_t)b * 4 + mlp) * a.HD + u] = fmaxf(((part[0] + part[1]) + (part[2] + part[3])) + a.bias[mlp][u], 0.0f);
 }
 
-// Batches >= 16: the four first layers as GEMMs.  Their input - the 7-vectors of the boxes BEFORE back-projection, flattened -
+// Batches >= 256: the four first layers as GEMMs.  Their input - the 7-vectors of the boxes BEFORE back-projection, flattened -
 // is strided (7 of box_stride floats per row) in the caller's tensors: pack it once into (2, B, ldx) rows, ldx = ceil4(7N),
 // zero tail (x7[0] = current boxes: newborn / fp, x7[1] = previous boxes: dead_trk / fn).
 __global__ __launch_bounds__(256) void box_pack7_kernel(const float* __restrict__ det, const float* __restrict__ prev, float* __restrict__ x7,
@@ -290,12 +290,13 @@ __global__ __launch_bounds__(256) void box_l2_tables_kernel(BoxL2Args a) {
 
 size_t anchor_split_workspace_bytes(int B, int K);
 bool anchor_split_serves(int B, int K, int x_batch_stride);
-void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, int B, int x_batch_stride, int np, const int* xexp,
+void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, int B, int x_batch_stride, int np, const unsigned* xmax,
                     hipStream_t st);
 void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part, int H, int K, int B, int* ks_out, int np,
-                            const int* wexp, hipStream_t st);
-void launch_x_exponents(const float* feat, const float* prev_feat, int K, int B, int x_batch_stride, int* xexp, hipStream_t st);
-void launch_w_exponents(const float* const W[4], int H, int K, int* wexp, hipStream_t st);
+                            const unsigned* wmax, hipStream_t st);
+int launch_x_maxima(const float* feat, const float* prev_feat, int K, int B, int x_batch_stride, unsigned* xmax, hipStream_t st);
+int launch_w_maxima(const float* const W[4], int H, int K, unsigned* wmax, hipStream_t st);
+
 
 // [split-K partials, worst-case KS = 64][hidden (B, 4H)][bf16 activation image of anchor_split.hip, batches > 32 only]
 size_t anchor_shape_workspace_bytes(int B, int N, int F) {
@@ -323,7 +324,7 @@ const float* anchor_shape_hidden(const void* ws, int B, int N, int F) {
 }
 
 int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes,
-                 hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const int* wexp) {
+                 hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const unsigned* wmax) {
     const int N = w->max_obj, F = w->feat_dim;
     const int K = N * F, H = K / 64;
     if (ws_bytes < anchor_shape_workspace_bytes(B, N, F)) {
@@ -356,21 +357,23 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     const bool force_f32 = (w->options & SHASTA_OPT_F32_WEIGHT_STREAM) != 0;
     void* xs = reinterpret_cast<char*>(hidden) + align_up((size_t)B * 4 * H * sizeof(float), 256);
     const bool split = !force_f32 && anchor_split_serves(B, K, a.x_batch_stride);
-    const bool f16x2 = split && (w->options & SHASTA_OPT_F16X2_WEIGHT_STREAM) != 0;
+    // above 64 frame-pairs the two-piece fp16 form when asked for (up to 64 the three-piece bf16 kernel's 64-row pass is the faster one)
+    const bool f16x2 = split && B > 64 && (w->options & SHASTA_OPT_F16X2_WEIGHT_STREAM) != 0;
     const int np = f16x2 ? 2 : 3;
-    int* xexp = reinterpret_cast<int*>(static_cast<char*>(xs) + anchor_split_workspace_bytes(B, K));
+    unsigned* xmax = reinterpret_cast<unsigned*>(static_cast<char*>(xs) + anchor_split_workspace_bytes(B, K));
     if (f16x2) {
-        if (!wexp) {  // stage entry point without a packed buffer: one extra pass over the weights into the workspace
-            int* we = reinterpret_cast<int*>(reinterpret_cast<char*>(xexp) + align_up((size_t)2 * B * sizeof(int), 256));
-            launch_w_exponents(a.W, H, K, we, st);
-            wexp = we;
+        int rc0;
+        if (!wmax) {  // stage entry point without a packed buffer: one extra pass over the weights into the workspace
+            unsigned* wm = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(xmax) + align_up((size_t)2 * B * sizeof(int), 256));
+            if ((rc0 = launch_w_maxima(a.W, H, K, wm, st))) return rc0;
+            wmax = wm;
         }
-        launch_x_exponents(feat, prev_feat, K, B, a.x_batch_stride, xexp, st);
+        if ((rc0 = launch_x_maxima(feat, prev_feat, K, B, a.x_batch_stride, xmax, st))) return rc0;
     }
-    if (split) launch_split_x(feat, prev_feat, xs, K, B, a.x_batch_stride, np, xexp, st);
+    if (split) launch_split_x(feat, prev_feat, xs, K, B, a.x_batch_stride, np, xmax, st);
     if (ev0) (void)hipEventRecord(ev0, st);
     if (B == 1) launch_l1<1, R>(a, st);
-    else if (split) launch_anchor_l1_split(a.W, xs, part, H, K, B, &a.KS, np, wexp, st);
+    else if (split) launch_anchor_l1_split(a.W, xs, part, H, K, B, &a.KS, np, wmax, st);
     else launch_anchor_l1_mfma(a.W, feat, prev_feat, part, H, K, B, a.x_batch_stride, &a.KS, st);
     if (ev1) (void)hipEventRecord(ev1, st);
     int rc = check_launch("anchor_l1");
@@ -378,7 +381,7 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     const int total = B * 4 * H;
     hipLaunchKernelGGL(anchor_hidden_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, part,
                        w->aug_shape[0][0].bias, w->aug_shape[1][0].bias, w->aug_shape[2][0].bias,
-                       w->aug_shape[3][0].bias, hidden, H, B, a.KS, f16x2 ? xexp : nullptr, wexp);
+                       w->aug_shape[3][0].bias, hidden, H, B, a.KS, f16x2 ? xmax : nullptr, wmax);
     rc = check_launch("anchor_hidden");
     if (rc) return rc;
     AnchorL2Args l2;
@@ -393,7 +396,7 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     l2.F = F;
     l2.N = N;
     l2.B = B;
-    if (B >= 16) {
+    if (B >= 256) {  // (measured: the four GEMMs take 80 - 100 us whatever the batch, the VALU kernel 39 us at 64 frame-pairs, 238 at 512)
         // a plain GEMM per MLP from here on: (B, H) x (F, H)^T on the matrix cores, |.| and the table row as the epilogue's
         // target (row N + (i & 1) of prev_feat for newborn / fp, of feat for dead_trk / fn; leading dimension = one batch item)
         const float* A[4];
@@ -438,7 +441,7 @@ int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* 
         a.N = N;
         a.B = B;
         a.box_stride = box_stride;
-        if (B >= 16) {
+        if (B >= 256) {
             const int ldx = (7 * N + 3) / 4 * 4;
             float* x7 = reinterpret_cast<float*>(reinterpret_cast<char*>(hid_ws) + align_up((size_t)B * 4 * HD * sizeof(float), 256));
             hipLaunchKernelGGL(box_pack7_kernel, dim3(cdiv(ldx, 256), B, 2), dim3(256), 0, st, det_boxes, prev_det_boxes, x7, B, N, box_stride, ldx);

@@ -48,27 +48,23 @@ __device__ __forceinline__ uint32_t pack_top(float even, float odd) {
     return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u);
 }
 
-// exponent e with max * 2^e in (2^13, 2^14]: the scaled values use fp16's normal range with room below 65504
-__device__ __forceinline__ int range_exponent(float mx) {
-    if (!(mx > 0.0f) || !(mx < INFINITY)) return 0;
-    int ex;
-    (void)frexpf(mx, &ex);  // mx = m 2^ex, m in [0.5, 1)
-    return max(-60, min(60, 14 - ex));
-}
-
-// one workgroup per (row, source): e = range_exponent(max |row|) over `len` floats (16-byte aligned rows, len % 4 == 0)
-struct RowExpArgs {
+// Largest magnitude of every row: grid (chunks, rows, sources), one atomicMax per workgroup on the bit pattern of a non-negative
+// float (order-preserving as unsigned).  `out` ([source][rows] uint32) must be zero on entry.  Rows are 16-byte aligned,
+// len % 4 == 0.  The consumers turn the maximum into the row's range exponent themselves (range_exponent_bits).
+struct RowMaxArgs {
     const float* base[4];
     long stride;     // floats between consecutive rows of one source
     int rows, len;   // rows per source, floats per row
-    int* out;        // [source][rows]
+    unsigned* out;   // [source][rows]
 };
-__global__ __launch_bounds__(256) void row_exponent_kernel(RowExpArgs a) {
+__global__ __launch_bounds__(256) void row_max_kernel(RowMaxArgs a) {
     __shared__ float red[4];
-    const int row = blockIdx.x, src = blockIdx.y;
+    const int row = blockIdx.y, src = blockIdx.z;
+    const int n4 = a.len / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
+    const int beg = blockIdx.x * per, end = min(n4, beg + per);
     const f32x4* p = reinterpret_cast<const f32x4*>(a.base[src] + (size_t)row * a.stride);
     float m = 0.0f;
-    for (int i = threadIdx.x; i < a.len / 4; i += 256) {
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
         const f32x4 v = __builtin_nontemporal_load(p + i);
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
@@ -76,30 +72,39 @@ __global__ __launch_bounds__(256) void row_exponent_kernel(RowExpArgs a) {
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) a.out[src * a.rows + row] = range_exponent(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (threadIdx.x == 0) atomicMax(a.out + src * a.rows + row, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
-// exponents of the batch rows of both feature tables (frame 0: feat, frame 1: prev_feat): x_exp[2][B]
-void launch_x_exponents(const float* feat, const float* prev_feat, int K, int B, int x_batch_stride, int* xexp, hipStream_t st) {
-    RowExpArgs r;
+static int row_max_chunks(int rows, int sources, int len) {  // enough workgroups to fill the chip, at least 16 KB per workgroup
+    int c = 1;
+    while (c < 64 && rows * sources * c < 2048 && len / (c * 2) >= 4096) c *= 2;
+    return c;
+}
+// maxima of the batch rows of both feature tables (frame 0: feat, frame 1: prev_feat): xmax[2][B]
+int launch_x_maxima(const float* feat, const float* prev_feat, int K, int B, int x_batch_stride, unsigned* xmax, hipStream_t st) {
+    if (hipMemsetAsync(xmax, 0, (size_t)2 * B * sizeof(unsigned), st) != hipSuccess) return SHASTA_E_LAUNCH;
+    RowMaxArgs r;
     r.base[0] = feat;
     r.base[1] = prev_feat;
     r.base[2] = r.base[3] = nullptr;
     r.stride = x_batch_stride;
     r.rows = B;
     r.len = K;
-    r.out = xexp;
-    hipLaunchKernelGGL(row_exponent_kernel, dim3(B, 2), dim3(256), 0, st, r);
+    r.out = xmax;
+    hipLaunchKernelGGL(row_max_kernel, dim3(row_max_chunks(B, 2, K), B, 2), dim3(256), 0, st, r);
+    return check_launch("row_max (activations)");
 }
-// exponents of the 4 x H weight rows of the aug_shape first layers (pack time): w_exp[4][H]
-void launch_w_exponents(const float* const W[4], int H, int K, int* wexp, hipStream_t st) {
-    RowExpArgs r;
+// maxima of the 4 x H weight rows of the aug_shape first layers (pack time): wmax[4][H]
+int launch_w_maxima(const float* const W[4], int H, int K, unsigned* wmax, hipStream_t st) {
+    if (hipMemsetAsync(wmax, 0, (size_t)4 * H * sizeof(unsigned), st) != hipSuccess) return SHASTA_E_LAUNCH;
+    RowMaxArgs r;
     for (int i = 0; i < 4; ++i) r.base[i] = W[i];
     r.stride = K;
     r.rows = H;
     r.len = K;
-    r.out = wexp;
-    hipLaunchKernelGGL(row_exponent_kernel, dim3(H, 4), dim3(256), 0, st, r);
+    r.out = wmax;
+    hipLaunchKernelGGL(row_max_kernel, dim3(row_max_chunks(H, 4, K), H, 4), dim3(256), 0, st, r);
+    return check_launch("row_max (weights)");
 }
 
 // Two-piece fp16 form (NP = 2): a * 2^e = h + l + err with h = fp16(a 2^e) and l = fp16(a 2^e - h), both rounded to nearest:
@@ -120,7 +125,7 @@ struct SplitXArgs {
     const float* x[2];
     uint32_t* xs;  // [2 frames][NBLK][KT][XT][2 k-steps][NP pieces][64 lanes][8 bf16 / fp16]
     int B, KT, NBLK, XT, x_batch_stride, NP;
-    const int* xexp;  // NP = 2: [2 frames][B] exponents e: batch row b of frame f is cut as x * 2^e (row_exponent_kernel)
+    const unsigned* xmax;  // NP = 2: [2 frames][B] row maxima (row_max_kernel): batch row b of frame f is cut as x * 2^e, e = its range exponent
 };
 
 // grid (cdiv(KT, 8), NBLK * XT, 2): 32 batch rows x 256 k per block, transposed through LDS so that both the fp32 reads
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void split_x_kernel(SplitXArgs a) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
         const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         if (a.NP == 2) {
-            const int e = a.xexp[src * a.B + min(brow0 + r, a.B - 1)];
+            const int e = range_exponent_bits(a.xmax[src * a.B + min(brow0 + r, a.B - 1)]);
             u32x4 hi, lo;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -186,7 +191,7 @@ struct AnchorSplitArgs {
     const uint32_t* xs;
     float* part;
     int H, K, B, KS, Kc, KT, NBLK, groups_per_mlp;
-    const int* wexp;  // NP = 2: [4][H] exponents of the weight rows (launch_w_exponents, pack time)
+    const unsigned* wmax;  // NP = 2: [4][H] maxima of the weight rows (launch_w_maxima, pack time)
 };
 
 #ifdef SHASTA_L1_STAMP  // diagnostic build only (tools/probes/l1_split_probe.hip): in-kernel clock and cycles per tile
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
     float ph = 0.0f, pm = 0.0f, pl = 0.0f;
     _Float16 qh = 0, ql = 0;
     int wex = 0;  // exponent of this lane's weight row
-    if constexpr (NP == 2) wex = a.wexp[mlp * a.H + min(r0 + frow, a.H - 1)];
+    if constexpr (NP == 2) wex = range_exponent_bits(a.wmax[mlp * a.H + min(r0 + frow, a.H - 1)]);
     auto cut_one = [&](Frag& f, int e) {
         const int s = e >> 3, d = (e & 7) >> 1;
         if constexpr (NP == 2) {
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
 }
 
 // np = pieces per operand: 3 = bf16 (six products), 2 = fp16 (three products, SHASTA_OPT_F16X2_WEIGHT_STREAM)
-static inline int split_xt(int B, int np) { return np == 2 ? (B > 128 ? 8 : 4) : (B <= 64 ? 2 : 4); }
+static inline int split_xt(int B, int np) { return np == 2 ? (B > 128 ? 8 : 4) : (B <= 64 ? 2 : 4); }  // np == 2 is used above 64 rows
 static inline int split_nblk(int B, int np) { return cdiv(B, 32 * split_xt(B, np)); }
 
 // bytes of the piece image of the activations (0 for batches the f32 kernels serve): sized for the larger of the two forms
@@ -436,7 +441,7 @@ size_t anchor_split_workspace_bytes(int B, int K) {
 bool anchor_split_serves(int B, int K, int x_batch_stride) { return B > 32 && K % 32 == 0 && (x_batch_stride & 3) == 0; }
 
 // cut the activations of both frames into the bf16 fragment image `xs`
-void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, int B, int x_batch_stride, int np, const int* xexp,
+void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, int B, int x_batch_stride, int np, const unsigned* xmax,
                     hipStream_t st) {
     const int XT = split_xt(B, np), NBLK = split_nblk(B, np), KT = K / 32;
     SplitXArgs sx;
@@ -449,12 +454,12 @@ void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, 
     sx.XT = XT;
     sx.x_batch_stride = x_batch_stride;
     sx.NP = np;
-    sx.xexp = xexp;
+    sx.xmax = xmax;
     hipLaunchKernelGGL(split_x_kernel, dim3(cdiv(KT, 8), NBLK * XT, 2), dim3(256), 0, st, sx);
 }
 
 void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part, int H, int K, int B, int* ks_out, int np,
-                            const int* wexp, hipStream_t st) {
+                            const unsigned* wmax, hipStream_t st) {
     const int XT = split_xt(B, np), NBLK = split_nblk(B, np), KT = K / 32;
     AnchorSplitArgs a;
     for (int i = 0; i < 4; ++i) a.W[i] = W[i];
@@ -466,7 +471,7 @@ void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part
     a.KT = KT;
     a.NBLK = NBLK;
     a.groups_per_mlp = cdiv(H, 32);
-    a.wexp = wexp;
+    a.wmax = wmax;
     const int quads = cdiv(2 * a.groups_per_mlp, 4);  // workgroups per (K chunk, frame)
     int ncu = 256;
     {

@@ -41,6 +41,17 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Range exponent of a row whose largest magnitude is mx (given as the bit pattern of the non-negative float, the form
+// row_max_kernel accumulates with atomicMax): the e with mx * 2^e in (2^13, 2^14], so that the scaled row uses fp16's normal range
+// with room below 65504 (two-piece fp16 form of the weight stream, anchor_split.hip; undone exactly in anchor_hidden_kernel).
+__device__ __forceinline__ int range_exponent_bits(unsigned bits) {
+    const float mx = __uint_as_float(bits);
+    if (!(mx > 0.0f) || !(mx < INFINITY)) return 0;
+    int ex;
+    (void)frexpf(mx, &ex);  // mx = m 2^ex, m in [0.5, 1)
+    return max(-60, min(60, 14 - ex));
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -9,7 +9,7 @@ size_t pair_workspace_bytes(int B, int N, int F);
 size_t aff_workspace_bytes(int B, int N);
 const float* anchor_shape_hidden(const void* ws, int B, int N, int F);
 int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes, hipStream_t st,
-                 hipEvent_t ev0, hipEvent_t ev1, const int* wexp);
+                 hipEvent_t ev0, hipEvent_t ev1, const unsigned* wmax);
 int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes, int box_stride,
                  float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st);
 int pair_residual(const shasta_weights* w, const float* packed, int B, const float* feat, const float* prev_feat,
@@ -92,7 +92,7 @@ extern "C" int shasta_anchor_shape_f32(const shasta_weights* w, int B, float* fe
     if (rc) return rc;
     SHASTA_REQUIRE(B >= 0 && feat && prev_feat && workspace, "anchor_shape: bad argument");
     SHASTA_REQUIRE(((uintptr_t)feat | (uintptr_t)prev_feat) % 16 == 0, "anchor_shape: tables must be 16-byte aligned");
-    // (this stage entry has no packed buffer: with SHASTA_OPT_F16X2_WEIGHT_STREAM the weight-row exponents are recomputed per call)
+    // (this stage entry has no packed buffer: with SHASTA_OPT_F16X2_WEIGHT_STREAM the weight-row maxima are recomputed per call)
     return anchor_shape(w, B, feat, prev_feat, workspace, workspace_bytes, as_stream(stream), nullptr, nullptr, nullptr);
 }
 
@@ -161,8 +161,8 @@ static int forward_impl(const shasta_weights* w, const void* packed, int B, floa
     void* stage = static_cast<char*>(workspace) + L.residual;
     const size_t stage_bytes = L.total - L.residual;
     const float* pk = static_cast<const float*>(packed);
-    const int* wexp = reinterpret_cast<const int*>(pk + PackedLayout(N, w->num_feats, F).l1wexp);
-    if ((rc = anchor_shape(w, B, feat, prev_feat, stage, stage_bytes, st, ev0, ev1, wexp))) return rc;
+    const unsigned* wmax = reinterpret_cast<const unsigned*>(pk + PackedLayout(N, w->num_feats, F).l1wexp);
+    if ((rc = anchor_shape(w, B, feat, prev_feat, stage, stage_bytes, st, ev0, ev1, wmax))) return rc;
     if (shape_hidden_out) {  // training: the backward re-uses the hidden activations instead of re-streaming the weights
         const size_t H = (size_t)N * F / 64;
         hipError_t e = hipMemcpyAsync(shape_hidden_out, anchor_shape_hidden(stage, B, N, F), (size_t)B * 4 * H * sizeof(float),

@@ -519,7 +519,7 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
 }
 
 int aff_pieces_pack(const shasta_weights* w, float* out, hipStream_t st);
-void launch_w_exponents(const float* const W[4], int H, int K, int* wexp, hipStream_t st);
+int launch_w_maxima(const float* const W[4], int H, int K, unsigned* wmax, hipStream_t st);
 
 int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {
     PackArgs a;
@@ -540,8 +540,7 @@ int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {
         const float* W[4];
         for (int i = 0; i < 4; ++i) W[i] = w->aug_shape[i][0].weight;
         const int K = w->max_obj * w->feat_dim, H = K / 64;
-        if (H > 0) launch_w_exponents(W, H, K, reinterpret_cast<int*>(packed + P.l1wexp), st);
-        rc = check_launch("w_exponents");
+        if (H > 0) rc = launch_w_maxima(W, H, K, reinterpret_cast<unsigned*>(packed + P.l1wexp), st);
     }
     return rc;
 }

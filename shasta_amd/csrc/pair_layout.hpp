@@ -97,7 +97,7 @@ struct PackedLayout {
         bbox_cur = o;   o += (size_t)32;               // [32]       fuse_det.0.bias
         aff0 = o;       o += (size_t)128 * Dp;         // aff.0.weight zero padded to (128, Dp)
         affp = o;       o += ap_layer_offset(6, D) * 256;  // the six aff layers as bf16 piece fragments (aff_pieces.hip)
-        // int32 range exponents of the 4 x (N F / 64) weight rows of the aug_shape first layers (fp16 form of anchor_split.hip;
+        // largest magnitudes (float bit patterns) of the 4 x (N F / 64) weight rows of the aug_shape first layers (fp16 form of anchor_split.hip;
         // filled by shasta_pack_weights_f32 when SHASTA_OPT_F16X2_WEIGHT_STREAM is set)
         l1wexp = o;     o += (size_t)((4 * (max_obj * f / 64) + 3) / 4 * 4);
         total = o;

@@ -311,7 +311,10 @@ def test_batched_forward_vs_oracle(name, B):
     with torch.no_grad():
         m1, m2, _ = m(ex, train_mode=False)
     np.testing.assert_allclose(ex["det_boxes"].cpu().numpy(), det_o.numpy(), rtol=0, atol=1e-5)
-    np.testing.assert_allclose(m.last_intermediates["residual"].cpu().numpy(), im["residual"].numpy(), rtol=1e-4, atol=1e-4)
+    ref_res = im["residual"].numpy()
+    # zero-padded rows put log(1e-10) terms of +-23 into the residual (shasta.py:280): entries of size 1 are then differences of
+    # terms of size 30, so the absolute tolerance follows the largest entry
+    np.testing.assert_allclose(m.last_intermediates["residual"].cpu().numpy(), ref_res, rtol=1e-4, atol=max(1e-4, 5e-5 * float(np.abs(ref_res).max())))
     ref_mat = im["matched"].numpy()
     np.testing.assert_allclose(m.last_intermediates["matched"].cpu().numpy(), ref_mat, rtol=1e-5, atol=2e-5 * float(np.abs(ref_mat).max()))
     tol = 2e-3 if c["sharp"] else 1e-6  # tests/helpers.py M_ATOL / M_ATOL_SHARP
