@@ -496,7 +496,8 @@ def test_f32_arithmetic_option_matches_oracle_and_pieces(name, B):
         np.testing.assert_allclose(outs[mode][1], r2.numpy(), rtol=0, atol=tol)
         ref = im["residual"].numpy()
         np.testing.assert_allclose(outs[mode][2], ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
-    assert not np.array_equal(outs["pieces"][2], outs["f32"][2]) and not np.array_equal(outs["pieces"][2], outs["f16x2"][2])  # different kernels ran
+    assert not np.array_equal(outs["pieces"][2], outs["f32"][2])  # different kernels ran
+    assert np.array_equal(outs["pieces"][2], outs["f16x2"][2]) == (B <= 64)  # the fp16 form serves batches above 64 frame-pairs
 
 
 def test_piece_kernels_are_fp32_accurate():
