@@ -1,4 +1,5 @@
-"""Condense rocprofv3 outputs under gpurun_out/ into the small, committed summaries under profiles/ (round tag r01)."""
+"""Condense rocprofv3 outputs under gpurun_out/ into the small, committed summaries under profiles/.
+usage: python tools/summarize_profiles.py <round tag, e.g. r02> <sub-directory of gpurun_out written by tools/measure_round.sh>"""
 import collections
 import csv
 import glob
@@ -50,33 +51,40 @@ def pmc(dirs, dst):
 
 if __name__ == "__main__":
     os.makedirs(P, exist_ok=True)
-    kernel_stats(os.path.join(G, SRC, "prof_default/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_default_b512.csv"))
-    kernel_stats(os.path.join(G, SRC, "prof_b128/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_b128.csv"))
-    kernel_stats(os.path.join(G, SRC, "prof_b64/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_b64.csv"))
-    kernel_stats(os.path.join(G, SRC, "prof_b1/d_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats_bench_b1.csv"))
-    pmc([("b1_fetch", SRC + "/pmc_fetch_b1"), ("b1_write", SRC + "/pmc_write_b1"), ("b32_fetch", SRC + "/pmc_fetch_b32"),
-         ("b32_write", SRC + "/pmc_write_b32"), ("b64_fetch", SRC + "/pmc_fetch_b64"), ("b64_write", SRC + "/pmc_write_b64"),
-         ("b128_fetch", SRC + "/pmc_fetch_b128"), ("b128_write", SRC + "/pmc_write_b128"), ("b512_fetch", SRC + "/pmc_fetch_b512"),
-         ("b512_write", SRC + "/pmc_write_b512"), ("b512_mfma", SRC + "/pmc_mfma_b512")],
-        os.path.join(P, TAG + "_pmc_summary.csv"))
-    for b in ("default", "b1", "b32", "b64", "b64_f32", "b128"):
-        src = os.path.join(G, SRC, "bench_%s.json" % b)
+    for name, dst in (("prof_default", "bench_default_b512"), ("prof_b128", "bench_b128"), ("prof_b64", "bench_b64"), ("prof_b1", "bench_b1"),
+                      ("prof_pieces", "bench_pieces_b512")):
+        src = os.path.join(G, SRC, name, "d_kernel_stats.csv")
         if os.path.exists(src):
-            line = [l for l in open(src) if l.startswith("{")][-1]
-            json.dump(json.loads(line), open(os.path.join(P, TAG + "_bench_%s.json" % b), "w"), indent=1)
-    # HBM bytes per launch of the dominant kernel (bench.py: roofline.traffic), FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md)
+            kernel_stats(src, os.path.join(P, "%s_kernel_stats_%s.csv" % (TAG, dst)))
+    runs = []
+    for d in sorted(os.listdir(os.path.join(G, SRC))):
+        if d.startswith("pmc_") and os.path.isdir(os.path.join(G, SRC, d)):
+            kind, b = d[4:].rsplit("_", 1)  # pmc_fetch_b512 -> (fetch, b512)
+            runs.append(("%s_%s" % (b, kind), SRC + "/" + d))
+    pmc(runs, os.path.join(P, TAG + "_pmc_summary.csv"))
+    for f in sorted(os.listdir(os.path.join(G, SRC))):
+        if f.startswith("bench_") and f.endswith(".json"):
+            lines = [l for l in open(os.path.join(G, SRC, f)) if l.startswith("{")]
+            if lines:
+                json.dump(json.loads(lines[-1]), open(os.path.join(P, TAG + "_" + f), "w"), indent=1)
+        if f.startswith("l1_check_") and f.endswith(".json"):
+            rows = [json.loads(l) for l in open(os.path.join(G, SRC, f)) if l.startswith("{")]
+            json.dump(rows, open(os.path.join(P, TAG + "_" + f), "w"), indent=1)
+    # HBM bytes per launch of the two heaviest kernels (bench.py: roofline.traffic), FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md)
     rows = list(csv.DictReader(open(os.path.join(P, TAG + "_pmc_summary.csv"))))
     traffic = {}
     for b in (1, 32, 64, 128, 512):
         for key, kern in (("batch_%d", "anchor_l1"), ("pair_batch_%d", "pair_mfma4")):
-            f = [float(r["mean_value_per_launch"]) for r in rows if r["run"] == "b%d_fetch" % b and kern in r["kernel"] and r["counter"] == "FETCH_SIZE"]
-            w = [float(r["mean_value_per_launch"]) for r in rows if r["run"] == "b%d_write" % b and kern in r["kernel"] and r["counter"] == "WRITE_SIZE"]
+            f = [float(r["mean_value_per_launch"]) for r in rows if r["run"] == "b%d_fetch" % b and kern in r["kernel"] and r["counter"] == "FETCH_SIZE"
+                 and int(r["launches"]) > 3]
+            w = [float(r["mean_value_per_launch"]) for r in rows if r["run"] == "b%d_write" % b and kern in r["kernel"] and r["counter"] == "WRITE_SIZE"
+                 and int(r["launches"]) > 3]
             if f and w:
                 traffic[key % b] = int((2 * f[0] + w[0]) * 1024)
-    traffic["_note"] = ("batch_B / pair_batch_B: HBM bytes per launch of anchor_l1*_kernel / pair_mfma4_kernel at B frame-pairs per step "
-                        "= (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc "
-                        "passes (profiles/%s_pmc_summary.csv); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the "
-                        "bytes of a wide coalesced stream)" % TAG)
+    traffic["_note"] = ("batch_B / pair_batch_B: HBM-side bytes per launch of anchor_l1*_kernel / pair_mfma4_kernel at B frame-pairs per step, default "
+                        "arithmetic, = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/%s_pmc_summary.csv); "
+                        "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-byte fabric requests of a wide coalesced stream at "
+                        "64 bytes; confirmed here by TCC_EA0_RDREQ_sum x 128 B)" % TAG)
     json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
     print(traffic)
-    print(os.listdir(P))
+    print(sorted(os.listdir(P)))
