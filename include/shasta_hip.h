@@ -129,8 +129,9 @@ typedef struct shasta_linear {
 #define SHASTA_OPT_F32_WEIGHT_STREAM 1 /* aug_shape first layer on v_mfma_f32_32x32x2_f32 for every batch size */
 #define SHASTA_OPT_F32_EMBED_GEMM 2    /* row-embedding GEMMs on v_mfma_f32_32x32x2_f32 for every row count */
 #define SHASTA_OPT_F32_AFF 4           /* the six aff layers on v_mfma_f32_16x16x4_f32 for every row count */
-#define SHASTA_OPT_F16X2_WEIGHT_STREAM 8 /* EXPERIMENTAL: aug_shape first layer above 32 frame-pairs from two fp16 pieces per operand
+#define SHASTA_OPT_F16X2_WEIGHT_STREAM 8 /* aug_shape first layer above 64 frame-pairs from two range-scaled fp16 pieces per operand
                                             (round to nearest, three products per fp32 product) instead of three bf16 pieces (six) */
+#define SHASTA_OPT_F16X2_PAIR 16         /* second layers of the three pair MLPs in the same two-piece fp16 form (feat_dim 256) */
 
 typedef struct shasta_weights {
     int max_obj;   /* N */

@@ -114,7 +114,8 @@ __global__ void pack_pair_weights_kernel(PackArgs a) {
 //   threads 0 .. (R1+32)/4-1:  E[row][H1 + j]       += Wbox[j][:nf] . box[:nf]                 (res_coeff.0 box columns)
 //                              E[row][H1 + R1 + j]   = Wbox[R1 + j][:nf] . box[:nf] (+ bias)   (fuse_det.0)
 //  blocks [nrow, nrow + nhand): one thread per table row:
-//                              hand[row] = [box7, 0, log(w+eps), log(l+eps), log(h+eps), cos(yaw), sin(yaw), 0, 0, 0]
+//                              hand[row] = [box7, 0, log(w+eps), log(l+eps), log(h+eps), cos(yaw), sin(yaw), max |E[row]|, 0, 0]
+//                              (slot 13, the row's largest embedding magnitude, is written by the first role)
 //  the remaining blocks: col_norm (shasta.py:278-279): d2[t][d] = sum_{k<nf} (prev_k - det_k)^2,
 //   denom[d] = max(||d2[:, d]||_2, 1e-12) (F.normalize acts along dim=1 = tracks); 16 detections x 16 track groups per block,
 //   read straight from the (B, T, 8) box tables (4 tracks in flight per thread, fixed-order reduction).
@@ -154,30 +155,41 @@ __global__ __launch_bounds__(256) void row_prep_kernel(RowPrepArgs a) {
         const int q = tid & 31, nq = J / 4;
         for (int it = 0; it < 4; ++it) {
             const int row = side_row0 + it * 8 + (tid >> 5);
-            if (row >= a.B * a.T || q >= nq) continue;
-            const f32x4* bp = reinterpret_cast<const f32x4*>(a.tab[which] + (size_t)row * 8);
-            const f32x4 b0 = bp[0], b1 = bp[1];
-            const float bx[7] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2]};
-            f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};  // columns >= nf are packed as 0; k-ordered fmaf chain per output
+            if (row >= a.B * a.T) continue;  // the 32 threads of a row leave together (the shuffles below stay inside the row)
+            float amax = 0.0f;  // largest |E[row][.]| over the columns this thread sees
+            if (q < nq) {
+                const f32x4* bp = reinterpret_cast<const f32x4*>(a.tab[which] + (size_t)row * 8);
+                const f32x4 b0 = bp[0], b1 = bp[1];
+                const float bx[7] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2]};
+                f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};  // columns >= nf are packed as 0; k-ordered fmaf chain per output
 #pragma unroll
-            for (int c = 0; c < 7; ++c) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wT[c * 104 + 4 * q]);
-                s[0] = fmaf(w4[0], bx[c], s[0]); s[1] = fmaf(w4[1], bx[c], s[1]);
-                s[2] = fmaf(w4[2], bx[c], s[2]); s[3] = fmaf(w4[3], bx[c], s[3]);
-            }
-            f32x4* e = reinterpret_cast<f32x4*>(a.emb[which] + (size_t)row * d.ET + d.H1 + 4 * q);
-            const int j = 4 * q;
-            if (j < d.R1) {
-                f32x4 v = *e;
-                v[0] += s[0]; v[1] += s[1]; v[2] += s[2]; v[3] += s[3];
-                *e = v;
-            } else {
-                if (which) {
+                for (int c = 0; c < 7; ++c) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wT[c * 104 + 4 * q]);
+                    s[0] = fmaf(w4[0], bx[c], s[0]); s[1] = fmaf(w4[1], bx[c], s[1]);
+                    s[2] = fmaf(w4[2], bx[c], s[2]); s[3] = fmaf(w4[3], bx[c], s[3]);
+                }
+                f32x4* e = reinterpret_cast<f32x4*>(a.emb[which] + (size_t)row * d.ET + d.H1 + 4 * q);
+                const int j = 4 * q;
+                if (j < d.R1) {
+                    f32x4 v = *e;
+                    s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+                } else if (which) {
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(a.packed + P.bbox_cur + (j - d.R1));
                     s[0] += bb[0]; s[1] += bb[1]; s[2] += bb[2]; s[3] += bb[3];
                 }
                 *e = s;
+                amax = fmaxf(fmaxf(fabsf(s[0]), fabsf(s[1])), fmaxf(fabsf(s[2]), fabsf(s[3])));
+            } else {  // the spare threads of the row look at the columns the GEMM alone wrote (fuse_shape part, [0, H1))
+                const f32x4* e = reinterpret_cast<const f32x4*>(a.emb[which] + (size_t)row * d.ET);
+                for (int c4 = q - nq; c4 < d.H1 / 4; c4 += 32 - nq) {
+                    const f32x4 v = e[c4];
+                    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                }
             }
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+            // slot 13 of the hand row: the row's largest embedding magnitude (range scaling of the fp16 pair kernel, pair_f16.hip)
+            if (q == 0) a.hand[which][(size_t)row * 16 + 13] = amax;
         }
         return;
     }
@@ -193,7 +205,10 @@ __global__ __launch_bounds__(256) void row_prep_kernel(RowPrepArgs a) {
         h[0] = b0;
         h[1] = f32x4{b1[0], b1[1], b1[2], 0.0f};
         h[2] = f32x4{logf(b0[3] + 1e-10f), logf(b1[0] + 1e-10f), logf(b1[1] + 1e-10f), cosf(b1[2])};
-        h[3] = f32x4{sinf(b1[2]), 0.0f, 0.0f, 0.0f};
+        float* h3 = a.hand[which] + (size_t)row * 16 + 12;  // slot 13 belongs to the row role above
+        h3[0] = sinf(b1[2]);
+        h3[2] = 0.0f;
+        h3[3] = 0.0f;
         return;
     }
     // ---- column norms ----
@@ -432,6 +447,9 @@ size_t pair_workspace_bytes(int B, int N, int F) {
     return s;
 }
 
+int pair_f16_pack(const shasta_weights* w, float* out, hipStream_t st);
+int launch_pair_f16(const float* packed, const float* p16, const float* UP, const float* UC, const float* hand_prev,
+                    const float* hand_det, const float* denom, float* residual, int B, int T, int D, int ld, int nf, hipStream_t st);
 int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
                    int N, int K, int act, hipStream_t st);
 int launch_gemm_nt_dual(const float* A0, const float* W0, const float* bias0, float* C0, const float* A1, const float* W1,
@@ -492,6 +510,13 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     hipLaunchKernelGGL(row_prep_kernel, dim3(rp.nrow_blocks + rp.nhand_blocks + rp.dblocks * B), dim3(256), 0, st, rp);
     rc = check_launch("row_prep");
     if (rc) return rc;
+    if ((w->options & SHASTA_OPT_F16X2_PAIR) && F == 256) {
+        // second layers of the three pair MLPs on the f16 matrix path (pair_f16.hip), everything else as below
+        if (ev0) (void)hipEventRecord(ev0, st);
+        rc = launch_pair_f16(packed, packed + P.p16, UP, UC, hand_prev, hand_det, denom, residual, B, T, D, ld, nf, st);
+        if (ev1) (void)hipEventRecord(ev1, st);
+        return rc;
+    }
     // lane = pair, 4x4x1 MFMA.  The 8 waves of a workgroup share one 64-detection UC tile and take different track ranges
     // (two workgroups per CU by LDS, 113 VGPRs in the VGPR MFMA form: 4 waves per SIMD).
     constexpr int wpb = 8;
@@ -536,6 +561,7 @@ int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {
     if (rc) return rc;
     const PackedLayout P(w->max_obj, w->num_feats, w->feat_dim);
     if ((rc = aff_pieces_pack(w, packed + P.affp, st))) return rc;
+    if (w->feat_dim == 256 && (rc = pair_f16_pack(w, packed + P.p16, st))) return rc;
     if (w->options & SHASTA_OPT_F16X2_WEIGHT_STREAM) {  // one pass over the four first-layer matrices (4.1 GB at N=500, F=256)
         const float* W[4];
         for (int i = 0; i < 4; ++i) W[i] = w->aug_shape[i][0].weight;

@@ -1,0 +1,397 @@
+// K4c, fp16-piece form (SHASTA_OPT_F16X2_PAIR, F = 256): the per-pair MLP tails of det3d/models/tracker/shasta.py:286-319 with
+// their SECOND layers - 1792 of the 1984 multiply-adds per pair - on the f16 matrix path, everything else as in pair_mfma4_kernel.
+//
+// Why only the second layers: the activations h1 = relu(UP[t] + UC[d]) exist per pair, so cutting them into pieces is VALU work
+// per pair; it pays where one cut value feeds 16 multiply-adds (layer 2: 64 -> 16, 32 -> 16, 32 -> 8) and not for the narrow
+// layers behind it.  Arithmetic (the two-piece fp16 form of anchor_split.hip): a * 2^e = h + l with h = fp16(a 2^e),
+// l = fp16(a 2^e - h), both rounded to nearest (|err| <= 2^-24 |a 2^e|); w * a = w_l a_h + w_h a_l + w_h a_h, three
+// v_mfma_f32_16x16x32_f16 instead of sixteen f32 4x4x1 MFMA slots per 16 x 16 x 32 block; fp32 accumulation.
+//
+// Layouts.  A wave owns 64 detections x a range of tracks (as before).  Per track:
+//  (1) four sub-steps of 16 detections in the MFMA layout lane = (pair p = lane & 15, k block kb = lane >> 4): the lane forms
+//      h1[32 s + 8 kb + j], j < 8, for the four 32-wide k steps s (fuse_shape | res_coeff lower half | upper half | fuse_det) from
+//      8 UP values (LDS broadcast, read once per track) and 8 UC values (LDS) each, scales by the track's power of two,
+//      converts (v_fma_mixlo/hi_f16), takes the residual (v_fma_mix_f32: s c - h, exact) and converts it (v_cvt_pk_f16_f32);
+//      12 MFMAs; the three result blocks (4 consecutive output features of pair p per lane) go to a wave-private LDS tile
+//      [64 pairs][40 features].
+//  (2) lane = pair: the lane reads its 40 layer-2 pre-activations, descales (exact power of two) and adds the bias with one
+//      fma each, and runs layers 3-4, the hand-designed residual and the combine exactly as pair_mfma4_kernel does.
+// Range: the scale 2^e of a track is the one that puts (max |UP[t]| + max over the tile's detections of max |UC[d]|) - an upper
+// bound of every h1 of the sub-steps - into (2^13, 2^14]; the row maxima come from row_prep (slot 13 of the hand rows).  The
+// second-layer weights are cut once at pack time with one exponent per MLP (pair_f16_pack_kernel).
+#include "common.hpp"
+#include "pair_layout.hpp"
+
+namespace shasta {
+
+typedef _Float16 ph16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ph16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t pu4 __attribute__((ext_vector_type(4)));
+
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+#define MFMA16H(a, b, c) \
+    __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ph16x8, (a)), __builtin_bit_cast(ph16x8, (b)), (c), 0, 0, 0)
+
+template <int F, int L>
+struct A4h {
+    static constexpr LayerDesc D = layer_desc(F, L);
+    static constexpr int NOB = a4_nob(F, L), KG = a4_kg(F, L), OFF = a4_offset(F, L), KIN = D.kin, BIAS = NOB * KG * 16;
+};
+
+// {fp16(s0 c), fp16(s1 c)}: scale (exact power of two) and convert in one instruction per value
+__device__ __forceinline__ uint32_t cvt2_scaled(float s0, float s1, float c) {
+    uint32_t d = 0;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(d) : "v"(s0), "v"(c));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(d) : "v"(s1), "v"(c));
+    return d;
+}
+// s c - h (exact in fp32), h = the low / high half of hpk
+__device__ __forceinline__ float res_lo(float s, float c, uint32_t hpk) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(s), "v"(c), "v"(hpk));
+    return r;
+}
+__device__ __forceinline__ float res_hi(float s, float c, uint32_t hpk) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(s), "v"(c), "v"(hpk));
+    return r;
+}
+__device__ __forceinline__ uint32_t cvt2(float a, float b) {
+    const ph16x2 v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// ---- pack: the three second layers as A operands of v_mfma_f32_16x16x32_f16 -----------------------------------------------
+// fragments (1 KB each = [64 lanes][8 fp16]): 0 fuse_shape.2 (16 x 32) | 1, 2 res_coeff.2 (16 x 64, two k steps) | 3 fuse_det.2
+// (8 x 32, rows 8..15 zero); lane (i = lane & 15, kb = lane >> 4) holds W[i][32 ks + 8 kb + j] * 2^e_mlp; high pieces then low pieces.
+// layout (dwords): [piece 2][fragment 4][lane 64][4], then 3 int exponents (fs, rc, fd), padded to 4.
+constexpr int P16_FRAG_DW = 2 * 4 * 64 * 4;
+constexpr int P16_DW = P16_FRAG_DW + 4;
+size_t pair_f16_packed_floats() { return P16_DW; }
+
+struct PairF16PackArgs {
+    const float* w_fs2;  // fuse_shape.2.weight (16, 32)
+    const float* w_rc2;  // res_coeff.2.weight (16, 64)
+    const float* w_fd2;  // fuse_det.2.weight (8, 32)
+    uint32_t* out;
+};
+
+__global__ __launch_bounds__(256) void pair_f16_pack_kernel(PairF16PackArgs a) {
+    __shared__ float red[3][4];
+    __shared__ int ex[3];
+    const int tid = threadIdx.x;
+    const float* W[3] = {a.w_fs2, a.w_rc2, a.w_fd2};
+    const int cnt[3] = {16 * 32, 16 * 64, 8 * 32};
+    for (int m = 0; m < 3; ++m) {
+        float mx = 0.0f;
+        for (int i = tid; i < cnt[m]; i += 256) mx = fmaxf(mx, fabsf(W[m][i]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        if ((tid & 63) == 0) red[m][tid >> 6] = mx;
+    }
+    __syncthreads();
+    if (tid < 3) {
+        const float mx = fmaxf(fmaxf(red[tid][0], red[tid][1]), fmaxf(red[tid][2], red[tid][3]));
+        ex[tid] = range_exponent_bits(__float_as_uint(mx));
+        reinterpret_cast<int*>(a.out)[P16_FRAG_DW + tid] = ex[tid];
+    }
+    if (tid == 3) a.out[P16_FRAG_DW + 3] = 0;
+    __syncthreads();
+    const int lane = tid & 63, frag = tid >> 6;  // 4 fragments, one wave each
+    const int i = lane & 15, kb = lane >> 4;
+    const int mlp = frag == 0 ? 0 : frag == 3 ? 2 : 1;
+    const int rows = mlp == 2 ? 8 : 16, kin = mlp == 1 ? 64 : 32, ks = frag == 2 ? 1 : 0;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = i < rows ? __builtin_ldexpf(W[mlp][i * kin + 32 * ks + 8 * kb + j], ex[mlp]) : 0.0f;
+    pu4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const _Float16 h0 = (_Float16)v[2 * j], h1 = (_Float16)v[2 * j + 1];
+        const ph16x2 hh = {h0, h1};
+        hi[j] = __builtin_bit_cast(uint32_t, hh);
+        lo[j] = cvt2(v[2 * j] - (float)h0, v[2 * j + 1] - (float)h1);
+    }
+    reinterpret_cast<pu4*>(a.out)[(0 * 4 + frag) * 64 + lane] = hi;
+    reinterpret_cast<pu4*>(a.out)[(1 * 4 + frag) * 64 + lane] = lo;
+}
+
+int pair_f16_pack(const shasta_weights* w, float* out, hipStream_t st) {
+    PairF16PackArgs a;
+    a.w_fs2 = w->fuse_shape[1].weight;
+    a.w_rc2 = w->res_coeff[1].weight;
+    a.w_fd2 = w->fuse_det[1].weight;
+    a.out = reinterpret_cast<uint32_t*>(out);
+    hipLaunchKernelGGL(pair_f16_pack_kernel, dim3(1), dim3(256), 0, st, a);
+    return check_launch("pair_f16_pack");
+}
+
+// ---- the kernel (F = 256: H1 = 32, R1 = 64, fuse_det 32; H2 = 16, R2 = 16, 8) ---------------------------------------------
+constexpr int PF_TS = 44;  // floats per pair in the transposition tile: 40 + 4 pad (conflict-free b128 reads at stride 44)
+
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restrict__ packed, const uint32_t* __restrict__ p16,
+                                                       const float* __restrict__ UP, const float* __restrict__ UC,
+                                                       const float* __restrict__ hand_prev, const float* __restrict__ hand_det,
+                                                       const float* __restrict__ denom, float* __restrict__ residual, int T,
+                                                       int D, int ld, int nf, int TW) {
+    constexpr int F = 256;
+    constexpr PairDims dm(F);
+    constexpr int ET = dm.ET, US = ET + 4;
+    static_assert(dm.H1 == 32 && dm.R1 == 64 && ET == 128 && dm.H2 == 16 && dm.R2 == 16, "pair_f16_kernel is laid out for F = 256");
+    constexpr int NA4 = a4_total(F);
+    extern __shared__ __attribute__((aligned(16))) float s_dynh[];
+    float* s_uc = s_dynh;                                  // [64][US]
+    float* s_a4 = s_dynh + 64 * US;                        // [NA4] 4x4x1 operand table (layers 3-4 and the layer-2 biases)
+    float* s_up = s_a4 + ((NA4 + 3) & ~3);                 // [WPB][3 slots][256 floats]
+    float* s_tr = s_up + WPB * 3 * 256;                    // [WPB][64 pairs][PF_TS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, d0 = blockIdx.x * 64;
+    const int d = d0 + lane, dcl = min(d, D - 1);
+    const PackedLayout P(0, 0, F);
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(UC);
+#pragma unroll 4
+        for (int e = tid; e < 64 * (ET / 4); e += 64 * WPB) {
+            const int r = e / (ET / 4), c = e - r * (ET / 4);
+            *reinterpret_cast<f32x4*>(&s_uc[r * US + 4 * c]) = src[((size_t)b * D + min(d0 + r, D - 1)) * (ET / 4) + c];
+        }
+        const f32x4* asrc = reinterpret_cast<const f32x4*>(packed + P.a4);
+#pragma unroll 2
+        for (int e = tid; e < NA4 / 4; e += 64 * WPB) reinterpret_cast<f32x4*>(s_a4)[e] = asrc[e];
+    }
+    float hd[12];
+    float mc;  // largest |UC| of this lane's detection row (row_prep), then of the whole 64-detection tile
+    {
+        const f32x4* h = reinterpret_cast<const f32x4*>(hand_det + ((size_t)b * D + dcl) * 16);
+        const f32x4 a = h[0], c = h[1], e = h[2], g = h[3];
+        hd[0] = a[0]; hd[1] = a[1]; hd[2] = a[2]; hd[3] = a[3]; hd[4] = c[0]; hd[5] = c[1]; hd[6] = c[2];
+        hd[7] = e[0]; hd[8] = e[1]; hd[9] = e[2]; hd[10] = e[3]; hd[11] = g[0];
+        mc = g[1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mc = fmaxf(mc, __shfl_xor(mc, off, 64));
+    const float dnm = denom[(size_t)b * D + dcl];
+    // second-layer weight pieces: 4 fragments x {high, low}, registers for the whole kernel
+    pu4 wh[4], wl[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        wh[f] = reinterpret_cast<const pu4*>(p16)[(0 * 4 + f) * 64 + lane];
+        wl[f] = reinterpret_cast<const pu4*>(p16)[(1 * 4 + f) * 64 + lane];
+    }
+    const int ew_fs = reinterpret_cast<const int*>(p16)[P16_FRAG_DW + 0], ew_rc = reinterpret_cast<const int*>(p16)[P16_FRAG_DW + 1],
+              ew_fd = reinterpret_cast<const int*>(p16)[P16_FRAG_DW + 2];
+    __syncthreads();
+    typedef __attribute__((address_space(3))) float lfloat;
+    typedef __attribute__((address_space(3))) f32x4 lf32x4;
+    const unsigned arow_base = (unsigned)(unsigned long long)(s_a4 + (lane & 3) * 4);
+    const unsigned abias_base = (unsigned)(unsigned long long)(s_a4 + (lane & 3));
+    const f32x4 zero4 = {0, 0, 0, 0};
+    const int p = lane & 15, kb = lane >> 4;
+    float* my_tr = s_tr + wid * (64 * PF_TS);
+
+    const int t_beg = (blockIdx.y * WPB + wid) * TW;
+    const int t_end = min(T, t_beg + TW);
+    float* my_up = s_up + wid * (3 * 256);
+    const bool hp_lane = lane >= ET / 4 && lane < ET / 4 + 4;
+    const int up_lane = 4 * min(lane, ET / 4 - 1), hp_off = 4 * (lane - ET / 4);
+    auto dma_up = [&](int row, int slot) {
+        const size_t r = (size_t)b * T + min(row, T - 1);
+        const float* src = hp_lane ? hand_prev + r * 16 + hp_off : UP + r * ET + up_lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(my_up + slot * 256), 16, 0, 0);
+    };
+    if (t_beg < t_end) {
+        dma_up(t_beg, 0);
+        dma_up(t_beg + 1, 1);
+    }
+    for (int t = t_beg; t < t_end; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dma_up(t + 2, (t - t_beg + 2) % 3);
+        unsigned upo = (unsigned)(unsigned long long)(my_up + ((t - t_beg) % 3) * 256);
+        asm volatile("" : "+v"(upo));
+        const lfloat* up = (const lfloat*)(unsigned long long)upo;
+        float hp[16];
+        {
+            const f32x4 h0 = *reinterpret_cast<const lf32x4*>(up + ET), h1 = *reinterpret_cast<const lf32x4*>(up + ET + 4),
+                        h2 = *reinterpret_cast<const lf32x4*>(up + ET + 8), h3 = *reinterpret_cast<const lf32x4*>(up + ET + 12);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                hp[k] = h0[k];
+                hp[4 + k] = h1[k];
+                hp[8 + k] = h2[k];
+                hp[12 + k] = h3[k];
+            }
+        }
+        // the track's scale: every h1 of this track and tile is at most max |UP[t]| + max |UC|
+        const int e1 = range_exponent_bits(__float_as_uint(hp[13] + mc));
+        const float c1 = __builtin_ldexpf(1.0f, e1);
+        // this lane's UP values: 8 per k step (the same address in the 16 lanes of a k block: LDS broadcast)
+        f32x4 upv[8];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            upv[2 * s] = *reinterpret_cast<const lf32x4*>(up + 32 * s + 8 * kb);
+            upv[2 * s + 1] = *reinterpret_cast<const lf32x4*>(up + 32 * s + 8 * kb + 4);
+        }
+        // Software pipeline over the four sub-steps: the UC reads of sub-step s+1 are issued before the arithmetic of sub-step s,
+        // and the pieces of sub-step s+1 are cut before the MFMAs of sub-step s are issued (they run under the cut of s+1).
+        auto load_uc = [&](int sub, f32x4 (&u)[8]) {
+            const float* ucr = s_uc + (16 * sub + p) * US + 8 * kb;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                u[2 * s] = *reinterpret_cast<const f32x4*>(ucr + 32 * s);
+                u[2 * s + 1] = *reinterpret_cast<const f32x4*>(ucr + 32 * s + 4);
+            }
+        };
+        auto cut = [&](const f32x4 (&u)[8], pu4 (&xh)[4], pu4 (&xl)[4]) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float h1v[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h1v[j] = fmaxf(upv[2 * s][j] + u[2 * s][j], 0.0f);
+                    h1v[4 + j] = fmaxf(upv[2 * s + 1][j] + u[2 * s + 1][j], 0.0f);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t hh = cvt2_scaled(h1v[2 * j], h1v[2 * j + 1], c1);
+                    xh[s][j] = hh;
+                    xl[s][j] = cvt2(res_lo(h1v[2 * j], c1, hh), res_hi(h1v[2 * j + 1], c1, hh));
+                }
+            }
+        };
+        auto mma_store = [&](int sub, const pu4 (&xh)[4], const pu4 (&xl)[4]) {
+            f32x4 a_fs = zero4, a_rc = zero4, a_fd = zero4;
+            a_fs = MFMA16H(wl[0], xh[0], a_fs);
+            a_rc = MFMA16H(wl[1], xh[1], a_rc);
+            a_fd = MFMA16H(wl[3], xh[3], a_fd);
+            a_fs = MFMA16H(wh[0], xl[0], a_fs);
+            a_rc = MFMA16H(wh[1], xl[1], a_rc);
+            a_fd = MFMA16H(wh[3], xl[3], a_fd);
+            a_rc = MFMA16H(wl[2], xh[2], a_rc);
+            a_fs = MFMA16H(wh[0], xh[0], a_fs);
+            a_fd = MFMA16H(wh[3], xh[3], a_fd);
+            a_rc = MFMA16H(wh[2], xl[2], a_rc);
+            a_rc = MFMA16H(wh[1], xh[1], a_rc);
+            a_rc = MFMA16H(wh[2], xh[2], a_rc);
+            // lane (p, kb) holds output features 4 kb .. 4 kb + 3 of pair 16 sub + p: [rc 16 | fs 16 | fd 8]
+            float* row = my_tr + (16 * sub + p) * PF_TS + 4 * kb;
+            *reinterpret_cast<f32x4*>(row) = a_rc;
+            *reinterpret_cast<f32x4*>(row + 16) = a_fs;
+            if (kb < 2) *reinterpret_cast<f32x4*>(row + 32) = a_fd;
+        };
+        {
+            f32x4 ua[8], ub[8];
+            pu4 xha[4], xla[4], xhb[4], xlb[4];
+            load_uc(0, ua);
+            load_uc(1, ub);
+            cut(ua, xha, xla);
+            load_uc(2, ua);
+            cut(ub, xhb, xlb);
+            mma_store(0, xha, xla);
+            load_uc(3, ub);
+            cut(ua, xha, xla);
+            mma_store(1, xhb, xlb);
+            cut(ub, xhb, xlb);
+            mma_store(2, xha, xla);
+            mma_store(3, xhb, xlb);
+        }
+        // ---- lane = pair from here on: descale + bias, layers 3-4, hand residual, combine (as pair_mfma4_kernel) ----
+        unsigned ao = arow_base, bo = abias_base;
+        asm volatile("" : "+v"(ao), "+v"(bo));
+        const lfloat* arow = (const lfloat*)(unsigned long long)ao;
+        const lfloat* abias = (const lfloat*)(unsigned long long)bo;
+        (void)abias;
+        const float i_rc = __builtin_ldexpf(1.0f, -(e1 + ew_rc)), i_fs = __builtin_ldexpf(1.0f, -(e1 + ew_fs)),
+                    i_fd = __builtin_ldexpf(1.0f, -(e1 + ew_fd));
+        f32x4 a_rc2[4], a_fs2[4], a_fd2[2];
+        {
+            const float* mine = my_tr + lane * PF_TS;
+            // the layer-2 biases sit behind the 4x4x1 operands of their layers in the LDS table ([ob][i], A4h<..>::BIAS)
+            const float* b_rc = s_a4 + A4h<F, L_RC2>::OFF + A4h<F, L_RC2>::BIAS;
+            const float* b_fs = s_a4 + A4h<F, L_FS2>::OFF + A4h<F, L_FS2>::BIAS;
+            const float* b_fd = s_a4 + A4h<F, L_FD2>::OFF + A4h<F, L_FD2>::BIAS;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(mine + 4 * g), bb = *reinterpret_cast<const f32x4*>(b_rc + 4 * g);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(mine + 16 + 4 * g), bf = *reinterpret_cast<const f32x4*>(b_fs + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a_rc2[g][j] = fmaf(v[j], i_rc, bb[j]);
+                    a_fs2[g][j] = fmaf(w[j], i_fs, bf[j]);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(mine + 32 + 4 * g), bb = *reinterpret_cast<const f32x4*>(b_fd + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a_fd2[g][j] = fmaf(v[j], i_fd, bb[j]);
+            }
+        }
+        auto init = [&](auto tag, f32x4* acc) {
+            using AL = decltype(tag);
+#pragma unroll
+            for (int ob = 0; ob < AL::NOB; ++ob) acc[ob] = MFMA4(abias[AL::OFF + AL::BIAS + ob * 4], 1.0f, zero4);
+        };
+        auto layer = [&](auto tag, const f32x4* in, f32x4* acc) {
+            using AL = decltype(tag);
+            init(tag, acc);
+#pragma unroll
+            for (int kg = 0; kg < AL::KG; ++kg) {
+                f32x4 a4[AL::NOB];
+#pragma unroll
+                for (int ob = 0; ob < AL::NOB; ++ob) a4[ob] = *reinterpret_cast<const lf32x4*>(arow + AL::OFF + (ob * AL::KG + kg) * 16);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (4 * kg + kk < AL::KIN) {
+                        const float h = fmaxf(in[kg][kk], 0.0f);
+#pragma unroll
+                        for (int ob = 0; ob < AL::NOB; ++ob) acc[ob] = MFMA4(a4[ob][kk], h, acc[ob]);
+                    }
+                }
+            }
+        };
+        f32x4 a_rc3[A4h<F, L_RC3>::NOB], a_fs3[A4h<F, L_FS3>::NOB], a_fs4[A4h<F, L_FS4>::NOB], a_fd3[A4h<F, L_FD3>::NOB];
+        layer(A4h<F, L_RC3>{}, a_rc2, a_rc3);
+        layer(A4h<F, L_FS3>{}, a_fs2, a_fs3);
+        layer(A4h<F, L_FD3>{}, a_fd2, a_fd3);
+        layer(A4h<F, L_FS4>{}, a_fs3, a_fs4);
+
+        // ---- hand-designed residual (shasta.py:277-283) ----
+        float d2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (k < nf) {
+                const float df = hp[k] - hd[k];
+                d2 += df * df;
+            }
+        float r = d2 / dnm;
+        const float dim = (fabsf(hp[8] - hd[7]) + fabsf(hp[9] - hd[8])) + fabsf(hp[10] - hd[9]);
+        const float dcs = hp[11] - hd[10], dsn = hp[12] - hd[11];
+        const float dist = (r + dim) + sqrtf(dcs * dcs + dsn * dsn);
+        // ---- combine (shasta.py:316-319) ----
+        const float res = (a_rc3[0][0] * a_fd3[0][0] + a_rc3[0][1] * dist) + a_rc3[0][2] * a_fs4[0][0];
+        if (d < D) residual[((size_t)b * T + t) * ld + d] = res;
+    }
+}
+
+size_t pair_f16_lds_bytes(int wpb) {
+    constexpr PairDims dm(256);
+    return ((size_t)64 * (dm.ET + 4) + ((a4_total(256) + 3) & ~3) + (size_t)wpb * 3 * 256 + (size_t)wpb * 64 * PF_TS) * sizeof(float);
+}
+
+int launch_pair_f16(const float* packed, const float* p16, const float* UP, const float* UC, const float* hand_prev,
+                    const float* hand_det, const float* denom, float* residual, int B, int T, int D, int ld, int nf, hipStream_t st) {
+    constexpr int wpb = 8;
+    int tw = 16;
+    while (tw > 2 && (long)B * cdiv(D, 64) * wpb * cdiv(T, wpb * tw) < 4096) tw >>= 1;
+    const size_t lds = pair_f16_lds_bytes(wpb);
+    (void)hipFuncSetAttribute((const void*)pair_f16_kernel<wpb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(cdiv(D, 64), cdiv(T, wpb * tw), B);
+    hipLaunchKernelGGL((pair_f16_kernel<wpb>), grid, dim3(64 * wpb), lds, st, packed, reinterpret_cast<const uint32_t*>(p16), UP, UC,
+                       hand_prev, hand_det, denom, residual, T, D, ld, nf, tw);
+    return check_launch("pair_f16");
+}
+
+}  // namespace shasta

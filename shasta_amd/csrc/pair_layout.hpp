@@ -77,7 +77,7 @@ SH_HD constexpr size_t ap_layer_offset(int layer, int D) {  // in fragments
 // Packed buffer sections (float offsets).  Dp = padded aff width (multiple of 4).
 struct PackedLayout {
     int F, nf, N, D, Dp, E12, ET;
-    size_t a4, wemb_prev, wemb_cur, bemb_cur, wbox_prev, wbox_cur, bbox_cur, aff0, affp, l1wexp, total;
+    size_t a4, wemb_prev, wemb_cur, bemb_cur, wbox_prev, wbox_cur, bbox_cur, aff0, affp, l1wexp, p16, total;
     SH_HD PackedLayout(int max_obj, int num_feats, int f) {
         const PairDims d(f);
         F = f;
@@ -100,6 +100,7 @@ struct PackedLayout {
         // largest magnitudes (float bit patterns) of the 4 x (N F / 64) weight rows of the aug_shape first layers (fp16 form of anchor_split.hip;
         // filled by shasta_pack_weights_f32 when SHASTA_OPT_F16X2_WEIGHT_STREAM is set)
         l1wexp = o;     o += (size_t)((4 * (max_obj * f / 64) + 3) / 4 * 4);
+        p16 = o;        o += (size_t)(2 * 4 * 64 * 4 + 4);  // second layers of the pair MLPs as fp16 piece fragments + 3 exponents (pair_f16.hip)
         total = o;
     }
 };

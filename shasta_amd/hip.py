@@ -23,6 +23,7 @@ OPT_F32_WEIGHT_STREAM = 1  # include/shasta_hip.h SHASTA_OPT_*
 OPT_F32_EMBED_GEMM = 2
 OPT_F32_AFF = 4
 OPT_F16X2_WEIGHT_STREAM = 8
+OPT_F16X2_PAIR = 16
 
 
 class Linear(C.Structure):

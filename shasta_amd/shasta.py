@@ -196,7 +196,7 @@ class Shasta(BaseTrack):
         if self.arithmetic not in ("pieces", "f32", "f16x2"):
             raise ValueError("Shasta.arithmetic must be 'pieces', 'f32' or 'f16x2'")
         w.options = {"pieces": 0, "f32": hip.OPT_F32_WEIGHT_STREAM | hip.OPT_F32_EMBED_GEMM | hip.OPT_F32_AFF,
-                     "f16x2": hip.OPT_F16X2_WEIGHT_STREAM}[self.arithmetic]
+                     "f16x2": hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_F16X2_PAIR}[self.arithmetic]
         for i in range(4):
             w.aug_shape[i][0], w.aug_shape[i][1] = lin(self.aug_shape[i][0]), lin(self.aug_shape[i][2])
             w.aug_dets[i][0], w.aug_dets[i][1] = lin(self.aug_dets[i][0]), lin(self.aug_dets[i][2])

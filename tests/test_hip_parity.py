@@ -497,7 +497,8 @@ def test_f32_arithmetic_option_matches_oracle_and_pieces(name, B):
         ref = im["residual"].numpy()
         np.testing.assert_allclose(outs[mode][2], ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
     assert not np.array_equal(outs["pieces"][2], outs["f32"][2])  # different kernels ran
-    assert np.array_equal(outs["pieces"][2], outs["f16x2"][2]) == (B <= 64)  # the fp16 form serves batches above 64 frame-pairs
+    # the fp16 forms serve the weight stream above 64 frame-pairs and the pair MLPs at feature width 256
+    assert np.array_equal(outs["pieces"][2], outs["f16x2"][2]) == (B <= 64 and c["np"] * 64 != 256)
 
 
 def test_piece_kernels_are_fp32_accurate():
@@ -523,6 +524,27 @@ def test_piece_kernels_are_fp32_accurate():
         assert a["max_abs_err"] <= 1.25 * b["max_abs_err"] + 1e-9, (a, b)
         assert p["max_abs_err"] <= 1.5 * b["max_abs_err"] + 1e-9, (p, b)
         assert max(a["max_abs_err"], p["max_abs_err"]) < 2e-5 * max(1.0, a["ref_scale"])
+
+
+def test_pair_kernels_are_fp32_accurate():
+    """The pair stage at F=256 runs its second layers on the f16 matrix path in the default arithmetic (pair_f16.hip) and entirely on
+    the f32 matrix path otherwise (pair_mfma4_kernel).  Both against a float64 evaluation of shasta.py:277-319 on the same tables
+    (tools/pair_check.py), default-init and sharpened pair weights: the fp16 form's error stays at the f32 kernel's level."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ["--gain", "2.0"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "pair_check.py"), "--max-obj", "150", "--batch", "2"] + extra,
+                           capture_output=True, text=True, cwd=root, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        rows = {d["arithmetic"]: d for d in (json.loads(l) for l in r.stdout.splitlines() if l.startswith("{"))}
+        assert set(rows) == {"f16x2", "pieces", "f32"}
+        f16, f32 = rows["f16x2"], rows["f32"]
+        assert f16["max_abs_err"] <= 2.0 * f32["max_abs_err"] + 1e-7 * f32["ref_scale"], (f16, f32)
+        assert f16["rms_err"] <= 1.5 * f32["rms_err"] + 1e-8 * f32["ref_scale"], (f16, f32)
+        assert f16["max_abs_err"] <= 1e-5 * f16["ref_scale"]
 
 
 def test_fp16_form_is_range_safe():
