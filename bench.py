@@ -263,13 +263,23 @@ def main():
     # `achieved` prices the USEFUL flops against the f32 MFMA peak.
     pair_useful = 2.0 * USEFUL_PAIR_MACS * PAIRS * B
     pair_tflops = pair_useful / (pair_ms * 1e-3) / 1e12
+    pair_f16 = args.arithmetic == "f16x2"  # F = 256: second layers (1792 of the 1984 MACs per pair) as three fp16 piece products each
     roof_pair = {"bound": "mfma", "achieved": pair_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": pair_tflops / MFMA_F32_PEAK_TFLOPS, "mfma_dtype": "f32", "traffic": _pmc_traffic(B, "pair"),
-                 "kernel": "pair_mfma4_kernel<256,8>: per-pair MLP tails + hand residual -> residual (B, 502, 502)",
-                 "useful_flops_per_launch": pair_useful, "executed_flops_per_launch": 2.0 * EXECUTED_PAIR_MACS * PAIRS * B,
+                 "frac": pair_tflops / MFMA_F32_PEAK_TFLOPS, "traffic": _pmc_traffic(B, "pair"),
+                 "useful_flops_per_launch": pair_useful,
                  "dense_algorithmic_flops_per_launch": 2.0 * DENSE_PAIR_MACS * PAIRS * B,
                  "dense_equivalent_tflops": 2.0 * DENSE_PAIR_MACS * PAIRS * B / (pair_ms * 1e-3) / 1e12,
                  "avg_launch_ms": pair_ms, "share_of_step": pair_ms / step_ms}
+    if pair_f16:
+        roof_pair.update({
+            "kernel": "pair_f16_kernel<8>: per-pair MLP tails (second layers on the f16 matrix path) + hand residual -> residual (B, 502, 502)",
+            "mfma_dtype": "f16 (layer 2: three piece products per fp32 product) + f32 (layers 3-4)",
+            "executed_flops_per_launch": 2.0 * (3 * 2048 + (EXECUTED_PAIR_MACS - 1792)) * PAIRS * B,
+            "note": "useful fp32 flops priced against the f32 MFMA peak, the yardstick of the f32 form (pair_mfma4_kernel, --arithmetic pieces); "
+                    "in this form the kernel is bound by VALU issue (cutting the activations) and LDS latency at 2 waves per SIMD, not by a matrix pipe"})
+    else:
+        roof_pair.update({"kernel": "pair_mfma4_kernel<256,8>: per-pair MLP tails + hand residual -> residual (B, 502, 502)",
+                          "mfma_dtype": "f32", "executed_flops_per_launch": 2.0 * EXECUTED_PAIR_MACS * PAIRS * B})
     # `roofline` is the kernel with the longer average launch; the other one rides along as `roofline_second`
     roof, second = (roof_l1, roof_pair) if l1_ms >= pair_ms else (roof_pair, roof_l1)
 
@@ -287,9 +297,10 @@ def main():
                    "parallelism": "replica x%d (frame-parallel, no data-path collective)" % world,
                    "hip_graph": bool(args.graph),
                    "arithmetic": {"f16x2": "fp32 operands in HBM, fp32 accumulation throughout; above 32 frame-pairs per step the first "
-                                           "aug_shape layer forms every fp32 product from three products of two range-scaled fp16 pieces per "
-                                           "operand (round to nearest; measured max error vs float64 5.5e-6, f32 MFMA kernel 7.0e-6); from "
-                                           "8192 table rows the row-embedding GEMMs and the aff layers use six products of three exact bf16 "
+                                           "aug_shape layer (above 64 frame-pairs) and the second layers of the pair MLPs form every fp32 product from three products of "
+                                           "two range-scaled fp16 pieces per operand (round to nearest; measured max error vs float64: weight "
+                                           "stream 5.5e-6 against 7.0e-6 for the f32 MFMA kernel, pair stage 1.8e-6 against 2.3e-6); from 8192 "
+                                           "table rows the row-embedding GEMMs and the aff layers use six products of three exact bf16 "
                                            "pieces (--arithmetic pieces / f32 select the other forms)",
                                   "pieces": "fp32 operands, fp32 accumulation throughout; above 32 frame-pairs per step the first aug_shape "
                                             "layer, and from 8192 table rows the row-embedding GEMMs and the aff layers, form every fp32 product "

@@ -74,7 +74,7 @@ if __name__ == "__main__":
     rows = list(csv.DictReader(open(os.path.join(P, TAG + "_pmc_summary.csv"))))
     traffic = {}
     for b in (1, 32, 64, 128, 512):
-        for key, kern in (("batch_%d", "anchor_l1"), ("pair_batch_%d", "pair_mfma4")):
+        for key, kern in (("batch_%d", "anchor_l1"), ("pair_batch_%d", "::pair_")):
             f = [float(r["mean_value_per_launch"]) for r in rows if r["run"] == "b%d_fetch" % b and kern in r["kernel"] and r["counter"] == "FETCH_SIZE"
                  and int(r["launches"]) > 3]
             w = [float(r["mean_value_per_launch"]) for r in rows if r["run"] == "b%d_write" % b and kern in r["kernel"] and r["counter"] == "WRITE_SIZE"
