@@ -76,6 +76,28 @@ def spawn_ranks(n, argv):
     return rc
 
 
+class EnergyCounter:
+    """The GPU's accumulated-energy counter (librocm_smi64: rsmi_dev_energy_count_get, 15.3 uJ units) read around the timed loop:
+    the step is power-limited, so joules per step is what its duration follows.  None when unavailable."""
+
+    def __init__(self, index):
+        self.lib, self.index = None, index
+        try:
+            lib = C.CDLL("librocm_smi64.so")
+            if lib.rsmi_init(C.c_uint64(0)) == 0:
+                self.lib = lib
+        except OSError:
+            pass
+
+    def joules(self):
+        if self.lib is None:
+            return None
+        cnt, res, ts = C.c_uint64(), C.c_float(), C.c_uint64()
+        if self.lib.rsmi_dev_energy_count_get(C.c_uint32(self.index), C.byref(cnt), C.byref(res), C.byref(ts)) != 0:
+            return None
+        return cnt.value * res.value * 1e-6
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +199,8 @@ def main():
             else:
                 m1, m2 = step()
         sync_all()
+        energy = EnergyCounter(local_rank)
+        e0 = energy.joules()
         t0 = time.perf_counter()
         for i in range(args.steps):
             if graph is not None:
@@ -185,6 +209,8 @@ def main():
                 m1, m2 = step(evs[i])
         sync_all()
         elapsed = time.perf_counter() - t0
+        e1 = energy.joules()
+    joules = (e1 - e0) if (e0 is not None and e1 is not None and e1 > e0) else None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -308,6 +334,9 @@ def main():
                                   "f32": "fp32 operands, fp32 accumulation throughout, f32 MFMA kernels only"}[args.arithmetic]},
         "dense_equivalent_tflops": DENSE_GFLOP_PER_PAIR * 1e9 * world * B * args.steps / elapsed / 1e12,
         "selfcheck_max_abs": selfcheck,
+        # rank 0's GPU over the timed loop, from the device's energy accumulator (null without librocm_smi64)
+        "energy": None if joules is None else {"joules_per_step": joules / args.steps, "avg_power_w": joules / elapsed,
+                                               "millijoules_per_frame_pair": joules / args.steps / B * 1e3},
         "roofline": roof,
         "roofline_second": second,
     }

@@ -212,7 +212,6 @@ size_t aff_workspace_bytes(int B, int N) {
     return align_up((size_t)B * T * Dp * sizeof(float), 256);  // matched (B, T, Dp) between the row MLP and the column softmax
 }
 
-size_t aff_pieces_lds_bytes(int Dp);
 bool aff_pieces_serves(int D);
 int launch_aff_pieces(const shasta_weights* w, const float* packed_pieces, const float* residual, int ld, float* matched, int ldm,
                       float* m1, int M, hipStream_t st);
@@ -242,7 +241,7 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
     // fp32 product) for tables up to 512 columns whose rows are 16-byte aligned; SHASTA_OPT_F32_AFF keeps the f32
     // kernel.  Small batches stay on the f32 kernel (16-row workgroups: more parallelism, less latency).
     const bool pieces = M >= 8192 && !(w->options & SHASTA_OPT_F32_AFF) && aff_pieces_serves(D) && ld % 4 == 0 &&
-                        (uintptr_t)residual % 16 == 0;
+                        (uintptr_t)residual % 16 == 0 && (uintptr_t)ws % 16 == 0;
     if (pieces) {
         if ((rc = launch_aff_pieces(w, packed + P.affp, residual, ld, matched, Dp, m1, M, st))) return rc;
     } else if (lds > 160 * 1024) {  // max_obj <= 2046 (check_weights) keeps 16 rows within 140 KB

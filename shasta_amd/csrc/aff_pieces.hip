@@ -10,21 +10,26 @@
 // lane&31, i.e. four groups of four CONSECUTIVE features: 8-byte piece writes into the next layer's image, 16-byte fp32 writes
 // into the output staging.
 //  * Weights are cut ONCE, at pack time, into fragment order ([layer][feature block][k step][piece][lane] x 16 B = 1 KB per
-//    fragment): a wave fetches its first operand with one coalesced global_load_dwordx4 per piece, no LDS, no VALU.
-//    What bounds this stage is the L2 -> CU weight traffic (0.9 MB of fragments per pass over the layers), so a workgroup owns
-//    128 residual rows = 4 row blocks and every fragment feeds 4 x 6 MFMAs (with 32 rows per workgroup the kernel measured
-//    1.44 ms for 257 k rows, slower than the f32 kernel's 1.33 ms).
-//  * Layer 1 (K = N+2) reads the residual rows straight from global memory (8 consecutive floats per lane and k step, the
-//    lines are shared by the four k steps that cover them) and cuts them in registers, in the shadow of the 12 MFMAs of the
-//    step: wave = (row block, two feature blocks).
+//    fragment): an operand is one coalesced 16-byte load per lane and piece, no VALU.  A workgroup owns 128 residual rows = 4 row
+//    blocks (64 = 2 row blocks while there are too few rows to fill the chip, ApShape) so that every fragment feeds 4 x 6 MFMAs.
+//  * Layer 1 (K = N+2): residual rows and weight fragments reach LDS by LDS-DMA, each byte once per workgroup, through a ring of
+//    32-column chunks laid over the piece images (see the kernel); wave = (row block, two feature blocks), the residual values
+//    are cut in registers.
 //  * Layers 2-5 (128 -> 64 -> 32 -> 64 -> 128) keep their activations in LDS as piece images [piece][row][k], alternating
 //    between image A (128 wide, row stride 272 B) and image B (64 wide, 144 B): every 16-lane phase of a ds_read_b128 covers
 //    all 64 banks; each value is cut once, by the producing wave.
 //  * Layer 6 (128 -> N+2): wave = 2 feature blocks x 4 row blocks = 8 accumulators.  The row softmax statistics are taken
 //    from the registers (per-wave partial max / sum through LDS, fixed order); the rows then pass through an fp32 staging
-//    [128][256] in two column passes and leave as whole row segments: `matched` raw, `matched1` = exp(x - max) / sum.
+//    [rows][256] in two column passes and leave as whole row segments (16-byte stores for `matched`, 8-byte stores for
+//    `matched1` = exp(x - max) / sum, four rows in flight per wave).
+//  Where a workgroup's time goes (tools/probes/aff_probe.hip, 128 rows, shader cycles): layer 1 56 k (MFMA 25 k, LDS reads 16 k
+//  and the cuts 15 k do not overlap: one barrier per chunk keeps the two waves of a SIMD in step), layers 2-5 31 k (latency of
+//  their weight loads and four barriers), layer 6 30 k (MFMA-bound), softmax statistics 30 k, output 61 k (20 k without the stores).
 #include "common.hpp"
 #include "pair_layout.hpp"
+
+// the LDS-DMA asm below names m0 in its clobber list on purpose (it writes it)
+#pragma clang diagnostic ignored "-Winline-asm"
 
 namespace shasta {
 
@@ -32,15 +37,29 @@ typedef __bf16 qbf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t qu32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t qu32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int AP_WAVES = 8, AP_ROWS = 128;    // 4 row blocks of 32 per workgroup: every weight fragment feeds 4 x 6 MFMAs
-constexpr int AP_AROW = 272;                  // bytes per row of image A (128 bf16 + 16 B pad: 68 dwords, conflict-free b128 reads)
-constexpr int AP_BROW = 144;                  // bytes per row of image B (64 bf16 + 16 B pad: 36 dwords, conflict-free)
-constexpr int AP_AIMG = AP_ROWS * AP_AROW;    // one piece of image A
-constexpr int AP_BIMG = AP_ROWS * AP_BROW;
-constexpr int AP_ABYTES = 3 * AP_AIMG, AP_BBYTES = 3 * AP_BIMG;  // 104448 + 55296 = 159744 B
-constexpr int AP_SCOLS = 256, AP_SROW = AP_SCOLS + 4;           // output staging: 128 rows x 256 features per pass (133120 B)
-constexpr int AP_STAT = AP_ROWS * AP_SROW * 4;                   // byte offset of the softmax scratch behind the staging
-static_assert(AP_STAT + (2 * AP_WAVES + 2) * AP_ROWS * 4 <= AP_ABYTES + AP_BBYTES, "staging + softmax scratch must fit the two images");
+constexpr int AP_AROW = 272;  // bytes per row of image A (128 bf16 + 16 B pad: 68 dwords, conflict-free b128 reads)
+constexpr int AP_BROW = 144;  // bytes per row of image B (64 bf16 + 16 B pad: 36 dwords, conflict-free)
+constexpr int AP_SCOLS = 256, AP_SROW = AP_SCOLS + 4;  // output staging: ROWS x 256 features per pass
+
+// Shape of a workgroup: ROWS residual rows (RB = ROWS / 32 row blocks) on WAVES = 2 RB wavefronts.
+//  <128, 8>: one workgroup per CU (160 KB of LDS); every weight fragment feeds 4 x 6 MFMAs.
+//  < 64, 4>: two workgroups per CU (80 KB each); fragments feed 2 x 6 MFMAs (twice the L2 -> CU weight traffic per row), but the
+//            phases of the two co-resident workgroups overlap: one streams its output rows while the other is in its MFMAs.
+template <int ROWS, int WAVES>
+struct ApShape {
+    static_assert(WAVES * 16 == ROWS, "WAVES = 2 * row blocks");
+    static constexpr int RB = ROWS / 32;
+    static constexpr int NFW = 16 / WAVES;                              // feature blocks of layer 6 per wave (tables up to 512 columns)
+    static constexpr int AIMG = ROWS * AP_AROW, BIMG = ROWS * AP_BROW;  // one piece of image A / B
+    static constexpr int ABYTES = 3 * AIMG, BBYTES = 3 * BIMG;          // 128 rows: 104448 + 55296 = 159744 B; 64 rows: 79872 B
+    static constexpr int STAT = ROWS * AP_SROW * 4;                     // byte offset of the softmax scratch behind the staging
+    static constexpr int L1X = ROWS * 128, L1SLOT = L1X + 24 * 1024;    // layer-1 ring slot: x chunk + 24 weight fragments
+    static constexpr int NS = (ABYTES + BBYTES) / L1SLOT >= 3 ? 3 : 2;  // ring slots
+    static constexpr int WPW = 24 / WAVES, PER = 2 + WPW;               // LDS-DMA instructions per chunk and wave: weights, total
+    static_assert(NS * L1SLOT <= ABYTES + BBYTES, "the layer-1 ring lies over the two images");
+    static_assert(STAT + (2 * WAVES + 2) * ROWS * 4 <= ABYTES + BBYTES, "staging + softmax scratch must fit the two images");
+    static_assert(PER * (NS - 1) <= 63, "vmcnt is 6 bits");
+};
 
 __device__ __forceinline__ void ap_cut3(float a, float& h, float& m, float& l) {
     h = __uint_as_float(__float_as_uint(a) & 0xffff0000u);
@@ -90,6 +109,14 @@ int aff_pieces_pack(const shasta_weights* w, float* out, hipStream_t st) {
     hipLaunchKernelGGL(aff_pieces_pack_kernel, dim3(128), dim3(256), 0, st, a);
     return check_launch("aff_pieces_pack");
 }
+
+#ifdef SHASTA_AFF_STAMP  // diagnostic build only (tools/probes/aff_probe.hip): s_memtime at the phase boundaries of a workgroup
+__device__ unsigned long long g_aff_stamp[4096][8];
+#define AP_STAMP(i) \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_aff_stamp[blockIdx.x][i] = __builtin_amdgcn_s_memtime()
+#else
+#define AP_STAMP(i)
+#endif
 
 struct AffPiecesArgs {
     const uint32_t* wp;  // piece fragments of the six layers
@@ -161,133 +188,198 @@ __device__ __forceinline__ void ap_hidden_task(const qu32x4* wl, int fb, int rb,
     }
 }
 
-__global__ __launch_bounds__(64 * AP_WAVES) void aff_pieces_kernel(AffPiecesArgs a) {
+template <int ROWS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void aff_pieces_kernel(AffPiecesArgs a) {
+    using S = ApShape<ROWS, WAVES>;
+    constexpr int RB = S::RB, NFW = S::NFW, AIMG = S::AIMG, BIMG = S::BIMG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* HA = smem;              // [3][128][272 B]: layer outputs of width 128 / 32
-    char* HB = smem + AP_ABYTES;  // [3][128][144 B]: layer outputs of width 64
+    char* HA = smem;              // [3][ROWS][272 B]: layer outputs of width 128 / 32
+    char* HB = smem + S::ABYTES;  // [3][ROWS][144 B]: layer outputs of width 64
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g0 = blockIdx.x * AP_ROWS;
+    const int g0 = blockIdx.x * ROWS;
     const int D = a.D;
     const qu32x4* wp = reinterpret_cast<const qu32x4*>(a.wp);
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef AP_EXP_SLEEP  // experiment: pace the kernel
+    for (int i = 0; i < AP_EXP_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+#ifdef AP_EXP_STAGGER  // experiment: de-phase the first round of workgroups
+    if (blockIdx.x < 256) {
+        const int q = (blockIdx.x >> 3) & 3;
+        for (int i = 0; i < q * AP_EXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+    AP_STAMP(0);
 
-    // ---- layer 1 (K = D -> 128): wave = (row block wid >> 1, feature blocks 2 (wid & 1) + {0, 1}); the residual rows come
-    // straight from global memory, 8 consecutive floats per lane and k step, and are cut in registers ----
+    // ---- layer 1 (K = D -> 128): wave = (row block wid >> 1, feature blocks 2 (wid & 1) + {0, 1}).  Residual rows and weight
+    // fragments reach LDS by LDS-DMA, each byte once per workgroup, in chunks of two k steps = 32 columns through a ring of NS
+    // slots laid over the (still unused) piece images: x [ROWS][8 x 16 B], the 16-byte piece c of row r at position
+    // c ^ ((r >> 1) & 7) (swizzle on the source address; ds_read_b128 of 16 rows then covers all banks), followed by the 24
+    // lane-linear weight fragments [feature block 4][k step 2][piece 3].  One barrier per chunk: a wave waits (counted vmcnt) for
+    // its own share of chunk c, the barrier certifies everybody's share and that chunk c-1 has been consumed, whose slot is then
+    // refilled with chunk c+NS-1.  (Fetching every operand from global memory per wave - each weight fragment 4 x, each residual
+    // line 8 x per workgroup - kept the vector memory pipe busy for 3 700 cycles per k step against 770 of MFMA.)
     {
-        const int nks = ap_ksteps(0, D), rb = wid >> 1, fb0 = 2 * (wid & 1);
-        const qu32x4* frag0 = wp + (size_t)fb0 * nks * 3 * 64;
-        const qu32x4* frag1 = frag0 + (size_t)nks * 3 * 64;
-        const int row = min(g0 + rb * 32 + (lane & 31), a.M - 1);
-        const float* xr = a.residual + (size_t)row * a.ld + (lane >> 5) * 8;
-        f32x16 acc0 = zero16, acc1 = zero16;
-        auto load_x = [&](int ks, float (&v)[8]) {
-            const int k0 = ks * 16 + (lane >> 5) * 8;
-            if (k0 + 8 <= D) {  // ld = Dp is a multiple of 4 and the rows are 16-byte aligned
-                const f32x4 p = *reinterpret_cast<const f32x4*>(xr + ks * 16), q = *reinterpret_cast<const f32x4*>(xr + ks * 16 + 4);
-                v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3]; v[4] = q[0]; v[5] = q[1]; v[6] = q[2]; v[7] = q[3];
-            } else {
+        constexpr int NS = S::NS, WPW = S::WPW, PER = S::PER;
+        const int nks = ap_ksteps(0, D), NC = (nks + 1) / 2, rb = wid >> 1, fb0 = 2 * (wid & 1);
+        const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)smem);
+        // x share of this wave: rows 16 wid + 8 j + (lane >> 3), j = 0, 1; position lane & 7
+        uint32_t xoff[2], xoff_last[2];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = k0 + j < D ? xr[ks * 16 + j] : 0.0f;
+        for (int jj = 0; jj < 2; ++jj) {
+            const int r = 16 * wid + 8 * jj + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+            const int rowoff = (min(g0 + r, a.M - 1) - g0) * a.ld;
+            xoff[jj] = (uint32_t)((rowoff + 4 * c) * 4);
+            // last chunk: a float4 beyond the row is fetched from the row's last float4 (zeroed when the step is cut)
+            xoff_last[jj] = (uint32_t)((rowoff + min(4 * c, a.ld - 4 - 32 * (NC - 1))) * 4);
+        }
+        const char* xbase = reinterpret_cast<const char*>(a.residual + (size_t)g0 * a.ld);
+        const char* wbase = reinterpret_cast<const char*>(wp);
+        const uint32_t woff = (uint32_t)(lane * 16);
+        auto issue = [&](int c, int slot) {
+            const uint32_t sl = lds0 + (uint32_t)(slot * S::L1SLOT);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const char* base = xbase + (size_t)c * 128;
+                const uint32_t dst = sl + (uint32_t)((16 * wid + 8 * jj) * 128);
+                const uint32_t vo = c == NC - 1 ? xoff_last[jj] : xoff[jj];
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(vo), "s"(base), "s"(dst) : "memory", "m0");
+            }
+#pragma unroll
+            for (int jj = 0; jj < WPW; ++jj) {
+                const int f24 = WPW * wid + jj, fb = f24 / 6, within = f24 % 6;  // within = 3 (k step) + piece
+                const char* base = wbase + ((size_t)(fb * nks + 2 * c) * 3 + within) * 1024;
+                const uint32_t dst = sl + (uint32_t)(S::L1X + f24 * 1024);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(woff), "s"(base), "s"(dst) : "memory", "m0");
             }
         };
-        qu32x4 w0c[3], w1c[3], w0n[3], w1n[3];
-        float xc[8], xn[8];
-        ap_load_w(frag0, lane, w0c);
-        ap_load_w(frag1, lane, w1c);
-        load_x(0, xc);
-        for (int ks = 0; ks < nks; ++ks) {
-            if (ks + 1 < nks) {
-                ap_load_w(frag0 + (size_t)(ks + 1) * 3 * 64, lane, w0n);
-                ap_load_w(frag1 + (size_t)(ks + 1) * 3 * 64, lane, w1n);
-                load_x(ks + 1, xn);
+        f32x16 acc0 = zero16, acc1 = zero16;
+        const int xrow = rb * 32 + (lane & 31), xsw = (xrow >> 1) & 7, hh2 = (lane >> 5) * 2;
+        auto compute = [&](int c, int slot) {
+            const char* sl = smem + slot * S::L1SLOT;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const f32x4 p = *reinterpret_cast<const f32x4*>(sl + xrow * 128 + ((4 * st + hh2) ^ xsw) * 16);
+                const f32x4 q = *reinterpret_cast<const f32x4*>(sl + xrow * 128 + ((4 * st + hh2 + 1) ^ xsw) * 16);
+                float v[8] = {p[0], p[1], p[2], p[3], q[0], q[1], q[2], q[3]};
+                const int ks = 2 * c + st;
+                if (ks * 16 + 16 > D) {  // wave-uniform: the step that holds column D (and a phantom step behind it)
+                    const int k0 = ks * 16 + (lane >> 5) * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = k0 + e < D ? v[e] : 0.0f;
+                }
+                qu32x4 w0[3], w1[3];
+                const qu32x4* wf = reinterpret_cast<const qu32x4*>(sl + S::L1X) + lane;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    w0[pc] = wf[(fb0 * 6 + st * 3 + pc) * 64];
+                    w1[pc] = wf[((fb0 + 1) * 6 + st * 3 + pc) * 64];
+                }
+                float h[8], m[8], l[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ap_cut3(v[e], h[e], m[e], l[e]);
+                qu32x4 x[3];
+                x[0] = qu32x4{ap_top2(h[0], h[1]), ap_top2(h[2], h[3]), ap_top2(h[4], h[5]), ap_top2(h[6], h[7])};
+                x[1] = qu32x4{ap_top2(m[0], m[1]), ap_top2(m[2], m[3]), ap_top2(m[4], m[5]), ap_top2(m[6], m[7])};
+                x[2] = qu32x4{ap_top2(l[0], l[1]), ap_top2(l[2], l[3]), ap_top2(l[4], l[5]), ap_top2(l[6], l[7])};
+                ap_step(w0, x, acc0);
+#ifdef AP_EXP_PACE
+                __builtin_amdgcn_s_sleep(AP_EXP_PACE);
+#endif
+                ap_step(w1, x, acc1);
+#ifdef AP_EXP_PACE
+                __builtin_amdgcn_s_sleep(AP_EXP_PACE);
+#endif
             }
-            float h[8], m[8], l[8];
+        };
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ap_cut3(xc[j], h[j], m[j], l[j]);
-            qu32x4 x[3];
-            x[0] = qu32x4{ap_top2(h[0], h[1]), ap_top2(h[2], h[3]), ap_top2(h[4], h[5]), ap_top2(h[6], h[7])};
-            x[1] = qu32x4{ap_top2(m[0], m[1]), ap_top2(m[2], m[3]), ap_top2(m[4], m[5]), ap_top2(m[6], m[7])};
-            x[2] = qu32x4{ap_top2(l[0], l[1]), ap_top2(l[2], l[3]), ap_top2(l[4], l[5]), ap_top2(l[6], l[7])};
-            ap_step(w0c, x, acc0);
-            ap_step(w1c, x, acc1);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                w0c[p] = w0n[p];
-                w1c[p] = w1n[p];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xc[j] = xn[j];
+        for (int c = 0; c < NS - 1; ++c)
+            if (c < NC) issue(c, c);
+        int slot = 0;
+#pragma unroll 1
+        for (int c = 0; c < NC; ++c) {
+            // chunks issued after chunk c: min(NS - 2, NC - 1 - c)
+            if (NS > 2 && c + NS - 2 < NC) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * (NS - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (c + NS - 1 < NC) issue(c + NS - 1, slot == 0 ? NS - 1 : slot - 1);
+            compute(c, slot);
+            slot = slot == NS - 1 ? 0 : slot + 1;
         }
-        ap_store_h<AP_AROW, AP_AIMG>(HA, fb0, rb, lane, acc0, a.bias[0]);
-        ap_store_h<AP_AROW, AP_AIMG>(HA, fb0 + 1, rb, lane, acc1, a.bias[0]);
+        __syncthreads();  // the ring lies over image A: every wave must be done reading it
+        ap_store_h<AP_AROW, AIMG>(HA, fb0, rb, lane, acc0, a.bias[0]);
+        ap_store_h<AP_AROW, AIMG>(HA, fb0 + 1, rb, lane, acc1, a.bias[0]);
     }
     __syncthreads();
+    AP_STAMP(1);
     const qu32x4* w2 = wp + ap_layer_offset(1, D) * 64;
     const qu32x4* w3 = wp + ap_layer_offset(2, D) * 64;
     const qu32x4* w4 = wp + ap_layer_offset(3, D) * 64;
     const qu32x4* w5 = wp + ap_layer_offset(4, D) * 64;
     const qu32x4* w6 = wp + ap_layer_offset(5, D) * 64;
-    {  // 128 -> 64: 2 feature blocks x 4 row blocks = one task per wave; A -> B
+    {  // 128 -> 64: 2 feature blocks x RB row blocks = one task per wave; A -> B
         f32x16 acc = zero16;
-        ap_hidden_task<8, AP_AROW, AP_AIMG>(w2, wid & 1, wid >> 1, HA, lane, acc);
-        ap_store_h<AP_BROW, AP_BIMG>(HB, wid & 1, wid >> 1, lane, acc, a.bias[1]);
+        ap_hidden_task<8, AP_AROW, AIMG>(w2, wid & 1, wid >> 1, HA, lane, acc);
+        ap_store_h<AP_BROW, BIMG>(HB, wid & 1, wid >> 1, lane, acc, a.bias[1]);
     }
     __syncthreads();
-    if (wid < 4) {  // 64 -> 32: 1 x 4 tasks; B -> A
+    if (wid < RB) {  // 64 -> 32: 1 x RB tasks; B -> A
         f32x16 acc = zero16;
-        ap_hidden_task<4, AP_BROW, AP_BIMG>(w3, 0, wid, HB, lane, acc);
-        ap_store_h<AP_AROW, AP_AIMG>(HA, 0, wid, lane, acc, a.bias[2]);
+        ap_hidden_task<4, AP_BROW, BIMG>(w3, 0, wid, HB, lane, acc);
+        ap_store_h<AP_AROW, AIMG>(HA, 0, wid, lane, acc, a.bias[2]);
     }
     __syncthreads();
-    {  // 32 -> 64: 2 x 4 tasks; A -> B
+    {  // 32 -> 64: 2 x RB tasks; A -> B
         f32x16 acc = zero16;
-        ap_hidden_task<2, AP_AROW, AP_AIMG>(w4, wid & 1, wid >> 1, HA, lane, acc);
-        ap_store_h<AP_BROW, AP_BIMG>(HB, wid & 1, wid >> 1, lane, acc, a.bias[3]);
+        ap_hidden_task<2, AP_AROW, AIMG>(w4, wid & 1, wid >> 1, HA, lane, acc);
+        ap_store_h<AP_BROW, BIMG>(HB, wid & 1, wid >> 1, lane, acc, a.bias[3]);
     }
     __syncthreads();
-    {  // 64 -> 128: 4 x 4 tasks, two per wave; B -> A
+    {  // 64 -> 128: 4 x RB tasks, two per wave; B -> A
         const int rb = wid >> 1;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             f32x16 acc = zero16;
-            ap_hidden_task<4, AP_BROW, AP_BIMG>(w5, 2 * (wid & 1) + i, rb, HB, lane, acc);
-            ap_store_h<AP_AROW, AP_AIMG>(HA, 2 * (wid & 1) + i, rb, lane, acc, a.bias[4]);
+            ap_hidden_task<4, AP_BROW, BIMG>(w5, 2 * (wid & 1) + i, rb, HB, lane, acc);
+            ap_store_h<AP_AROW, AIMG>(HA, 2 * (wid & 1) + i, rb, lane, acc, a.bias[4]);
         }
     }
     __syncthreads();
-    // ---- layer 6 (128 -> D): wave = feature blocks {wid, wid + 8} x the 4 row blocks: 8 accumulators; every weight fragment
-    // feeds 4 x 6 MFMAs ----
+    AP_STAMP(2);
+    // ---- layer 6 (128 -> D): wave = feature blocks {wid + WAVES i} x the RB row blocks: 8 accumulators; every weight fragment
+    // feeds RB x 6 MFMAs ----
     const int nfb = ap_fblocks(5, D);
-    f32x16 acc[2][4];
+    f32x16 acc[NFW][RB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NFW; ++i)
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[i][rb] = zero16;
+        for (int rb = 0; rb < RB; ++rb) acc[i][rb] = zero16;
 #pragma unroll 1
     for (int ks = 0; ks < 8; ++ks) {
-        qu32x4 x[4][3];
+        qu32x4 x[RB][3];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) ap_load_h<AP_AROW, AP_AIMG>(HA, rb, ks, lane, x[rb]);
+        for (int rb = 0; rb < RB; ++rb) ap_load_h<AP_AROW, AIMG>(HA, rb, ks, lane, x[rb]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int fb = wid + 8 * i;
+        for (int i = 0; i < NFW; ++i) {
+            const int fb = wid + WAVES * i;
             if (fb < nfb) {  // wave-uniform
                 qu32x4 w[3];
                 ap_load_w(w6 + ((size_t)fb * 8 + ks) * 3 * 64, lane, w);
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb) ap_step(w, x[rb], acc[i][rb]);
+                for (int rb = 0; rb < RB; ++rb) ap_step(w, x[rb], acc[i][rb]);
             }
         }
     }
+    AP_STAMP(3);
     // bias; per-row maximum over this wave's features (features >= D do not take part)
     const int n = lane & 31, hh = lane >> 5;
-    float mx[4];
+    float mx[RB];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) mx[rb] = -INFINITY;
+    for (int rb = 0; rb < RB; ++rb) mx[rb] = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int fb = wid + 8 * i;
+    for (int i = 0; i < NFW; ++i) {
+        const int fb = wid + WAVES * i;
         if (fb >= nfb) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -296,7 +388,7 @@ __global__ __launch_bounds__(64 * AP_WAVES) void aff_pieces_kernel(AffPiecesArgs
                 const int f = fb * 32 + 8 * g + 4 * hh + j;
                 const float bv = f < D ? a.bias[5][f] : 0.0f;
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
+                for (int rb = 0; rb < RB; ++rb) {
                     const float v = acc[i][rb][4 * g + j] + bv;
                     acc[i][rb][4 * g + j] = v;
                     if (f < D) mx[rb] = fmaxf(mx[rb], v);
@@ -304,29 +396,29 @@ __global__ __launch_bounds__(64 * AP_WAVES) void aff_pieces_kernel(AffPiecesArgs
             }
     }
     __syncthreads();  // every wave is done reading image A: the staging and the softmax scratch may overwrite it
-    float* xs = reinterpret_cast<float*>(smem);                       // [128][AP_SROW] staging
-    float* pmax = reinterpret_cast<float*>(smem + AP_STAT);           // [8 waves][128 rows]
-    float* psum = pmax + AP_WAVES * AP_ROWS;                          // [8 waves][128 rows]
-    float* rmax = psum + AP_WAVES * AP_ROWS;                          // [128]
-    float* rinv = rmax + AP_ROWS;                                     // [128]
+    float* xs = reinterpret_cast<float*>(smem);                  // [ROWS][AP_SROW] staging
+    float* pmax = reinterpret_cast<float*>(smem + S::STAT);      // [WAVES][ROWS]
+    float* psum = pmax + WAVES * ROWS;                           // [WAVES][ROWS]
+    float* rmax = psum + WAVES * ROWS;                           // [ROWS]
+    float* rinv = rmax + ROWS;                                   // [ROWS]
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
+    for (int rb = 0; rb < RB; ++rb) {
         const float o = fmaxf(mx[rb], __shfl_xor(mx[rb], 32, 64));
-        if (hh == 0) pmax[wid * AP_ROWS + rb * 32 + n] = o;
+        if (hh == 0) pmax[wid * ROWS + rb * 32 + n] = o;
     }
     __syncthreads();
-    float rm[4], se[4];
+    float rm[RB], se[RB];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
+    for (int rb = 0; rb < RB; ++rb) {
         float m = pmax[rb * 32 + n];
 #pragma unroll
-        for (int w = 1; w < AP_WAVES; ++w) m = fmaxf(m, pmax[w * AP_ROWS + rb * 32 + n]);
+        for (int w = 1; w < WAVES; ++w) m = fmaxf(m, pmax[w * ROWS + rb * 32 + n]);
         rm[rb] = m;
         se[rb] = 0.0f;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int fb = wid + 8 * i;
+    for (int i = 0; i < NFW; ++i) {
+        const int fb = wid + WAVES * i;
         if (fb >= nfb) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -335,67 +427,93 @@ __global__ __launch_bounds__(64 * AP_WAVES) void aff_pieces_kernel(AffPiecesArgs
                 const int f = fb * 32 + 8 * g + 4 * hh + j;
                 if (f < D) {
 #pragma unroll
-                    for (int rb = 0; rb < 4; ++rb) se[rb] += expf(acc[i][rb][4 * g + j] - rm[rb]);
+                    for (int rb = 0; rb < RB; ++rb) se[rb] += expf(acc[i][rb][4 * g + j] - rm[rb]);
                 }
             }
     }
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
+    for (int rb = 0; rb < RB; ++rb) {
         const float o = se[rb] + __shfl_xor(se[rb], 32, 64);
-        if (hh == 0) psum[wid * AP_ROWS + rb * 32 + n] = o;
+        if (hh == 0) psum[wid * ROWS + rb * 32 + n] = o;
     }
     __syncthreads();
-    if (tid < AP_ROWS) {
+    if (tid < ROWS) {
         float s = psum[tid];
 #pragma unroll
-        for (int w = 1; w < AP_WAVES; ++w) s += psum[w * AP_ROWS + tid];  // fixed order
-        rmax[tid] = pmax[tid];
+        for (int w = 1; w < WAVES; ++w) s += psum[w * ROWS + tid];  // fixed order
         float m = pmax[tid];
 #pragma unroll
-        for (int w = 1; w < AP_WAVES; ++w) m = fmaxf(m, pmax[w * AP_ROWS + tid]);
+        for (int w = 1; w < WAVES; ++w) m = fmaxf(m, pmax[w * ROWS + tid]);
         rmax[tid] = m;
         rinv[tid] = 1.0f / s;
     }
+    AP_STAMP(4);
     // ---- output: two passes of 8 feature blocks (256 columns) through the staging, whole row segments to global memory ----
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         __syncthreads();  // pass 0: rmax / rinv visible; pass 1: the read-out of pass 0 is finished
-        const int fb = wid + 8 * i;
-        if (fb < nfb) {
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
+        for (int k = i * NFW / 2; k < (i + 1) * NFW / 2; ++k) {
+            const int fb = wid + WAVES * k;
+            if (fb < nfb) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<f32x4*>(xs + (rb * 32 + n) * AP_SROW + wid * 32 + 8 * g + 4 * hh) =
-                        f32x4{acc[i][rb][4 * g], acc[i][rb][4 * g + 1], acc[i][rb][4 * g + 2], acc[i][rb][4 * g + 3]};
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f32x4*>(xs + (rb * 32 + n) * AP_SROW + (fb - 8 * i) * 32 + 8 * g + 4 * hh) =
+                            f32x4{acc[k][rb][4 * g], acc[k][rb][4 * g + 1], acc[k][rb][4 * g + 2], acc[k][rb][4 * g + 3]};
+            }
         }
         __syncthreads();
-        const int c0 = i * AP_SCOLS, ncol = min(AP_SCOLS, D - c0);
-        if (ncol <= 0) continue;
-        // a wave writes one row at a time: `matched` (raw) and, for t < N, matched1 = exp(x - max) / sum
-        for (int r = wid; r < AP_ROWS; r += AP_WAVES) {
-            const int gr = g0 + r;
-            if (gr >= a.M) break;
-            const float* x = xs + r * AP_SROW;
-            float* mo = a.matched + (size_t)gr * a.ldm + c0;
-            const int b = gr / a.T, t = gr - b * a.T;
-            float* o = a.m1 + ((size_t)b * a.N + t) * D + c0;
-            const float m = rmax[r], inv = rinv[r];
-            for (int d = lane; d < ncol; d += 64) {
-                const float v = x[d];
-                mo[d] = v;
-                if (t < a.N) o[d] = expf(v - m) * inv;
+        const int c0 = i * AP_SCOLS;
+        if (c0 >= D) continue;
+        // a wave writes whole 256-column row segments: one ds_read_b128 per lane and row, `matched` (raw) as one 16-byte store,
+        // matched1 = exp(x - max) / sum (rows t < N) as 8-byte stores (its rows are D floats apart)
+        const int col = c0 + 4 * lane;
+        const bool even = (D & 1) == 0;  // wave-uniform
+#pragma unroll 4
+        for (int rr = 0; rr < ROWS / WAVES; ++rr) {
+            const int r = wid + rr * WAVES, gr = g0 + r;
+            if (gr < a.M && col < a.ldm) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(xs + r * AP_SROW + 4 * lane);
+                const float m = rmax[r], inv = rinv[r];
+                const int b = gr / a.T, t = gr - b * a.T;
+                float e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    e[q] = expf(v[q] - m) * inv;
+                    if (col + q >= D) v[q] = 0.0f;  // the padding columns of `matched`
+                }
+                *reinterpret_cast<f32x4*>(a.matched + (size_t)gr * a.ldm + col) = v;
+                if (t < a.N) {
+                    float* o = a.m1 + ((size_t)b * a.N + t) * D + col;
+                    if (even) {
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        if (col + 1 < D) *reinterpret_cast<f32x2*>(o) = f32x2{e[0], e[1]};
+                        if (col + 3 < D) *reinterpret_cast<f32x2*>(o + 2) = f32x2{e[2], e[3]};
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (col + q < D) o[q] = e[q];
+                    }
+                }
             }
         }
     }
+    AP_STAMP(5);
 }
 
-// LDS bytes of aff_pieces_kernel (independent of the table width, which must not exceed 512 columns)
-size_t aff_pieces_lds_bytes(int Dp) {
-    (void)Dp;
-    return (size_t)AP_ABYTES + AP_BBYTES;
-}
+// LDS bytes of the workgroup shapes (independent of the table width, which must not exceed 512 columns)
 bool aff_pieces_serves(int D) { return D <= 2 * AP_SCOLS; }
+
+template <int ROWS, int WAVES>
+static int launch_aff_pieces_shape(const AffPiecesArgs& a, hipStream_t st) {
+    using S = ApShape<ROWS, WAVES>;
+    const size_t lds = (size_t)S::ABYTES + S::BBYTES;
+    (void)hipFuncSetAttribute((const void*)aff_pieces_kernel<ROWS, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((aff_pieces_kernel<ROWS, WAVES>), dim3(cdiv(a.M, ROWS)), dim3(64 * WAVES), lds, st, a);
+    return check_launch("aff_pieces");
+}
 
 int launch_aff_pieces(const shasta_weights* w, const float* packed_pieces, const float* residual, int ld, float* matched, int ldm,
                       float* m1, int M, hipStream_t st) {
@@ -413,10 +531,15 @@ int launch_aff_pieces(const shasta_weights* w, const float* packed_pieces, const
     a.Dp = Dp;
     a.ld = ld;
     a.ldm = ldm;
-    const size_t lds = aff_pieces_lds_bytes(Dp);
-    (void)hipFuncSetAttribute((const void*)aff_pieces_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(aff_pieces_kernel, dim3(cdiv(M, AP_ROWS)), dim3(64 * AP_WAVES), lds, st, a);
-    return check_launch("aff_pieces");
+    // 128-row workgroups once they fill the 256 CUs (0.825 ms against 0.837 ms for 257 k rows); below that the 64-row shape puts
+    // twice as many workgroups on the chip
+#if defined(AP_SHAPE_64)
+    return launch_aff_pieces_shape<64, 4>(a, st);
+#elif defined(AP_SHAPE_128)
+    return launch_aff_pieces_shape<128, 8>(a, st);
+#else
+    return cdiv(M, 128) >= 256 ? launch_aff_pieces_shape<128, 8>(a, st) : launch_aff_pieces_shape<64, 4>(a, st);
+#endif
 }
 
 }  // namespace shasta

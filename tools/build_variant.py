@@ -1,0 +1,29 @@
+"""Build a variant of the library for A/B runs: one source recompiled with extra -D flags, linked with the objects of the
+normal build.  usage: python tools/build_variant.py <name> <source.hip> [-DFLAG ...]  ->  tools/probes/_bin/libshasta_<name>.so
+(load it with SHASTA_HIP_LIB=<path>, see tools/gpu_ab.sh)"""
+import os
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from shasta_amd import build as B  # noqa: E402
+
+
+def main():
+    name, src, flags = sys.argv[1], sys.argv[2], sys.argv[3:]
+    B.build()
+    objdir = os.path.join(B.CSRC, "build")
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "_bin")
+    os.makedirs(out, exist_ok=True)
+    obj = os.path.join(out, "%s_%s.o" % (name, src.replace(".hip", "")))
+    cmd = [B._hipcc()] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + flags + ["-c", os.path.join(B.CSRC, src), "-o", obj]
+    subprocess.run(cmd, check=True)
+    objs = [obj if s == src else os.path.join(objdir, s.replace(".hip", ".o")) for s in B.SOURCES]
+    lib = os.path.join(out, "libshasta_%s.so" % name)
+    subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(B.CSRC, "exports.map"),
+                    "-o", lib] + objs, check=True)
+    print(lib)
+
+
+if __name__ == "__main__":
+    main()
