@@ -40,6 +40,9 @@ typedef uint32_t qu32x2 __attribute__((ext_vector_type(2)));
 constexpr int AP_AROW = 272;  // bytes per row of image A (128 bf16 + 16 B pad: 68 dwords, conflict-free b128 reads)
 constexpr int AP_BROW = 144;  // bytes per row of image B (64 bf16 + 16 B pad: 36 dwords, conflict-free)
 constexpr int AP_SCOLS = 256, AP_SROW = AP_SCOLS + 4;  // output staging: ROWS x 256 features per pass
+#ifndef AP_PACE
+#define AP_PACE 4  // s_sleep units between the MFMA groups of layer 1 (see there)
+#endif
 
 // Shape of a workgroup: ROWS residual rows (RB = ROWS / 32 row blocks) on WAVES = 2 RB wavefronts.
 //  <128, 8>: one workgroup per CU (160 KB of LDS); every weight fragment feeds 4 x 6 MFMAs.
@@ -201,15 +204,6 @@ __global__ __launch_bounds__(64 * WAVES) void aff_pieces_kernel(AffPiecesArgs a)
     const int D = a.D;
     const qu32x4* wp = reinterpret_cast<const qu32x4*>(a.wp);
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#ifdef AP_EXP_SLEEP  // experiment: pace the kernel
-    for (int i = 0; i < AP_EXP_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
-#ifdef AP_EXP_STAGGER  // experiment: de-phase the first round of workgroups
-    if (blockIdx.x < 256) {
-        const int q = (blockIdx.x >> 3) & 3;
-        for (int i = 0; i < q * AP_EXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     AP_STAMP(0);
 
     // ---- layer 1 (K = D -> 128): wave = (row block wid >> 1, feature blocks 2 (wid & 1) + {0, 1}).  Residual rows and weight
@@ -283,14 +277,14 @@ __global__ __launch_bounds__(64 * WAVES) void aff_pieces_kernel(AffPiecesArgs a)
                 x[0] = qu32x4{ap_top2(h[0], h[1]), ap_top2(h[2], h[3]), ap_top2(h[4], h[5]), ap_top2(h[6], h[7])};
                 x[1] = qu32x4{ap_top2(m[0], m[1]), ap_top2(m[2], m[3]), ap_top2(m[4], m[5]), ap_top2(m[6], m[7])};
                 x[2] = qu32x4{ap_top2(l[0], l[1]), ap_top2(l[2], l[3]), ap_top2(l[4], l[5]), ap_top2(l[6], l[7])};
+                // 256 idle cycles behind each group of six MFMAs.  Without them this phase (eight waves issuing MFMAs back to back
+                // next to the LDS-DMA) makes the chip fall into a lower clock state for the WHOLE step: measured on three boxes
+                // (tools/gpu_ab.sh, alternating): 12.00 - 12.06 ms per step and 1075 W without the pauses against 11.52 - 11.65 ms
+                // and 1140 W with them (2, 4, 6 or 8 units of 64 cycles alike), although the kernel itself is 8 % shorter without.
                 ap_step(w0, x, acc0);
-#ifdef AP_EXP_PACE
-                __builtin_amdgcn_s_sleep(AP_EXP_PACE);
-#endif
+                __builtin_amdgcn_s_sleep(AP_PACE);
                 ap_step(w1, x, acc1);
-#ifdef AP_EXP_PACE
-                __builtin_amdgcn_s_sleep(AP_EXP_PACE);
-#endif
+                __builtin_amdgcn_s_sleep(AP_PACE);
             }
         };
 #pragma unroll

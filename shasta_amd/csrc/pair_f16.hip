@@ -38,23 +38,32 @@ struct A4h {
     static constexpr int NOB = a4_nob(F, L), KG = a4_kg(F, L), OFF = a4_offset(F, L), KIN = D.kin, BIAS = NOB * KG * 16;
 };
 
-// {fp16(s0 c), fp16(s1 c)}: scale (exact power of two) and convert in one instruction per value
-__device__ __forceinline__ uint32_t cvt2_scaled(float s0, float s1, float c) {
-    uint32_t d = 0;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(d) : "v"(s0), "v"(c));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(d) : "v"(s1), "v"(c));
-    return d;
-}
-// s c - h (exact in fp32), h = the low / high half of hpk
-__device__ __forceinline__ float res_lo(float s, float c, uint32_t hpk) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(s), "v"(c), "v"(hpk));
+// {clamp01(a0 * c + b0), clamp01(a1 * c + b1)}: with a, b pre-scaled so that every sum is at most 1, the clamp IS the ReLU
+typedef float pf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pf2 fma2_relu01(pf2 a, pf2 c, pf2 b) {
+    pf2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(c), "v"(b));
     return r;
 }
-__device__ __forceinline__ float res_hi(float s, float c, uint32_t hpk) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(s), "v"(c), "v"(hpk));
-    return r;
+// Four values at once: high pieces hA = {fp16(s0 c), fp16(s1 c)}, hB = {fp16(s2 c), fp16(s3 c)} and the four residuals s c - h
+// (exact in fp32; the caller converts them to the low pieces).
+// ONE asm statement on purpose: gfx950 needs a wait state between an instruction that writes half of a VGPR (v_fma_mixlo/hi_f16)
+// and the next reader of that VGPR, and the compiler does not look for that hazard around inline asm (separate statements,
+// scheduled freely, gave wrong low pieces for a fraction of a per cent of the values).  Inside, every half-write is at least one
+// instruction away from the first reader of its register, and the two writes of a register are not adjacent.
+// (Forming the low piece directly, v_fma_mixlo_f16 d, s, c, -h with h as an f16 operand, is bit-identical and two instructions
+// shorter per four values, but measured 6 % slower for the kernel: four dependent half-write pairs instead of two.)
+__device__ __forceinline__ void cut4(float s0, float s1, float s2, float s3, float c, uint32_t& hA, uint32_t& hB, float (&r)[4]) {
+    asm("v_fma_mixlo_f16 %0, %6, %10, 0\n\t"
+        "v_fma_mixlo_f16 %1, %8, %10, 0\n\t"
+        "v_fma_mixhi_f16 %0, %7, %10, 0\n\t"
+        "v_fma_mixhi_f16 %1, %9, %10, 0\n\t"
+        "v_fma_mix_f32 %2, %6, %10, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %4, %8, %10, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %3, %7, %10, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %5, %9, %10, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hA), "=&v"(hB), "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+        : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(c));
 }
 __device__ __forceinline__ uint32_t cvt2(float a, float b) {
     const ph16x2 v = {(_Float16)a, (_Float16)b};
@@ -226,13 +235,20 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
         }
         // the track's scale: every h1 of this track and tile is at most max |UP[t]| + max |UC|
         const int e1 = range_exponent_bits(__float_as_uint(hp[13] + mc));
-        const float c1 = __builtin_ldexpf(1.0f, e1);
-        // this lane's UP values: 8 per k step (the same address in the 16 lanes of a k block: LDS broadcast)
-        f32x4 upv[8];
+        // h1 = relu(UP + UC) is formed as clamp01(UC cs + UP cs) with cs = 2^(e1 - 14): every sum is at most 1 after the scaling
+        // (exact, a power of two), so the clamp of one packed fma is the ReLU of two values; the conversion multiplies by 2^14.
+        const float cs = __builtin_ldexpf(1.0f, e1 - 14);
+        const pf2 cs2 = {cs, cs};
+        constexpr float c1 = 16384.0f;
+        // this lane's UP values, scaled: 8 per k step (the same address in the 16 lanes of a k block: LDS broadcast)
+        pf2 upv[16];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            upv[2 * s] = *reinterpret_cast<const lf32x4*>(up + 32 * s + 8 * kb);
-            upv[2 * s + 1] = *reinterpret_cast<const lf32x4*>(up + 32 * s + 8 * kb + 4);
+            const f32x4 a = *reinterpret_cast<const lf32x4*>(up + 32 * s + 8 * kb), c = *reinterpret_cast<const lf32x4*>(up + 32 * s + 8 * kb + 4);
+            upv[4 * s] = pf2{a[0], a[1]} * cs2;
+            upv[4 * s + 1] = pf2{a[2], a[3]} * cs2;
+            upv[4 * s + 2] = pf2{c[0], c[1]} * cs2;
+            upv[4 * s + 3] = pf2{c[2], c[3]} * cs2;
         }
         // Software pipeline over the four sub-steps: the UC reads of sub-step s+1 are issued before the arithmetic of sub-step s,
         // and the pieces of sub-step s+1 are cut before the MFMAs of sub-step s are issued (they run under the cut of s+1).
@@ -247,17 +263,18 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
         auto cut = [&](const f32x4 (&u)[8], pu4 (&xh)[4], pu4 (&xl)[4]) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float h1v[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    h1v[j] = fmaxf(upv[2 * s][j] + u[2 * s][j], 0.0f);
-                    h1v[4 + j] = fmaxf(upv[2 * s + 1][j] + u[2 * s + 1][j], 0.0f);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t hh = cvt2_scaled(h1v[2 * j], h1v[2 * j + 1], c1);
-                    xh[s][j] = hh;
-                    xl[s][j] = cvt2(res_lo(h1v[2 * j], c1, hh), res_hi(h1v[2 * j + 1], c1, hh));
+                for (int j2 = 0; j2 < 2; ++j2) {  // the float4 u[2 s + j2] = four values
+                    const f32x4 uu = u[2 * s + j2];
+                    const pf2 ha = fma2_relu01(pf2{uu[0], uu[1]}, cs2, upv[4 * s + 2 * j2]);
+                    const pf2 hb = fma2_relu01(pf2{uu[2], uu[3]}, cs2, upv[4 * s + 2 * j2 + 1]);
+                    uint32_t hA, hB;
+                    float r[4];
+                    cut4(ha[0], ha[1], hb[0], hb[1], c1, hA, hB, r);
+                    xh[s][2 * j2] = hA;
+                    xh[s][2 * j2 + 1] = hB;
+                    xl[s][2 * j2] = cvt2(r[0], r[1]);
+                    xl[s][2 * j2 + 1] = cvt2(r[2], r[3]);
                 }
             }
         };
