@@ -28,5 +28,6 @@ done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_b512 -o p -- python3 $R/bench.py --batch 512 --steps 5 --warmup 2 --no-cpu-baseline > $O/pmc_mfma_b512.log 2>&1
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum --kernel-trace --output-format csv -d $O/pmc_rdreq_b512 -o p -- python3 $R/bench.py --batch 512 --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_rdreq_b512.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $O/pmc_hit_b512 -o p -- python3 $R/bench.py --batch 512 --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_hit_b512.log 2>&1
+(cd $R && python3 tools/stage_power.py 512 2 > $O/stage_power.log 2>&1)
 grep -h '^{' $O/bench_default.json $O/bench_b1.json $O/bench_b32.json $O/bench_b64.json $O/bench_b128.json $O/bench_b256.json $O/bench_pieces.json $O/bench_f32.json $O/bench_b1024.json $O/bench_torchrun.json | cut -c1-230
 ls $O

@@ -67,6 +67,10 @@ if __name__ == "__main__":
             lines = [l for l in open(os.path.join(G, SRC, f)) if l.startswith("{")]
             if lines:
                 json.dump(json.loads(lines[-1]), open(os.path.join(P, TAG + "_" + f), "w"), indent=1)
+        if f == "stage_power.log":
+            lines = [l for l in open(os.path.join(G, SRC, f)) if l.startswith("{")]
+            if lines:
+                json.dump(json.loads(lines[-1]), open(os.path.join(P, TAG + "_stage_power.json"), "w"), indent=1)
         if f.startswith("l1_check_") and f.endswith(".json"):
             rows = [json.loads(l) for l in open(os.path.join(G, SRC, f)) if l.startswith("{")]
             json.dump(rows, open(os.path.join(P, TAG + "_" + f), "w"), indent=1)
