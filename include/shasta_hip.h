@@ -254,8 +254,10 @@ int shasta_decode_flags_f32(const float* matched1, const float* matched2, const 
 
 /* Strided form (training path: dX = dY.W and dW = dY^T.X of every nn.Linear, torch autograd's addmm backward):
  *   C[m][n] = act(sum_k A[m*sa_m + k*sa_k] * W[n*sw_n + k*sw_k] + bias[n]) * (relu_mask[m][n] > 0)
- * act: 0 none, 1 relu, 2 abs, +4: accumulate into C.  splitk_ws (optional): scratch for a deterministic split of long
- * reductions (weight gradients). */
+ * act: 0 none, 1 relu, 2 abs, +4: accumulate into C, +8: bf16 operands (A and W are rounded to bf16, nearest even, on chip and
+ * multiplied on the bf16 matrix path; accumulation, bias, epilogue and C stay fp32 - the reduced-precision option of the
+ * training GEMMs, fp32 master weights).  splitk_ws (optional): scratch for a deterministic split of long reductions
+ * (weight gradients). */
 int shasta_gemm_strided_f32(const float* A, long sa_m, long sa_k, const float* W, long sw_n, long sw_k,
                             const float* bias, const float* relu_mask, int ldmask, float* C, int ldc, int M,
                             int N, int K, int act, void* splitk_ws, size_t splitk_ws_bytes,

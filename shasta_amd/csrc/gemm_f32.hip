@@ -263,6 +263,27 @@ __device__ __forceinline__ void store_slice_strided(float* S, long s_r, long s_k
     }
 }
 
+// shared epilogue of the strided kernels: bias, activation, ReLU mask, accumulate
+__device__ __forceinline__ void strided_epilogue(const GemmS& g, const f32x16& acc, int m0, int n0, int wm, int wn, int lane) {
+    float* C = g.C + (long)blockIdx.z * g.slice_stride;
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col < g.N) {
+        const float bv = (g.bias && blockIdx.z == 0) ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < g.M) {
+                float v = acc[r] + bv;
+                if ((g.act & 3) == 1) v = fmaxf(v, 0.0f);
+                else if ((g.act & 3) == 2) v = fabsf(v);
+                if (g.mask && !(g.mask[(long)row * g.ldmask + col] > 0.0f)) v = 0.0f;
+                if (g.act & 4) v += C[(long)row * g.ldc + col];
+                C[(long)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void gemm_strided_f32_kernel(GemmS g) {
     __shared__ float As[BM * LDS_LD];
     __shared__ float Ws[BN * LDS_LD];
@@ -292,23 +313,72 @@ __global__ __launch_bounds__(256) void gemm_strided_f32_kernel(GemmS g) {
         for (int s = 0; s < BK / 2; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2 * s], wf[2 * s], acc, 0, 0, 0);
     }
-    float* C = g.C + (long)blockIdx.z * g.slice_stride;
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col < g.N) {
-        const float bv = (g.bias && blockIdx.z == 0) ? g.bias[col] : 0.0f;
+    strided_epilogue(g, acc, m0, n0, wm, wn, lane);
+}
+
+// bf16 operands (act & 8; BASELINE config 5's reduced-precision option for the training GEMMs): the fp32 operands in HBM are
+// rounded to bf16 (nearest even) when a K slice is stored to LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation - master weights, activations in HBM, bias / activation epilogue and the split-K sums all stay fp32.
+// LDS rows are 32 + 8 bf16 = 80 bytes: the 16 lanes of a ds_read_b128 phase start 20 banks apart and cover all 64 banks.
+constexpr int LDH = BK + 8;
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint16_t to_bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+
+__device__ __forceinline__ void store_slice_strided_bf16(uint16_t* S, long s_r, long s_k, int tid, const float (&reg)[2][4]) {
+    if (s_k == 1 || s_r != 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < g.M) {
-                float v = acc[r] + bv;
-                if ((g.act & 3) == 1) v = fmaxf(v, 0.0f);
-                else if ((g.act & 3) == 2) v = fabsf(v);
-                if (g.mask && !(g.mask[(long)row * g.ldmask + col] > 0.0f)) v = 0.0f;
-                if (g.act & 4) v += C[(long)row * g.ldc + col];
-                C[(long)row * g.ldc + col] = v;
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 3, c4 = idx & 7;
+            uint32_t* d = reinterpret_cast<uint32_t*>(S + row * LDH + 4 * c4);
+            d[0] = (uint32_t)to_bf16_bits(reg[i][0]) | ((uint32_t)to_bf16_bits(reg[i][1]) << 16);
+            d[1] = (uint32_t)to_bf16_bits(reg[i][2]) | ((uint32_t)to_bf16_bits(reg[i][3]) << 16);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = (i * 4 + j) * 256 + tid;
+                S[(e & 63) * LDH + (e >> 6)] = to_bf16_bits(reg[i][j]);
             }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_strided_bf16_kernel(GemmS g) {
+    __shared__ __attribute__((aligned(16))) uint16_t As[BM * LDH];
+    __shared__ __attribute__((aligned(16))) uint16_t Ws[BN * LDH];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.kslice, kend = min(g.K, kbeg + g.kslice);
+    float ra[2][4], rw[2][4];
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        load_slice_strided(g.A, g.sa_m, g.sa_k, g.M, kend, m0, kbeg, tid, g.vec_a != 0, ra);
+        load_slice_strided(g.W, g.sw_n, g.sw_k, g.N, kend, n0, kbeg, tid, g.vec_w != 0, rw);
+    }
+    const uint16_t* af = As + (wm * 32 + (lane & 31)) * LDH + (lane >> 5) * 8;
+    const uint16_t* wf = Ws + (wn * 32 + (lane & 31)) * LDH + (lane >> 5) * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        store_slice_strided_bf16(As, g.sa_m, g.sa_k, tid, ra);
+        store_slice_strided_bf16(Ws, g.sw_n, g.sw_k, tid, rw);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            load_slice_strided(g.A, g.sa_m, g.sa_k, g.M, kend, m0, kbeg + (kt + 1) * BK, tid, g.vec_a != 0, ra);
+            load_slice_strided(g.W, g.sw_n, g.sw_k, g.N, kend, n0, kbeg + (kt + 1) * BK, tid, g.vec_w != 0, rw);
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const gu32x4 a = *reinterpret_cast<const gu32x4*>(af + 16 * s), w = *reinterpret_cast<const gu32x4*>(wf + 16 * s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, a), __builtin_bit_cast(gbf16x8, w), acc, 0, 0, 0);
         }
     }
+    strided_epilogue(g, acc, m0, n0, wm, wn, lane);
 }
 
 // C[row][col] = sum_z part[z*stride + i], i = row*N + col: 16 elements x 16 z-groups per block, each group sums its
@@ -344,23 +414,25 @@ int launch_gemm_strided(const float* A, long sa_m, long sa_k, const float* W, lo
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     int nz = 1;
     // long reductions with few output tiles (weight gradients): split the reduction over grid.z
-    if (splitk_ws && K >= 1024 && tiles < 128 && !mask && act == 0 && !bias) {
+    if (splitk_ws && K >= 1024 && tiles < 128 && !mask && (act & 7) == 0 && !bias) {
         nz = min(min(512, cdiv(1024, tiles)), cdiv(K, 256));
         while (nz > 1 && (size_t)nz * M * N * sizeof(float) > splitk_ws_bytes) --nz;
     }
     if (nz <= 1) {
         g.kslice = cdiv(max(K, 1), BK) * BK;
         g.slice_stride = 0;
-        hipLaunchKernelGGL(gemm_strided_f32_kernel, dim3(cdiv(N, BN), cdiv(M, BM), 1), dim3(256), 0, st, g);
-        return check_launch("gemm_strided_f32");
+        if (act & 8) hipLaunchKernelGGL(gemm_strided_bf16_kernel, dim3(cdiv(N, BN), cdiv(M, BM), 1), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(gemm_strided_f32_kernel, dim3(cdiv(N, BN), cdiv(M, BM), 1), dim3(256), 0, st, g);
+        return check_launch("gemm_strided");
     }
     g.kslice = cdiv(cdiv(K, nz), BK) * BK;
     nz = cdiv(K, g.kslice);
     g.C = splitk_ws;
     g.ldc = N;
     g.slice_stride = (long)M * N;
-    hipLaunchKernelGGL(gemm_strided_f32_kernel, dim3(cdiv(N, BN), cdiv(M, BM), nz), dim3(256), 0, st, g);
-    int rc = check_launch("gemm_strided_f32(split-K)");
+    if (act & 8) hipLaunchKernelGGL(gemm_strided_bf16_kernel, dim3(cdiv(N, BN), cdiv(M, BM), nz), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_strided_f32_kernel, dim3(cdiv(N, BN), cdiv(M, BM), nz), dim3(256), 0, st, g);
+    int rc = check_launch("gemm_strided(split-K)");
     if (rc) return rc;
     const long n = (long)M * N;
     hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, splitk_ws, g.slice_stride, nz, C, n, N, ldc);
@@ -375,7 +447,8 @@ extern "C" int shasta_gemm_strided_f32(const float* A, long sa_m, long sa_k, con
     using namespace shasta;
     SHASTA_REQUIRE(A && W && C, "gemm_strided: null pointer");
     SHASTA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && ldc >= N, "gemm_strided: bad size");
-    SHASTA_REQUIRE(act >= 0 && act <= 6 && (act & 3) != 3, "gemm_strided: bad activation (0 none, 1 relu, 2 abs, +4 accumulate into C)");
+    SHASTA_REQUIRE(act >= 0 && act <= 14 && (act & 3) != 3,
+                   "gemm_strided: bad activation (0 none, 1 relu, 2 abs, +4 accumulate into C, +8 bf16 operands)");
     return launch_gemm_strided(A, sa_m, sa_k, W, sw_n, sw_k, bias, relu_mask, ldmask, C, ldc, M, N, K, act,
                                static_cast<float*>(splitk_ws), splitk_ws_bytes, as_stream(stream));
 }

@@ -119,6 +119,9 @@ class Shasta(BaseTrack):
         #            and the aff layers use three exact bf16 pieces per operand, six products per fp32 product;
         #   "f32":   the f32 MFMA kernels everywhere.
         self.arithmetic = "f16x2"
+        # training backward (shasta_amd/training.py): "fp32" (parity path, like the reference's train.py:149) or "bf16": the GEMMs of
+        # the pair MLPs and of aff take bf16 operands with fp32 accumulation (BASELINE config 5's reduced-precision option)
+        self.train_precision = "fp32"
         self.keep_intermediates = False  # tests: also return residual / matched via self.last_intermediates
         self.last_intermediates = None
 

@@ -20,9 +20,10 @@ import torch
 from . import hip
 
 
-def _gemm(lib, A, sa, W, sw, M, N, K, out, ldc=None, bias=None, act=0, mask=None, ldmask=0, accum=False, ws=None):
+def _gemm(lib, A, sa, W, sw, M, N, K, out, ldc=None, bias=None, act=0, mask=None, ldmask=0, accum=False, ws=None, bf16=False):
+    """bf16: operands rounded to bf16 on chip, bf16 matrix path, fp32 accumulation and output (`Shasta.train_precision = "bf16"`)"""
     hip.check(lib.shasta_gemm_strided_f32(hip.ptr_view(A), sa[0], sa[1], hip.ptr_view(W), sw[0], sw[1], hip.ptr(bias), hip.ptr(mask), ldmask,
-                                          hip.ptr_view(out), ldc if ldc is not None else N, M, N, K, act + (4 if accum else 0),
+                                          hip.ptr_view(out), ldc if ldc is not None else N, M, N, K, act + (4 if accum else 0) + (8 if bf16 else 0),
                                           hip.ptr(ws), ws.numel() * 4 if ws is not None else 0, hip.stream_ptr()),
               "shasta_gemm_strided_f32")
     return out
@@ -46,8 +47,8 @@ def _colsum(lib, Y, ldy, M, N, out, ws):
 class _Mlp:
     """Recompute-and-backprop helper for a Sequential(Linear, ReLU, ..., Linear) applied to the rows of X (M, ldx)."""
 
-    def __init__(self, lib, layers, ws):
-        self.lib, self.layers, self.ws = lib, layers, ws  # layers: list of (weight (out,in), bias (out,))
+    def __init__(self, lib, layers, ws, bf16=False):
+        self.lib, self.layers, self.ws, self.bf16 = lib, layers, ws, bf16  # layers: list of (weight (out,in), bias (out,))
 
     def forward(self, X, ldx, M):
         acts = [X]
@@ -55,7 +56,7 @@ class _Mlp:
         for i, (w, b) in enumerate(self.layers):
             out = torch.empty(M, w.shape[0], device=X.device)
             last = i + 1 == len(self.layers)
-            _gemm(self.lib, acts[-1], (ld, 1), w, (w.shape[1], 1), M, w.shape[0], w.shape[1], out, bias=b, act=0 if last else 1)
+            _gemm(self.lib, acts[-1], (ld, 1), w, (w.shape[1], 1), M, w.shape[0], w.shape[1], out, bias=b, act=0 if last else 1, bf16=self.bf16)
             acts.append(out)
             ld = w.shape[0]
         self.acts, self.ldx, self.M = acts, ldx, M
@@ -64,7 +65,7 @@ class _Mlp:
     def backward(self, gY, need_gx=True, gx_ld=None, mask_input=False):
         """gY (M, out_last).  Returns (list of (gW, gb)), gX (M, gx_ld) or None.  mask_input: X is itself a ReLU output and
         the returned gradient is the one of its pre-activation."""
-        lib, M = self.lib, self.M
+        lib, M, bf = self.lib, self.M, self.bf16
         grads = [None] * len(self.layers)
         g = gY
         for i in range(len(self.layers) - 1, -1, -1):
@@ -73,18 +74,18 @@ class _Mlp:
             ldx = self.ldx if i == 0 else self.layers[i - 1][0].shape[0]
             nout, nin = w.shape
             gW = torch.empty_like(w)
-            _gemm(lib, g, (1, nout), x, (1, ldx), nout, nin, M, gW, ws=self.ws)          # dW = dY^T X
+            _gemm(lib, g, (1, nout), x, (1, ldx), nout, nin, M, gW, ws=self.ws, bf16=bf)  # dW = dY^T X
             gb = torch.empty_like(b)
             _colsum(lib, g, nout, M, nout, gb, self.ws)
             grads[i] = (gW, gb)
             if i > 0:
                 gx = torch.empty(M, nin, device=g.device)
-                _gemm(lib, g, (nout, 1), w, (1, nin), M, nin, nout, gx, mask=x, ldmask=ldx)  # dX = (dY W) * relu'(x)
+                _gemm(lib, g, (nout, 1), w, (1, nin), M, nin, nout, gx, mask=x, ldmask=ldx, bf16=bf)  # dX = (dY W) * relu'(x)
                 g = gx
             elif need_gx:
                 ld = gx_ld if gx_ld is not None else nin
                 gx = torch.zeros(M, ld, device=g.device) if ld != nin else torch.empty(M, nin, device=g.device)
-                _gemm(lib, g, (nout, 1), w, (1, nin), M, nin, nout, gx, ldc=ld, mask=x if mask_input else None, ldmask=ldx)
+                _gemm(lib, g, (nout, 1), w, (1, nin), M, nin, nout, gx, ldc=ld, mask=x if mask_input else None, ldmask=ldx, bf16=bf)
                 g = gx
             else:
                 g = None
@@ -115,6 +116,9 @@ class _AffinityTrainFn(torch.autograd.Function):
         Dp = (D + 3) // 4 * 4
         P = B * T * D
         ws = torch.empty(64 * 1024 * 1024 // 4, device=dev)  # split-K scratch
+        # BASELINE config 5's reduced-precision option: the GEMMs of the pair MLPs and of `aff` (recomputation and gradients) take bf16
+        # operands with fp32 accumulation; parameters, their gradients, Adam and the anchor MLPs stay fp32
+        bf = getattr(model, "train_precision", "fp32") == "bf16"
         st = hip.stream_ptr
         g1 = g1.contiguous().float()
         g2 = g2.contiguous().float()
@@ -125,7 +129,7 @@ class _AffinityTrainFn(torch.autograd.Function):
                   "shasta_softmax_bwd_f32")
         # ---- aff (shasta.py:323): recompute the hidden activations, then back-propagate ----
         residual = S["residual"].reshape(B * T, D).contiguous()
-        aff = _Mlp(lib, [(model.aff[k].weight.detach(), model.aff[k].bias.detach()) for k in (0, 2, 4, 6, 8, 10)], ws)
+        aff = _Mlp(lib, [(model.aff[k].weight.detach(), model.aff[k].bias.detach()) for k in (0, 2, 4, 6, 8, 10)], ws, bf16=bf)
         aff.forward(residual, D, B * T)
         gmc = gm[:, :D].contiguous()
         aff_grads, gres = aff.backward(gmc, need_gx=True, gx_ld=Dp)  # gres (B*T, Dp)
@@ -154,7 +158,7 @@ class _AffinityTrainFn(torch.autograd.Function):
             col, offs = 0, []
             for side, U in ((0, UP), (1, UC)):
                 for k, (tab, ld, wd, _) in enumerate(parts[name][side]):
-                    _gemm(lib, tab, (ld, 1), w0[:, col:], (kin, 1), R, E, wd, U, bias=b0 if (side == 1 and k == 0) else None, accum=k > 0)
+                    _gemm(lib, tab, (ld, 1), w0[:, col:], (kin, 1), R, E, wd, U, bias=b0 if (side == 1 and k == 0) else None, accum=k > 0, bf16=bf)
                     offs.append(col)
                     col += wd
             H = torch.empty(P, E, device=dev)
@@ -174,15 +178,15 @@ class _AffinityTrainFn(torch.autograd.Function):
                 for tab, ld, wd, gtab in parts[name][side]:
                     col = offs[k]
                     k += 1
-                    _gemm(lib, gU, (1, E), tab, (1, ld), E, wd, R, gW0[:, col:], ldc=kin, ws=ws)          # dW0 block = gU^T X
-                    _gemm(lib, gU, (E, 1), w0[:, col:], (1, kin), R, wd, E, gtab, ldc=ld, accum=True)      # dX += gU W0 block
+                    _gemm(lib, gU, (1, E), tab, (1, ld), E, wd, R, gW0[:, col:], ldc=kin, ws=ws, bf16=bf)          # dW0 block = gU^T X
+                    _gemm(lib, gU, (E, 1), w0[:, col:], (1, kin), R, wd, E, gtab, ldc=ld, accum=True, bf16=bf)      # dX += gU W0 block
             return gW0, gb0
 
         tails, Hs, offs_ = {}, {}, {}
         outs = {}
         for name in ("fs", "rc", "fd"):
             Hs[name], offs_[name] = first_layer(name)
-            tails[name] = _Mlp(lib, mods[name][1:], ws)
+            tails[name] = _Mlp(lib, mods[name][1:], ws, bf16=bf)
             outs[name] = tails[name].forward(Hs[name], Hs[name].shape[1], P)
         shape, coeff, fused = outs["fs"], outs["rc"], outs["fd"]  # (P,1), (P,3), (P,1)
         dist = torch.empty(B * T, Dp, device=dev)

@@ -671,6 +671,44 @@ def test_forward_can_be_captured_in_a_hip_graph():
     assert torch.equal(g1, e1) and torch.equal(g2, e2)
 
 
+@pytest.mark.parametrize("M,N,K", [(92, 128, 92), (8464, 40, 646), (70, 33, 5000), (257, 16, 64)])
+def test_gemm_strided_bf16_operands(M, N, K):
+    """act + 8: both operands rounded to bf16 (nearest even) on chip, bf16 matrix path, fp32 accumulation.  Products of bf16 values
+    are exact in fp32, so the result equals a float64 matmul of the ROUNDED operands up to the fp32 accumulation (1e-5 relative),
+    in the three forms of an nn.Linear; and it differs from the fp32 GEMM by what bf16 rounding of the operands costs (~2^-8)."""
+    from shasta_amd import hip
+    dev = _dev()
+    lib = hip.load()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    X = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    dY = torch.randn(M, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    Xd, Wd, dYd, bd = X.to(dev), W.to(dev), dY.to(dev), bias.to(dev)
+    ws = torch.empty(64 * 1024 * 1024 // 4, device=dev)
+    r = lambda t: t.bfloat16().double()  # noqa: E731  (torch rounds to nearest even)
+
+    def run(A, sa, Wt, sw, m, n, k, act, b=None):
+        out = torch.empty(m, n, device=dev)
+        hip.check(lib.shasta_gemm_strided_f32(hip.ptr(A), sa[0], sa[1], hip.ptr(Wt), sw[0], sw[1], hip.ptr(b), None, 0,
+                                              hip.ptr(out), n, m, n, k, act, hip.ptr(ws), ws.numel() * 4, hip.stream_ptr()), "gemm_strided")
+        return out.cpu().double()
+
+    def check(got, ref):
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 2e-5 * scale, "bf16 GEMM differs from the matmul of the rounded operands"
+
+    y = run(Xd, (K, 1), Wd, (K, 1), M, N, K, 8 + 1, bd)             # forward with bias + ReLU
+    check(y, torch.relu(r(X) @ r(W).t() + bias.double()))
+    y32 = run(Xd, (K, 1), Wd, (K, 1), M, N, K, 1, bd)
+    rel = float((y - y32).abs().max()) / float(y32.abs().max())
+    assert 1e-5 < rel < 3e-2, "the bf16 form must differ from the fp32 form by bf16 rounding, got %.2e" % rel
+    check(run(dYd, (N, 1), Wd, (1, K), M, K, N, 8), r(dY) @ r(W))    # dX = dY W
+    dw = run(dYd, (1, N), Xd, (1, K), N, K, M, 8)                  # dW = dY^T X (split-K for the long reductions)
+    check(dw, r(dY).t() @ r(X))
+    assert torch.equal(dw, run(dYd, (1, N), Xd, (1, K), N, K, M, 8))
+
+
 @pytest.mark.parametrize("M,N,K", [(92, 128, 92), (8464, 40, 646), (70, 33, 5000), (3, 450, 28800)])
 def test_gemm_strided_backward_forms(M, N, K):
     """The strided GEMM in the three forms of an nn.Linear (Y = X W^T, dX = dY W, dW = dY^T X), incl. the deterministic

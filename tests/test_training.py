@@ -73,6 +73,47 @@ def test_backward_matches_autograd_of_oracle(N, nf, npnt, B, n_real):
 
 
 @pytest.mark.gpu
+def test_bf16_training_option_tracks_the_fp32_gradients():
+    """Shasta.train_precision = "bf16" (BASELINE config 5's reduced-precision option): the GEMMs of the pair MLPs and of aff take bf16
+    operands with fp32 accumulation in the backward; forward values, parameters and the anchor MLPs stay fp32.  Every gradient must stay
+    point the same way as the fp32 one - bf16 rounding (2^-9 per operand) accumulated over the nine layers a gradient crosses, and
+    sums over pairs that nearly cancel in a random-init net: cosine >= 0.97 for every tensor (measured worst: the aug_shape first
+    layers, relative L2 error 14 %), relative L2 error of the layers the option touches directly below 20 % (measured up to 13 %) - and the option must
+    really change the arithmetic."""
+    from shasta_amd import training
+    c, model, w, a, b, det, prev, gt = _case(20, 7, 5, 3, seed=11)
+    dev = torch.device("cuda:0")
+    model = model.to(dev).train()
+    grads = {}
+    for prec in ("fp32", "bf16"):
+        model.train_precision = prec
+        model.zero_grad(set_to_none=True)
+        ad, bd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        m1, m2 = training.affinity_train(model, ad, bd, det.to(dev).contiguous(), prev.to(dev).contiguous())
+        loss = training.affinity_loss(m1, m2, gt.to(dev))
+        loss.backward()
+        torch.cuda.synchronize()
+        grads[prec] = ({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, ad.grad.clone(), float(loss.detach()))
+    model.train_precision = "fp32"
+    assert grads["fp32"][2] == grads["bf16"][2], "the forward does not depend on the option"
+    differs, worst = 0, {}
+    for k, g32 in grads["fp32"][0].items():
+        g16 = grads["bf16"][0][k]
+        a16, a32 = g16.double().flatten(), g32.double().flatten()
+        cos = float(a16 @ a32) / max(float(a16.norm() * a32.norm()), 1e-300)
+        rel = float((a16 - a32).norm()) / max(float(a32.norm()), 1e-300)
+        worst[k] = (cos, rel)
+        assert cos >= 0.97, "%s: cosine between the bf16 and the fp32 gradient %.4f (relative L2 error %.3e)" % (k, cos, rel)
+        if k.startswith(("aff.", "fuse_shape.6", "res_coeff.4", "fuse_det.4")):
+            assert rel <= 0.2, "%s: relative L2 error %.3e" % (k, rel)
+        differs += int(not torch.equal(g16, g32))
+    a16, a32 = grads["bf16"][1].double().flatten(), grads["fp32"][1].double().flatten()
+    assert float(a16 @ a32) / float(a16.norm() * a32.norm()) >= 0.97, "d bev"
+    print("bf16 vs fp32 gradients, worst cosine / relative L2:", min(v[0] for v in worst.values()), max(v[1] for v in worst.values()))
+    assert differs >= 20, "bf16 operands must show in the gradients of the pair / aff layers (changed: %d)" % differs
+
+
+@pytest.mark.gpu
 def test_training_step_reduces_loss_and_inference_sees_new_weights():
     """A few Adam steps (tools/nusc_shasta/train.py:213-218) on one batch: the loss goes down, and the inference path picks
     up the updated parameters (packed weights are re-packed when a parameter version changes)."""

@@ -20,6 +20,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--hw", type=int, default=180)
 ap.add_argument("--json", action="store_true", help="print one JSON line instead of text")
 ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused HIP step")
+ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32", help="Shasta.train_precision: operands of the pair / aff GEMMs of the backward")
 a = ap.parse_args()
 rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
 torch.cuda.set_device(local_rank)
@@ -33,6 +34,7 @@ cfg = dict(type="Shasta", reader=None, backbone=None, neck=None,
            bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
            max_obj=a.max_obj, num_feats=a.feats, num_point=a.points, in_channels=512)
 model = shasta_amd.build_simp_track(cfg).to(dev).train()
+model.train_precision = a.precision
 params = training.affinity_params(model)
 opt = torch.optim.Adam(params, lr=1e-4) if a.torch_adam else training.FusedAdam(params, lr=1e-4)
 N, B = a.max_obj, a.batch
