@@ -520,8 +520,11 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     // lane = pair, 4x4x1 MFMA.  The 8 waves of a workgroup share one 64-detection UC tile and take different track ranges
     // (two workgroups per CU by LDS, 113 VGPRs in the VGPR MFMA form: 4 waves per SIMD).
     constexpr int wpb = 8;
-    int tw = 16;
-    while (tw > 2 && (long)B * cdiv(D, 64) * wpb * cdiv(T, wpb * tw) < 4096) tw >>= 1;
+    // tracks per wave: the T tracks dealt evenly to the waves of the ny workgroups of a detection tile, ny the smallest power of two
+    // that leaves 1024 workgroups (two rounds at two workgroups per CU); see launch_pair_f16
+    int ny = 1;
+    while ((long)B * cdiv(D, 64) * ny < 1024 && cdiv(T, wpb * ny * 2) >= 2) ny *= 2;
+    const int tw = cdiv(T, wpb * ny);
     const size_t lds = ((size_t)64 * (d.ET + 4) + ((a4_total(F) + 3) & ~3) + (size_t)wpb * 3 * 256) * sizeof(float);
     dim3 grid(cdiv(D, 64), cdiv(T, wpb * tw), B);
 #define SHASTA_LAUNCH_PAIR4(FF)                                                                                                        \

@@ -401,12 +401,13 @@ size_t pair_f16_lds_bytes(int wpb) {
 int launch_pair_f16(const float* packed, const float* p16, const float* UP, const float* UC, const float* hand_prev,
                     const float* hand_det, const float* denom, float* residual, int B, int T, int D, int ld, int nf, hipStream_t st) {
     constexpr int wpb = 8;
-    // tracks per wave: as many as leave 512 workgroups (two rounds of the CU array; 512 / 1024 / 2048 / 4096 measured alike within
-    // the run-to-run spread at 32 - 256 frame-pairs, the larger tiles slightly ahead).  A workgroup's prologue - the detection tile
-    // and the operand table into LDS behind a barrier - is paid once per 8 x tw tracks: 5.42 / 5.23 / 5.11 / 5.05 ms for 8 / 16 / 32 / 64
-    // tracks per wave at 512 frame-pairs
-    int tw = 64;
-    while (tw > 2 && (long)B * cdiv(D, 64) * cdiv(T, wpb * tw) < 512) tw >>= 1;
+    // tracks per wave: the T tracks dealt evenly to the 8 ny waves of the ny workgroups of a detection tile, ny the smallest power of two
+    // that leaves 512 workgroups (two rounds of the CU array).  A workgroup's prologue - the detection tile and the operand table
+    // into LDS behind a barrier - is paid once per 8 tw tracks: 5.42 / 5.23 / 5.11 / 5.05 ms for 8 / 16 / 32 / 64 tracks per wave at
+    // 512 frame-pairs (T = 502: 63 per wave, the last wave 61, instead of 64 and 54).
+    int ny = 1;
+    while ((long)B * cdiv(D, 64) * ny < 512 && cdiv(T, wpb * ny * 2) >= 2) ny *= 2;
+    const int tw = cdiv(T, wpb * ny);
     const size_t lds = pair_f16_lds_bytes(wpb);
     (void)hipFuncSetAttribute((const void*)pair_f16_kernel<wpb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(cdiv(D, 64), cdiv(T, wpb * tw), B);
