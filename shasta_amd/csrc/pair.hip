@@ -225,19 +225,28 @@ __global__ __launch_bounds__(256) void row_prep_kernel(RowPrepArgs a) {
     float mask[7];  // columns >= nf do not take part: zero both sides
 #pragma unroll
     for (int k = 0; k < 7; ++k) mask[k] = k < nf ? 1.0f : 0.0f;
+    // the frame's previous boxes pass through LDS in chunks of 512 rows (one coalesced copy per chunk, then broadcast reads):
+    // straight from global memory every thread paid a load latency per four tracks
+    __shared__ __attribute__((aligned(16))) f32x4 sp[2 * 512];
     const f32x4* hp = reinterpret_cast<const f32x4*>(a.tab[0] + (size_t)b * T * 8);
     float ssq = 0.0f;
+    for (int t0 = 0; t0 < T; t0 += 512) {
+        const int nt = min(512, T - t0);
+        if (t0) __syncthreads();
+        for (int e = tid; e < 2 * nt; e += 256) sp[e] = hp[(size_t)t0 * 2 + e];
+        __syncthreads();
 #pragma unroll 4
-    for (int t = tg; t < T; t += 16) {
-        const f32x4 x = hp[(size_t)t * 2], c = hp[(size_t)t * 2 + 1];
-        const float p[7] = {x[0], x[1], x[2], x[3], c[0], c[1], c[2]};
-        float d2 = 0.0f;
+        for (int t = tg; t < nt; t += 16) {  // the same tracks, in the same order, as a loop over t0 + t = tg, tg + 16, ...
+            const f32x4 x = sp[2 * t], c = sp[2 * t + 1];
+            const float p[7] = {x[0], x[1], x[2], x[3], c[0], c[1], c[2]};
+            float d2 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const float df = (p[k] - db[k]) * mask[k];
-            d2 += df * df;
+            for (int k = 0; k < 7; ++k) {
+                const float df = (p[k] - db[k]) * mask[k];
+                d2 += df * df;
+            }
+            ssq += d2 * d2;
         }
-        ssq += d2 * d2;
     }
     red[dl][tg] = ssq;
     __syncthreads();
@@ -457,6 +466,11 @@ int launch_gemm_nt_dual(const float* A0, const float* W0, const float* bias0, fl
 int launch_gemm_nt_pieces(const float* A0, const float* W0, const float* bias0, float* C0, const float* A1, const float* W1,
                           const float* bias1, float* C1, int lda, int ldw, int ldc, int M, int N, int K, int act, hipStream_t st);
 
+int embed_pack(const shasta_weights* w, float* packed, hipStream_t st);
+bool embed_rows_serves(int F);
+int launch_embed_rows(const shasta_weights* w, const float* packed, const float* prev_feat, const float* feat, const float* prev_tab,
+                      const float* det_tab, float* UP, float* UC, float* hand_prev, float* hand_det, int M, hipStream_t st);
+
 int pair_residual(const shasta_weights* w, const float* packed, int B, const float* feat, const float* prev_feat,
                   const float* det_tab, const float* prev_tab, float* residual, int ld, void* ws, size_t ws_bytes,
                   hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
@@ -479,13 +493,14 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     base += align_up((size_t)B * T * 16 * sizeof(float), 256);
     float* denom = reinterpret_cast<float*>(base);
 
-    // row embeddings UP / UC: from 8192 table rows on the bf16-piece GEMM (gemm_pieces.hip: 128-row tiles, 1.35x the f32 MFMA
-    // kernel at 64 k rows), below that the 64-row f32 tiles fill the chip better.  SHASTA_OPT_F32_EMBED_GEMM keeps the f32 kernel.
+    // row embeddings UP / UC: from 8192 table rows one fused kernel per launch forms the feature part on the bf16-piece matrix path,
+    // adds the box columns and takes the row maxima (embed_rows.hip); below that the 64-row f32 GEMM tiles fill the chip better and
+    // row_prep's row role adds the box columns.  SHASTA_OPT_F32_EMBED_GEMM keeps the f32 GEMM.
     const bool gemm_f32 = (w->options & SHASTA_OPT_F32_EMBED_GEMM) != 0;
+    const bool fused = B * T >= 8192 && !gemm_f32 && embed_rows_serves(F) && ((uintptr_t)feat | (uintptr_t)prev_feat) % 16 == 0;
     int rc;
-    if (B * T >= 8192 && !gemm_f32 && F % 4 == 0)
-        rc = launch_gemm_nt_pieces(prev_feat, packed + P.wemb_prev, nullptr, UP, feat, packed + P.wemb_cur, packed + P.bemb_cur, UC, F,
-                                   F, d.ET, B * T, P.E12, F, 0, st);
+    if (fused)
+        rc = launch_embed_rows(w, packed, prev_feat, feat, prev_tab, det_tab, UP, UC, hand_prev, hand_det, B * T, st);
     else
         rc = launch_gemm_nt_dual(prev_feat, packed + P.wemb_prev, nullptr, UP, feat, packed + P.wemb_cur, packed + P.bemb_cur, UC, F, F,
                                  d.ET, B * T, P.E12, F, 0, st);
@@ -504,7 +519,7 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     rp.N = N;
     rp.nf = nf;
     rp.F = F;
-    rp.nrow_blocks = 2 * cdiv(B * T, 32);
+    rp.nrow_blocks = fused ? 0 : 2 * cdiv(B * T, 32);  // the fused kernel has added the box columns already
     rp.nhand_blocks = cdiv(2 * B * T, 256);
     rp.dblocks = cdiv(D, 16);
     hipLaunchKernelGGL(row_prep_kernel, dim3(rp.nrow_blocks + rp.nhand_blocks + rp.dblocks * B), dim3(256), 0, st, rp);
@@ -565,6 +580,7 @@ int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {
     const PackedLayout P(w->max_obj, w->num_feats, w->feat_dim);
     if ((rc = aff_pieces_pack(w, packed + P.affp, st))) return rc;
     if (w->feat_dim == 256 && (rc = pair_f16_pack(w, packed + P.p16, st))) return rc;
+    if (embed_rows_serves(w->feat_dim) && (rc = embed_pack(w, packed, st))) return rc;
     if (w->options & SHASTA_OPT_F16X2_WEIGHT_STREAM) {  // one pass over the four first-layer matrices (4.1 GB at N=500, F=256)
         const float* W[4];
         for (int i = 0; i < 4; ++i) W[i] = w->aug_shape[i][0].weight;
