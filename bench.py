@@ -277,7 +277,7 @@ def main():
                            % ("f16" if f16x2 else "bf16", nprod)}
     roof_l1.update({"kernel": "anchor_l1_kernel (B=1) / anchor_l1_mfma_kernel (B<=32) / anchor_l1_split_kernel (B>32): "
                               "aug_shape.*.0, 4 x 2000 x 128000 fp32 weight stream",
-                    "traffic": _pmc_traffic(B), "algorithmic_bytes_per_launch": alg, "weight_passes_executed": passes,
+                    "traffic": _pmc_traffic(B) if args.arithmetic == "f16x2" else None, "algorithmic_bytes_per_launch": alg, "weight_passes_executed": passes,
                     "executed_weight_bytes_per_launch": passes * 4 * (K // 64) * K * 4,
                     "algorithmic_flops_per_launch": l1_flops, "executed_flops_per_launch": nprod * l1_flops,
                     "avg_launch_ms": l1_ms, "algorithmic_hbm_gbs": hbm_gbs, "fp32_tflops": l1_tflops,
@@ -291,7 +291,7 @@ def main():
     pair_tflops = pair_useful / (pair_ms * 1e-3) / 1e12
     pair_f16 = args.arithmetic == "f16x2"  # F = 256: second layers (1792 of the 1984 MACs per pair) as three fp16 piece products each
     roof_pair = {"bound": "mfma", "achieved": pair_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": pair_tflops / MFMA_F32_PEAK_TFLOPS, "traffic": _pmc_traffic(B, "pair"),
+                 "frac": pair_tflops / MFMA_F32_PEAK_TFLOPS, "traffic": _pmc_traffic(B, "pair") if args.arithmetic == "f16x2" else None,
                  "useful_flops_per_launch": pair_useful,
                  "dense_algorithmic_flops_per_launch": 2.0 * DENSE_PAIR_MACS * PAIRS * B,
                  "dense_equivalent_tflops": 2.0 * DENSE_PAIR_MACS * PAIRS * B / (pair_ms * 1e-3) / 1e12,
@@ -349,8 +349,8 @@ def main():
 
 
 def _pmc_traffic(B, kernel="l1"):
-    """HBM bytes per launch of one of the two heaviest kernels from the committed rocprofv3 PMC passes (profiles/),
-    corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE doubled on gfx950); None when no profile for this batch size
+    """HBM bytes per launch of one of the two heaviest kernels of the DEFAULT arithmetic from the committed rocprofv3 PMC passes
+    (profiles/), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE doubled on gfx950); None when no profile for this batch size
     exists."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:

@@ -90,5 +90,17 @@ if __name__ == "__main__":
                         "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-byte fabric requests of a wide coalesced stream at "
                         "64 bytes; confirmed here by TCC_EA0_RDREQ_sum x 128 B)" % TAG)
     json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+    # the bench lines of this pass were printed with the PREVIOUS pmc_traffic.json (bench.py reads the committed file): give their
+    # `traffic` fields the figures of the PMC passes of the same pass
+    for f in sorted(os.listdir(P)):
+        if f.startswith(TAG + "_bench_") and f.endswith(".json"):
+            d = json.load(open(os.path.join(P, f)))
+            if d.get("config", {}).get("arithmetic", "").startswith("fp32 operands in HBM, fp32 accumulation throughout; above 32 frame-pairs per step the first aug_shape layer (above 64"):
+                b = d["config"]["frame_pairs_per_step_per_gpu"]
+                for key in ("roofline", "roofline_second"):
+                    k = ("pair_batch_%d" if d[key]["kernel"].startswith("pair") else "batch_%d") % b
+                    if k in traffic:
+                        d[key]["traffic"] = traffic[k]
+                json.dump(d, open(os.path.join(P, f), "w"), indent=1)
     print(traffic)
     print(sorted(os.listdir(P)))
