@@ -630,6 +630,41 @@ def test_edge_shapes_vs_oracle(N, nf, npnt, B, n_real):
     np.testing.assert_allclose(m2.cpu().numpy(), r2.numpy(), rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("N,nf,npnt,B", [(30, 7, 1, 260), (62, 3, 4, 130), (20, 7, 5, 380)])
+def test_fused_row_embeddings_all_widths(N, nf, npnt, B):
+    """From 8192 table rows the row embeddings come from embed_rows_kernel (bf16-piece MFMA feature part from pre-cut fragments, box
+    columns, bias and row maxima in one pass): its three instantiations F = 64 / 256 / 320 (2 / 3 / 4 feature blocks; ring of 3 / 3 / 2
+    slots), each with a ragged last 256-row workgroup, pinned through the residual (which is made of nothing but these embeddings
+    and the pair MLP tails) and the outputs against the CPU oracle."""
+    import shasta_amd
+    dev = _dev()
+    torch.manual_seed(N * 10 + npnt)
+    m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54],
+                                                            voxel_size=[0.075, 0.075], out_stride=8),
+                                         max_obj=N, num_feats=nf, num_point=npnt, in_channels=8)).eval()
+    assert B * (N + 2) >= 8192 and B * (N + 2) % 256 != 0
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(7)
+    bev = torch.relu(torch.randn(B, 32, 32, 64, generator=g))
+    pbev = torch.relu(torch.randn(B, 32, 32, 64, generator=g))
+    det, prev = O.synth_boxes(g, B, N, None), O.synth_boxes(g, B, N, None)  # no zero-padded rows: no +-23 log terms in the residual
+    for t in (det, prev):  # inside the 19 m map, so that the gathered features differ from row to row
+        t[:, :, 0] = t[:, :, 0] % 15.0 - 52.0
+        t[:, :, 1] = t[:, :, 1] % 15.0 - 52.0
+    r1, r2, im = O.forward_from_bev(w, bev, pbev, det.clone(), prev.clone(), nf, npnt, return_intermediates=True)
+    m = m.to(dev)
+    m.keep_intermediates = True
+    ex = dict(det_boxes=det.to(dev), prev_det_boxes=prev.to(dev), bev_feature=bev.to(dev), prev_bev_feature=pbev.to(dev))
+    with torch.no_grad():
+        m1, m2, _ = m(ex, train_mode=False)
+    ref_res = im["residual"].numpy()
+    np.testing.assert_allclose(m.last_intermediates["residual"].cpu().numpy(), ref_res, rtol=1e-4,
+                               atol=max(1e-4, 5e-5 * float(np.abs(ref_res).max())))
+    np.testing.assert_allclose(m1.cpu().numpy(), r1.numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(m2.cpu().numpy(), r2.numpy(), rtol=0, atol=1e-6)
+
+
 def test_empty_batch_is_a_no_op():
     dev = _dev()
     z, c, m, bev, pbev, det, prev = _case("tiny_4_7_5")
