@@ -10,14 +10,15 @@
 // Layouts.  A wave owns 64 detections x a range of tracks (as before).  Per track:
 //  (1) four sub-steps of 16 detections in the MFMA layout lane = (pair p = lane & 15, k block kb = lane >> 4): the lane forms
 //      h1[32 s + 8 kb + j], j < 8, for the four 32-wide k steps s (fuse_shape | res_coeff lower half | upper half | fuse_det) from
-//      8 UP values (LDS broadcast, read once per track) and 8 UC values (LDS) each, scales by the track's power of two,
-//      converts (v_fma_mixlo/hi_f16), takes the residual (v_fma_mix_f32: s c - h, exact) and converts it (v_cvt_pk_f16_f32);
+//      8 UP values (LDS broadcast, read once per track) and 8 UC values (LDS) each - ReLU and range scaling are one packed
+//      v_pk_fma_f32 with clamp per two values (fma2_relu01) -, converts (v_fma_mixlo/hi_f16), takes the residual
+//      (v_fma_mix_f32: s c - h, exact) and converts it (v_cvt_pk_f16_f32): one hazard-free asm block per four values (cut4);
 //      12 MFMAs; the three result blocks (4 consecutive output features of pair p per lane) go to a wave-private LDS tile
 //      [64 pairs][40 features].
 //  (2) lane = pair: the lane reads its 40 layer-2 pre-activations, descales (exact power of two) and adds the bias with one
 //      fma each, and runs layers 3-4, the hand-designed residual and the combine exactly as pair_mfma4_kernel does.
 // Range: the scale 2^e of a track is the one that puts (max |UP[t]| + max over the tile's detections of max |UC[d]|) - an upper
-// bound of every h1 of the sub-steps - into (2^13, 2^14]; the row maxima come from row_prep (slot 13 of the hand rows).  The
+// bound of every h1 of the sub-steps - into (2^13, 2^14]; the row maxima come from embed_rows / row_prep (slot 13 of the hand rows).  The
 // second-layer weights are cut once at pack time with one exponent per MLP (pair_f16_pack_kernel).
 #include "common.hpp"
 #include "pair_layout.hpp"
