@@ -527,10 +527,12 @@ int launch_aff_pieces(const shasta_weights* w, const float* packed_pieces, const
     a.ldm = ldm;
     // 128-row workgroups once they fill the 256 CUs (0.825 ms against 0.837 ms for 257 k rows); below that the 64-row shape puts
     // twice as many workgroups on the chip
-#if defined(AP_SHAPE_64)
+#if defined(AP_SHAPE_64) || defined(AP_SHAPE_128)  // probe builds only (tools/probes/aff_probe.hip): force one shape
+#ifdef AP_SHAPE_64
     return launch_aff_pieces_shape<64, 4>(a, st);
-#elif defined(AP_SHAPE_128)
+#else
     return launch_aff_pieces_shape<128, 8>(a, st);
+#endif
 #else
     return cdiv(M, 128) >= 256 ? launch_aff_pieces_shape<128, 8>(a, st) : launch_aff_pieces_shape<64, 4>(a, st);
 #endif

@@ -385,9 +385,6 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
             }
             if (i >= 1 && i - 1 < NR) read_one(sn, nxt, i - 1);
             if (i >= 6 && (i - 6) % SG == 0 && (i - 6) / SG < 16) cut_one(nxt, (i - 6) / SG);
-#ifdef SPLIT_EXP_PACE  // experiment: idle slots between the MFMAs (every SPLIT_EXP_PACE_EVERY-th gets s_sleep SPLIT_EXP_PACE)
-            if (i % SPLIT_EXP_PACE_EVERY == SPLIT_EXP_PACE_EVERY - 1) __builtin_amdgcn_s_sleep(SPLIT_EXP_PACE);
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     };
