@@ -535,7 +535,9 @@ def test_pair_kernels_are_fp32_accurate():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ([], ["--gain", "2.0"]):
+    # --spread 3: feature rows from 1e-3 to 1e3 times the usual size meet in one detection tile: the per-track range scaling of the
+    # fp16 form (largest |UP[t]| + the tile's largest |UC|) must neither overflow nor cost more than the f32 kernel's error at that scale
+    for extra in ([], ["--gain", "2.0"], ["--spread", "3"]):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "pair_check.py"), "--max-obj", "150", "--batch", "2"] + extra,
                            capture_output=True, text=True, cwd=root, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -18,6 +18,8 @@ ap.add_argument("--feats", type=int, default=7)
 ap.add_argument("--points", type=int, default=4)
 ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--gain", type=float, default=1.0, help="scale of the pair-MLP weight matrices (sharpened weights)")
+ap.add_argument("--spread", type=float, default=0.0, help="the BEV maps are scaled by 10^(+-spread) across their width: table rows of very "
+                                                          "different magnitude meet in one detection tile (range scaling of the fp16 form)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -35,6 +37,9 @@ N, B = a.max_obj, a.batch
 g = torch.Generator(device=dev).manual_seed(3)
 bev = torch.relu(torch.randn(B, 180, 180, 64, device=dev, generator=g))
 pbev = torch.relu(torch.randn(B, 180, 180, 64, device=dev, generator=g))
+if a.spread:
+    ramp = torch.pow(10.0, torch.linspace(-a.spread, a.spread, 180, device=dev)).view(1, 1, 180, 1)
+    bev, pbev = bev * ramp, pbev * ramp
 gc = torch.Generator().manual_seed(4)
 det0, prev = O.synth_boxes(gc, B, N).to(dev), O.synth_boxes(gc, B, N).to(dev)
 model.keep_intermediates = True
