@@ -165,7 +165,10 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
 #pragma unroll 4
         for (int e = tid; e < 64 * (ET / 4); e += 64 * WPB) {
             const int r = e / (ET / 4), c = e - r * (ET / 4);
-            *reinterpret_cast<f32x4*>(&s_uc[r * US + 4 * c]) = src[((size_t)b * D + min(d0 + r, D - 1)) * (ET / 4) + c];
+            // float4 c of the row = k step c >> 3, k block (c >> 1) & 3, half c & 1: stored k-block-major, the blocks in the order
+            // 0, 2, 1, 3 (see load_uc: blocks 0 / 1 and 2 / 3 must sit 64 floats apart)
+            const int cp = (((c >> 1) & 1) << 4) | (((c >> 2) & 1) << 3) | ((c >> 3) << 1) | (c & 1);
+            *reinterpret_cast<f32x4*>(&s_uc[r * US + 4 * cp]) = src[((size_t)b * D + min(d0 + r, D - 1)) * (ET / 4) + c];
         }
         const f32x4* asrc = reinterpret_cast<const f32x4*>(packed + P.a4);
 #pragma unroll 2
@@ -254,11 +257,16 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
         // Software pipeline over the four sub-steps: the UC reads of sub-step s+1 are issued before the arithmetic of sub-step s,
         // and the pieces of sub-step s+1 are cut before the MFMAs of sub-step s are issued (they run under the cut of s+1).
         auto load_uc = [&](int sub, f32x4 (&u)[8]) {
-            const float* ucr = s_uc + (16 * sub + p) * US + 8 * kb;
+            // A ds_read_b128 serves lanes {0-3, 12-15, 20-23, 24-27}, {4-11, 16-19, 28-31} (and the same + 32) together - not 16
+            // consecutive lanes (tools/probes/lds_pattern_probe.hip).  In this layout lane = (p, kb) a group mixes rows p of k blocks
+            // kb and kb + 1; with the four k blocks of a step 8 floats apart those fell on each other's banks (every read took 8
+            // cycles instead of 4, the kernel's LDS busy 57 % of the time).  The tile therefore keeps a row k-block-major with the
+            // blocks of a pair 64 floats = one bank round apart: 16 rows x 2 blocks then cover the 64 banks exactly once.
+            const float* ucr = s_uc + (16 * sub + p) * US + ((kb & 1) << 6) + ((kb >> 1) << 5);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                u[2 * s] = *reinterpret_cast<const f32x4*>(ucr + 32 * s);
-                u[2 * s + 1] = *reinterpret_cast<const f32x4*>(ucr + 32 * s + 4);
+                u[2 * s] = *reinterpret_cast<const f32x4*>(ucr + 8 * s);
+                u[2 * s + 1] = *reinterpret_cast<const f32x4*>(ucr + 8 * s + 4);
             }
         };
         auto cut = [&](const f32x4 (&u)[8], pu4 (&xh)[4], pu4 (&xl)[4]) {
