@@ -11,8 +11,8 @@
 //  (1) four sub-steps of 16 detections in the MFMA layout lane = (pair p = lane & 15, k block kb = lane >> 4): the lane forms
 //      h1[32 s + 8 kb + j], j < 8, for the four 32-wide k steps s (fuse_shape | res_coeff lower half | upper half | fuse_det) from
 //      8 UP values (LDS broadcast, read once per track) and 8 UC values (LDS) each - ReLU and range scaling are one packed
-//      v_pk_fma_f32 with clamp per two values (fma2_relu01) -, converts (v_fma_mixlo/hi_f16), takes the residual
-//      (v_fma_mix_f32: s c - h, exact) and converts it (v_cvt_pk_f16_f32): one hazard-free asm block per four values (cut4);
+//      v_pk_fma_f32 with clamp per two values (fma2_relu01) -, multiplies by 2^14 (packed), converts (v_cvt_pk_f16_f32), takes the
+//      residual (v_fma_mix_f32: x - h with h as an f16 operand, exact) and converts it: 2.5 issue slots of 5 - 8 cycles per value;
 //      12 MFMAs; the three result blocks (4 consecutive output features of pair p per lane) go to a wave-private LDS tile
 //      [64 pairs][40 features].
 //  (2) lane = pair: the lane reads its 40 layer-2 pre-activations, descales (exact power of two) and adds the bias with one
@@ -46,25 +46,16 @@ __device__ __forceinline__ pf2 fma2_relu01(pf2 a, pf2 c, pf2 b) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(c), "v"(b));
     return r;
 }
-// Four values at once: high pieces hA = {fp16(s0 c), fp16(s1 c)}, hB = {fp16(s2 c), fp16(s3 c)} and the four residuals s c - h
-// (exact in fp32; the caller converts them to the low pieces).
-// ONE asm statement on purpose: gfx950 needs a wait state between an instruction that writes half of a VGPR (v_fma_mixlo/hi_f16)
-// and the next reader of that VGPR, and the compiler does not look for that hazard around inline asm (separate statements,
-// scheduled freely, gave wrong low pieces for a fraction of a per cent of the values).  Inside, every half-write is at least one
-// instruction away from the first reader of its register, and the two writes of a register are not adjacent.
-// (Forming the low piece directly, v_fma_mixlo_f16 d, s, c, -h with h as an f16 operand, is bit-identical and two instructions
-// shorter per four values, but measured 6 % slower for the kernel: four dependent half-write pairs instead of two.)
-__device__ __forceinline__ void cut4(float s0, float s1, float s2, float s3, float c, uint32_t& hA, uint32_t& hB, float (&r)[4]) {
-    asm("v_fma_mixlo_f16 %0, %6, %10, 0\n\t"
-        "v_fma_mixlo_f16 %1, %8, %10, 0\n\t"
-        "v_fma_mixhi_f16 %0, %7, %10, 0\n\t"
-        "v_fma_mixhi_f16 %1, %9, %10, 0\n\t"
-        "v_fma_mix_f32 %2, %6, %10, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %4, %8, %10, -%1 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %3, %7, %10, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %5, %9, %10, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(hA), "=&v"(hB), "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
-        : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(c));
+// x - h (exact in fp32) with h = the low / high half of a packed f16 pair read as an f16 operand
+__device__ __forceinline__ float res_lo(float x, uint32_t hpk) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(hpk));
+    return r;
+}
+__device__ __forceinline__ float res_hi(float x, uint32_t hpk) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(hpk));
+    return r;
 }
 __device__ __forceinline__ uint32_t cvt2(float a, float b) {
     const ph16x2 v = {(_Float16)a, (_Float16)b};
@@ -243,7 +234,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
         // (exact, a power of two), so the clamp of one packed fma is the ReLU of two values; the conversion multiplies by 2^14.
         const float cs = __builtin_ldexpf(1.0f, e1 - 14);
         const pf2 cs2 = {cs, cs};
-        constexpr float c1 = 16384.0f;
+        const pf2 c14 = {16384.0f, 16384.0f};
         // this lane's UP values, scaled: 8 per k step (the same address in the 16 lanes of a k block: LDS broadcast)
         pf2 upv[16];
 #pragma unroll
@@ -275,15 +266,17 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
 #pragma unroll
                 for (int j2 = 0; j2 < 2; ++j2) {  // the float4 u[2 s + j2] = four values
                     const f32x4 uu = u[2 * s + j2];
-                    const pf2 ha = fma2_relu01(pf2{uu[0], uu[1]}, cs2, upv[4 * s + 2 * j2]);
-                    const pf2 hb = fma2_relu01(pf2{uu[2], uu[3]}, cs2, upv[4 * s + 2 * j2 + 1]);
-                    uint32_t hA, hB;
-                    float r[4];
-                    cut4(ha[0], ha[1], hb[0], hb[1], c1, hA, hB, r);
+                    // scaled to [0, 2^14]: high piece = the packed conversion (round to nearest even), residual exact, low piece =
+                    // its conversion.  Only full-register writes: the v_fma_mixlo / mixhi_f16 pair this replaces cost 17.8 cycles per
+                    // two values against 13.4 for multiply + convert (tools/probes/valu_cost_probe.hip) and needed a hand-placed wait
+                    // state between a half-register write and its reader that the compiler does not insert around inline asm.
+                    const pf2 sa = fma2_relu01(pf2{uu[0], uu[1]}, cs2, upv[4 * s + 2 * j2]) * c14;
+                    const pf2 sb = fma2_relu01(pf2{uu[2], uu[3]}, cs2, upv[4 * s + 2 * j2 + 1]) * c14;
+                    const uint32_t hA = cvt2(sa[0], sa[1]), hB = cvt2(sb[0], sb[1]);
                     xh[s][2 * j2] = hA;
                     xh[s][2 * j2 + 1] = hB;
-                    xl[s][2 * j2] = cvt2(r[0], r[1]);
-                    xl[s][2 * j2 + 1] = cvt2(r[2], r[3]);
+                    xl[s][2 * j2] = cvt2(res_lo(sa[0], hA), res_hi(sa[1], hA));
+                    xl[s][2 * j2 + 1] = cvt2(res_lo(sb[0], hB), res_hi(sb[1], hB));
                 }
             }
         };
