@@ -331,22 +331,21 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
             const float* b_rc = s_a4 + A4h<F, L_RC2>::OFF + A4h<F, L_RC2>::BIAS;
             const float* b_fs = s_a4 + A4h<F, L_FS2>::OFF + A4h<F, L_FS2>::BIAS;
             const float* b_fd = s_a4 + A4h<F, L_FD2>::OFF + A4h<F, L_FD2>::BIAS;
+            // descale + bias as packed fmas (two values per 5-cycle slot instead of one per 6)
+            auto fma4 = [&](const f32x4& v, float sc, const f32x4& bb) {
+                const pf2 s2 = {sc, sc};
+                const pf2 lo = __builtin_elementwise_fma(pf2{v[0], v[1]}, s2, pf2{bb[0], bb[1]});
+                const pf2 hi = __builtin_elementwise_fma(pf2{v[2], v[3]}, s2, pf2{bb[2], bb[3]});
+                return f32x4{lo[0], lo[1], hi[0], hi[1]};
+            };
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(mine + 4 * g), bb = *reinterpret_cast<const f32x4*>(b_rc + 4 * g);
-                const f32x4 w = *reinterpret_cast<const f32x4*>(mine + 16 + 4 * g), bf = *reinterpret_cast<const f32x4*>(b_fs + 4 * g);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    a_rc2[g][j] = fmaf(v[j], i_rc, bb[j]);
-                    a_fs2[g][j] = fmaf(w[j], i_fs, bf[j]);
-                }
+                a_rc2[g] = fma4(*reinterpret_cast<const f32x4*>(mine + 4 * g), i_rc, *reinterpret_cast<const f32x4*>(b_rc + 4 * g));
+                a_fs2[g] = fma4(*reinterpret_cast<const f32x4*>(mine + 16 + 4 * g), i_fs, *reinterpret_cast<const f32x4*>(b_fs + 4 * g));
             }
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(mine + 32 + 4 * g), bb = *reinterpret_cast<const f32x4*>(b_fd + 4 * g);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a_fd2[g][j] = fmaf(v[j], i_fd, bb[j]);
-            }
+            for (int g = 0; g < 2; ++g)
+                a_fd2[g] = fma4(*reinterpret_cast<const f32x4*>(mine + 32 + 4 * g), i_fd, *reinterpret_cast<const f32x4*>(b_fd + 4 * g));
         }
         auto init = [&](auto tag, f32x4* acc) {
             using AL = decltype(tag);
