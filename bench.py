@@ -12,7 +12,10 @@ the elapsed time.
 
 `python bench.py --gpus N` with N > 1 and no launcher environment starts its own N ranks (fresh child processes, one per
 GPU, started before this process touches the GPU; rank 0's JSON line is the output).  Rank 0 prints ONE JSON line (see
-DESIGN.md "Measurement" for the definition of every field).
+DESIGN.md "Measurement" for the definition of every field).  On one GPU the same line carries, under `extra`, the other
+operating points SURVEY.md 8(d) asks for, measured by the same process right after the headline run: frame-pairs per step
+1 / 8 / 64 (the reference's eval loop runs batch 1), the strict-f32 and bf16-piece arithmetic at the headline batch, and the
+reference's shipped car configuration (max_obj 90, num_point 5 -> F = 320, num_feats 3).
 """
 import argparse
 import ctypes as C
@@ -31,25 +34,38 @@ N_OBJ, NF, NPOINT, CH = 500, 7, 4, 64  # N=M=500, F=256, nf=7
 HW = 180
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: dense f32-input MFMA peak (= f32 vector peak); no xf32 on gfx950
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (no sparsity)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 / f16 MFMA peak (no sparsity)
+DENSE_GFLOP_PER_PAIR = 28.65            # whole forward at N=M=500, F=256, dense formulation: 26.45 pair MLPs + 2.05 anchors + 0.15 aff
+HEADLINE = dict(max_obj=N_OBJ, num_feats=NF, num_point=NPOINT)
+CAR = dict(max_obj=90, num_feats=3, num_point=5)  # configs/nusc/car.py:22-39 of the reference (BASELINE configs 2-3)
 
 
-# Algorithmic work per frame-pair at N=M=500, F=256, nf=7; P = (N+2)^2 = 252 004 pairs
-PAIRS = (N_OBJ + 2) ** 2
-DENSE_PAIR_MACS = 17032 + 712 + 34736   # fuse_shape + fuse_det + res_coeff per pair in the reference's dense formulation
-USEFUL_PAIR_MACS = 1984                 # layers 2-4 of the three pair MLPs (the first layers are factorised over table rows)
-EXECUTED_PAIR_MACS = 2108               # the same with every layer width rounded up to the 4-wide MFMA block
-DENSE_GFLOP_PER_PAIR = 28.65            # whole forward, dense formulation: 26.45 pair MLPs + 2.05 anchors + 0.15 aff
+class Work:
+    """Algorithmic work of one frame-pair for a configuration; T = D = N + 2, P = T * D pairs."""
 
+    def __init__(self, max_obj, num_feats, num_point):
+        self.N, self.nf, self.np = max_obj, num_feats, num_point
+        F = self.F = CH * num_point
+        self.K, self.H = max_obj * F, max_obj * F // 64
+        self.pairs = (max_obj + 2) ** 2
+        h1, h2, h3, r1, r2 = F // 8, F // 16, F // 32, 32 + F // 8, 8 + F // 32
+        nf = num_feats
+        # multiply-adds per pair: the reference's dense formulation of the three pair MLPs (first layers on the concatenated pair
+        # tensor), what is left once the first layers are factorised over the table rows, and that with every layer width rounded up
+        # to the 4-wide block of the 4x4x1 MFMA
+        self.dense_pair_macs = (2 * F * h1 + h1 * h2 + h2 * h3 + h3) + (2 * nf * 32 + 32 * 8 + 8) + ((2 * F + 2 * nf) * r1 + r1 * r2 + r2 * 3)
+        self.layer2_macs = h1 * h2 + r1 * r2 + 32 * 8
+        self.useful_pair_macs = self.layer2_macs + h2 * h3 + h3 + r2 * 3 + 8
+        r4 = lambda x: (x + 3) // 4 * 4  # noqa: E731
+        layers = ((h1, h2), (h2, h3), (h3, 1), (r1, r2), (r2, 3), (32, 8), (8, 1))  # (in, out) of layers 2-4; + one bias slot per output
+        self.executed_pair_macs = sum(r4(i) * r4(o) + r4(o) for i, o in layers)
 
-def l1_algorithmic_bytes(B):
-    """aug_shape first layer (anchor_l1*_kernel).  ALGORITHMIC HBM bytes of one launch over B frame-pairs: every weight of the
-    four (N*F/64, N*F) fp32 matrices ONCE (4.096 GB, whatever the batch), the two (N*F) activation vectors of each batch item
-    once, one (4*N*F/64) partial vector per batch item written.  (The kernel makes ceil(B/128) weight passes above 128
-    frame-pairs per launch; those re-reads are executed traffic, not algorithmic - reported as `weight_passes_executed`.)"""
-    K = N_OBJ * CH * NPOINT
-    H = K // 64
-    return 4 * H * K * 4 + 2 * B * K * 4 + B * 4 * H * 4
+    def l1_algorithmic_bytes(self, B):
+        """aug_shape first layer (anchor_l1*_kernel).  ALGORITHMIC HBM bytes of one launch over B frame-pairs: every weight of the
+        four (N*F/64, N*F) fp32 matrices ONCE (4.096 GB at the headline size, whatever the batch), the two (N*F) activation vectors
+        of each batch item once, one (4*N*F/64) partial vector per batch item written.  (Weight passes beyond the first are executed
+        traffic, not algorithmic - reported as `weight_passes_executed`.)"""
+        return 4 * self.H * self.K * 4 + 2 * B * self.K * 4 + B * 4 * self.H * 4
 
 
 def _free_port():
@@ -60,9 +76,11 @@ def _free_port():
     return p
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, timeout_s=1800.0):
     """`python bench.py --gpus N` typed as is: start N fresh children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
-    torch.distributed.run would), before this process has made any GPU call; rank 0's stdout (the JSON line) is passed through."""
+    torch.distributed.run would), before this process has made any GPU call; rank 0's stdout (the JSON line) is passed through.
+    All children are polled: the first one that fails (or the overall time limit) ends the others - they are fresh processes of
+    ours, killed by PID - so a dead rank is an error code, not a hang in the other ranks' rendezvous."""
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     procs = []
     for r in range(n):
@@ -70,23 +88,65 @@ def spawn_ranks(n, argv):
                    MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    deadline = time.monotonic() + timeout_s
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live and rc == 0:
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                if code != 0:
+                    rc = abs(code)
+                    print("bench.py: rank %d exited with code %d; stopping the other ranks" % (procs.index(p), code), file=sys.stderr)
+        if rc == 0 and live:
+            if time.monotonic() > deadline:
+                rc = 124
+                print("bench.py: ranks still running after %.0f s; stopping them" % timeout_s, file=sys.stderr)
+            else:
+                time.sleep(0.05)
+    for p in live:
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
     return rc
 
 
 class EnergyCounter:
-    """The GPU's accumulated-energy counter (librocm_smi64: rsmi_dev_energy_count_get, 15.3 uJ units) read around the timed loop:
-    the step is power-limited, so joules per step is what its duration follows.  None when unavailable."""
+    """The GPU's accumulated-energy counter (librocm_smi64: rsmi_dev_energy_count_get) read around the timed loop: the step is
+    power-limited, so joules per step is what its duration follows.  The rocm_smi device index is NOT the
+    HIP ordinal under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES or a remapped lease: the device is matched by PCI bus id
+    (rsmi_dev_pci_id_get against the HIP device's domain:bus:device); no match -> no energy figure (null), never another GPU's."""
 
-    def __init__(self, index):
-        self.lib, self.index = None, index
+    def __init__(self, torch_device):
+        self.lib, self.index, self.pci = None, None, None
         try:
+            import torch
+            pr = torch.cuda.get_device_properties(torch_device)
+            want = tuple(int(getattr(pr, k, -1)) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
             lib = C.CDLL("librocm_smi64.so")
-            if lib.rsmi_init(C.c_uint64(0)) == 0:
-                self.lib = lib
-        except OSError:
+            if lib.rsmi_init(C.c_uint64(0)) != 0:
+                return
+            n = C.c_uint32()
+            if lib.rsmi_num_monitor_devices(C.byref(n)) != 0:
+                return
+            if n.value == 1 and torch.cuda.device_count() == 1:  # nothing to confuse
+                self.lib, self.index, self.pci = lib, 0, "%04x:%02x:%02x (only device)" % want
+                return
+            for i in range(n.value):
+                bdf = C.c_uint64()
+                if lib.rsmi_dev_pci_id_get(C.c_uint32(i), C.byref(bdf)) != 0:
+                    continue
+                v = bdf.value  # ((domain & 0xffffffff) << 32) | ((bus & 0xff) << 8) | ((device & 0x1f) << 3) | function
+                if ((v >> 32) & 0xffffffff, (v >> 8) & 0xff, (v >> 3) & 0x1f) == want:
+                    self.lib, self.index = lib, i
+                    self.pci = "%04x:%02x:%02x" % want
+                    break
+        except (OSError, AttributeError, RuntimeError, AssertionError):
             pass
 
     def joules(self):
@@ -98,164 +158,163 @@ class EnergyCounter:
         return cnt.value * res.value * 1e-6
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512, help="frame-pairs per step per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (no HIP-event roofline)")
-    ap.add_argument("--cpu-sample", type=int, default=16, help="frame-pairs timed on the host for cpu_baseline")
-    ap.add_argument("--arithmetic", choices=["f16x2", "pieces", "f32"], default="f16x2",
-                    help="Shasta.arithmetic: how fp32 products are formed on the matrix cores above the batch thresholds: two fp16 pieces for "
-                         "the weight stream + three bf16 pieces elsewhere (default), three bf16 pieces everywhere, or f32 MFMA kernels only")
-    ap.add_argument("--dry-run", action="store_true",
-                    help="launcher / rendezvous / reduction plumbing only, on the CPU with gloo (no GPU, no forward): for the CPU test suite")
-    args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+class Bench:
+    """One process = one GPU.  Holds the resident inputs (sized for the largest batch) and measures operating points."""
 
-    import torch
-    import torch.distributed as dist
+    def __init__(self, args, dev, rank, world, dist):
+        import torch
+        import shasta_amd
+        from shasta_amd import hip
+        self.torch, self.hip, self.shasta = torch, hip, shasta_amd
+        self.args, self.dev, self.rank, self.world, self.dist = args, dev, rank, world, dist
+        self.lib = hip.load()
+        self.gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        self.models, self.inputs = {}, {}
+        B = args.batch
+        self.bev = torch.relu(torch.randn(B, HW, HW, CH, device=dev, generator=self.gen))
+        self.pbev = torch.relu(torch.randn(B, HW, HW, CH, device=dev, generator=self.gen))
 
-    import shasta_amd
-    from shasta_amd import hip
+    def model(self, cfg):
+        key = tuple(sorted(cfg.items()))
+        if key not in self.models:
+            self.torch.manual_seed(0)
+            with self.torch.device(self.dev):  # random-init weights of the named architecture, created directly in HBM
+                self.models[key] = self.shasta.build_simp_track(dict(
+                    type="Shasta", reader=None, backbone=None, neck=None,
+                    bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
+                    **cfg)).eval()
+        return self.models[key]
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if args.dry_run:
-        return dry_run(args, rank, world)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
-    assert args.gpus == world, "--gpus must equal the number of launched ranks (WORLD_SIZE)"
+    def boxes(self, cfg):
+        """(det0, prev): (B, N, 11) rows [x, y, z, w, l, h, yaw, vx, vy, dt, score] as SURVEY.md 8(d) draws them"""
+        key = cfg["max_obj"]
+        if key not in self.inputs:
+            torch, dev, g, B, n = self.torch, self.dev, self.gen, self.args.batch, cfg["max_obj"]
 
-    lib = hip.load()
-    B = args.batch
-    torch.manual_seed(0)
-    with torch.device(dev):  # random-init weights of the named architecture, created directly in HBM (4.1 GB)
-        model = shasta_amd.build_simp_track(dict(
-            type="Shasta", reader=None, backbone=None, neck=None,
-            bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
-            max_obj=N_OBJ, num_feats=NF, num_point=NPOINT)).eval()
-    model.arithmetic = args.arithmetic
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    bev = torch.relu(torch.randn(B, HW, HW, CH, device=dev, generator=g))
-    pbev = torch.relu(torch.randn(B, HW, HW, CH, device=dev, generator=g))
+            def one():
+                b = torch.zeros(B, n, 11, device=dev)
+                b[..., 0:2] = torch.rand(B, n, 2, device=dev, generator=g) * 100 - 50
+                b[..., 2] = torch.randn(B, n, device=dev, generator=g)
+                b[..., 3:6] = torch.rand(B, n, 3, device=dev, generator=g) * 4 + 0.5
+                b[..., 6] = (torch.rand(B, n, device=dev, generator=g) * 2 - 1) * 3.14159265
+                b[..., 7:9] = torch.randn(B, n, 2, device=dev, generator=g)
+                b[..., 9] = 0.5
+                b[..., 10] = torch.rand(B, n, device=dev, generator=g)
+                return b
+            self.inputs[key] = (one(), one())
+        return self.inputs[key]
 
-    def boxes():
-        b = torch.zeros(B, N_OBJ, 11, device=dev)
-        b[..., 0:2] = torch.rand(B, N_OBJ, 2, device=dev, generator=g) * 100 - 50
-        b[..., 2] = torch.randn(B, N_OBJ, device=dev, generator=g)
-        b[..., 3:6] = torch.rand(B, N_OBJ, 3, device=dev, generator=g) * 4 + 0.5
-        b[..., 6] = (torch.rand(B, N_OBJ, device=dev, generator=g) * 2 - 1) * 3.14159265
-        b[..., 7:9] = torch.randn(B, N_OBJ, 2, device=dev, generator=g)
-        b[..., 9] = 0.5
-        b[..., 10] = torch.rand(B, N_OBJ, device=dev, generator=g)
-        return b
+    def sync_all(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
 
-    det0, prev = boxes(), boxes()
-    det = det0.clone()
+    def measure(self, cfg, B, steps, warmup, arithmetic, graph=False, energy=None, selfcheck=False):
+        """W untimed + K timed steps of B frame-pairs (the first B of the resident inputs) bracketed by barrier + synchronize; HIP
+        events around the two heaviest kernels of every timed step, on the launch stream (shasta_affinity_forward_timed_f32)."""
+        torch, hip, lib = self.torch, self.hip, self.lib
+        model = self.model(cfg)
+        model.arithmetic = arithmetic
+        det0, prev = self.boxes(cfg)
+        det0, prev, bev, pbev = det0[:B], prev[:B], self.bev[:B], self.pbev[:B]
+        det = det0.clone()
+        evs = []  # per step: (L1 start, L1 stop, pair start, pair stop)
+        for _ in range(steps):
+            four = tuple(C.c_void_p() for _ in range(4))
+            for e in four:
+                hip.check(lib.shasta_event_create(C.byref(e)), "event_create")
+            evs.append(four)
 
-    evs = []  # per step: (L1 start, L1 stop, pair start, pair stop)
-    for _ in range(args.steps):
-        four = tuple(C.c_void_p() for _ in range(4))
-        for e in four:
-            hip.check(lib.shasta_event_create(C.byref(e)), "event_create")
-        evs.append(four)
+        def step(ev=None):
+            det.copy_(det0)  # forward back-projects det_boxes in place (shasta.py:270): restore the input
+            return model.affinity_from_bev(bev, pbev, det, prev, l1_events=ev)
 
-    def step(ev=None):
-        det.copy_(det0)  # forward back-projects det_boxes in place (shasta.py:270): restore the input
-        return model.affinity_from_bev(bev, pbev, det, prev, l1_events=ev)
-
-    def sync_all():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    graph = None
-    with torch.no_grad():
-        if args.graph:
-            # capture one step (all launches go through the C ABI on the capture stream; outputs are static tensors)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    m1, m2 = step()
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                m1, m2 = step()
-        for _ in range(args.warmup):
-            if graph is not None:
-                graph.replay()
-            else:
-                m1, m2 = step()
-        sync_all()
-        energy = EnergyCounter(local_rank)
-        e0 = energy.joules()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            if graph is not None:
-                graph.replay()
-            else:
-                m1, m2 = step(evs[i])
-        sync_all()
-        elapsed = time.perf_counter() - t0
-        e1 = energy.joules()
-    joules = (e1 - e0) if (e0 is not None and e1 is not None and e1 > e0) else None
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert bool(torch.isfinite(m1).all()) and abs(float(m1[0, 0].sum()) - 1.0) < 1e-4
-    # self-check of the operating point: three frame-pairs of the timed batch recomputed one at a time (batch 1 runs the VALU
-    # weight-stream kernel and the small-batch tiles of every other stage) must reproduce the batched result
-    selfcheck = 0.0
-    with torch.no_grad():
-        for i in sorted({0, B // 2, B - 1}):
-            s1, s2 = model.affinity_from_bev(bev[i:i + 1], pbev[i:i + 1], det0[i:i + 1].clone(), prev[i:i + 1])
-            selfcheck = max(selfcheck, float((s1 - m1[i:i + 1]).abs().max()), float((s2 - m2[i:i + 1]).abs().max()))
-    assert selfcheck <= 1e-6, "self-check failed: batched and one-at-a-time results differ by %.3e" % selfcheck
-
-    ms = C.c_float()
-    l1, pair = [], []
-    if graph is not None:  # the per-step events were not recorded under graph replay: time the two kernels separately
+        g = None
         with torch.no_grad():
-            for i in range(args.steps):
-                step(evs[i])
-        torch.cuda.synchronize()
-    for four in evs:
-        hip.check(lib.shasta_event_elapsed_ms(four[0], four[1], C.byref(ms)), "event_elapsed")
-        l1.append(ms.value)
-        hip.check(lib.shasta_event_elapsed_ms(four[2], four[3], C.byref(ms)), "event_elapsed")
-        pair.append(ms.value)
-        for e in four:
-            lib.shasta_event_destroy(e)
-    l1_ms, pair_ms = sum(l1) / len(l1), sum(pair) / len(pair)
-    step_ms = elapsed / args.steps * 1e3
-    # Kernel 1: aug_shape first layer = the 4.1 GB fp32 weight stream.
-    #   B <= 32: f32 MFMA kernel, 1024 matrix-pipe cycles per 4 KB weight tile against ~1300 of HBM        -> HBM-bound
-    #   pieces: B <= 64: bf16-piece kernel (each fp32 product = 6 exact bf16 piece products), 768 cycles per tile   -> HBM-bound
-    #           B  > 64: the same with 128 items per weight pass, 1536 cycles per tile -> bound by the bf16 matrix pipe: priced as
-    #                    EXECUTED bf16 flops (6 piece products per fp32 product) against the dense bf16 MFMA peak
-    #   f16x2 (default): as pieces up to 64 frame-pairs; above, 3 fp16 piece products: 128 items per pass (768 cycles per tile,
-    #                    HBM-bound) up to 128 frame-pairs, 256 items per pass (1536 cycles) above: EXECUTED f16 flops (3 per fp32
-    #                    product) against the dense f16 MFMA peak
-    #   --arithmetic f32 and B > 32: f32 MFMA kernel, 64 items per pass, 2048 cycles per tile -> f32 matrix pipe
-    alg = l1_algorithmic_bytes(B)
+            if graph:
+                # capture one step (all launches go through the C ABI on the capture stream; outputs are static tensors)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        m1, m2 = step()
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    m1, m2 = step()
+            for _ in range(warmup):
+                if g is not None:
+                    g.replay()
+                else:
+                    m1, m2 = step()
+            self.sync_all()
+            e0 = energy.joules() if energy else None
+            t0 = time.perf_counter()
+            for i in range(steps):
+                if g is not None:
+                    g.replay()
+                else:
+                    m1, m2 = step(evs[i])
+            self.sync_all()
+            elapsed = time.perf_counter() - t0
+            e1 = energy.joules() if energy else None
+        joules = (e1 - e0) if (e0 is not None and e1 is not None and e1 > e0) else None
+        if self.world > 1:
+            t = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert bool(torch.isfinite(m1).all()) and abs(float(m1[0, 0].sum()) - 1.0) < 1e-4
+        check = None
+        if selfcheck:
+            # self-check of the operating point: three frame-pairs of the timed batch recomputed one at a time (batch 1 runs the VALU
+            # weight-stream kernel and the small-batch tiles of every other stage) must reproduce the batched result
+            check = 0.0
+            with torch.no_grad():
+                for i in sorted({0, B // 2, B - 1}):
+                    s1, s2 = model.affinity_from_bev(bev[i:i + 1], pbev[i:i + 1], det0[i:i + 1].clone(), prev[i:i + 1])
+                    check = max(check, float((s1 - m1[i:i + 1]).abs().max()), float((s2 - m2[i:i + 1]).abs().max()))
+            assert check <= 1e-6, "self-check failed: batched and one-at-a-time results differ by %.3e" % check
+        ms = C.c_float()
+        l1, pair = [], []
+        if g is not None:  # the per-step events were not recorded under graph replay: time the two kernels separately
+            with torch.no_grad():
+                for i in range(steps):
+                    step(evs[i])
+            torch.cuda.synchronize()
+        for four in evs:
+            hip.check(lib.shasta_event_elapsed_ms(four[0], four[1], C.byref(ms)), "event_elapsed")
+            l1.append(ms.value)
+            hip.check(lib.shasta_event_elapsed_ms(four[2], four[3], C.byref(ms)), "event_elapsed")
+            pair.append(ms.value)
+            for e in four:
+                lib.shasta_event_destroy(e)
+        return dict(B=B, steps=steps, warmup=warmup, elapsed=elapsed, ms_per_step=elapsed / steps * 1e3,
+                    value=self.world * B * steps / elapsed, l1_ms=sum(l1) / len(l1), pair_ms=sum(pair) / len(pair), joules=joules,
+                    selfcheck=check)
+
+
+def rooflines(cfg, arithmetic, r, with_traffic=True):
+    """`roofline` objects of the two kernels that carry a step, from the HIP-event launch times of measurement r.
+    Kernel 1: aug_shape first layer = the fp32 weight stream (4.096 GB at the headline size).
+      B == 1: VALU GEMV; B <= 32: f32 MFMA kernel, 1024 matrix-pipe cycles per 4 KB weight tile against ~1300 of HBM  -> HBM-bound
+      pieces: B <= 64: bf16-piece kernel (each fp32 product = 6 exact bf16 piece products), 768 cycles per tile        -> HBM-bound
+              B  > 64: the same with 128 items per weight pass, 1536 cycles per tile -> bf16 matrix pipe: priced as EXECUTED bf16
+                       flops (6 piece products per fp32 product) against the dense bf16 MFMA peak
+      f16x2 (default): as pieces up to 64 frame-pairs; above, 3 fp16 piece products: 128 items per pass (768 cycles per tile,
+                       HBM-bound) up to 128 frame-pairs, 256 items per pass (1536 cycles) above: EXECUTED f16 flops against the
+                       dense f16 MFMA peak
+      f32 and B > 32: f32 MFMA kernel, 64 items per pass, 2048 cycles per tile -> f32 matrix pipe
+    Kernel 2: the pair kernel = layers 2-4 of fuse_shape / res_coeff / fuse_det for all (N+2)^2 pairs.  Three flop counts per
+    launch: `dense` = the reference's formulation, `useful` = what is left once the first layers are factorised
+    over the table rows, `executed`.  `achieved` prices the USEFUL flops against the f32 MFMA peak."""
+    wk = Work(**cfg)
+    B, l1_ms, pair_ms, step_ms = r["B"], r["l1_ms"], r["pair_ms"], r["ms_per_step"]
+    headline = cfg == HEADLINE
+    alg = wk.l1_algorithmic_bytes(B)
     hbm_gbs = alg / (l1_ms * 1e-3) / 1e9
-    K = N_OBJ * CH * NPOINT
-    l1_flops = 2.0 * B * 4 * (K // 64) * K  # dense fp32 flops of the four first layers for B frame-pairs (algorithmic = executed)
+    l1_flops = 2.0 * B * 4 * wk.H * wk.K  # dense fp32 flops of the four first layers for B frame-pairs (algorithmic = executed)
     l1_tflops = l1_flops / (l1_ms * 1e-3) / 1e12
-    f32_forced, f16x2 = args.arithmetic == "f32", args.arithmetic == "f16x2" and B > 64  # up to 64 frame-pairs the bf16-piece kernel serves
+    f32_forced, f16x2 = arithmetic == "f32", arithmetic == "f16x2" and B > 64  # up to 64 frame-pairs the bf16-piece kernel serves
     if B <= 32:
         passes, nprod = 1, 1
     elif f32_forced:
@@ -275,46 +334,109 @@ def main():
                    "frac": nprod * l1_tflops / MFMA_BF16_PEAK_TFLOPS, "mfma_dtype": "f16" if f16x2 else "bf16",
                    "note": "executed %s MFMA flops = %d piece products per fp32 product, against the dense bf16 / f16 peak"
                            % ("f16" if f16x2 else "bf16", nprod)}
-    roof_l1.update({"kernel": "anchor_l1_kernel (B=1) / anchor_l1_mfma_kernel (B<=32) / anchor_l1_split_kernel (B>32): "
-                              "aug_shape.*.0, 4 x 2000 x 128000 fp32 weight stream",
-                    "traffic": _pmc_traffic(B) if args.arithmetic == "f16x2" else None, "algorithmic_bytes_per_launch": alg, "weight_passes_executed": passes,
-                    "executed_weight_bytes_per_launch": passes * 4 * (K // 64) * K * 4,
+    l1_kernel = ("anchor_l1_kernel<1,8> (VALU GEMV)" if B == 1 else "anchor_l1_mfma_kernel (f32 MFMA)" if (B <= 32 or f32_forced)
+                 else "anchor_l1_split_kernel (fp16 pieces)" if f16x2 else "anchor_l1_split_kernel (bf16 pieces)")
+    tr, src = _pmc_traffic(B, "l1", l1_kernel) if (with_traffic and headline and arithmetic == "f16x2") else (None, None)
+    roof_l1.update({"kernel": "%s: aug_shape.*.0, 4 x %d x %d fp32 weight stream" % (l1_kernel, wk.H, wk.K),
+                    "traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": alg, "weight_passes_executed": passes,
+                    "executed_weight_bytes_per_launch": passes * 4 * wk.H * wk.K * 4,
                     "algorithmic_flops_per_launch": l1_flops, "executed_flops_per_launch": nprod * l1_flops,
                     "avg_launch_ms": l1_ms, "algorithmic_hbm_gbs": hbm_gbs, "fp32_tflops": l1_tflops,
                     "share_of_step": l1_ms / step_ms})
-    # Kernel 2: the pair kernel = layers 2-4 of fuse_shape / res_coeff / fuse_det for all (N+2)^2 pairs on the f32 matrix pipe.
-    # Three flop counts per launch: `dense` = the reference's formulation of the three pair MLPs (first layers
-    # on the concatenated pair tensor), `useful` = what is left for the pair kernel once the first layers are factorised over
-    # the table rows (their GEMMs run in gemm_nt_*), `executed` = useful with every width rounded up to the MFMA block.
-    # `achieved` prices the USEFUL flops against the f32 MFMA peak.
-    pair_useful = 2.0 * USEFUL_PAIR_MACS * PAIRS * B
+    pair_useful = 2.0 * wk.useful_pair_macs * wk.pairs * B
     pair_tflops = pair_useful / (pair_ms * 1e-3) / 1e12
-    pair_f16 = args.arithmetic == "f16x2"  # F = 256: second layers (1792 of the 1984 MACs per pair) as three fp16 piece products each
+    pair_f16 = arithmetic == "f16x2" and wk.F in PAIR_F16_WIDTHS  # second layers as three fp16 piece products each
+    pair_kernel = "pair_f16_kernel" if pair_f16 else "pair_mfma4_kernel"
+    tr, src = _pmc_traffic(B, "pair", pair_kernel) if (with_traffic and headline and arithmetic == "f16x2") else (None, None)
     roof_pair = {"bound": "mfma", "achieved": pair_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": pair_tflops / MFMA_F32_PEAK_TFLOPS, "traffic": _pmc_traffic(B, "pair") if args.arithmetic == "f16x2" else None,
+                 "frac": pair_tflops / MFMA_F32_PEAK_TFLOPS, "traffic": tr, "traffic_source": src,
                  "useful_flops_per_launch": pair_useful,
-                 "dense_algorithmic_flops_per_launch": 2.0 * DENSE_PAIR_MACS * PAIRS * B,
-                 "dense_equivalent_tflops": 2.0 * DENSE_PAIR_MACS * PAIRS * B / (pair_ms * 1e-3) / 1e12,
+                 "dense_algorithmic_flops_per_launch": 2.0 * wk.dense_pair_macs * wk.pairs * B,
+                 "dense_equivalent_tflops": 2.0 * wk.dense_pair_macs * wk.pairs * B / (pair_ms * 1e-3) / 1e12,
                  "avg_launch_ms": pair_ms, "share_of_step": pair_ms / step_ms}
+    T = wk.N + 2
     if pair_f16:
         roof_pair.update({
-            "kernel": "pair_f16_kernel<8>: per-pair MLP tails (second layers on the f16 matrix path) + hand residual -> residual (B, 502, 502)",
+            "kernel": "pair_f16_kernel: per-pair MLP tails (second layers on the f16 matrix path) + hand residual -> residual (B, %d, %d)" % (T, T),
             "mfma_dtype": "f16 (layer 2: three piece products per fp32 product) + f32 (layers 3-4)",
-            "executed_flops_per_launch": 2.0 * (3 * 2048 + (EXECUTED_PAIR_MACS - 1792)) * PAIRS * B,
+            "executed_flops_per_launch": 2.0 * (3 * PAIR_F16_LAYER2_SLOTS[wk.F] + (wk.executed_pair_macs - wk.layer2_macs)) * wk.pairs * B,
             "note": "useful fp32 flops priced against the f32 MFMA peak, the yardstick of the f32 form (pair_mfma4_kernel, --arithmetic pieces); "
-                    "in this form the kernel is bound by VALU issue (cutting the activations) and LDS latency at 2 waves per SIMD, not by a matrix pipe"})
+                    "in this form the kernel is bound by VALU issue (cutting the activations into fp16 pieces), not by a matrix pipe"})
     else:
-        roof_pair.update({"kernel": "pair_mfma4_kernel<256,8>: per-pair MLP tails + hand residual -> residual (B, 502, 502)",
-                          "mfma_dtype": "f32", "executed_flops_per_launch": 2.0 * EXECUTED_PAIR_MACS * PAIRS * B})
-    # `roofline` is the kernel with the longer average launch; the other one rides along as `roofline_second`
-    roof, second = (roof_l1, roof_pair) if l1_ms >= pair_ms else (roof_pair, roof_l1)
+        roof_pair.update({"kernel": "pair_mfma4_kernel<%d,8>: per-pair MLP tails + hand residual -> residual (B, %d, %d)" % (wk.F, T, T),
+                          "mfma_dtype": "f32", "executed_flops_per_launch": 2.0 * wk.executed_pair_macs * wk.pairs * B})
+    return roof_l1, roof_pair
 
+
+PAIR_F16_WIDTHS = (256,)                 # feature widths pair_f16_kernel is instantiated for
+PAIR_F16_LAYER2_SLOTS = {256: 2048}      # multiply-add slots of its layer-2 MFMAs per pair and piece product (16 rows x 128 k)
+
+
+def brief(cfg, arithmetic, r):
+    """One extra operating point, condensed: throughput, step time, and the roofline of each of the two heavy kernels."""
+    a, b = rooflines(cfg, arithmetic, r, with_traffic=False)
+    keep = ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "share_of_step", "mfma_dtype")
+    first, second = (a, b) if r["l1_ms"] >= r["pair_ms"] else (b, a)
+    out = {"value": r["value"], "unit": "frame-pairs/s", "frame_pairs_per_step": r["B"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+           "warmup": r["warmup"], "arithmetic": arithmetic,
+           "roofline": dict({k: first[k] for k in keep if k in first}, kernel=first["kernel"].split(":")[0]),
+           "roofline_second": dict({k: second[k] for k in keep if k in second}, kernel=second["kernel"].split(":")[0])}
+    if r["B"] == 1:
+        out["latency_ms"] = r["ms_per_step"]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="frame-pairs per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline operating point only (no `extra` object)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (no HIP-event roofline)")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="frame-pairs timed on the host for cpu_baseline")
+    ap.add_argument("--arithmetic", choices=["f16x2", "pieces", "f32"], default="f16x2",
+                    help="Shasta.arithmetic: how fp32 products are formed on the matrix cores above the batch thresholds: two fp16 pieces for "
+                         "the weight stream + three bf16 pieces elsewhere (default), three bf16 pieces everywhere, or f32 MFMA kernels only")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / reduction plumbing only, on the CPU with gloo (no GPU, no forward): for the CPU test suite")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert args.gpus == world, "--gpus must equal the number of launched ranks (WORLD_SIZE)"
+
+    bench = Bench(args, dev, rank, world, dist)
+    B = args.batch
+    energy = EnergyCounter(dev)
+    r = bench.measure(HEADLINE, B, args.steps, args.warmup, args.arithmetic, graph=args.graph, energy=energy, selfcheck=True)
+    roof_l1, roof_pair = rooflines(HEADLINE, args.arithmetic, r)
+    # `roofline` is the kernel with the longer average launch; the other one rides along as `roofline_second`
+    roof, second = (roof_l1, roof_pair) if r["l1_ms"] >= r["pair_ms"] else (roof_pair, roof_l1)
+    joules, elapsed = r["joules"], r["elapsed"]
     out = {
         "metric": "affinity frame-pairs/sec at N=M=500, F=256",
-        "value": world * B * args.steps / elapsed,
+        "value": r["value"],
         "unit": "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": r["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "synthetic N=M=500, F=256 (num_point=4, C=64), nf=7 affinity forward from HBM-resident "
@@ -327,37 +449,76 @@ def main():
                                            "two range-scaled fp16 pieces per operand (round to nearest; measured max error vs float64: weight "
                                            "stream 5.5e-6 against 7.0e-6 for the f32 MFMA kernel, pair stage 1.8e-6 against 2.3e-6); from 8192 "
                                            "table rows the row-embedding GEMMs and the aff layers use six products of three exact bf16 "
-                                           "pieces (--arithmetic pieces / f32 select the other forms)",
+                                           "pieces (--arithmetic pieces / f32 select the other forms; extra.arithmetic_f32 is the strict-fp32 figure)",
                                   "pieces": "fp32 operands, fp32 accumulation throughout; above 32 frame-pairs per step the first aug_shape "
                                             "layer, and from 8192 table rows the row-embedding GEMMs and the aff layers, form every fp32 product "
                                             "from six exact bf16 piece products on the bf16 MFMA path",
                                   "f32": "fp32 operands, fp32 accumulation throughout, f32 MFMA kernels only"}[args.arithmetic]},
-        "dense_equivalent_tflops": DENSE_GFLOP_PER_PAIR * 1e9 * world * B * args.steps / elapsed / 1e12,
-        "selfcheck_max_abs": selfcheck,
-        # rank 0's GPU over the timed loop, from the device's energy accumulator (null without librocm_smi64)
+        "dense_equivalent_tflops": DENSE_GFLOP_PER_PAIR * 1e9 * r["value"] / 1e12,
+        "selfcheck_max_abs": r["selfcheck"],
+        # rank 0's GPU over the timed loop, from the device's energy accumulator (null when the rocm_smi device cannot be matched)
         "energy": None if joules is None else {"joules_per_step": joules / args.steps, "avg_power_w": joules / elapsed,
-                                               "millijoules_per_frame_pair": joules / args.steps / B * 1e3},
+                                               "millijoules_per_frame_pair": joules / args.steps / B * 1e3, "pci": energy.pci},
         "roofline": roof,
         "roofline_second": second,
     }
+    if rank == 0 and world == 1 and not args.no_extras and not args.graph:
+        out["extra"] = extras(bench, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(model, args.cpu_sample)
+        out["cpu_baseline"] = cpu_baseline(bench.model(HEADLINE), args.cpu_sample)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def _pmc_traffic(B, kernel="l1"):
-    """HBM bytes per launch of one of the two heaviest kernels of the DEFAULT arithmetic from the committed rocprofv3 PMC passes
-    (profiles/), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE doubled on gfx950); None when no profile for this batch size
-    exists."""
+def extras(bench, args):
+    """The other operating points of SURVEY.md 8(d), same process, same resident inputs (the first b frame-pairs), short runs:
+    B in {1, 8, 64} at the headline size (B = 1 is the reference's eval batch, tools/nusc_shasta/eval.py:96-101: its step time is the
+    latency), the other two arithmetic forms at the headline batch (`arithmetic_f32` = strict fp32 products on the f32 MFMA
+    instructions), and the shipped car configuration (configs/nusc/car.py:22-39: max_obj 90, num_point 5 -> F = 320, num_feats 3)."""
+    B = args.batch
+    ex = {"note": "measured by the same process after the headline run; each entry: W warm-up + K timed steps, barrier + synchronize "
+                  "on both sides; rooflines from HIP events on the launch stream as in the headline"}
+    sweep = {}
+    for b, k in ((1, 200), (8, 100), (64, 50)):
+        if b <= B:
+            sweep["b%d" % b] = brief(HEADLINE, args.arithmetic, bench.measure(HEADLINE, b, k, 5, args.arithmetic))
+    ex["batch_sweep"] = sweep
+    for mode in ("f32", "pieces"):
+        if mode != args.arithmetic:
+            ex["arithmetic_" + mode] = brief(HEADLINE, mode, bench.measure(HEADLINE, B, 10, 3, mode))
+    car = {}
+    for b, k in ((1, 200), (8, 200), (B, 30)):
+        if b <= B:
+            car["b%d" % b] = brief(CAR, args.arithmetic, bench.measure(CAR, b, k, 5, args.arithmetic))
+    if B >= 64:
+        car["b%d_pieces" % B] = brief(CAR, "pieces", bench.measure(CAR, B, 30, 5, "pieces"))
+    car["config"] = "max_obj 90, num_point 5 (F = 320), num_feats 3: configs/nusc/car.py:22-39 of the reference; 180 x 180 x 64 BEV maps"
+    ex["car_90_320_3"] = car
+    bench.model(HEADLINE).arithmetic = args.arithmetic
+    return ex
+
+
+def _pmc_traffic(B, kernel, running):
+    """(HBM bytes per launch, source) of one of the two heaviest kernels of the DEFAULT arithmetic.  The figure is NOT measured by
+    this run: it comes from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json: (2 FETCH_SIZE + WRITE_SIZE) 1024,
+    FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes), and is reported only when that file was recorded for the kernel
+    this run launches; (None, reason) otherwise."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get(("batch_%d" if kernel == "l1" else "pair_batch_%d") % B)
+            d = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, "no profiles/pmc_traffic.json"
+    meta = d.get("_meta", {})
+    key = ("batch_%d" if kernel == "l1" else "pair_batch_%d") % B
+    if d.get(key) is None:
+        return None, "profiles/pmc_traffic.json holds no pass at %d frame-pairs per step" % B
+    recorded = meta.get("kernels", {}).get(key, "")
+    if not recorded or recorded.split("<")[0].split(" ")[0] != running.split("<")[0].split(" ")[0]:
+        return None, "profiles/pmc_traffic.json was recorded for %r, this run launches %r" % (recorded, running)
+    return d[key], "static: profiles/pmc_traffic.json (%s; kernel %s), not measured by this run" % (meta.get("pass", "rocprofv3 --pmc pass"), recorded)
 
 
 def cpu_baseline(model, sample):
@@ -402,6 +563,8 @@ def dry_run(args, rank, world):
     reduction over ranks that bracket the timed region, and the rank-0 JSON line with `value` null."""
     import torch
     import torch.distributed as dist
+    if os.environ.get("SHASTA_BENCH_DRY_FAIL_RANK") == str(rank):  # test hook: a rank that dies before the rendezvous
+        sys.exit(7)
     if world > 1:
         dist.init_process_group(backend="gloo")
         dist.barrier()

@@ -9,7 +9,12 @@
  * `options` bits of shasta_weights), `int` status (0 = ok, <0 = SHASTA_E_*), never exit()/abort().
  * The shared library exports exactly the functions declared here (built with -fvisibility=hidden).
  * All pointers are DEVICE pointers unless a parameter name starts with `h_`.
- * All arithmetic is fp32 (the reference runs apex O0 = fp32, tools/nusc_shasta/train.py:149).
+ * Arithmetic: fp32 operands in HBM and fp32 accumulation everywhere (the reference runs apex O0 = fp32,
+ * tools/nusc_shasta/train.py:149).  HOW an fp32 product is formed on the matrix cores is a per-call choice
+ * (shasta_weights.options below): by default (options = 0) large batches form it from six products of three exact bf16
+ * pieces per operand; SHASTA_OPT_F16X2_* form it from three products of two range-scaled, round-to-nearest fp16 pieces
+ * per operand (a 23-bit operand representation, |error| <= 2^-24 per operand: one rounding more than a true fp32
+ * multiply); SHASTA_OPT_F32_* use the f32 MFMA instructions only (strict fp32 products).
  *
  * Each entry point cites the reference code it replaces (paths relative to the reference root).
  */
@@ -144,14 +149,23 @@ typedef struct shasta_weights {
     shasta_linear fuse_det[3];     /* fuse_det.{0,2,4}:     2nf->32->8->1               */
     shasta_linear res_coeff[3];    /* res_coeff.{0,2,4}:    2F+2nf->32+F/8->8+F/32->3   */
     shasta_linear aff[6];          /* aff.{0,2,4,6,8,10}:   N+2->128->64->32->64->128->N+2 */
+    const void* aug_shape_aux;     /* shasta_aug_shape_aux_f32 output for the CURRENT aug_shape.{i}.0.weight, or NULL */
 } shasta_weights;
 
-/* Packed (kernel-ready) copy of the small pair/aff weights: MFMA fragments of the pair MLPs,
- * the factorised first layers, zero padded aff matrices.  The 4 GB aug_shape matrices are used
- * in place and never copied.  Re-pack whenever the weights change. */
+/* Packed (kernel-ready) copy of the SMALL weights: MFMA fragments of the pair MLPs (fuse_shape, fuse_det, res_coeff),
+ * their factorised first layers, the six aff layers as piece fragments.  It depends on those tensors only - not on the
+ * aug_shape / aug_dets matrices and not on `options` - and must be re-packed whenever one of them changes. */
 size_t shasta_packed_bytes(int max_obj, int num_feats, int feat_dim);
 int shasta_pack_weights_f32(const shasta_weights* w, void* packed, size_t packed_bytes,
                             shasta_stream_t stream);
+
+/* Companion of the four aug_shape.{i}.0.weight matrices (N*F/64, N*F), which are used in place and never copied (4.1 GB at
+ * N=500, F=256): the largest magnitude of every weight row = the range exponents of the fp16 form of the weight stream
+ * (SHASTA_OPT_F16X2_WEIGHT_STREAM, more than 64 frame-pairs per call).  One pass over the matrices.  Hand it to the forward as
+ * shasta_weights.aug_shape_aux and recompute it whenever one of the four matrices changes; with aug_shape_aux == NULL a forward
+ * that needs it recomputes it into its workspace on every call (correct, one extra pass over the weights per call). */
+size_t shasta_aug_shape_aux_bytes(int max_obj, int feat_dim);
+int shasta_aug_shape_aux_f32(const shasta_weights* w, void* aux, size_t aux_bytes, shasta_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K3-K6  affinity forward after the gather: Shasta.forward, det3d/models/tracker/shasta.py:240-325
@@ -275,6 +289,24 @@ int shasta_gemm_strided_f32(const float* A, long sa_m, long sa_k, const float* W
 size_t shasta_nms_workspace_bytes(int num_boxes);
 int shasta_nms_rotated_f32(const float* boxes_sorted, int num_boxes, float thresh, void* workspace, size_t workspace_bytes,
                            int32_t* keep, int32_t* num_keep, shasta_stream_t stream);
+
+/* The same with the axis-aligned IoU of the BEV footprints (heading ignored): `nms_normal_gpu`
+ * (src/iou3d_nms.cpp:146-188, nms_normal_kernel + iou_normal src/iou3d_nms_kernel.cu:313-372, called from
+ * det3d/ops/iou3d_nms/iou3d_nms_utils.py:93-106).  Same arguments and workspace as shasta_nms_rotated_f32. */
+int shasta_nms_normal_f32(const float* boxes_sorted, int num_boxes, float thresh, void* workspace, size_t workspace_bytes,
+                          int32_t* keep, int32_t* num_keep, shasta_stream_t stream);
+
+/* Pairwise BEV matrices of det3d/ops/iou3d_nms: `boxes_overlap_bev_gpu` / `boxes_iou_bev_gpu` (src/iou3d_nms.cpp:56-97,
+ * boxes_overlap_kernel / boxes_iou_bev_kernel src/iou3d_nms_kernel.cu:236-265) and the 3-D IoU that
+ * det3d/ops/iou3d_nms/iou3d_nms_utils.py:35-72 (`boxes_iou3d_gpu`) builds on the overlap.
+ *  boxes_a (num_a, 7), boxes_b (num_b, 7) fp32 [x, y, z, dx, dy, dz, heading]; out (num_a, num_b) fp32
+ *  mode 0: overlap area of the rotated footprints; 1: BEV IoU = overlap / max(sa + sb - overlap, 1e-8);
+ *  mode 2: 3-D IoU = overlap * overlap_h / max(vol_a + vol_b - overlap * overlap_h, 1e-6)
+ * The overlap is the exact intersection area (float64 convex clip, rounded to fp32); the reference's fp32 routine additionally
+ * counts corners up to 1e-2 outside the other box as inside (iou3d_nms_kernel.cu:51-61), so it can exceed the exact area for
+ * nearly touching boxes. */
+int shasta_boxes_bev_f32(const float* boxes_a, int num_a, const float* boxes_b, int num_b, int mode, float* out,
+                         shasta_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Public tracker step, device part: centre-distance matrix + greedy assignment for `scenes` independent scenes

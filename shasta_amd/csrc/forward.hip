@@ -18,6 +18,7 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
 int aff_softmax(const shasta_weights* w, const float* packed, int B, const float* residual, int ld, float* m1,
                 float* m2, float* matched_out, void* ws, size_t ws_bytes, hipStream_t st);
 int pack_weights(const shasta_weights* w, float* packed, hipStream_t st);
+int launch_w_maxima(const float* const W[4], int H, int K, unsigned* wmax, hipStream_t st);
 
 static int check_weights(const shasta_weights* w) {
     SHASTA_REQUIRE(w, "null weights");
@@ -81,6 +82,24 @@ extern "C" int shasta_pack_weights_f32(const shasta_weights* w, void* packed, si
     return pack_weights(w, static_cast<float*>(packed), as_stream(stream));
 }
 
+extern "C" size_t shasta_aug_shape_aux_bytes(int max_obj, int feat_dim) {
+    return align_up((size_t)4 * ((size_t)max_obj * feat_dim / 64) * sizeof(unsigned), 256);
+}
+
+extern "C" int shasta_aug_shape_aux_f32(const shasta_weights* w, void* aux, size_t aux_bytes, shasta_stream_t stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    SHASTA_REQUIRE(aux && (uintptr_t)aux % 16 == 0, "aug_shape_aux: buffer null or not 16-byte aligned");
+    if (aux_bytes < shasta_aug_shape_aux_bytes(w->max_obj, w->feat_dim)) {
+        set_error_msg("aug_shape_aux: buffer too small");
+        return SHASTA_E_WORKSPACE;
+    }
+    const float* W[4];
+    for (int i = 0; i < 4; ++i) W[i] = w->aug_shape[i][0].weight;
+    const int K = w->max_obj * w->feat_dim, H = K / 64;
+    return launch_w_maxima(W, H, K, static_cast<unsigned*>(aux), as_stream(stream));
+}
+
 extern "C" size_t shasta_forward_workspace_bytes(int B, int max_obj, int num_feats, int feat_dim) {
     (void)num_feats;
     return FwdWs(B, max_obj, feat_dim).total;
@@ -92,8 +111,8 @@ extern "C" int shasta_anchor_shape_f32(const shasta_weights* w, int B, float* fe
     if (rc) return rc;
     SHASTA_REQUIRE(B >= 0 && feat && prev_feat && workspace, "anchor_shape: bad argument");
     SHASTA_REQUIRE(((uintptr_t)feat | (uintptr_t)prev_feat) % 16 == 0, "anchor_shape: tables must be 16-byte aligned");
-    // (this stage entry has no packed buffer: with SHASTA_OPT_F16X2_WEIGHT_STREAM the weight-row maxima are recomputed per call)
-    return anchor_shape(w, B, feat, prev_feat, workspace, workspace_bytes, as_stream(stream), nullptr, nullptr, nullptr);
+    return anchor_shape(w, B, feat, prev_feat, workspace, workspace_bytes, as_stream(stream), nullptr, nullptr,
+                        static_cast<const unsigned*>(w->aug_shape_aux));
 }
 
 extern "C" int shasta_anchor_boxes_f32(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes,
@@ -161,8 +180,9 @@ static int forward_impl(const shasta_weights* w, const void* packed, int B, floa
     void* stage = static_cast<char*>(workspace) + L.residual;
     const size_t stage_bytes = L.total - L.residual;
     const float* pk = static_cast<const float*>(packed);
-    const unsigned* wmax = reinterpret_cast<const unsigned*>(pk + PackedLayout(N, w->num_feats, F).l1wexp);
-    if ((rc = anchor_shape(w, B, feat, prev_feat, stage, stage_bytes, st, ev0, ev1, wmax))) return rc;
+    // row maxima of the first-layer weights (fp16 form of the weight stream): the caller's companion buffer, or recomputed per call
+    if ((rc = anchor_shape(w, B, feat, prev_feat, stage, stage_bytes, st, ev0, ev1, static_cast<const unsigned*>(w->aug_shape_aux))))
+        return rc;
     if (shape_hidden_out) {  // training: the backward re-uses the hidden activations instead of re-streaming the weights
         const size_t H = (size_t)N * F / 64;
         hipError_t e = hipMemcpyAsync(shape_hidden_out, anchor_shape_hidden(stage, B, N, F), (size_t)B * 4 * H * sizeof(float),

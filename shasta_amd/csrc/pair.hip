@@ -562,8 +562,6 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
 }
 
 int aff_pieces_pack(const shasta_weights* w, float* out, hipStream_t st);
-int launch_w_maxima(const float* const W[4], int H, int K, unsigned* wmax, hipStream_t st);
-
 int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {
     PackArgs a;
     for (int i = 0; i < 4; ++i) a.fs[i] = w->fuse_shape[i];
@@ -581,12 +579,6 @@ int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {
     if ((rc = aff_pieces_pack(w, packed + P.affp, st))) return rc;
     if (w->feat_dim == 256 && (rc = pair_f16_pack(w, packed + P.p16, st))) return rc;
     if (embed_rows_serves(w->feat_dim) && (rc = embed_pack(w, packed, st))) return rc;
-    if (w->options & SHASTA_OPT_F16X2_WEIGHT_STREAM) {  // one pass over the four first-layer matrices (4.1 GB at N=500, F=256)
-        const float* W[4];
-        for (int i = 0; i < 4; ++i) W[i] = w->aug_shape[i][0].weight;
-        const int K = w->max_obj * w->feat_dim, H = K / 64;
-        if (H > 0) rc = launch_w_maxima(W, H, K, reinterpret_cast<unsigned*>(packed + P.l1wexp), st);
-    }
     return rc;
 }
 

@@ -23,6 +23,8 @@
 #include "common.hpp"
 #include "pair_layout.hpp"
 
+#include <type_traits>
+
 namespace shasta {
 
 typedef _Float16 ph16x8 __attribute__((ext_vector_type(8)));
@@ -331,12 +333,12 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
             const float* b_rc = s_a4 + A4h<F, L_RC2>::OFF + A4h<F, L_RC2>::BIAS;
             const float* b_fs = s_a4 + A4h<F, L_FS2>::OFF + A4h<F, L_FS2>::BIAS;
             const float* b_fd = s_a4 + A4h<F, L_FD2>::OFF + A4h<F, L_FD2>::BIAS;
-            // descale + bias as packed fmas (two values per 5-cycle slot instead of one per 6)
+            // descale + bias as packed fmas (two values per 5-cycle slot instead of one per 6), ReLU right behind them
             auto fma4 = [&](const f32x4& v, float sc, const f32x4& bb) {
                 const pf2 s2 = {sc, sc};
                 const pf2 lo = __builtin_elementwise_fma(pf2{v[0], v[1]}, s2, pf2{bb[0], bb[1]});
                 const pf2 hi = __builtin_elementwise_fma(pf2{v[2], v[3]}, s2, pf2{bb[2], bb[3]});
-                return f32x4{lo[0], lo[1], hi[0], hi[1]};
+                return f32x4{fmaxf(lo[0], 0.0f), fmaxf(lo[1], 0.0f), fmaxf(hi[0], 0.0f), fmaxf(hi[1], 0.0f)};
             };
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -347,12 +349,17 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
             for (int g = 0; g < 2; ++g)
                 a_fd2[g] = fma4(*reinterpret_cast<const f32x4*>(mine + 32 + 4 * g), i_fd, *reinterpret_cast<const f32x4*>(b_fd + 4 * g));
         }
+        // All forty ReLUs of the layer-2 outputs are done before the first MFMA of layers 3-4 (the empty asm pins them there): a VALU
+        // result read by the MFMA right behind it costs two wait states, and the compiler had put one v_max + s_nop 1 in front of
+        // every 4x4x1.  With the third layers interleaved below: 53 -> 36 s_nop per track, pair kernel 4.73 - 4.95 -> 4.56 - 4.62 ms.
+        asm volatile("" : "+v"(a_rc2[0]), "+v"(a_rc2[1]), "+v"(a_rc2[2]), "+v"(a_rc2[3]), "+v"(a_fs2[0]), "+v"(a_fs2[1]), "+v"(a_fs2[2]),
+                     "+v"(a_fs2[3]), "+v"(a_fd2[0]), "+v"(a_fd2[1]));
         auto init = [&](auto tag, f32x4* acc) {
             using AL = decltype(tag);
 #pragma unroll
             for (int ob = 0; ob < AL::NOB; ++ob) acc[ob] = MFMA4(abias[AL::OFF + AL::BIAS + ob * 4], 1.0f, zero4);
         };
-        auto layer = [&](auto tag, const f32x4* in, f32x4* acc) {
+        auto layer = [&](auto tag, const f32x4* in, f32x4* acc, auto relu_done) {
             using AL = decltype(tag);
             init(tag, acc);
 #pragma unroll
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     if (4 * kg + kk < AL::KIN) {
-                        const float h = fmaxf(in[kg][kk], 0.0f);
+                        const float h = decltype(relu_done)::value ? in[kg][kk] : fmaxf(in[kg][kk], 0.0f);
 #pragma unroll
                         for (int ob = 0; ob < AL::NOB; ++ob) acc[ob] = MFMA4(a4[ob][kk], h, acc[ob]);
                     }
@@ -371,10 +378,32 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
             }
         };
         f32x4 a_rc3[A4h<F, L_RC3>::NOB], a_fs3[A4h<F, L_FS3>::NOB], a_fs4[A4h<F, L_FS4>::NOB], a_fd3[A4h<F, L_FD3>::NOB];
-        layer(A4h<F, L_RC3>{}, a_rc2, a_rc3);
-        layer(A4h<F, L_FS3>{}, a_fs2, a_fs3);
-        layer(A4h<F, L_FD3>{}, a_fd2, a_fd3);
-        layer(A4h<F, L_FS4>{}, a_fs3, a_fs4);
+        {
+            // the three third layers side by side: every accumulator is touched once per round, so no 4x4x1 waits for the one before it
+            using RC = A4h<F, L_RC3>;
+            using FS = A4h<F, L_FS3>;
+            using FD = A4h<F, L_FD3>;
+            static_assert(RC::NOB == 1 && FS::NOB == 2 && FD::NOB == 1 && RC::KG == 4 && FS::KG == 4 && FD::KG == 2, "F = 256");
+            init(RC{}, a_rc3);
+            init(FS{}, a_fs3);
+            init(FD{}, a_fd3);
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                const f32x4 w_rc = *reinterpret_cast<const lf32x4*>(arow + RC::OFF + kg * 16);
+                const f32x4 w_f0 = *reinterpret_cast<const lf32x4*>(arow + FS::OFF + kg * 16);
+                const f32x4 w_f1 = *reinterpret_cast<const lf32x4*>(arow + FS::OFF + (FS::KG + kg) * 16);
+                f32x4 w_fd = zero4;
+                if (kg < 2) w_fd = *reinterpret_cast<const lf32x4*>(arow + FD::OFF + kg * 16);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    a_rc3[0] = MFMA4(w_rc[kk], a_rc2[kg][kk], a_rc3[0]);
+                    a_fs3[0] = MFMA4(w_f0[kk], a_fs2[kg][kk], a_fs3[0]);
+                    a_fs3[1] = MFMA4(w_f1[kk], a_fs2[kg][kk], a_fs3[1]);
+                    if (kg < 2) a_fd3[0] = MFMA4(w_fd[kk], a_fd2[kg][kk], a_fd3[0]);
+                }
+            }
+        }
+        layer(A4h<F, L_FS4>{}, a_fs3, a_fs4, std::false_type{});
 
         // ---- hand-designed residual (shasta.py:277-283) ----
         float d2 = 0.0f;

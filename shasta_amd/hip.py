@@ -9,7 +9,7 @@ import os
 
 import torch
 
-ABI_VERSION = 6  # must equal shasta_abi_version() of the loaded library
+ABI_VERSION = 7  # must equal shasta_abi_version() of the loaded library
 # SHASTA_HIP_LIB: load another build of the same ABI (A/B timing of kernel variants on one box)
 _LIB_PATH = os.environ.get("SHASTA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libshasta_hip.so")
 _lib = None
@@ -34,7 +34,7 @@ class Weights(C.Structure):
     _fields_ = [("max_obj", C.c_int), ("num_feats", C.c_int), ("feat_dim", C.c_int), ("options", C.c_int),
                 ("aug_shape", (Linear * 2) * 4), ("aug_dets", (Linear * 2) * 4),
                 ("fuse_shape", Linear * 4), ("fuse_det", Linear * 3), ("res_coeff", Linear * 3),
-                ("aff", Linear * 6)]
+                ("aff", Linear * 6), ("aug_shape_aux", C.c_void_p)]
 
 
 # every symbol include/shasta_hip.h declares: name -> (restype, argtypes)
@@ -55,6 +55,8 @@ SYMBOLS = {
     "shasta_shared_conv_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "shasta_packed_bytes": (_Z, [_I, _I, _I]),
     "shasta_pack_weights_f32": (_I, [_WP, _P, _Z, _P]),
+    "shasta_aug_shape_aux_bytes": (_Z, [_I, _I]),
+    "shasta_aug_shape_aux_f32": (_I, [_WP, _P, _Z, _P]),
     "shasta_forward_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "shasta_affinity_forward_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "shasta_affinity_forward_train_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
@@ -83,6 +85,8 @@ SYMBOLS = {
     "shasta_bev_gather_bwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
     "shasta_nms_workspace_bytes": (_Z, [_I]),
     "shasta_nms_rotated_f32": (_I, [_P, _I, _F, _P, _Z, _P, _P, _P]),
+    "shasta_nms_normal_f32": (_I, [_P, _I, _F, _P, _Z, _P, _P, _P]),
+    "shasta_boxes_bev_f32": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "shasta_center_greedy_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "shasta_decode_flags_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "shasta_gemm_strided_f32": (_I, [_P, C.c_long, C.c_long, _P, C.c_long, C.c_long, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),

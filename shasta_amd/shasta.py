@@ -106,6 +106,8 @@ class Shasta(BaseTrack):
         # HIP-side state (not parameters, not in state_dict)
         self._packed = None
         self._packed_key = None
+        self._aux = None
+        self._aux_key = None
         self._conv_packed = None
         self._conv_key = None
         self._wstruct = None
@@ -213,9 +215,8 @@ class Shasta(BaseTrack):
         return w
 
     def _ensure_packed(self, w, device):
-        key = tuple((p.data_ptr(), p._version) for p in self._small_params()) + (self.arithmetic,)
-        if self.arithmetic == "f16x2":  # the packed buffer then also holds the range exponents of the first-layer weight rows
-            key += tuple((self.aug_shape[i][0].weight.data_ptr(), self.aug_shape[i][0].weight._version) for i in range(4))
+        """Packed copy of the small pair / aff weights (shasta_pack_weights_f32): rebuilt when one of those tensors changed."""
+        key = tuple((p.data_ptr(), p._version) for p in self._small_params())
         if self._packed is not None and self._packed_key == key and self._packed.device == device:
             return
         lib = hip.load()
@@ -226,6 +227,25 @@ class Shasta(BaseTrack):
         hip.check(lib.shasta_pack_weights_f32(C.byref(w), hip.ptr(self._packed), nbytes, hip.stream_ptr()),
                   "shasta_pack_weights_f32")
         self._packed_key = key
+
+    def _ensure_aux(self, w, B, device):
+        """Companion of the four aug_shape first-layer matrices (their row maxima, shasta_aug_shape_aux_f32): one pass over 4.1 GB at
+        N=500, so it is computed lazily - only for a forward that takes the fp16 weight stream (arithmetic "f16x2", more than 64
+        frame-pairs) - and again only after one of the four matrices changed (an optimizer step bumps their versions; training
+        batches <= 64 never pay for it).  Without it the library recomputes the maxima inside every such call."""
+        need = self.arithmetic == "f16x2" and B > 64 and self.max_obj * self.aug_shape_output >= 64
+        if not need:
+            w.aug_shape_aux = None
+            return
+        key = tuple((self.aug_shape[i][0].weight.data_ptr(), self.aug_shape[i][0].weight._version) for i in range(4))
+        if self._aux is None or self._aux_key != key or self._aux.device != device:
+            lib = hip.load()
+            nbytes = lib.shasta_aug_shape_aux_bytes(self.max_obj, self.aug_shape_output)
+            self._aux = torch.empty(nbytes // 4, dtype=torch.int32, device=device)
+            w.aug_shape_aux = None
+            hip.check(lib.shasta_aug_shape_aux_f32(C.byref(w), hip.ptr(self._aux), nbytes, hip.stream_ptr()), "shasta_aug_shape_aux_f32")
+            self._aux_key = key
+        w.aug_shape_aux = self._aux.data_ptr()
 
     def _work_buffers(self, B, device):
         """Feature / box tables and the stage workspace.  ONE set per device, sized for the largest batch seen so far and
@@ -339,6 +359,7 @@ class Shasta(BaseTrack):
             return torch.empty(0, N, N + 2, device=dev), torch.empty(0, N + 2, N, device=dev)
         w = self._weights()
         self._ensure_packed(w, dev)
+        self._ensure_aux(w, B, dev)
         bufs = self._work_buffers(B, dev)
         self.bev_extractor.gather_boxes(bev_nhwc, det_boxes, self.num_point, bufs["feat"])
         self.bev_extractor.gather_boxes(prev_bev_nhwc, prev_det_boxes, self.num_point, bufs["prev_feat"])

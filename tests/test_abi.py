@@ -21,7 +21,7 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "library does not export " + n
         assert n in hip.SYMBOLS, "ctypes binding missing for " + n
-    assert lib.shasta_abi_version() == hip.ABI_VERSION == 6
+    assert lib.shasta_abi_version() == hip.ABI_VERSION == 7
     assert b"gfx950" in lib.shasta_build_info()
 
 
@@ -46,6 +46,7 @@ def test_size_queries_do_not_need_a_gpu():
     lib = hip.load()
     assert lib.shasta_packed_bytes(500, 7, 256) > 0
     assert lib.shasta_packed_bytes(500, 7, 128) == 0  # unsupported feature width is reported, not guessed
+    assert lib.shasta_aug_shape_aux_bytes(500, 256) >= 4 * 2000 * 4  # one maximum per first-layer weight row
     assert lib.shasta_forward_workspace_bytes(8, 500, 7, 256) > 8 * 502 * 504 * 4
     assert lib.shasta_voxelize_workspace_bytes(300000, 160000, 10) > 160000 * 10 * 4
     import ctypes as C

@@ -42,3 +42,15 @@ def test_bench_rank_count_mismatch_fails():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                        timeout=120, env=env, cwd=ROOT)
     assert r.returncode != 0
+
+
+def test_a_dead_rank_ends_the_launch_instead_of_hanging_it():
+    """Round-2 advisor finding: rank 1 dies before the rendezvous (test hook of --dry-run); rank 0 would wait in init_process_group
+    for ever.  The launcher polls all children, stops the survivors and returns the failing rank's code."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=240, env=dict(_env(), SHASTA_BENCH_DRY_FAIL_RANK="1"), cwd=ROOT)
+    assert r.returncode == 7, (r.returncode, r.stderr[-1000:])
+    assert "rank 1 exited with code 7" in r.stderr and not _json_lines(r.stdout)
+    assert time.monotonic() - t0 < 120

@@ -347,6 +347,68 @@ def test_forward_is_deterministic_and_repack_tracks_weights():
     assert not torch.equal(a1, a3)
 
 
+def test_aug_shape_aux_is_lazy_tracks_the_weights_and_is_optional():
+    """ABI 7 (round-2 advisor finding): the row maxima of the four aug_shape first-layer matrices are a companion buffer of their
+    own (shasta_aug_shape_aux_f32 / shasta_weights.aug_shape_aux), not a section of the packed small weights.  The module computes
+    it only for a forward that takes the fp16 weight stream (more than 64 frame-pairs), again after the matrices changed, and a C
+    caller that passes NULL gets the same tables (the library recomputes the maxima per call)."""
+    import shasta_amd
+    from shasta_amd import hip
+    dev = _dev()
+    torch.manual_seed(3)
+    N, B = 40, 70
+    m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075],
+                                                            out_stride=8), max_obj=N, num_feats=7, num_point=4, in_channels=8)).eval().to(dev)
+    m.keep_intermediates = True
+    g = torch.Generator().manual_seed(4)
+    bev = torch.relu(torch.randn(B, 60, 60, 64, generator=g)).to(dev)
+    m.bev_extractor.out_stride = 24
+    det, prev = O.synth_boxes(g, B, N).to(dev), O.synth_boxes(g, B, N).to(dev)
+
+    def anchors(mode, nb=B):
+        m.arithmetic = mode
+        with torch.no_grad():
+            m.affinity_from_bev(bev[:nb], bev[:nb], det[:nb].clone(), prev[:nb])
+        im = m.last_intermediates
+        return torch.cat([im["feature"][:, N:], im["prev_feature"][:, N:]], 1).clone()
+
+    anchors("f16x2", 8)
+    assert m._aux is None  # a training-size batch never takes the fp16 weight stream: no pass over the first-layer weights
+    a16, a32 = anchors("f16x2"), anchors("f32")
+    assert m._aux is not None
+    key0 = m._aux_key
+    assert float((a16 - a32).abs().max()) <= 2e-5 * float(a32.abs().max())
+    anchors("f16x2")
+    assert m._aux_key == key0  # unchanged weights: not recomputed
+    with torch.no_grad():  # rows scaled by 1e-3 ... 1e3: stale exponents would overflow fp16 or lose the small rows
+        H = m.aug_shape[0][0].weight.shape[0]
+        for i in range(4):
+            m.aug_shape[i][0].weight.mul_(torch.logspace(-3, 3, H, device=dev).flip(0 if i & 1 else -1).unsqueeze(1))
+    b16, b32 = anchors("f16x2"), anchors("f32")
+    assert m._aux_key != key0
+    assert torch.isfinite(b16).all() and float((b16 - b32).abs().max()) <= 2e-5 * float(b32.abs().max())
+    # C caller: NULL companion == companion given, bit for bit
+    lib = hip.load()
+    m.arithmetic = "f16x2"
+    w = m._weights()
+    tabs = {}
+    for given in (True, False):
+        m._ensure_aux(w, B, dev)
+        if not given:
+            w.aug_shape_aux = None
+        f1, f2 = m.last_intermediates["feature"].clone(), m.last_intermediates["prev_feature"].clone()
+        f1[:, N:] = 0
+        f2[:, N:] = 0
+        wsb = lib.shasta_forward_workspace_bytes(B, N, 7, 256)
+        ws = torch.zeros(wsb // 4 + 1, device=dev)
+        hip.check(lib.shasta_anchor_shape_f32(C.byref(w), B, hip.ptr(f1), hip.ptr(f2), hip.ptr(ws), wsb, hip.stream_ptr()), "anchor_shape")
+        torch.cuda.synchronize()
+        tabs[given] = (f1, f2)
+    assert torch.equal(tabs[True][0], tabs[False][0]) and torch.equal(tabs[True][1], tabs[False][1])
+    assert torch.equal(tabs[True][0][:, N:], b16[:, :2])
+
+
 def test_anchor_boxes_are_fresh_tensors_and_work_buffers_are_bounded():
     """shasta.py:260-267 leaves newborn / fp / dead_trk / fn on the module as tensors of that forward: a later forward (another
     batch, same size) must not change them.  The work buffers are one set per device (largest batch), not one per batch size."""

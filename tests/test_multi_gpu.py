@@ -1,0 +1,109 @@
+"""Multi-rank paths on REAL GPUs over RCCL (rows e / BASELINE configs 4-5).  Every other multi-rank test of the suite runs on
+gloo / CPU; these run whenever the box has at least two GPUs and skip on a 1-GPU lease, so the first bigger box exercises them:
+  (i)  bench.py --gpus 2 typed as is: two replicas, one JSON line, n_gpus == 2, throughput about twice one replica's;
+  (ii) the data-parallel training step of tools/nusc_shasta/train.py:155-156,198-218 on two ranks: SyncBatchNorm statistics over
+       both ranks, the rank-B factor all-gather inside the HIP backward, allreduce_gradients for the rest - equal to ONE process
+       over the whole batch (the same reference computation as tests/test_training_ddp.py uses on gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.test_training_ddp import _ddp_case, _free_port
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _need(n):
+    if torch.cuda.device_count() < n:
+        pytest.skip("needs %d GPUs, this box has %d" % (n, torch.cuda.device_count()))
+
+
+def _bench(gpus):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "6", "--warmup", "2", "--batch", "64",
+                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return lines[0]
+
+
+def test_bench_two_replicas_on_two_gpus():
+    _need(2)
+    one, two = _bench(1), _bench(2)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert two["config"]["frame_pairs_per_step_per_gpu"] == 64 and two["selfcheck_max_abs"] <= 1e-6
+    # replicas, no data-path collective: the whole-job rate is the sum (MAX over ranks of the time; allow clock / box spread)
+    assert 1.6 * one["value"] <= two["value"] <= 2.3 * one["value"], (one["value"], two["value"])
+
+
+def _nccl_train_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from shasta_amd import training
+    from shasta_amd.sync_bn import convert_syncbn_model
+    model, bev, pbev, det, prev, gt = _ddp_case()
+    model = model.to(dev)
+    convert_syncbn_model(model)
+    model.train()
+    sl = slice(rank * 2, rank * 2 + 2)
+    ex = dict(det_boxes=det[sl].to(dev).contiguous(), prev_det_boxes=prev[sl].to(dev).contiguous(), bev_map=bev[sl].to(dev),
+              prev_bev_map=pbev[sl].to(dev))
+    m1, m2, _ = model(ex, train_mode=True)       # shared_conv in train() mode (SyncBN) -> affinity_train (HIP forward + backward)
+    training.affinity_loss(m1, m2, gt[sl].to(dev)).backward()
+    flagged = [bool(getattr(model.aug_shape[i][0].weight, "_shasta_grad_is_global", False)) for i in range(4)]
+    training.allreduce_gradients([p for p in model.parameters() if p.grad is not None])
+    out = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None}
+    out["__running_mean"] = model.shared_conv[1].running_mean.cpu().numpy()
+    out["__flagged"] = flagged
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_two_rank_rccl_train_step_equals_the_single_process_step():
+    _need(2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    assert all(res[r]["__flagged"] == [True] * 4 for r in range(2))  # the factor exchange ran (world 2), not the dense all-reduce
+    # one process over the whole batch: BatchNorm statistics of all four maps, mean of the two per-rank losses (CPU autograd of the oracle)
+    from oracle import shasta_oracle as O
+    model, bev, pbev, det, prev, gt = _ddp_case()
+    model.train()
+    w = dict(model.named_parameters())
+    w.update(dict(model.named_buffers()))
+    a = model.shared_conv(bev).permute(0, 2, 3, 1).contiguous()
+    b = model.shared_conv(pbev).permute(0, 2, 3, 1).contiguous()
+    loss = 0
+    for r in range(2):
+        sl = slice(2 * r, 2 * r + 2)
+        m1, m2 = O.forward_from_bev(w, a[sl], b[sl], det[sl].clone(), prev[sl].clone(), 3, 4, grad=True)
+        loss = loss + O.affinity_loss(m1, m2, gt[sl]) / 2
+    loss.backward()
+    want = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert len(want) > 60 and set(want) <= set(res[0])
+    for n, g in want.items():
+        for r in range(2):
+            scale = max(float(g.abs().max()), 1e-8)
+            assert float((torch.from_numpy(res[r][n]) - g).abs().max()) <= 2e-3 * scale + 1e-7, (n, r)  # HIP backward vs autograd: 2e-3 as in test_training.py
+    assert torch.allclose(torch.from_numpy(res[0]["__running_mean"]), model.shared_conv[1].running_mean, rtol=1e-4, atol=1e-6)
+    assert (res[0]["__running_mean"] == res[1]["__running_mean"]).all()

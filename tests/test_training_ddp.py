@@ -150,3 +150,68 @@ def test_two_rank_train_step_equals_the_single_process_step():
     for k, ref in (("__running_mean", model.shared_conv[1].running_mean), ("__running_var", model.shared_conv[1].running_var)):
         assert torch.allclose(torch.from_numpy(res[0][k]), ref, rtol=1e-4, atol=1e-6), k
         assert torch.equal(torch.from_numpy(res[0][k]), torch.from_numpy(res[1][k]))
+
+
+def _syncbn_worker(rank, world, port, q):
+    """SyncBatchNorm corner cases (round-2 advisor findings): activations with |mean| >> std, ragged per-rank counts, affine=False,
+    track_running_stats=False, 1-D inputs, a root module that is itself a BatchNorm.  Reference = one process over the whole batch."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from shasta_amd.sync_bn import SyncBatchNorm, convert_syncbn_model
+    g = torch.Generator().manual_seed(5)
+    full = torch.randn(7, 6, 5, 4, generator=g) * 1e-2 + 3e3       # mean 3000, std 0.01: E[x^2] - mean^2 has no bits left in fp32
+    cut = 3                                                        # ragged: 3 and 4 items
+    mine = (full[:cut] if rank == 0 else full[cut:]).clone().requires_grad_(True)
+    ok = True
+    for affine, track in ((True, True), (False, True), (True, False)):
+        torch.manual_seed(1)
+        ref_bn = torch.nn.BatchNorm2d(6, affine=affine, track_running_stats=track).double()
+        if affine:
+            with torch.no_grad():
+                ref_bn.weight.uniform_(0.5, 1.5)
+                ref_bn.bias.uniform_(-1, 1)
+        bn = convert_syncbn_model(torch.nn.BatchNorm2d(6, affine=affine, track_running_stats=track))  # root module converted
+        ok = ok and isinstance(bn, SyncBatchNorm)
+        if affine:
+            with torch.no_grad():
+                bn.weight.copy_(ref_bn.weight.float())
+                bn.bias.copy_(ref_bn.bias.float())
+        x64 = full.double().requires_grad_(True)
+        yr = ref_bn(x64)
+        yr.square().sum().backward()
+        y = bn(mine)
+        y.square().sum().backward()
+        want = yr[:cut] if rank == 0 else yr[cut:]
+        ok = ok and float((y.double() - want).abs().max()) < 2e-2 * float(want.abs().max())  # x itself carries 2.4e-4 / 1e-2 of noise
+        ok = ok and bool(torch.isfinite(mine.grad).all())
+        if track:
+            ok = ok and torch.allclose(bn.running_var.double(), ref_bn.running_var, rtol=5e-2) and int(bn.num_batches_tracked) == 1
+        else:
+            ok = ok and bn.running_mean is None
+        mine.grad = None
+    # well-conditioned data: tight agreement incl. gradients, 1-D input (N, C)
+    x = torch.randn(10, 4, generator=g)
+    ref = torch.nn.BatchNorm1d(4).double()
+    bn1 = convert_syncbn_model(torch.nn.Sequential(torch.nn.BatchNorm1d(4)))[0]
+    xr = x.double().requires_grad_(True)
+    (ref(xr) * torch.arange(4.0)).sum().backward()
+    part = (x[:6] if rank == 0 else x[6:]).clone().requires_grad_(True)
+    (bn1(part) * torch.arange(4.0)).sum().backward()
+    gref = xr.grad[:6] if rank == 0 else xr.grad[6:]
+    ok = ok and torch.allclose(part.grad.double(), gref, atol=1e-5)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_syncbn_is_stable_for_large_means_and_handles_the_optional_parts():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

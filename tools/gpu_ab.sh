@@ -9,7 +9,7 @@ cd $R
 for round in $(seq 1 ${AB_ROUNDS:-2}); do
   for lib in "$@"; do
     name=$(basename $lib .so)
-    SHASTA_HIP_LIB=$R/$lib python bench.py --no-cpu-baseline --steps ${AB_STEPS:-40} > $O/${name}_$round.json 2> $O/${name}_$round.err
+    SHASTA_HIP_LIB=$R/$lib python bench.py --no-cpu-baseline --no-extras --steps ${AB_STEPS:-40} > $O/${name}_$round.json 2> $O/${name}_$round.err
     python - <<PY
 import json
 d=json.loads(open("$O/${name}_$round.json").read().strip().splitlines()[-1])

@@ -16,7 +16,7 @@ for k in ("roofline","roofline_second"):
     print(k, d[k]["kernel"][:30], "ms %.3f frac %.3f" % (d[k]["avg_launch_ms"], d[k]["frac"]))
 PY
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o d -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o d -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/prof.log 2>&1
 python - <<PY
 import csv
 rows=list(csv.DictReader(open("$O/prof/d_kernel_stats.csv")))

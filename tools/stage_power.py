@@ -27,6 +27,7 @@ with torch.device(dev):
 lib = hip.load()
 w = m._weights()
 m._ensure_packed(w, dev)
+m._ensure_aux(w, B, dev)
 F, T = CH * NP, N + 2
 g = torch.Generator(device=dev).manual_seed(1)
 feat = torch.rand(B, T, F, device=dev, generator=g)
