@@ -215,6 +215,7 @@ class Bench:
         torch, hip, lib = self.torch, self.hip, self.lib
         model = self.model(cfg)
         model.arithmetic = arithmetic
+        model.precut_weight_stream = not self.args.no_precut
         det0, prev = self.boxes(cfg)
         det0, prev, bev, pbev = det0[:B], prev[:B], self.bev[:B], self.pbev[:B]
         det = det0.clone()
@@ -314,16 +315,17 @@ def rooflines(cfg, arithmetic, r, with_traffic=True):
     hbm_gbs = alg / (l1_ms * 1e-3) / 1e9
     l1_flops = 2.0 * B * 4 * wk.H * wk.K  # dense fp32 flops of the four first layers for B frame-pairs (algorithmic = executed)
     l1_tflops = l1_flops / (l1_ms * 1e-3) / 1e12
-    f32_forced, f16x2 = arithmetic == "f32", arithmetic == "f16x2" and B > 64  # up to 64 frame-pairs the bf16-piece kernel serves
-    if B <= 32:
+    # the two-piece fp16 weight stream serves B > 64, and with the pre-cut weight image (default) every batch of at least 17
+    f32_forced, f16x2 = arithmetic == "f32", arithmetic == "f16x2" and (B > 64 or (PRECUT and B >= 17))
+    if B == 1 or (B <= 32 and not f16x2):
         passes, nprod = 1, 1
     elif f32_forced:
         passes, nprod = -(-B // 64), 1
-    elif f16x2:  # 128 items per weight pass up to 128 frame-pairs, 256 above; three fp16 piece products per fp32 product
+    elif f16x2:  # 32 / 64 / 128 items per weight pass up to 128 frame-pairs, 256 above; three fp16 piece products per fp32 product
         passes, nprod = (1 if B <= 128 else -(-B // 256)), 3
     else:        # 64 / 128 items per pass; six bf16 piece products
         passes, nprod = (1 if B <= 64 else -(-B // 128)), 6
-    hbm_bound = B <= 32 or (not f32_forced and (B <= 128 if f16x2 else B <= 64))  # <= 768 matrix cycles per 4 KB weight tile
+    hbm_bound = B == 1 or (B <= 32 and not f16x2) or (not f32_forced and (B <= 128 if f16x2 else B <= 64))  # <= 1024 matrix cycles per 4 KB weight tile
     if hbm_bound:
         roof_l1 = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS}
     elif f32_forced:
@@ -334,8 +336,9 @@ def rooflines(cfg, arithmetic, r, with_traffic=True):
                    "frac": nprod * l1_tflops / MFMA_BF16_PEAK_TFLOPS, "mfma_dtype": "f16" if f16x2 else "bf16",
                    "note": "executed %s MFMA flops = %d piece products per fp32 product, against the dense bf16 / f16 peak"
                            % ("f16" if f16x2 else "bf16", nprod)}
-    l1_kernel = ("anchor_l1_kernel<1,8> (VALU GEMV)" if B == 1 else "anchor_l1_mfma_kernel (f32 MFMA)" if (B <= 32 or f32_forced)
-                 else "anchor_l1_split_kernel (fp16 pieces)" if f16x2 else "anchor_l1_split_kernel (bf16 pieces)")
+    l1_kernel = ("anchor_l1_kernel<1,8> (VALU GEMV)" if B == 1 else
+                 ("anchor_l1_split_kernel (fp16 pieces%s)" % (", pre-cut weight image" if PRECUT else "")) if f16x2 else
+                 "anchor_l1_mfma_kernel (f32 MFMA)" if (B <= 32 or f32_forced) else "anchor_l1_split_kernel (bf16 pieces)")
     tr, src = _pmc_traffic(B, "l1", l1_kernel) if (with_traffic and headline and arithmetic == "f16x2") else (None, None)
     roof_l1.update({"kernel": "%s: aug_shape.*.0, 4 x %d x %d fp32 weight stream" % (l1_kernel, wk.H, wk.K),
                     "traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": alg, "weight_passes_executed": passes,
@@ -368,6 +371,7 @@ def rooflines(cfg, arithmetic, r, with_traffic=True):
     return roof_l1, roof_pair
 
 
+PRECUT = True                            # Shasta.precut_weight_stream of this run (main() clears it for --no-precut)
 PAIR_F16_WIDTHS = (256,)                 # feature widths pair_f16_kernel is instantiated for
 PAIR_F16_LAYER2_SLOTS = {256: 2048}      # multiply-add slots of its layer-2 MFMAs per pair and piece product (16 rows x 128 k)
 
@@ -399,6 +403,8 @@ def main():
     ap.add_argument("--arithmetic", choices=["f16x2", "pieces", "f32"], default="f16x2",
                     help="Shasta.arithmetic: how fp32 products are formed on the matrix cores above the batch thresholds: two fp16 pieces for "
                          "the weight stream + three bf16 pieces elsewhere (default), three bf16 pieces everywhere, or f32 MFMA kernels only")
+    ap.add_argument("--no-precut", action="store_true", help="Shasta.precut_weight_stream = False: cut the fp32 first-layer weights inside the "
+                                                             "weight-stream kernel instead of streaming the pre-cut fp16 piece image (+4.1 GB resident)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only, on the CPU with gloo (no GPU, no forward): for the CPU test suite")
     args = ap.parse_args()
@@ -423,6 +429,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
     assert args.gpus == world, "--gpus must equal the number of launched ranks (WORLD_SIZE)"
 
+    global PRECUT
+    PRECUT = not args.no_precut
     bench = Bench(args, dev, rank, world, dist)
     B = args.batch
     energy = EnergyCounter(dev)
@@ -443,7 +451,7 @@ def main():
                                "NHWC BEV features (SURVEY 8a rows 4-16)", "frame_pairs_per_step_per_gpu": B,
                    "max_obj": N_OBJ, "num_feats": NF, "num_point": NPOINT, "bev_hw": HW,
                    "parallelism": "replica x%d (frame-parallel, no data-path collective)" % world,
-                   "hip_graph": bool(args.graph),
+                   "hip_graph": bool(args.graph), "precut_weight_stream": not args.no_precut,
                    "arithmetic": {"f16x2": "fp32 operands in HBM, fp32 accumulation throughout; above 32 frame-pairs per step the first "
                                            "aug_shape layer (above 64 frame-pairs) and the second layers of the pair MLPs form every fp32 product from three products of "
                                            "two range-scaled fp16 pieces per operand (round to nearest; measured max error vs float64: weight "

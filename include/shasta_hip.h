@@ -137,6 +137,9 @@ typedef struct shasta_linear {
 #define SHASTA_OPT_F16X2_WEIGHT_STREAM 8 /* aug_shape first layer above 64 frame-pairs from two range-scaled fp16 pieces per operand
                                             (round to nearest, three products per fp32 product) instead of three bf16 pieces (six) */
 #define SHASTA_OPT_F16X2_PAIR 16         /* second layers of the three pair MLPs in the same two-piece fp16 form (feat_dim 256) */
+#define SHASTA_OPT_PRECUT_WEIGHT_STREAM 32 /* with SHASTA_OPT_F16X2_WEIGHT_STREAM: stream the aug_shape first-layer weights as pre-cut fp16
+                                              pieces from the companion buffer (shasta_aug_shape_aux_f32 built with this bit: + 4 bytes per
+                                              weight resident) instead of cutting the fp32 tensors on the fly; same arithmetic, same results */
 
 typedef struct shasta_weights {
     int max_obj;   /* N */
@@ -161,10 +164,12 @@ int shasta_pack_weights_f32(const shasta_weights* w, void* packed, size_t packed
 
 /* Companion of the four aug_shape.{i}.0.weight matrices (N*F/64, N*F), which are used in place and never copied (4.1 GB at
  * N=500, F=256): the largest magnitude of every weight row = the range exponents of the fp16 form of the weight stream
- * (SHASTA_OPT_F16X2_WEIGHT_STREAM, more than 64 frame-pairs per call).  One pass over the matrices.  Hand it to the forward as
+ * (SHASTA_OPT_F16X2_WEIGHT_STREAM, more than 64 frame-pairs per call) and, when w->options holds
+ * SHASTA_OPT_PRECUT_WEIGHT_STREAM, the pre-cut fp16 piece image of the matrices behind them (a forward may only use that option with
+ * a companion built with it).  One pass over the matrices.  Hand it to the forward as
  * shasta_weights.aug_shape_aux and recompute it whenever one of the four matrices changes; with aug_shape_aux == NULL a forward
  * that needs it recomputes it into its workspace on every call (correct, one extra pass over the weights per call). */
-size_t shasta_aug_shape_aux_bytes(int max_obj, int feat_dim);
+size_t shasta_aug_shape_aux_bytes(int max_obj, int feat_dim, int options);
 int shasta_aug_shape_aux_f32(const shasta_weights* w, void* aux, size_t aux_bytes, shasta_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -192,6 +197,20 @@ int shasta_affinity_forward_f32(const shasta_weights* w, const void* packed, int
                                 int box_stride, float* det_tab, float* prev_tab, float* matched1,
                                 float* matched2, float* residual_out, float* matched_out,
                                 void* workspace, size_t workspace_bytes, shasta_stream_t stream);
+
+/* The same forward INCLUDING the gather (K2): rows [0,N) of feat / prev_feat are filled from the NHWC maps bev / prev_bev (B,H,W,C),
+ * C = feat_dim / num_point, with the boxes' geometry arguments of shasta_bev_gather_f32 (the gather reads det_boxes BEFORE the
+ * back-projection, as shasta.py:231-239 does) - i.e. all of Shasta.forward behind shared_conv (shasta.py:231-325) in one call.  Same
+ * results as shasta_bev_gather_f32 x 2 + shasta_affinity_forward_f32, bit for bit; when the fp16 weight stream follows, the gather
+ * also produces the activation row maxima that stream needs, which otherwise take a pass of their own over the tables.
+ * h_events4: NULL, or four events from shasta_event_create recorded around the weight-stream kernel [0],[1] and the pair kernel
+ * [2],[3] (bench.py's live roofline). */
+int shasta_affinity_from_bev_f32(const shasta_weights* w, const void* packed, int B, const float* bev, const float* prev_bev,
+                                 int H, int W, int C, float pc_x0, float pc_y0, float vs_x, float vs_y, float out_stride,
+                                 float* feat, float* prev_feat, float* det_boxes, const float* prev_det_boxes, int box_stride,
+                                 float* det_tab, float* prev_tab, float* matched1, float* matched2, float* residual_out,
+                                 float* matched_out, void* workspace, size_t workspace_bytes, shasta_stream_t stream,
+                                 void* const* h_events4);
 
 /* Training forward: the same kernels and values as shasta_affinity_forward_f32; additionally keeps what the backward
  * needs and the inference path throws away: residual_out (B, N+2, N+2) and shape_hidden_out (B, 4*H), H = N*F/64, the ReLU

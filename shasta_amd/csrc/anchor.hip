@@ -293,16 +293,19 @@ bool anchor_split_serves(int B, int K, int x_batch_stride);
 void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, int B, int x_batch_stride, int np, const unsigned* xmax,
                     hipStream_t st);
 void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part, int H, int K, int B, int* ks_out, int np,
-                            const unsigned* wmax, hipStream_t st);
+                            const unsigned* wmax, const void* wimg, hipStream_t st);
 int launch_x_maxima(const float* feat, const float* prev_feat, int K, int B, int x_batch_stride, unsigned* xmax, hipStream_t st);
 int launch_w_maxima(const float* const W[4], int H, int K, unsigned* wmax, hipStream_t st);
 
 
 // [split-K partials, worst-case KS = 64][hidden (B, 4H)][bf16 activation image of anchor_split.hip, batches > 32 only]
+size_t bev_absmax_slot_bytes(int items);
+
 size_t anchor_shape_workspace_bytes(int B, int N, int F) {
     const int H = N * F / 64;
     return align_up((size_t)64 * B * 4 * H * sizeof(float), 256) + align_up((size_t)B * 4 * H * sizeof(float), 256) +
-           anchor_split_workspace_bytes(B, N * F) + align_up((size_t)2 * B * sizeof(int), 256) + align_up((size_t)4 * H * sizeof(int), 256);
+           anchor_split_workspace_bytes(B, N * F) + align_up((size_t)2 * B * sizeof(int), 256) + align_up((size_t)4 * H * sizeof(int), 256) +
+           bev_absmax_slot_bytes(2 * B);
 }
 
 int launch_anchor_l1_mfma(const float* const W[4], const float* feat, const float* prev_feat, float* part, int H, int K,
@@ -323,8 +326,42 @@ const float* anchor_shape_hidden(const void* ws, int B, int N, int F) {
     return reinterpret_cast<const float*>(static_cast<const char*>(ws) + align_up((size_t)64 * B * 4 * H * sizeof(float), 256));
 }
 
+// the pre-cut piece image of the first-layer weights (SHASTA_OPT_PRECUT_WEIGHT_STREAM + a companion buffer built with it), or null
+static const void* precut_image(const shasta_weights* w) {
+    const int K = w->max_obj * w->feat_dim, H = K / 64;
+    const bool on = (w->options & SHASTA_OPT_F16X2_WEIGHT_STREAM) && (w->options & SHASTA_OPT_PRECUT_WEIGHT_STREAM) &&
+                    !(w->options & SHASTA_OPT_F32_WEIGHT_STREAM) && w->aug_shape_aux && K % 32 == 0 && H > 0;
+    return on ? static_cast<const char*>(w->aug_shape_aux) + align_up((size_t)4 * H * sizeof(unsigned), 256) : nullptr;
+}
+// from how many frame-pairs per call the pre-cut fp16 stream replaces the f32 MFMA / bf16-piece kernels of the smaller batches.
+// Measured per step at N=500 (with / without): 2: 0.828 / 0.769 ms, 8: 0.922 / 0.878, 16: 1.019 / 1.006 (the 16x16x4 f32 kernel
+// streams 16 rows at 0.60 - 0.65 ms and needs no row maxima / activation image), 32: 1.250 / 1.335, 48: 1.534 / 1.707,
+// 64: 1.715 / 1.893, 128: 2.844 / 2.872.
+constexpr int PRECUT_MIN_BATCH = 17;
+// does anchor_shape take the two-piece fp16 weight stream for this call (and therefore need the activation row maxima)?
+bool anchor_shape_uses_xmax(const shasta_weights* w, int B) {
+    const int N = w->max_obj, F = w->feat_dim;
+    if ((w->options & SHASTA_OPT_F32_WEIGHT_STREAM) || !(w->options & SHASTA_OPT_F16X2_WEIGHT_STREAM)) return false;
+    if (precut_image(w) && B >= PRECUT_MIN_BATCH) return true;
+    return anchor_split_serves(B, N * F, (N + 2) * F) && B > 64;
+}
+// where anchor_shape keeps those maxima ([2 frames: feat, prev_feat][B] float bit patterns): a producer of the tables that already
+// knows them (the gather of shasta_affinity_from_bev_f32) writes them here and passes xmax_ready
+unsigned* anchor_shape_xmax(void* ws, int B, int N, int F) {
+    const size_t H = (size_t)N * F / 64;
+    char* hidden = static_cast<char*>(ws) + align_up((size_t)64 * B * 4 * H * sizeof(float), 256);
+    char* xs = hidden + align_up((size_t)B * 4 * H * sizeof(float), 256);
+    return reinterpret_cast<unsigned*>(xs + anchor_split_workspace_bytes(B, N * F));
+}
+// ... and the scratch lines the gather posts into before they are reduced to those maxima (bev_gather.hip): [2 B][slots][128 B]
+unsigned* anchor_shape_xmax_slots(void* ws, int B, int N, int F) {
+    const size_t H = (size_t)N * F / 64;
+    return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(anchor_shape_xmax(ws, B, N, F)) + align_up((size_t)2 * B * sizeof(int), 256) +
+                                       align_up((size_t)4 * H * sizeof(int), 256));
+}
+
 int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes,
-                 hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const unsigned* wmax) {
+                 hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const unsigned* wmax, bool xmax_ready) {
     const int N = w->max_obj, F = w->feat_dim;
     const int K = N * F, H = K / 64;
     if (ws_bytes < anchor_shape_workspace_bytes(B, N, F)) {
@@ -356,9 +393,12 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     // w->options the f32 MFMA kernel serves every B >= 2 (64 items per pass, matrix-pipe bound).  K = N*F is a multiple of 64.
     const bool force_f32 = (w->options & SHASTA_OPT_F32_WEIGHT_STREAM) != 0;
     void* xs = reinterpret_cast<char*>(hidden) + align_up((size_t)B * 4 * H * sizeof(float), 256);
-    const bool split = !force_f32 && anchor_split_serves(B, K, a.x_batch_stride);
-    // above 64 frame-pairs the two-piece fp16 form when asked for (up to 64 the three-piece bf16 kernel's 64-row pass is the faster one)
-    const bool f16x2 = split && B > 64 && (w->options & SHASTA_OPT_F16X2_WEIGHT_STREAM) != 0;
+    // the two-piece fp16 form when asked for: above 64 frame-pairs (up to 64 the three-piece bf16 kernel's 64-row pass is the faster one
+    // while the weights are cut inside the kernel), and from PRECUT_MIN_BATCH frame-pairs when the pre-cut image is there: with nothing
+    // but DMA, LDS reads and 6 / 12 MFMAs per 4 KB weight tile the small batches run at the speed of the stream as well
+    const void* wimg = B >= PRECUT_MIN_BATCH ? precut_image(w) : nullptr;
+    const bool f16x2 = anchor_shape_uses_xmax(w, B);
+    const bool split = !force_f32 && (anchor_split_serves(B, K, a.x_batch_stride) || f16x2);
     const int np = f16x2 ? 2 : 3;
     unsigned* xmax = reinterpret_cast<unsigned*>(static_cast<char*>(xs) + anchor_split_workspace_bytes(B, K));
     if (f16x2) {
@@ -368,12 +408,12 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
             if ((rc0 = launch_w_maxima(a.W, H, K, wm, st))) return rc0;
             wmax = wm;
         }
-        if ((rc0 = launch_x_maxima(feat, prev_feat, K, B, a.x_batch_stride, xmax, st))) return rc0;
+        if (!xmax_ready && (rc0 = launch_x_maxima(feat, prev_feat, K, B, a.x_batch_stride, xmax, st))) return rc0;
     }
     if (split) launch_split_x(feat, prev_feat, xs, K, B, a.x_batch_stride, np, xmax, st);
     if (ev0) (void)hipEventRecord(ev0, st);
     if (B == 1) launch_l1<1, R>(a, st);
-    else if (split) launch_anchor_l1_split(a.W, xs, part, H, K, B, &a.KS, np, wmax, st);
+    else if (split) launch_anchor_l1_split(a.W, xs, part, H, K, B, &a.KS, np, wmax, f16x2 ? wimg : nullptr, st);
     else launch_anchor_l1_mfma(a.W, feat, prev_feat, part, H, K, B, a.x_batch_stride, &a.KS, st);
     if (ev1) (void)hipEventRecord(ev1, st);
     int rc = check_launch("anchor_l1");

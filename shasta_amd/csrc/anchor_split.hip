@@ -186,7 +186,65 @@ __global__ __launch_bounds__(256) void split_x_kernel(SplitXArgs a) {
     }
 }
 
+// ---- pre-cut weight image (SHASTA_OPT_PRECUT_WEIGHT_STREAM) ---------------------------------------------------------------------
+// The fp16 form cuts every fp32 weight into its two pieces on the VALU, between the MFMAs, once per BATCH BLOCK (twice per step at
+// 512 frame-pairs).  The image holds the pieces instead: per (MLP, 32-row group, 32-wide k tile) one 4 KB block =
+// [k step 2][piece 2][lane 64][8 fp16] - exactly the four A-operand fragments of a wave, in lane order - i.e. the same 4 bytes per
+// weight on the stream, +4.1 GB resident next to the fp32 checkpoint tensors at N=500, and nothing but LDS-DMA, ds_read and MFMA
+// in the loop.  Built by shasta_aug_shape_aux_f32 behind the row maxima; rebuilt when the weights change, like them.
+struct PrecutArgs {
+    const float* W[4];
+    const unsigned* wmax;  // [4][H]
+    uint32_t* img;
+    int H, K, KT, G;       // G = 32-row groups per MLP
+};
+// grid (cdiv(KT, 8), G, 4), 256 threads: 32 rows x 256 k through LDS (whole 1 KB row segments in, whole 4 KB blocks out)
+__global__ __launch_bounds__(256) void precut_weights_kernel(PrecutArgs a) {
+    __shared__ __attribute__((aligned(16))) float tile[32][260];
+    const int mlp = blockIdx.z, g = blockIdx.y, kt0 = blockIdx.x * 8, nkt = min(8, a.KT - kt0);
+    const float* W = a.W[mlp];
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int r = i >> 6, c4 = i & 63, row = g * 32 + r;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (row < a.H && (c4 >> 3) < nkt) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(W + (size_t)row * a.K + (size_t)kt0 * 32) + c4);
+        *reinterpret_cast<f32x4*>(&tile[r][c4 * 4]) = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, frow = lane & 31, fh = lane >> 5;
+    const int wex = range_exponent_bits(a.wmax[mlp * a.H + min(g * 32 + frow, a.H - 1)]);
+    for (int f = threadIdx.x >> 6; f < 2 * nkt; f += 4) {  // (k tile, k step) pairs, one per wave
+        const int ktl = f >> 1, sstep = f & 1;
+        const float* p = &tile[frow][ktl * 32 + 16 * sstep + 8 * fh];
+        u32x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            _Float16 h0, l0, h1, l1;
+            split2h(__builtin_ldexpf(p[2 * j], wex), h0, l0);
+            split2h(__builtin_ldexpf(p[2 * j + 1], wex), h1, l1);
+            hi[j] = pack_h2(h0, h1);
+            lo[j] = pack_h2(l0, l1);
+        }
+        u32x4* o = reinterpret_cast<u32x4*>(a.img) + ((((size_t)mlp * a.G + g) * a.KT + kt0 + ktl) * 4 + sstep * 2) * 64 + lane;
+        o[0] = hi;
+        o[64] = lo;
+    }
+}
+size_t precut_image_bytes(int H, int K) { return (K % 32 != 0 || H == 0) ? 0 : (size_t)4 * cdiv(H, 32) * (K / 32) * 4096; }
+int launch_precut_weights(const float* const W[4], const unsigned* wmax, void* img, int H, int K, hipStream_t st) {
+    PrecutArgs a;
+    for (int i = 0; i < 4; ++i) a.W[i] = W[i];
+    a.wmax = wmax;
+    a.img = static_cast<uint32_t*>(img);
+    a.H = H;
+    a.K = K;
+    a.KT = K / 32;
+    a.G = cdiv(H, 32);
+    hipLaunchKernelGGL(precut_weights_kernel, dim3(cdiv(a.KT, 8), a.G, 4), dim3(256), 0, st, a);
+    return check_launch("precut_weights");
+}
+
 struct AnchorSplitArgs {
+    const uint32_t* wimg;  // PRECUT: the piece image of the weights (above), else unused
     const float* W[4];
     const uint32_t* xs;
     float* part;
@@ -204,8 +262,9 @@ __device__ __forceinline__ void wait_vm_split() {
 }
 
 // XT = batch rows per pass / 32 (2, 4 or 8); NS = ring slots; NP = pieces per operand: 3 (bf16, six products) or 2 (fp16, three)
-template <int XT, int NS, int NP>
+template <int XT, int NS, int NP, bool PRECUT = false>
 __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a) {
+    static_assert(!PRECUT || NP == 2, "the pre-cut image holds fp16 pieces");
     constexpr int NPROD = NP == 3 ? 6 : 3;
     constexpr int XCH = 2 * NP * XT;             // 1 KB fragments of one x tile
     constexpr int XPW = XCH / 4;                 // of which every wave fetches this many
@@ -216,8 +275,10 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
     constexpr int NM = 2 * NPROD * XT;           // MFMAs per tile
     constexpr int ND = PER_TILE;                 // LDS-DMA instructions per tile and wave
     constexpr int NR = 4 + XCH;                  // ds_read_b128 per tile and wave
-    constexpr int SG = (NM - 8) / 16;            // MFMA gaps between two weight elements being cut
-    static_assert(1 + NR < NM && 6 + 15 * SG < NM, "side work must fit the MFMA gaps of one tile");
+    constexpr int SG = PRECUT ? 1 : (NM - 8) / 16;  // MFMA gaps between two weight elements being cut
+    constexpr int RPG = PRECUT ? (NR + NM - 2) / (NM - 1) : 1;  // ds_read_b128 per MFMA gap (the pre-cut form also serves 32 / 64 items per pass)
+    static_assert(PRECUT ? (1 + (NR + RPG - 1) / RPG <= NM && 1 + ND <= NM) : (1 + NR < NM && 6 + 15 * SG < NM),
+                  "side work must fit the MFMA gaps of one tile");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -239,7 +300,8 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
     const int kt_beg = ks * tpc, NT = min(a.KT, kt_beg + tpc) - kt_beg;
 
     const float* wbase = mlp == 0 ? a.W[0] : mlp == 1 ? a.W[1] : mlp == 2 ? a.W[2] : a.W[3];
-    const char* wub = reinterpret_cast<const char*>(wbase + (size_t)r0 * a.K + (size_t)kt_beg * 32);
+    const char* wub = PRECUT ? reinterpret_cast<const char*>(a.wimg) + (((size_t)mlp * a.groups_per_mlp + (r0 >> 5)) * a.KT + kt_beg) * 4096
+                             : reinterpret_cast<const char*>(wbase + (size_t)r0 * a.K + (size_t)kt_beg * 32);
     const char* xub = reinterpret_cast<const char*>(a.xs) + ((((size_t)src * a.NBLK + bblk) * a.KT + kt_beg) * XCH) * 1024;
     uint32_t woff[4];
     {
@@ -250,15 +312,16 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
             const int c = cpos ^ ((r >> 1) & 7);
             woff[j] = (uint32_t)(((min(r0 + r, a.H - 1) - r0) * a.K + 4 * c) * 4);
         }
+        if (PRECUT) woff[0] = (uint32_t)(lane * 16);  // fragments are lane-linear in the image
     }
     const uint32_t xoff = (uint32_t)(lane * 16 + wid * 1024);
     const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) float*)lds);
     // instruction idx of this wave for tile t (relative to kt_beg) into ring slot `slot`; no VALU: scalar base + 32-bit lane offset
     auto dma = [&](int t, int slot, int idx) {
         if (idx < 4) {
-            const char* base = wub + (size_t)t * 128;
+            const char* base = PRECUT ? wub + (size_t)t * 4096 + (size_t)idx * 1024 : wub + (size_t)t * 128;
             const uint32_t dst = lds0 + (uint32_t)((slot * SLOT + wid * 1024 + idx * 256) * 4);
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(woff[idx]), "s"(base), "s"(dst)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(PRECUT ? woff[0] : woff[idx]), "s"(base), "s"(dst)
                          : "memory", "m0");
         } else {
             const int i = idx - 4;
@@ -283,7 +346,8 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
         const float* sl = lds + slot * SLOT;
         if (idx < 4) {
             const int s = idx >> 1, qq = idx & 1;
-            raw[idx] = *reinterpret_cast<const f32x4*>(sl + wid * 1024 + frow * 32 + (((4 * s + 2 * fh + qq) ^ fsw) * 4));
+            if constexpr (PRECUT) f.A[s][qq] = *reinterpret_cast<const u32x4*>(sl + wid * 1024 + idx * 256 + lane * 4);  // [k step][piece]
+            else raw[idx] = *reinterpret_cast<const f32x4*>(sl + wid * 1024 + frow * 32 + (((4 * s + 2 * fh + qq) ^ fsw) * 4));
         } else {
             const int j = idx - 4;
             f.X[j / (2 * NP)][(j / NP) % 2][j % NP] = *reinterpret_cast<const u32x4*>(sl + 4096 + j * 256 + lane * 4);
@@ -294,8 +358,9 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
     float ph = 0.0f, pm = 0.0f, pl = 0.0f;
     _Float16 qh = 0, ql = 0;
     int wex = 0;  // exponent of this lane's weight row
-    if constexpr (NP == 2) wex = range_exponent_bits(a.wmax[mlp * a.H + min(r0 + frow, a.H - 1)]);
+    if constexpr (NP == 2 && !PRECUT) wex = range_exponent_bits(a.wmax[mlp * a.H + min(r0 + frow, a.H - 1)]);
     auto cut_one = [&](Frag& f, int e) {
+        if constexpr (PRECUT) return;
         const int s = e >> 3, d = (e & 7) >> 1;
         if constexpr (NP == 2) {
             _Float16 h, l;
@@ -383,8 +448,14 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
             if (i >= 1 && i - 1 < ND) {
                 if constexpr (STEADY) dma(t + NS, sc, i - 1);
             }
-            if (i >= 1 && i - 1 < NR) read_one(sn, nxt, i - 1);
-            if (i >= 6 && (i - 6) % SG == 0 && (i - 6) / SG < 16) cut_one(nxt, (i - 6) / SG);
+            if (i >= 1) {
+#pragma unroll
+                for (int r = 0; r < RPG; ++r)
+                    if ((i - 1) * RPG + r < NR) read_one(sn, nxt, (i - 1) * RPG + r);
+            }
+            if constexpr (!PRECUT) {
+                if (i >= 6 && (i - 6) % SG == 0 && (i - 6) / SG < 16) cut_one(nxt, (i - 6) / SG);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -431,12 +502,13 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
 }
 
 // np = pieces per operand: 3 = bf16 (six products), 2 = fp16 (three products, SHASTA_OPT_F16X2_WEIGHT_STREAM)
-static inline int split_xt(int B, int np) { return np == 2 ? (B > 128 ? 8 : 4) : (B <= 64 ? 2 : 4); }  // np == 2 is used above 64 rows
+// np == 2 without the pre-cut image is used above 64 rows only; with it, 32 / 64 items per pass serve the smaller batches too
+static inline int split_xt(int B, int np) { return np == 2 ? (B > 128 ? 8 : B > 64 ? 4 : B > 32 ? 2 : 1) : (B <= 64 ? 2 : 4); }
 static inline int split_nblk(int B, int np) { return cdiv(B, 32 * split_xt(B, np)); }
 
 // bytes of the piece image of the activations (0 for batches the f32 kernels serve): sized for the larger of the two forms
 size_t anchor_split_workspace_bytes(int B, int K) {
-    if (B <= 32 || K % 32 != 0) return 0;
+    if (B < 2 || K % 32 != 0) return 0;
     const size_t b3 = (size_t)2 * split_nblk(B, 3) * 32 * split_xt(B, 3) * (size_t)K * 6;
     const size_t b2 = (size_t)2 * split_nblk(B, 2) * 32 * split_xt(B, 2) * (size_t)K * 4;
     return align_up(b3 > b2 ? b3 : b2, 256);
@@ -464,7 +536,7 @@ void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, 
 }
 
 void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part, int H, int K, int B, int* ks_out, int np,
-                            const unsigned* wmax, hipStream_t st) {
+                            const unsigned* wmax, const void* wimg, hipStream_t st) {
     const int XT = split_xt(B, np), NBLK = split_nblk(B, np), KT = K / 32;
     AnchorSplitArgs a;
     for (int i = 0; i < 4; ++i) a.W[i] = W[i];
@@ -477,6 +549,7 @@ void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part
     a.NBLK = NBLK;
     a.groups_per_mlp = cdiv(H, 32);
     a.wmax = wmax;
+    a.wimg = static_cast<const uint32_t*>(wimg);
     const int quads = cdiv(2 * a.groups_per_mlp, 4);  // workgroups per (K chunk, frame)
     int ncu = 256;
     {
@@ -511,7 +584,12 @@ void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         hipLaunchKernelGGL(kern, dim3(2 * a.KS * quads * NBLK), dim3(256), ldsb, st, a);
     };
-    if (np == 2) {
+    if (np == 2 && wimg) {
+        if (XT == 1) launch(anchor_l1_split_kernel<1, 6, 2, true>, 6, 1);
+        else if (XT == 2) launch(anchor_l1_split_kernel<2, 5, 2, true>, 5, 2);
+        else if (XT == 4) launch(anchor_l1_split_kernel<4, 4, 2, true>, 4, 4);
+        else launch(anchor_l1_split_kernel<8, 3, 2, true>, 3, 8);
+    } else if (np == 2) {
         if (XT == 4) launch(anchor_l1_split_kernel<4, 4, 2>, 4, 4);
         else launch(anchor_l1_split_kernel<8, 3, 2>, 3, 8);
     } else if (XT == 2) launch(anchor_l1_split_kernel<2, 5, 3>, 5, 2);  // 4 slots measure the same: the ring depth is not the limit

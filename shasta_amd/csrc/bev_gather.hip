@@ -17,15 +17,23 @@ namespace shasta {
 // (__fmul_rn/__fadd_rn/__fsub_rn, never contracted) because the reference evaluates them as
 // separate ATen ops; the metric->pixel map keeps the reference's two successive divisions
 // (bird_eye_view.py:19-20) -- a fused reciprocal changes floor() for ~1e-6 of coordinates.
+// ABSMAX: additionally the largest magnitude written per batch item (bit pattern of a non-negative float, atomicMax: order
+// independent) into the ABSMAX_SLOTS x 128-byte lines absmax[b][slot][0] - the range exponent of the fp16 form of the aug_shape
+// weight stream (anchor_split.hip), which otherwise costs a pass of its own over the tables (row_max_kernel: 0.12 ms at 512
+// frame-pairs).  The lines must be zero on entry.
+constexpr int ABSMAX_SLOTS = 8;
+template <bool ABSMAX>
 __global__ __launch_bounds__(256) void bev_gather_kernel(
     const float* __restrict__ bev, int H, int W, int C, const float* __restrict__ boxes, int N,
     int box_stride, int box_batch_stride, int num_point, float pc_x0, float pc_y0, float vs_x,
     float vs_y, float out_stride_px, float* __restrict__ out, int out_row_stride,
-    int out_batch_stride, int total_points) {
+    int out_batch_stride, int total_points, unsigned* __restrict__ absmax) {
     // 16 lanes per point: each lane owns 4 consecutive channels (one 16-byte load per corner), 4 points per wave
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int wave_raw = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int lane = threadIdx.x & 15;
-    if (wave >= total_points) return;
+    if (!ABSMAX && wave_raw >= total_points) return;
+    const bool live = wave_raw < total_points;
+    const int wave = live ? wave_raw : total_points - 1;  // ABSMAX: a spare group repeats the last point (no store) and joins the shuffles
     const int pt = wave % num_point;
     const int n = (wave / num_point) % N;
     const int b = wave / (num_point * N);
@@ -86,6 +94,7 @@ __global__ __launch_bounds__(256) void bev_gather_kernel(
     const float* Ic = im + ((size_t)y0 * W + x1) * C;
     const float* Id = im + ((size_t)y1 * W + x1) * C;
     float* o = out + (size_t)b * out_batch_stride + (size_t)n * out_row_stride + (size_t)pt * C;
+    float amax = 0.0f;
     if ((C & 3) == 0) {
         for (int c4 = lane; c4 < C / 4; c4 += 16) {
             const f32x4 a = reinterpret_cast<const f32x4*>(Ia)[c4], b4 = reinterpret_cast<const f32x4*>(Ib)[c4];
@@ -98,8 +107,9 @@ __global__ __launch_bounds__(256) void bev_gather_kernel(
                 v = __fadd_rn(v, __fmul_rn(c[q], wc));
                 v = __fadd_rn(v, __fmul_rn(d[q], wd));
                 r[q] = v;
+                if (ABSMAX) amax = fmaxf(amax, fabsf(v));
             }
-            reinterpret_cast<f32x4*>(o)[c4] = r;
+            if (live) reinterpret_cast<f32x4*>(o)[c4] = r;
         }
     } else {
         for (int ch = lane; ch < C; ch += 16) {
@@ -107,9 +117,64 @@ __global__ __launch_bounds__(256) void bev_gather_kernel(
             v = __fadd_rn(v, __fmul_rn(Ib[ch], wb));
             v = __fadd_rn(v, __fmul_rn(Ic[ch], wc));
             v = __fadd_rn(v, __fmul_rn(Id[ch], wd));
-            o[ch] = v;
+            if (ABSMAX) amax = fmaxf(amax, fabsf(v));
+            if (live) o[ch] = v;
         }
     }
+    if constexpr (ABSMAX) {
+        // 16 lanes -> one value per point -> (normally) one per wave, posted into one of ABSMAX_SLOTS cache lines of the batch item
+        // (consecutive waves take consecutive lines): every wave of a batch item hitting ONE address serialises on a single L2
+        // channel - measured: one atomic per 16-point block 211 -> 267 us per call, a read-then-atomic per wave 2.0 ms.  No LDS, no
+        // barrier.  The consumer reduces the lines (absmax_finalize_kernel).  fmaxf drops a NaN; a NaN / inf in the tables then
+        // shows up in the products themselves.
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 16));
+        if (!live) amax = 0.0f;
+        const int slot = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (ABSMAX_SLOTS - 1);
+        const int b_first = __shfl(b, 0, 64), b_last = __shfl(b, 48, 64);  // batch items are non-decreasing along the wave's four points
+        if (b_first == b_last) {
+            amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            if ((threadIdx.x & 63) == 0) atomicMax(absmax + ((size_t)b * ABSMAX_SLOTS + slot) * 32, __float_as_uint(amax));
+        } else if (lane == 0) {
+            atomicMax(absmax + ((size_t)b * ABSMAX_SLOTS + slot) * 32, __float_as_uint(amax));
+        }
+    }
+}
+
+// out[i] = max over the ABSMAX_SLOTS lines of item i (i < n)
+__global__ __launch_bounds__(256) void absmax_finalize_kernel(const unsigned* __restrict__ slots, unsigned* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned m = 0;
+#pragma unroll
+    for (int s = 0; s < ABSMAX_SLOTS; ++s) m = max(m, slots[((size_t)i * ABSMAX_SLOTS + s) * 32]);
+    out[i] = m;
+}
+
+size_t bev_absmax_slot_bytes(int items) { return (size_t)items * ABSMAX_SLOTS * 128; }
+int launch_absmax_finalize(const unsigned* slots, unsigned* out, int items, hipStream_t st) {
+    hipLaunchKernelGGL(absmax_finalize_kernel, dim3(cdiv(items, 256)), dim3(256), 0, st, slots, out, items);
+    return check_launch("absmax_finalize");
+}
+
+int launch_bev_gather(const float* bev, int B, int H, int W, int C, const float* boxes, int N, int box_stride, int box_batch_stride,
+                      int num_point, float pc_x0, float pc_y0, float vs_x, float vs_y, float out_stride, float* out, int out_row_stride,
+                      int out_batch_stride, unsigned* absmax, hipStream_t st) {
+    const long total = (long)B * N * num_point;
+    if (total == 0) return SHASTA_OK;
+    SHASTA_REQUIRE(total < (1L << 30), "bev_gather: too many points");
+    const int points_per_block = 16;  // 256 threads, 16 lanes per point
+    const int blocks = cdiv((int)total, points_per_block);
+    if (absmax)
+        hipLaunchKernelGGL(bev_gather_kernel<true>, dim3(blocks), dim3(16 * points_per_block), 0, st, bev, H, W, C, boxes, N, box_stride,
+                           box_batch_stride, num_point, pc_x0, pc_y0, vs_x, vs_y, out_stride, out, out_row_stride, out_batch_stride, (int)total,
+                           absmax);
+    else
+        hipLaunchKernelGGL(bev_gather_kernel<false>, dim3(blocks), dim3(16 * points_per_block), 0, st, bev, H, W, C, boxes, N, box_stride,
+                           box_batch_stride, num_point, pc_x0, pc_y0, vs_x, vs_y, out_stride, out, out_row_stride, out_batch_stride, (int)total,
+                           nullptr);
+    return check_launch("bev_gather");
 }
 
 }  // namespace shasta
@@ -124,13 +189,6 @@ extern "C" int shasta_bev_gather_f32(const float* bev, int B, int H, int W, int 
     SHASTA_REQUIRE(B >= 0 && N >= 0 && H > 0 && W > 0 && C > 0, "bev_gather: bad size");
     SHASTA_REQUIRE(num_point == 1 || num_point == 4 || num_point == 5, "bev_gather: num_point must be 1, 4 or 5");
     SHASTA_REQUIRE(box_stride >= (num_point == 1 ? 2 : 7) && out_row_stride >= num_point * C, "bev_gather: bad stride");
-    const long total = (long)B * N * num_point;
-    if (total == 0) return SHASTA_OK;
-    SHASTA_REQUIRE(total < (1L << 30), "bev_gather: too many points");
-    const int points_per_block = 16;  // 256 threads, 16 lanes per point
-    const int blocks = cdiv((int)total, points_per_block);
-    hipLaunchKernelGGL(bev_gather_kernel, dim3(blocks), dim3(16 * points_per_block), 0, as_stream(stream), bev,
-                       H, W, C, boxes, N, box_stride, box_batch_stride, num_point, pc_x0, pc_y0, vs_x, vs_y,
-                       out_stride, out, out_row_stride, out_batch_stride, (int)total);
-    return check_launch("bev_gather");
+    return launch_bev_gather(bev, B, H, W, C, boxes, N, box_stride, box_batch_stride, num_point, pc_x0, pc_y0, vs_x, vs_y, out_stride, out,
+                             out_row_stride, out_batch_stride, nullptr, as_stream(stream));
 }

@@ -9,7 +9,15 @@ size_t pair_workspace_bytes(int B, int N, int F);
 size_t aff_workspace_bytes(int B, int N);
 const float* anchor_shape_hidden(const void* ws, int B, int N, int F);
 int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes, hipStream_t st,
-                 hipEvent_t ev0, hipEvent_t ev1, const unsigned* wmax);
+                 hipEvent_t ev0, hipEvent_t ev1, const unsigned* wmax, bool xmax_ready);
+bool anchor_shape_uses_xmax(const shasta_weights* w, int B);
+unsigned* anchor_shape_xmax(void* ws, int B, int N, int F);
+unsigned* anchor_shape_xmax_slots(void* ws, int B, int N, int F);
+size_t bev_absmax_slot_bytes(int items);
+int launch_absmax_finalize(const unsigned* slots, unsigned* out, int items, hipStream_t st);
+int launch_bev_gather(const float* bev, int B, int H, int W, int C, const float* boxes, int N, int box_stride, int box_batch_stride,
+                      int num_point, float pc_x0, float pc_y0, float vs_x, float vs_y, float out_stride, float* out, int out_row_stride,
+                      int out_batch_stride, unsigned* absmax, hipStream_t st);
 int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes, int box_stride,
                  float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st);
 int pair_residual(const shasta_weights* w, const float* packed, int B, const float* feat, const float* prev_feat,
@@ -19,6 +27,8 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
                 float* m2, float* matched_out, void* ws, size_t ws_bytes, hipStream_t st);
 int pack_weights(const shasta_weights* w, float* packed, hipStream_t st);
 int launch_w_maxima(const float* const W[4], int H, int K, unsigned* wmax, hipStream_t st);
+size_t precut_image_bytes(int H, int K);
+int launch_precut_weights(const float* const W[4], const unsigned* wmax, void* img, int H, int K, hipStream_t st);
 
 static int check_weights(const shasta_weights* w) {
     SHASTA_REQUIRE(w, "null weights");
@@ -82,22 +92,29 @@ extern "C" int shasta_pack_weights_f32(const shasta_weights* w, void* packed, si
     return pack_weights(w, static_cast<float*>(packed), as_stream(stream));
 }
 
-extern "C" size_t shasta_aug_shape_aux_bytes(int max_obj, int feat_dim) {
-    return align_up((size_t)4 * ((size_t)max_obj * feat_dim / 64) * sizeof(unsigned), 256);
+extern "C" size_t shasta_aug_shape_aux_bytes(int max_obj, int feat_dim, int options) {
+    const size_t H = (size_t)max_obj * feat_dim / 64;
+    size_t n = align_up((size_t)4 * H * sizeof(unsigned), 256);
+    if (options & SHASTA_OPT_PRECUT_WEIGHT_STREAM) n += precut_image_bytes((int)H, max_obj * feat_dim);
+    return n;
 }
 
 extern "C" int shasta_aug_shape_aux_f32(const shasta_weights* w, void* aux, size_t aux_bytes, shasta_stream_t stream) {
     int rc = check_weights(w);
     if (rc) return rc;
     SHASTA_REQUIRE(aux && (uintptr_t)aux % 16 == 0, "aug_shape_aux: buffer null or not 16-byte aligned");
-    if (aux_bytes < shasta_aug_shape_aux_bytes(w->max_obj, w->feat_dim)) {
+    if (aux_bytes < shasta_aug_shape_aux_bytes(w->max_obj, w->feat_dim, w->options)) {
         set_error_msg("aug_shape_aux: buffer too small");
         return SHASTA_E_WORKSPACE;
     }
     const float* W[4];
     for (int i = 0; i < 4; ++i) W[i] = w->aug_shape[i][0].weight;
     const int K = w->max_obj * w->feat_dim, H = K / 64;
-    return launch_w_maxima(W, H, K, static_cast<unsigned*>(aux), as_stream(stream));
+    if ((rc = launch_w_maxima(W, H, K, static_cast<unsigned*>(aux), as_stream(stream)))) return rc;
+    if ((w->options & SHASTA_OPT_PRECUT_WEIGHT_STREAM) && precut_image_bytes(H, K))
+        rc = launch_precut_weights(W, static_cast<const unsigned*>(aux), static_cast<char*>(aux) + align_up((size_t)4 * H * sizeof(unsigned), 256),
+                                   H, K, as_stream(stream));
+    return rc;
 }
 
 extern "C" size_t shasta_forward_workspace_bytes(int B, int max_obj, int num_feats, int feat_dim) {
@@ -112,7 +129,7 @@ extern "C" int shasta_anchor_shape_f32(const shasta_weights* w, int B, float* fe
     SHASTA_REQUIRE(B >= 0 && feat && prev_feat && workspace, "anchor_shape: bad argument");
     SHASTA_REQUIRE(((uintptr_t)feat | (uintptr_t)prev_feat) % 16 == 0, "anchor_shape: tables must be 16-byte aligned");
     return anchor_shape(w, B, feat, prev_feat, workspace, workspace_bytes, as_stream(stream), nullptr, nullptr,
-                        static_cast<const unsigned*>(w->aug_shape_aux));
+                        static_cast<const unsigned*>(w->aug_shape_aux), false);
 }
 
 extern "C" int shasta_anchor_boxes_f32(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes,
@@ -155,11 +172,18 @@ extern "C" int shasta_aff_softmax_f32(const shasta_weights* w, const void* packe
                        workspace, workspace_bytes, as_stream(stream));
 }
 
+struct BevSource {
+    const float *bev, *prev_bev;
+    int H, W, C;
+    float pc_x0, pc_y0, vs_x, vs_y, out_stride;
+};
+
 static int forward_impl(const shasta_weights* w, const void* packed, int B, float* feat, float* prev_feat,
                         float* det_boxes, const float* prev_det_boxes, int box_stride, float* det_tab, float* prev_tab,
                         float* matched1, float* matched2, float* residual_out, float* matched_out, void* workspace,
                         size_t workspace_bytes, shasta_stream_t stream, hipEvent_t ev0, hipEvent_t ev1,
-                        float* shape_hidden_out = nullptr, hipEvent_t ev_pair0 = nullptr, hipEvent_t ev_pair1 = nullptr) {
+                        float* shape_hidden_out = nullptr, hipEvent_t ev_pair0 = nullptr, hipEvent_t ev_pair1 = nullptr,
+                        const BevSource* src = nullptr) {
     int rc = check_weights(w);
     if (rc) return rc;
     SHASTA_REQUIRE(B >= 0 && packed && feat && prev_feat && det_boxes && prev_det_boxes && det_tab && prev_tab &&
@@ -180,8 +204,28 @@ static int forward_impl(const shasta_weights* w, const void* packed, int B, floa
     void* stage = static_cast<char*>(workspace) + L.residual;
     const size_t stage_bytes = L.total - L.residual;
     const float* pk = static_cast<const float*>(packed);
+    bool xmax_ready = false;
+    if (src) {
+        // rows [0, N) of both tables straight from the BEV maps; when the fp16 weight stream follows, the gather also leaves the
+        // largest magnitude of every batch item where anchor_shape looks for it (no separate pass over the tables)
+        unsigned* slots = nullptr;
+        if (anchor_shape_uses_xmax(w, B)) {
+            slots = anchor_shape_xmax_slots(stage, B, N, F);
+            if (hipMemsetAsync(slots, 0, bev_absmax_slot_bytes(2 * B), st) != hipSuccess) return SHASTA_E_LAUNCH;
+            xmax_ready = true;
+        }
+        const int np = F / src->C;
+        if ((rc = launch_bev_gather(src->bev, B, src->H, src->W, src->C, det_boxes, N, box_stride, N * box_stride, np, src->pc_x0, src->pc_y0,
+                                    src->vs_x, src->vs_y, src->out_stride, feat, F, T * F, slots, st)))
+            return rc;
+        if ((rc = launch_bev_gather(src->prev_bev, B, src->H, src->W, src->C, prev_det_boxes, N, box_stride, N * box_stride, np, src->pc_x0,
+                                    src->pc_y0, src->vs_x, src->vs_y, src->out_stride, prev_feat, F, T * F,
+                                    slots ? slots + bev_absmax_slot_bytes(B) / sizeof(unsigned) : nullptr, st)))
+            return rc;
+        if (slots && (rc = launch_absmax_finalize(slots, anchor_shape_xmax(stage, B, N, F), 2 * B, st))) return rc;
+    }
     // row maxima of the first-layer weights (fp16 form of the weight stream): the caller's companion buffer, or recomputed per call
-    if ((rc = anchor_shape(w, B, feat, prev_feat, stage, stage_bytes, st, ev0, ev1, static_cast<const unsigned*>(w->aug_shape_aux))))
+    if ((rc = anchor_shape(w, B, feat, prev_feat, stage, stage_bytes, st, ev0, ev1, static_cast<const unsigned*>(w->aug_shape_aux), xmax_ready)))
         return rc;
     if (shape_hidden_out) {  // training: the backward re-uses the hidden activations instead of re-streaming the weights
         const size_t H = (size_t)N * F / 64;
@@ -238,6 +282,28 @@ extern "C" int shasta_affinity_forward_timed_f32(const shasta_weights* w, const 
                         matched2, nullptr, nullptr, workspace, workspace_bytes, stream,
                         static_cast<hipEvent_t>(ev_l1_start), static_cast<hipEvent_t>(ev_l1_stop), nullptr,
                         static_cast<hipEvent_t>(ev_pair_start), static_cast<hipEvent_t>(ev_pair_stop));
+}
+
+extern "C" int shasta_affinity_from_bev_f32(const shasta_weights* w, const void* packed, int B, const float* bev, const float* prev_bev,
+                                            int H, int W, int C, float pc_x0, float pc_y0, float vs_x, float vs_y, float out_stride,
+                                            float* feat, float* prev_feat, float* det_boxes, const float* prev_det_boxes, int box_stride,
+                                            float* det_tab, float* prev_tab, float* matched1, float* matched2, float* residual_out,
+                                            float* matched_out, void* workspace, size_t workspace_bytes, shasta_stream_t stream,
+                                            void* const* h_events4) {
+    SHASTA_REQUIRE(w && bev && prev_bev, "affinity_from_bev: null pointer");
+    SHASTA_REQUIRE(H > 0 && W > 0 && C > 0 && w->feat_dim % C == 0, "affinity_from_bev: feat_dim must be num_point * C");
+    const int np = w->feat_dim / C;
+    SHASTA_REQUIRE(np == 1 || np == 4 || np == 5, "affinity_from_bev: num_point = feat_dim / C must be 1, 4 or 5");
+    SHASTA_REQUIRE(box_stride >= 10, "affinity_from_bev: box rows need [x,y,z,w,l,h,yaw,vx,vy,dt]");
+    const BevSource src{bev, prev_bev, H, W, C, pc_x0, pc_y0, vs_x, vs_y, out_stride};
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (h_events4)
+        for (int i = 0; i < 4; ++i) {
+            SHASTA_REQUIRE(h_events4[i], "affinity_from_bev: null event");
+            e[i] = static_cast<hipEvent_t>(h_events4[i]);
+        }
+    return forward_impl(w, packed, B, feat, prev_feat, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, matched1, matched2,
+                        residual_out, matched_out, workspace, workspace_bytes, stream, e[0], e[1], nullptr, e[2], e[3], &src);
 }
 
 extern "C" int shasta_event_create(void** ev) {

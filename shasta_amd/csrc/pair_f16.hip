@@ -150,7 +150,10 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
     float* s_tr = s_up + WPB * 3 * 256;                    // [WPB][64 pairs][PF_TS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (Placing the 8 detection tiles of a frame-pair on ONE XCD - they all read that frame-pair's UP / hand tables, 265 KB, which with
+    // the plain order is fetched into eight L2s - was measured: 1.5 % less energy per step, pair kernel 4.21 - 4.30 -> 4.35 ms; not kept.)
     const int b = blockIdx.z, d0 = blockIdx.x * 64;
+    const int by = blockIdx.y;
     const int d = d0 + lane, dcl = min(d, D - 1);
     const PackedLayout P(0, 0, F);
     {
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
     const int p = lane & 15, kb = lane >> 4;
     float* my_tr = s_tr + wid * (64 * PF_TS);
 
-    const int t_beg = (blockIdx.y * WPB + wid) * TW;
+    const int t_beg = (by * WPB + wid) * TW;
     const int t_end = min(T, t_beg + TW);
     float* my_up = s_up + wid * (3 * 256);
     const bool hp_lane = lane >= ET / 4 && lane < ET / 4 + 4;
@@ -282,8 +285,8 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
                 }
             }
         };
-        auto mma_store = [&](int sub, const pu4 (&xh)[4], const pu4 (&xl)[4]) {
-            f32x4 a_fs = zero4, a_rc = zero4, a_fd = zero4;
+        auto mma = [&](const pu4 (&xh)[4], const pu4 (&xl)[4], f32x4& a_fs, f32x4& a_rc, f32x4& a_fd) {
+            a_fs = a_rc = a_fd = zero4;
             a_fs = MFMA16H(wl[0], xh[0], a_fs);
             a_rc = MFMA16H(wl[1], xh[1], a_rc);
             a_fd = MFMA16H(wl[3], xh[3], a_fd);
@@ -296,6 +299,10 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
             a_rc = MFMA16H(wh[2], xl[2], a_rc);
             a_rc = MFMA16H(wh[1], xh[1], a_rc);
             a_rc = MFMA16H(wh[2], xh[2], a_rc);
+        };
+        // (storing a sub-step's results behind the NEXT sub-step's MFMAs instead of right behind their own - where each store waits
+        // 5 - 7 idle states for its accumulator - measured slower: 4.20 -> 4.30 ms; the compiler fills those states elsewhere)
+        auto store = [&](int sub, const f32x4& a_fs, const f32x4& a_rc, const f32x4& a_fd) {
             // lane (p, kb) holds output features 4 kb .. 4 kb + 3 of pair 16 sub + p: [rc 16 | fs 16 | fd 8]
             float* row = my_tr + (16 * sub + p) * PF_TS + 4 * kb;
             *reinterpret_cast<f32x4*>(row) = a_rc;
@@ -305,18 +312,23 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
         {
             f32x4 ua[8], ub[8];
             pu4 xha[4], xla[4], xhb[4], xlb[4];
+            f32x4 fsA, rcA, fdA, fsB, rcB, fdB;
             load_uc(0, ua);
             load_uc(1, ub);
             cut(ua, xha, xla);
             load_uc(2, ua);
             cut(ub, xhb, xlb);
-            mma_store(0, xha, xla);
+            mma(xha, xla, fsA, rcA, fdA);
+            store(0, fsA, rcA, fdA);
             load_uc(3, ub);
             cut(ua, xha, xla);
-            mma_store(1, xhb, xlb);
+            mma(xhb, xlb, fsB, rcB, fdB);
+            store(1, fsB, rcB, fdB);
             cut(ub, xhb, xlb);
-            mma_store(2, xha, xla);
-            mma_store(3, xhb, xlb);
+            mma(xha, xla, fsA, rcA, fdA);
+            store(2, fsA, rcA, fdA);
+            mma(xhb, xlb, fsB, rcB, fdB);
+            store(3, fsB, rcB, fdB);
         }
         // ---- lane = pair from here on: descale + bias, layers 3-4, hand residual, combine (as pair_mfma4_kernel) ----
         unsigned ao = arow_base, bo = abias_base;

@@ -24,6 +24,8 @@ OPT_F32_EMBED_GEMM = 2
 OPT_F32_AFF = 4
 OPT_F16X2_WEIGHT_STREAM = 8
 OPT_F16X2_PAIR = 16
+OPT_PRECUT_WEIGHT_STREAM = 32
+PRECUT_MIN_BATCH = 17  # csrc/anchor.hip: from this many frame-pairs per call the pre-cut fp16 weight stream serves the call
 
 
 class Linear(C.Structure):
@@ -55,10 +57,12 @@ SYMBOLS = {
     "shasta_shared_conv_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "shasta_packed_bytes": (_Z, [_I, _I, _I]),
     "shasta_pack_weights_f32": (_I, [_WP, _P, _Z, _P]),
-    "shasta_aug_shape_aux_bytes": (_Z, [_I, _I]),
+    "shasta_aug_shape_aux_bytes": (_Z, [_I, _I, _I]),
     "shasta_aug_shape_aux_f32": (_I, [_WP, _P, _Z, _P]),
     "shasta_forward_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "shasta_affinity_forward_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "shasta_affinity_from_bev_f32": (_I, [_WP, _P, _I, _P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P,
+                                          C.POINTER(C.c_void_p)]),
     "shasta_affinity_forward_train_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "shasta_affinity_forward_timed_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P]),
     "shasta_event_create": (_I, [C.POINTER(C.c_void_p)]),

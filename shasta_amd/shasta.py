@@ -121,6 +121,11 @@ class Shasta(BaseTrack):
         #            and the aff layers use three exact bf16 pieces per operand, six products per fp32 product;
         #   "f32":   the f32 MFMA kernels everywhere.
         self.arithmetic = "f16x2"
+        # "f16x2" only: keep the first aug_shape layers ALSO as pre-cut fp16 pieces (+4 bytes per weight resident: 4.1 GB at N=500, built
+        # lazily with the row maxima for the first forward of more than 64 frame-pairs) and stream those instead of cutting the fp32
+        # tensors inside the kernel (SHASTA_OPT_PRECUT_WEIGHT_STREAM): bit-identical results, weight-stream kernel 2.75 -> 2.56 ms at
+        # 512 frame-pairs.  False keeps only the fp32 checkpoint tensors resident.
+        self.precut_weight_stream = True
         # training backward (shasta_amd/training.py): "fp32" (parity path, like the reference's train.py:149) or "bf16": the GEMMs of
         # the pair MLPs and of aff take bf16 operands with fp32 accumulation (BASELINE config 5's reduced-precision option)
         self.train_precision = "fp32"
@@ -180,7 +185,7 @@ class Shasta(BaseTrack):
         place, moves go through _apply, and a re-assigned parameter is caught by the pointer probe over one tensor per block."""
         probe = tuple(t.data_ptr() for t in (self.aug_shape[0][0].weight, self.aug_shape[3][2].weight, self.aug_dets[0][0].weight,
                                              self.fuse_shape[0].weight, self.fuse_det[0].weight, self.res_coeff[0].weight,
-                                             self.aff[0].weight, self.aff[10].weight)) + (self.arithmetic,)
+                                             self.aff[0].weight, self.aff[10].weight)) + (self.arithmetic, self.precut_weight_stream)
         ws = getattr(self, "_wstruct", None)
         if ws is not None and ws[1] == probe:
             return ws[0]
@@ -202,6 +207,8 @@ class Shasta(BaseTrack):
             raise ValueError("Shasta.arithmetic must be 'pieces', 'f32' or 'f16x2'")
         w.options = {"pieces": 0, "f32": hip.OPT_F32_WEIGHT_STREAM | hip.OPT_F32_EMBED_GEMM | hip.OPT_F32_AFF,
                      "f16x2": hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_F16X2_PAIR}[self.arithmetic]
+        if self.arithmetic == "f16x2" and self.precut_weight_stream:
+            w.options |= hip.OPT_PRECUT_WEIGHT_STREAM
         for i in range(4):
             w.aug_shape[i][0], w.aug_shape[i][1] = lin(self.aug_shape[i][0]), lin(self.aug_shape[i][2])
             w.aug_dets[i][0], w.aug_dets[i][1] = lin(self.aug_dets[i][0]), lin(self.aug_dets[i][2])
@@ -228,19 +235,24 @@ class Shasta(BaseTrack):
                   "shasta_pack_weights_f32")
         self._packed_key = key
 
-    def _ensure_aux(self, w, B, device):
-        """Companion of the four aug_shape first-layer matrices (their row maxima, shasta_aug_shape_aux_f32): one pass over 4.1 GB at
-        N=500, so it is computed lazily - only for a forward that takes the fp16 weight stream (arithmetic "f16x2", more than 64
-        frame-pairs) - and again only after one of the four matrices changed (an optimizer step bumps their versions; training
-        batches <= 64 never pay for it).  Without it the library recomputes the maxima inside every such call."""
-        need = self.arithmetic == "f16x2" and B > 64 and self.max_obj * self.aug_shape_output >= 64
+    def _ensure_aux(self, w, B, device, training=False):
+        """Companion of the four aug_shape first-layer matrices (shasta_aug_shape_aux_f32: their row maxima and, with
+        precut_weight_stream, their pre-cut fp16 piece image): one pass over 4.1 GB at N=500, so it is built lazily - only for a
+        forward that takes the fp16 weight stream - and again only after one of the four matrices changed (an optimizer step bumps
+        their versions).  The fp16 stream serves more than 64 frame-pairs per call; with the pre-cut image also every inference call
+        of at least 17 (its loop then holds nothing but DMA, LDS reads and MFMAs: 32 / 64 items per weight pass run at the speed of
+        the stream; up to 16 the f32 16x16x4 kernel is as fast and needs no activation image).  Training steps (weights change every step) never build the image for it: they keep the kernels that read the fp32
+        tensors.  Without a companion the library recomputes the maxima inside every call that needs them."""
+        small = self.precut_weight_stream and not training and B >= hip.PRECUT_MIN_BATCH
+        need = self.arithmetic == "f16x2" and (B > 64 or small) and self.max_obj * self.aug_shape_output >= 64
         if not need:
             w.aug_shape_aux = None
             return
-        key = tuple((self.aug_shape[i][0].weight.data_ptr(), self.aug_shape[i][0].weight._version) for i in range(4))
+        key = tuple((self.aug_shape[i][0].weight.data_ptr(), self.aug_shape[i][0].weight._version) for i in range(4)) + (w.options,)
         if self._aux is None or self._aux_key != key or self._aux.device != device:
             lib = hip.load()
-            nbytes = lib.shasta_aug_shape_aux_bytes(self.max_obj, self.aug_shape_output)
+            nbytes = lib.shasta_aug_shape_aux_bytes(self.max_obj, self.aug_shape_output, w.options)
+            self._aux = None
             self._aux = torch.empty(nbytes // 4, dtype=torch.int32, device=device)
             w.aug_shape_aux = None
             hip.check(lib.shasta_aug_shape_aux_f32(C.byref(w), hip.ptr(self._aux), nbytes, hip.stream_ptr()), "shasta_aug_shape_aux_f32")
@@ -359,10 +371,8 @@ class Shasta(BaseTrack):
             return torch.empty(0, N, N + 2, device=dev), torch.empty(0, N + 2, N, device=dev)
         w = self._weights()
         self._ensure_packed(w, dev)
-        self._ensure_aux(w, B, dev)
+        self._ensure_aux(w, B, dev, training=_train_keep is not None)
         bufs = self._work_buffers(B, dev)
-        self.bev_extractor.gather_boxes(bev_nhwc, det_boxes, self.num_point, bufs["feat"])
-        self.bev_extractor.gather_boxes(prev_bev_nhwc, prev_det_boxes, self.num_point, bufs["prev_feat"])
         m1 = torch.empty(B, N, N + 2, device=dev)
         m2 = torch.empty(B, N + 2, N, device=dev)
         res = mat = None
@@ -370,6 +380,8 @@ class Shasta(BaseTrack):
             res = torch.empty(B, N + 2, N + 2, device=dev)
             mat = torch.empty(B, N + 2, N + 2, device=dev)
         if _train_keep is not None:  # training.py: same kernels, keeps the residual and the anchor hidden activations
+            self.bev_extractor.gather_boxes(bev_nhwc, det_boxes, self.num_point, bufs["feat"])
+            self.bev_extractor.gather_boxes(prev_bev_nhwc, prev_det_boxes, self.num_point, bufs["prev_feat"])
             H4 = 4 * (N * self.aug_shape_output // 64)
             _train_keep["residual"] = torch.empty(B, N + 2, N + 2, device=dev)
             _train_keep["shape_hidden"] = torch.empty(B, max(H4, 1), device=dev)
@@ -381,18 +393,20 @@ class Shasta(BaseTrack):
                 "shasta_affinity_forward_train_f32")
             for k in ("feat", "prev_feat", "det_tab", "prev_tab"):
                 _train_keep[k] = bufs[k].clone()
-        elif l1_events is not None:  # bench.py: hipEvents around the two heaviest kernels (L1 start/stop, pair start/stop)
-            hip.check(lib.shasta_affinity_forward_timed_f32(
-                C.byref(w), hip.ptr(self._packed), B, hip.ptr(bufs["feat"]), hip.ptr(bufs["prev_feat"]),
-                hip.ptr(det_boxes), hip.ptr(prev_det_boxes), det_boxes.shape[2], hip.ptr(bufs["det_tab"]),
-                hip.ptr(bufs["prev_tab"]), hip.ptr(m1), hip.ptr(m2), hip.ptr(bufs["ws"]), bufs["ws_bytes"],
-                hip.stream_ptr(), *l1_events[:4]), "shasta_affinity_forward_timed_f32")
         else:
-            hip.check(lib.shasta_affinity_forward_f32(
-                C.byref(w), hip.ptr(self._packed), B, hip.ptr(bufs["feat"]), hip.ptr(bufs["prev_feat"]),
-                hip.ptr(det_boxes), hip.ptr(prev_det_boxes), det_boxes.shape[2], hip.ptr(bufs["det_tab"]),
-                hip.ptr(bufs["prev_tab"]), hip.ptr(m1), hip.ptr(m2), hip.ptr(res), hip.ptr(mat), hip.ptr(bufs["ws"]),
-                bufs["ws_bytes"], hip.stream_ptr()), "shasta_affinity_forward_f32")
+            # inference: gather + rows 6-16 in ONE call (shasta_affinity_from_bev_f32); l1_events (bench.py): hipEvents around the two
+            # heaviest kernels (L1 start / stop, pair start / stop)
+            if bev_nhwc.shape != prev_bev_nhwc.shape or bev_nhwc.shape[0] != B or bev_nhwc.shape[3] * self.num_point != self.aug_shape_output:
+                raise ValueError("BEV maps must be (B, H, W, C) with C * num_point = %d, both of one shape" % self.aug_shape_output)
+            if prev_det_boxes.shape[2] != det_boxes.shape[2]:
+                raise ValueError("det_boxes and prev_det_boxes must have the same row width")
+            x0, y0, vx, vy, stp = self.bev_extractor._geom()
+            evs = None if l1_events is None else (C.c_void_p * 4)(*[e.value for e in l1_events[:4]])
+            hip.check(lib.shasta_affinity_from_bev_f32(
+                C.byref(w), hip.ptr(self._packed), B, hip.ptr(bev_nhwc), hip.ptr(prev_bev_nhwc), bev_nhwc.shape[1], bev_nhwc.shape[2],
+                bev_nhwc.shape[3], x0, y0, vx, vy, stp, hip.ptr(bufs["feat"]), hip.ptr(bufs["prev_feat"]), hip.ptr(det_boxes),
+                hip.ptr(prev_det_boxes), det_boxes.shape[2], hip.ptr(bufs["det_tab"]), hip.ptr(bufs["prev_tab"]), hip.ptr(m1), hip.ptr(m2),
+                hip.ptr(res), hip.ptr(mat), hip.ptr(bufs["ws"]), bufs["ws_bytes"], hip.stream_ptr(), evs), "shasta_affinity_from_bev_f32")
         # shasta.py:260-267 leaves the four anchor boxes on the module as fresh tensors: copy them out of the work buffers
         # (two small copies), which the next forward overwrites
         pa, da = bufs["prev_tab"][:, N:, :7].clone(), bufs["det_tab"][:, N:, :7].clone()

@@ -46,7 +46,8 @@ def test_size_queries_do_not_need_a_gpu():
     lib = hip.load()
     assert lib.shasta_packed_bytes(500, 7, 256) > 0
     assert lib.shasta_packed_bytes(500, 7, 128) == 0  # unsupported feature width is reported, not guessed
-    assert lib.shasta_aug_shape_aux_bytes(500, 256) >= 4 * 2000 * 4  # one maximum per first-layer weight row
+    assert lib.shasta_aug_shape_aux_bytes(500, 256, 0) >= 4 * 2000 * 4  # one maximum per first-layer weight row
+    assert lib.shasta_aug_shape_aux_bytes(500, 256, 32) >= 4 * 2000 * 128000 * 4  # + the pre-cut piece image: 4 bytes per weight
     assert lib.shasta_forward_workspace_bytes(8, 500, 7, 256) > 8 * 502 * 504 * 4
     assert lib.shasta_voxelize_workspace_bytes(300000, 160000, 10) > 160000 * 10 * 4
     import ctypes as C

@@ -361,6 +361,7 @@ def test_aug_shape_aux_is_lazy_tracks_the_weights_and_is_optional():
                                          bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075],
                                                             out_stride=8), max_obj=N, num_feats=7, num_point=4, in_channels=8)).eval().to(dev)
     m.keep_intermediates = True
+    m.precut_weight_stream = False  # this test is about the row maxima alone (the pre-cut image: test_precut_weight_stream_is_bit_identical)
     g = torch.Generator().manual_seed(4)
     bev = torch.relu(torch.randn(B, 60, 60, 64, generator=g)).to(dev)
     m.bev_extractor.out_stride = 24
@@ -407,6 +408,104 @@ def test_aug_shape_aux_is_lazy_tracks_the_weights_and_is_optional():
         tabs[given] = (f1, f2)
     assert torch.equal(tabs[True][0], tabs[False][0]) and torch.equal(tabs[True][1], tabs[False][1])
     assert torch.equal(tabs[True][0][:, N:], b16[:, :2])
+
+
+@pytest.mark.parametrize("B,npnt", [(3, 4), (70, 4), (66, 5), (130, 1)])
+def test_fused_from_bev_entry_equals_gather_plus_forward(B, npnt):
+    """shasta_affinity_from_bev_f32 (the gather inside the forward call; above 64 frame-pairs the gather also produces the row maxima of
+    the fp16 weight stream, instead of a pass of its own over the tables) against shasta_bev_gather_f32 x 2 + shasta_affinity_forward_f32
+    on the same inputs: identical bit for bit - tables, back-projected boxes, residual, logits, both outputs."""
+    import shasta_amd
+    from shasta_amd import hip
+    dev = _dev()
+    torch.manual_seed(11)
+    N, nf, hw = 37, 7, 48
+    F = 64 * npnt
+    m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075],
+                                                            out_stride=30), max_obj=N, num_feats=nf, num_point=npnt, in_channels=8)).eval().to(dev)
+    g = torch.Generator().manual_seed(B)
+    bev = (torch.randn(B, hw, hw, 64, generator=g) * torch.logspace(-2, 2, B).view(B, 1, 1, 1)).to(dev)  # batch items of very different range
+    pbev = torch.relu(torch.randn(B, hw, hw, 64, generator=g)).to(dev)
+    det0, prev = O.synth_boxes(g, B, N).to(dev), O.synth_boxes(g, B, N).to(dev)
+    m.keep_intermediates = True
+    with torch.no_grad():
+        det = det0.clone()
+        m1, m2 = m.affinity_from_bev(bev, pbev, det, prev)
+    im = {k: v.clone() for k, v in m.last_intermediates.items()}
+    # the same through the separate entry points
+    lib = hip.load()
+    w = m._weights()
+    T = N + 2
+    feat, pfeat = torch.zeros(B, T, F, device=dev), torch.zeros(B, T, F, device=dev)
+    m.bev_extractor.gather_boxes(bev, det0, npnt, feat)
+    m.bev_extractor.gather_boxes(pbev, prev, npnt, pfeat)
+    det2 = det0.clone()
+    dtab, ptab = torch.zeros(B, T, 8, device=dev), torch.zeros(B, T, 8, device=dev)
+    a1, a2 = torch.empty(B, N, T, device=dev), torch.empty(B, T, N, device=dev)
+    res, mat = torch.empty(B, T, T, device=dev), torch.empty(B, T, T, device=dev)
+    wsb = lib.shasta_forward_workspace_bytes(B, N, nf, F)
+    ws = torch.zeros(wsb // 4 + 1, device=dev)
+    hip.check(lib.shasta_affinity_forward_f32(C.byref(w), hip.ptr(m._packed), B, hip.ptr(feat), hip.ptr(pfeat), hip.ptr(det2), hip.ptr(prev), 11,
+                                              hip.ptr(dtab), hip.ptr(ptab), hip.ptr(a1), hip.ptr(a2), hip.ptr(res), hip.ptr(mat), hip.ptr(ws), wsb,
+                                              hip.stream_ptr()), "forward")
+    torch.cuda.synchronize()
+    assert torch.equal(det, det2) and torch.equal(im["feature"], feat) and torch.equal(im["prev_feature"], pfeat)
+    assert torch.equal(im["residual"], res) and torch.equal(im["matched"], mat) and torch.equal(m1, a1) and torch.equal(m2, a2)
+    assert torch.isfinite(m1).all()
+    # argument checks of the new entry: C must divide feat_dim into 1 / 4 / 5 points
+    bad = lib.shasta_affinity_from_bev_f32(C.byref(w), hip.ptr(m._packed), B, hip.ptr(bev), hip.ptr(pbev), hw, hw, 48, -54.0, -54.0, 0.075, 0.075, 30.0,
+                                           hip.ptr(feat), hip.ptr(pfeat), hip.ptr(det2), hip.ptr(prev), 11, hip.ptr(dtab), hip.ptr(ptab), hip.ptr(a1),
+                                           hip.ptr(a2), None, None, hip.ptr(ws), wsb, hip.stream_ptr(), None)
+    assert bad == -1
+
+
+@pytest.mark.parametrize("N,B", [(40, 70), (37, 140), (90, 300)])
+def test_precut_weight_stream_is_bit_identical(N, B):
+    """SHASTA_OPT_PRECUT_WEIGHT_STREAM (Shasta.precut_weight_stream): the fp16 weight stream reads its weight pieces from the image
+    shasta_aug_shape_aux_f32 built instead of cutting the fp32 matrices inside the kernel - the same pieces, so the same results bit
+    for bit (both batch-block shapes of the kernel: 128 and 256 items per pass; H not a multiple of 32), and the image follows a
+    weight update."""
+    import shasta_amd
+    dev = _dev()
+    torch.manual_seed(N)
+    m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075],
+                                                            out_stride=30), max_obj=N, num_feats=7, num_point=4, in_channels=8)).eval().to(dev)
+    m.keep_intermediates = True
+    g = torch.Generator().manual_seed(B)
+    bev = torch.relu(torch.randn(B, 48, 48, 64, generator=g)).to(dev)
+    det, prev = O.synth_boxes(g, B, N).to(dev), O.synth_boxes(g, B, N).to(dev)
+
+    def run(precut):
+        m.precut_weight_stream = precut
+        with torch.no_grad():
+            m1, m2 = m.affinity_from_bev(bev, bev, det.clone(), prev)
+        im = m.last_intermediates
+        return m1.clone(), m2.clone(), im["feature"][:, N:].clone(), im["prev_feature"][:, N:].clone()
+
+    plain, pre = run(False), run(True)
+    assert all(torch.equal(a, b) for a, b in zip(plain, pre)) and torch.isfinite(pre[0]).all()
+    # with the image the fp16 stream also serves small inference batches (32 / 64 items per weight pass): same arithmetic form as above
+    # 64, different kernels from the f32 MFMA / bf16-piece ones that serve them otherwise - equal to rounding, every item equal to its
+    # value inside the big batch up to the split-K order
+    for nb in (17, 33, 64):
+        m.precut_weight_stream = True
+        with torch.no_grad():
+            m.affinity_from_bev(bev[:nb], bev[:nb], det[:nb].clone(), prev[:nb])
+        small = torch.cat([m.last_intermediates["feature"][:, N:], m.last_intermediates["prev_feature"][:, N:]], 1).clone()
+        m.precut_weight_stream = False
+        with torch.no_grad():
+            m.affinity_from_bev(bev[:nb], bev[:nb], det[:nb].clone(), prev[:nb])
+        other = torch.cat([m.last_intermediates["feature"][:, N:], m.last_intermediates["prev_feature"][:, N:]], 1)
+        big = torch.cat([pre[2], pre[3]], 1)[:nb]
+        scale = float(big.abs().max())
+        assert not torch.equal(small, other)
+        assert float((small - other).abs().max()) <= 2e-5 * scale and float((small - big).abs().max()) <= 2e-5 * scale
+    with torch.no_grad():
+        m.aug_shape[1][0].weight.mul_(1.5)
+    plain2, pre2 = run(False), run(True)
+    assert all(torch.equal(a, b) for a, b in zip(plain2, pre2)) and not torch.equal(pre2[3], pre[3])
 
 
 def test_anchor_boxes_are_fresh_tensors_and_work_buffers_are_bounded():
@@ -547,8 +646,9 @@ def test_f32_arithmetic_option_matches_oracle_and_pieces(name, B):
     m = m.to(dev)
     m.keep_intermediates = True
     outs = {}
-    for mode in ("f16x2", "pieces", "f32"):
-        m.arithmetic = mode
+    for mode in ("f16x2", "f16x2-cut-in-kernel", "pieces", "f32"):
+        m.arithmetic = mode.split("-")[0]
+        m.precut_weight_stream = mode == "f16x2"  # default: the pre-cut fp16 weight image serves every batch of at least 17
         ex = dict(det_boxes=det.clone().to(dev), prev_det_boxes=prev.to(dev), bev_feature=bev.to(dev), prev_bev_feature=pbev.to(dev))
         with torch.no_grad():
             m1, m2, _ = m(ex, train_mode=False)
@@ -559,8 +659,10 @@ def test_f32_arithmetic_option_matches_oracle_and_pieces(name, B):
         ref = im["residual"].numpy()
         np.testing.assert_allclose(outs[mode][2], ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
     assert not np.array_equal(outs["pieces"][2], outs["f32"][2])  # different kernels ran
-    # the fp16 forms serve the weight stream above 64 frame-pairs and the pair MLPs at feature width 256
-    assert np.array_equal(outs["pieces"][2], outs["f16x2"][2]) == (B <= 64 and c["np"] * 64 != 256)
+    # without the pre-cut image the fp16 forms serve the weight stream above 64 frame-pairs and the pair MLPs at feature width 256 ...
+    assert np.array_equal(outs["pieces"][2], outs["f16x2-cut-in-kernel"][2]) == (B <= 64 and c["np"] * 64 != 256)
+    # ... with it (default) the fp16 weight stream serves every batch size from 17; above 64 both read the same pieces
+    assert np.array_equal(outs["f16x2"][2], outs["f16x2-cut-in-kernel"][2]) == (B > 64)
 
 
 def test_piece_kernels_are_fp32_accurate():
