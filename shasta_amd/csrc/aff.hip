@@ -190,7 +190,7 @@ __device__ __forceinline__ void aff_layer(const float* __restrict__ W, int ldw, 
             for (int rg = 0; rg < RG; ++rg) {
                 if (RELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[rg][r] = fmaxf(acc[rg][r], 0.0f);
+                    for (int r = 0; r < 4; ++r) acc[rg][r] = relu_nan(acc[rg][r]);
                 }
                 if (f0 < out_limit) *reinterpret_cast<f32x4*>(hout + (p + 16 * rg) * ldout + f0) = acc[rg];
             }

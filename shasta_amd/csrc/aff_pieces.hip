@@ -168,7 +168,7 @@ __device__ __forceinline__ void ap_store_h(char* H, int fb, int rb, int lane, co
         const float b[4] = {bias[f0], bias[f0 + 1], bias[f0 + 2], bias[f0 + 3]};
         float h[4], m[4], l[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ap_cut3(fmaxf(acc[4 * g + j] + b[j], 0.0f), h[j], m[j], l[j]);
+        for (int j = 0; j < 4; ++j) ap_cut3(relu_nan(acc[4 * g + j] + b[j]), h[j], m[j], l[j]);
         char* dst = H + n * ROW + f0 * 2;
         *reinterpret_cast<qu32x2*>(dst) = qu32x2{ap_top2(h[0], h[1]), ap_top2(h[2], h[3])};
         *reinterpret_cast<qu32x2*>(dst + IMG) = qu32x2{ap_top2(m[0], m[1]), ap_top2(m[2], m[3])};

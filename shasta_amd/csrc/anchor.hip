@@ -90,7 +90,7 @@ __global__ void anchor_hidden_kernel(const float* __restrict__ part, const float
     for (int ks = 1; ks < KS; ++ks) s += part[(size_t)ks * total + i];
     // two-piece fp16 form of the weight stream: undo the row scalings 2^e_b (activations of batch row b) and 2^e_r (weight row), exactly
     if (xmax) s = __builtin_ldexpf(s, -(range_exponent_bits(xmax[(mlp >> 1) * B + i / (4 * H)]) + range_exponent_bits(wmax[r])));
-    hidden[i] = fmaxf(s + bias[j], 0.0f);
+    hidden[i] = relu_nan(s + bias[j]);
 }
 
 struct AnchorL2Args {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void box_l1_kernel(BoxL1Args a) {
             const float v = wave_sum(s[u][b]);
             const int uu = ug * UT + u;
             if (lane == 0 && uu < a.HD && b0 + b < a.B)
-                a.hid[((size_t)(b0 + b) * 4 + mlp) * a.HD + uu] = fmaxf(v + a.bias[mlp][uu], 0.0f);
+                a.hid[((size_t)(b0 + b) * 4 + mlp) * a.HD + uu] = relu_nan(v + a.bias[mlp][uu]);
         }
 }
 
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void box_l1_small_kernel(BoxL1Args a) {
     if (lane == 0) part[q] = v;
     __syncthreads();
     if (threadIdx.x == 0)
-        a.hid[((size_t)b * 4 + mlp) * a.HD + u] = fmaxf(((part[0] + part[1]) + (part[2] + part[3])) + a.bias[mlp][u], 0.0f);
+        a.hid[((size_t)b * 4 + mlp) * a.HD + u] = relu_nan(((part[0] + part[1]) + (part[2] + part[3])) + a.bias[mlp][u]);
 }
 
 // Batches >= 256: the four first layers as GEMMs.  Their input - the 7-vectors of the boxes BEFORE back-projection, flattened -

@@ -52,6 +52,15 @@ __device__ __forceinline__ int range_exponent_bits(unsigned bits) {
     return max(-60, min(60, 14 - ex));
 }
 
+// Largest of two magnitudes (both non-negative or NaN with the sign cleared, i.e. results of fabsf) by their bit patterns: a NaN
+// (0x7fc00000 ...) beats an infinity (0x7f800000) beats every finite value, so - unlike fmaxf, which drops a NaN - a non-finite
+// entry of a row survives in the row's maximum and the kernels that scale by it can see it (pair_f16.hip).
+__device__ __forceinline__ float absmax_keep_nan(float a, float b) { return __uint_as_float(max(__float_as_uint(a), __float_as_uint(b))); }
+
+// ReLU as torch computes it: a NaN stays a NaN (v_maximum3_f32, the IEEE-754-2019 maximum; fmaxf / v_max_f32 return the other
+// operand, i.e. turn a NaN into 0 and every later layer into finite numbers)
+__device__ __forceinline__ float relu_nan(float x) { return __builtin_elementwise_maximum(x, 0.0f); }
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -296,13 +296,13 @@ __global__ __launch_bounds__(64 * ER_WAVES) void embed_rows_kernel(EmbedArgs a) 
             }
             s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
             *reinterpret_cast<f32x4*>(a.emb[side] + (size_t)row * d.ET + j) = s;
-            amax[it] = fmaxf(amax[it], fmaxf(fmaxf(fabsf(s[0]), fabsf(s[1])), fmaxf(fabsf(s[2]), fabsf(s[3]))));
+            amax[it] = absmax_keep_nan(amax[it], absmax_keep_nan(absmax_keep_nan(fabsf(s[0]), fabsf(s[1])), absmax_keep_nan(fabsf(s[2]), fabsf(s[3]))));
         }
     }
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1)
 #pragma unroll
-        for (int it = 0; it < RPT; ++it) amax[it] = fmaxf(amax[it], __shfl_xor(amax[it], off, 64));
+        for (int it = 0; it < RPT; ++it) amax[it] = absmax_keep_nan(amax[it], __shfl_xor(amax[it], off, 64));
     if (q == 0) {
 #pragma unroll
         for (int it = 0; it < RPT; ++it) {

@@ -79,7 +79,7 @@ __device__ __forceinline__ void gemm_nt_tile(float* As, float* Ws, const float* 
             const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < M) {
                 float v = acc[r] + bv;
-                if (act == 1) v = fmaxf(v, 0.0f);
+                if (act == 1) v = relu_nan(v);
                 else if (act == 2) v = fabsf(v);
                 C[(size_t)row * ldc + col] = v;
             }
@@ -274,7 +274,7 @@ __device__ __forceinline__ void strided_epilogue(const GemmS& g, const f32x16& a
             const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < g.M) {
                 float v = acc[r] + bv;
-                if ((g.act & 3) == 1) v = fmaxf(v, 0.0f);
+                if ((g.act & 3) == 1) v = relu_nan(v);
                 else if ((g.act & 3) == 2) v = fabsf(v);
                 if (g.mask && !(g.mask[(long)row * g.ldmask + col] > 0.0f)) v = 0.0f;
                 if (g.act & 4) v += C[(long)row * g.ldc + col];

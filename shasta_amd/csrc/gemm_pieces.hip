@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_nt_pieces_kernel(GemmPieces g) {
                 const int row = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < g.M) {
                     float v = acc[i][j][r] + bv;
-                    if (g.act == 1) v = fmaxf(v, 0.0f);
+                    if (g.act == 1) v = relu_nan(v);
                     else if (g.act == 2) v = fabsf(v);
                     C[(size_t)row * g.ldc + col] = v;
                 }

@@ -178,16 +178,16 @@ __global__ __launch_bounds__(256) void row_prep_kernel(RowPrepArgs a) {
                     s[0] += bb[0]; s[1] += bb[1]; s[2] += bb[2]; s[3] += bb[3];
                 }
                 *e = s;
-                amax = fmaxf(fmaxf(fabsf(s[0]), fabsf(s[1])), fmaxf(fabsf(s[2]), fabsf(s[3])));
+                amax = absmax_keep_nan(absmax_keep_nan(fabsf(s[0]), fabsf(s[1])), absmax_keep_nan(fabsf(s[2]), fabsf(s[3])));
             } else {  // the spare threads of the row look at the columns the GEMM alone wrote (fuse_shape part, [0, H1))
                 const f32x4* e = reinterpret_cast<const f32x4*>(a.emb[which] + (size_t)row * d.ET);
                 for (int c4 = q - nq; c4 < d.H1 / 4; c4 += 32 - nq) {
                     const f32x4 v = e[c4];
-                    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                    amax = absmax_keep_nan(amax, absmax_keep_nan(absmax_keep_nan(fabsf(v[0]), fabsf(v[1])), absmax_keep_nan(fabsf(v[2]), fabsf(v[3]))));
                 }
             }
 #pragma unroll
-            for (int off = 16; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+            for (int off = 16; off > 0; off >>= 1) amax = absmax_keep_nan(amax, __shfl_xor(amax, off, 64));
             // slot 13 of the hand row: the row's largest embedding magnitude (range scaling of the fp16 pair kernel, pair_f16.hip)
             if (q == 0) a.hand[which][(size_t)row * 16 + 13] = amax;
         }
@@ -275,7 +275,10 @@ struct A4 {
     static constexpr int NOB = a4_nob(F, L), KG = a4_kg(F, L), OFF = a4_offset(F, L), KIN = D.kin, BIAS = NOB * KG * 16;
 };
 
-template <int F, int WPB>
+// DT = detections per wave: 64 (one track per iteration), or 32 with TWO tracks per iteration (lanes 32..63 take track t + 1): the
+// same instruction stream covers 2 x 32 pairs, so a table of D = 92 rows (the shipped car configuration: max_obj 90) fills 3 x 32
+// lanes-of-work at 96 % instead of 2 x 64 at 72 %, and D = 22 (bus) one tile at 69 % instead of 34 %.
+template <int F, int WPB, int DT = 64>
 __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __restrict__ packed, const float* __restrict__ UP,
                                                          const float* __restrict__ UC, const float* __restrict__ hand_prev,
                                                          const float* __restrict__ hand_det, const float* __restrict__ denom,
@@ -284,23 +287,27 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
     constexpr PairDims dm(F);
     constexpr int H1 = dm.H1, R1 = dm.R1, ET = dm.ET, US = ET + 4;
     constexpr int NA4 = a4_total(F);
+    static_assert(DT == 64 || DT == 32, "64 detections x 1 track or 32 detections x 2 tracks per wave");
+    constexpr int TPI = 64 / DT;       // tracks per iteration
+    constexpr int RING = 3 * TPI;      // UP row slots per wave: the rows in use, and two iterations ahead
     extern __shared__ __attribute__((aligned(16))) float s_dyn4[];
-    float* s_uc = s_dyn4;              // [64][US]
-    float* s_a4 = s_dyn4 + 64 * US;    // [NA4]
+    float* s_uc = s_dyn4;              // [DT][US]
+    float* s_a4 = s_dyn4 + DT * US;    // [NA4]
     // UP rows (the per-track half of the first layers) of the next two tracks, per wave: [WPB][3 slots][256 floats].  They
     // were scalar loads before; SMEM and LDS share lgkmcnt, so every s_load had to be waited for with lgkmcnt(0) before the
     // next LDS result could be used - nine full scalar-memory latencies per track (measured: 25 % of the wave time parked).
     // An LDS-DMA (counted on vmcnt) fetches row t+2 while row t is in use; the values are then read back as LDS broadcasts.
-    float* s_up = s_dyn4 + 64 * US + ((NA4 + 3) & ~3);
+    float* s_up = s_dyn4 + DT * US + ((NA4 + 3) & ~3);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, d0 = blockIdx.x * 64;
-    const int d = d0 + lane, dcl = min(d, D - 1);
+    const int dlane = lane & (DT - 1), th = lane / DT;  // detection of the tile, track of the iteration
+    const int b = blockIdx.z, d0 = blockIdx.x * DT;
+    const int d = d0 + dlane, dcl = min(d, D - 1);
     const PackedLayout P(0, 0, F);
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(UC);
 #pragma unroll 4
-        for (int e = tid; e < 64 * (ET / 4); e += 64 * WPB) {
+        for (int e = tid; e < DT * (ET / 4); e += 64 * WPB) {
             const int r = e / (ET / 4), c = e - r * (ET / 4);
             *reinterpret_cast<f32x4*>(&s_uc[r * US + 4 * c]) = src[((size_t)b * D + min(d0 + r, D - 1)) * (ET / 4) + c];
         }
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
     }
     const float dnm = denom[(size_t)b * D + dcl];
     __syncthreads();
-    const float* ucrow = s_uc + lane * US;
+    const float* ucrow = s_uc + dlane * US;
     typedef __attribute__((address_space(3))) float lfloat;
     typedef __attribute__((address_space(3))) f32x4 lf32x4;
     // LDS byte address of this lane's row i = lane & 3 inside every [i][kk] group of the A table
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
 
     const int t_beg = (blockIdx.y * WPB + wid) * TW;
     const int t_end = min(T, t_beg + TW);
-    float* my_up = s_up + wid * (3 * 256);
+    float* my_up = s_up + wid * (RING * 256);
     // lanes [0, ET/4): the UP row; the next 4 lanes: the 16-float hand row of the same track (lands right behind it); the
     // remaining lanes repeat the last UP chunk (their LDS words are unused)
     const bool hp_lane = lane >= ET / 4 && lane < ET / 4 + 4;
@@ -339,14 +346,17 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
                                          (__attribute__((address_space(3))) void*)(my_up + slot * 256), 16, 0, 0);
     };
     if (t_beg < t_end) {
-        dma_up(t_beg, 0);
-        dma_up(t_beg + 1, 1);
+#pragma unroll
+        for (int i = 0; i < 2 * TPI; ++i) dma_up(t_beg + i, i);
     }
-    for (int t = t_beg; t < t_end; ++t) {
-        // rows t and t+1 were requested at least one whole iteration ago (or in the prologue): nothing younger is in flight
+    for (int t = t_beg; t < t_end; t += TPI) {
+        // the rows of this and of the next iteration were requested at least one whole iteration ago (or in the prologue): nothing
+        // younger is in flight
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        dma_up(t + 2, (t - t_beg + 2) % 3);
-        unsigned upo = (unsigned)(unsigned long long)(my_up + ((t - t_beg) % 3) * 256);
+#pragma unroll
+        for (int i = 0; i < TPI; ++i) dma_up(t + 2 * TPI + i, (t - t_beg + 2 * TPI + i) % RING);
+        const int tt = t + th;  // this lane's track
+        unsigned upo = (unsigned)(unsigned long long)(my_up + ((t - t_beg + th) % RING) * 256);
         asm volatile("" : "+v"(upo));
         const lfloat* up = (const lfloat*)(unsigned long long)upo;
         float hp[16];
@@ -383,14 +393,14 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
 #pragma unroll
             for (int kg = 0; kg < AL::KG; ++kg) {
                 const f32x4 u = *reinterpret_cast<const f32x4*>(ucrow + seg + 4 * kg);
-                const f32x4 upv = *reinterpret_cast<const lf32x4*>(up + seg + 4 * kg);  // same address in every lane: LDS broadcast
+                const f32x4 upv = *reinterpret_cast<const lf32x4*>(up + seg + 4 * kg);  // one address per track: LDS broadcast(s)
                 f32x4 a4[AL::NOB];
 #pragma unroll
                 for (int ob = 0; ob < AL::NOB; ++ob) a4[ob] = *reinterpret_cast<const lf32x4*>(arow + AL::OFF + (ob * AL::KG + kg) * 16);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     if (4 * kg + kk < AL::KIN) {
-                        const float h = fmaxf(upv[kk] + u[kk], 0.0f);
+                        const float h = relu_nan(upv[kk] + u[kk]);
 #pragma unroll
                         for (int ob = 0; ob < AL::NOB; ++ob) acc[ob] = MFMA4(a4[ob][kk], h, acc[ob]);
                     }
@@ -409,7 +419,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     if (4 * kg + kk < AL::KIN) {
-                        const float h = fmaxf(in[kg][kk], 0.0f);
+                        const float h = relu_nan(in[kg][kk]);
 #pragma unroll
                         for (int ob = 0; ob < AL::NOB; ++ob) acc[ob] = MFMA4(a4[ob][kk], h, acc[ob]);
                     }
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
         const float dist = (r + dim) + sqrtf(dcs * dcs + dsn * dsn);
         // ---- combine (shasta.py:316-319) ----
         const float res = (a_rc3[0][0] * a_fd3[0][0] + a_rc3[0][1] * dist) + a_rc3[0][2] * a_fs4[0][0];
-        if (d < D) residual[((size_t)b * T + t) * ld + d] = res;
+        if (d < D && tt < t_end) residual[((size_t)b * T + tt) * ld + d] = res;
     }
 }
 
@@ -535,19 +545,27 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     // lane = pair, 4x4x1 MFMA.  The 8 waves of a workgroup share one 64-detection UC tile and take different track ranges
     // (two workgroups per CU by LDS, 113 VGPRs in the VGPR MFMA form: 4 waves per SIMD).
     constexpr int wpb = 8;
+    // 32-detection tiles (two tracks per wave iteration) where they waste fewer lanes than 64-detection tiles: D = 92 (car), 22 (bus) ...
+    const double fill64 = (double)D / (64.0 * cdiv(D, 64)), fill32 = (double)D / (32.0 * cdiv(D, 32));
+    const int dt = fill32 > 1.1 * fill64 ? 32 : 64, tpi = 64 / dt;
     // tracks per wave: the T tracks dealt evenly to the waves of the ny workgroups of a detection tile, ny the smallest power of two
     // that leaves 1024 workgroups (two rounds at two workgroups per CU); see launch_pair_f16
     int ny = 1;
-    while ((long)B * cdiv(D, 64) * ny < 1024 && cdiv(T, wpb * ny * 2) >= 2) ny *= 2;
-    const int tw = cdiv(T, wpb * ny);
-    const size_t lds = ((size_t)64 * (d.ET + 4) + ((a4_total(F) + 3) & ~3) + (size_t)wpb * 3 * 256) * sizeof(float);
-    dim3 grid(cdiv(D, 64), cdiv(T, wpb * tw), B);
-#define SHASTA_LAUNCH_PAIR4(FF)                                                                                                        \
-    do {                                                                                                                              \
-        if (lds > 64 * 1024)                                                                                                          \
-            (void)hipFuncSetAttribute((const void*)pair_mfma4_kernel<FF, wpb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((pair_mfma4_kernel<FF, wpb>), grid, dim3(64 * wpb), lds, st, packed, UP, UC, hand_prev, hand_det, denom,   \
-                           residual, T, D, ld, nf, tw);                                                                               \
+    while ((long)B * cdiv(D, dt) * ny < 1024 && cdiv(T, wpb * ny * 2) >= 2 * tpi) ny *= 2;
+    const int tw = cdiv(cdiv(T, wpb * ny), tpi) * tpi;
+    const size_t lds = ((size_t)dt * (d.ET + 4) + ((a4_total(F) + 3) & ~3) + (size_t)wpb * 3 * tpi * 256) * sizeof(float);
+    dim3 grid(cdiv(D, dt), cdiv(T, wpb * tw), B);
+#define SHASTA_LAUNCH_PAIR4_DT(FF, DD)                                                                                                    \
+    do {                                                                                                                                  \
+        if (lds > 64 * 1024)                                                                                                              \
+            (void)hipFuncSetAttribute((const void*)pair_mfma4_kernel<FF, wpb, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((pair_mfma4_kernel<FF, wpb, DD>), grid, dim3(64 * wpb), lds, st, packed, UP, UC, hand_prev, hand_det, denom,   \
+                           residual, T, D, ld, nf, tw);                                                                                   \
+    } while (0)
+#define SHASTA_LAUNCH_PAIR4(FF)                 \
+    do {                                        \
+        if (dt == 32) SHASTA_LAUNCH_PAIR4_DT(FF, 32); \
+        else SHASTA_LAUNCH_PAIR4_DT(FF, 64);    \
     } while (0)
     if (ev0) (void)hipEventRecord(ev0, st);  // bench.py: HIP events around the pair kernel alone
     switch (F) {
@@ -557,6 +575,7 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
         default: set_error_msg("pair_residual: feat_dim must be 64, 256 or 320"); return SHASTA_E_ARG;
     }
     if (ev1) (void)hipEventRecord(ev1, st);
+#undef SHASTA_LAUNCH_PAIR4_DT
 #undef SHASTA_LAUNCH_PAIR4
     return check_launch("pair_mfma4");
 }

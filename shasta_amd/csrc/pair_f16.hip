@@ -41,6 +41,10 @@ struct A4h {
     static constexpr int NOB = a4_nob(F, L), KG = a4_kg(F, L), OFF = a4_offset(F, L), KIN = D.kin, BIAS = NOB * KG * 16;
 };
 
+// HAZARD RULE for the three asm helpers below: the compiler inserts the wait states a VALU result needs before an MFMA or a
+// half-register reader consumes it only for its OWN instructions, not around inline asm.  Every result of these helpers must
+// therefore pass through a compiler-generated VALU instruction (here: the packed multiply, v_cvt_pk_f16_f32) before it reaches an
+// MFMA operand; feeding one straight into an MFMA needs an explicit "s_nop 1" (the clamp-fma tried in pair_mfma4).
 // {clamp01(a0 * c + b0), clamp01(a1 * c + b1)}: with a, b pre-scaled so that every sum is at most 1, the clamp IS the ReLU
 typedef float pf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pf2 fma2_relu01(pf2 a, pf2 c, pf2 b) {
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
         mc = g[1];
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mc = fmaxf(mc, __shfl_xor(mc, off, 64));
+    for (int off = 32; off > 0; off >>= 1) mc = absmax_keep_nan(mc, __shfl_xor(mc, off, 64));  // a NaN / inf row maximum survives
     const float dnm = denom[(size_t)b * D + dcl];
     // second-layer weight pieces: 4 fragments x {high, low}, registers for the whole kernel
     pu4 wh[4], wl[4];
@@ -234,7 +238,12 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
             }
         }
         // the track's scale: every h1 of this track and tile is at most max |UP[t]| + max |UC|
-        const int e1 = range_exponent_bits(__float_as_uint(hp[13] + mc));
+        // Non-finite embeddings: the clamp of the packed fma below turns a NaN into 0 and saturates an infinity at 1, so they would come
+        // out as finite residuals; the row maxima keep them (absmax_keep_nan), and a track whose bound is not finite gets NaN for the
+        // whole tile - more NaNs than the reference's element-wise propagation, never a finite number in their place.
+        const float bound = hp[13] + mc;
+        const bool finite_bound = bound < INFINITY;  // false for NaN and +inf
+        const int e1 = range_exponent_bits(__float_as_uint(bound));
         // h1 = relu(UP + UC) is formed as clamp01(UC cs + UP cs) with cs = 2^(e1 - 14): every sum is at most 1 after the scaling
         // (exact, a power of two), so the clamp of one packed fma is the ReLU of two values; the conversion multiplies by 2^14.
         const float cs = __builtin_ldexpf(1.0f, e1 - 14);
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
                 const pf2 s2 = {sc, sc};
                 const pf2 lo = __builtin_elementwise_fma(pf2{v[0], v[1]}, s2, pf2{bb[0], bb[1]});
                 const pf2 hi = __builtin_elementwise_fma(pf2{v[2], v[3]}, s2, pf2{bb[2], bb[3]});
-                return f32x4{fmaxf(lo[0], 0.0f), fmaxf(lo[1], 0.0f), fmaxf(hi[0], 0.0f), fmaxf(hi[1], 0.0f)};
+                return f32x4{relu_nan(lo[0]), relu_nan(lo[1]), relu_nan(hi[0]), relu_nan(hi[1])};
             };
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     if (4 * kg + kk < AL::KIN) {
-                        const float h = decltype(relu_done)::value ? in[kg][kk] : fmaxf(in[kg][kk], 0.0f);
+                        const float h = decltype(relu_done)::value ? in[kg][kk] : relu_nan(in[kg][kk]);
 #pragma unroll
                         for (int ob = 0; ob < AL::NOB; ++ob) acc[ob] = MFMA4(a4[ob][kk], h, acc[ob]);
                     }
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
         const float dist = (r + dim) + sqrtf(dcs * dcs + dsn * dsn);
         // ---- combine (shasta.py:316-319) ----
         const float res = (a_rc3[0][0] * a_fd3[0][0] + a_rc3[0][1] * dist) + a_rc3[0][2] * a_fs4[0][0];
-        if (d < D) residual[((size_t)b * T + t) * ld + d] = res;
+        if (d < D) residual[((size_t)b * T + t) * ld + d] = finite_bound ? res : __builtin_nanf("");
     }
 }
 

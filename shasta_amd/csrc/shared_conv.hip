@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void shared_conv_kernel(const float* __restric
             if (px < W) {
                 const float a = nb ? acc1[r] : acc0[r];
                 const float v = (a + bias) * alpha + beta2;
-                orow[(size_t)px * 64 + chn] = fmaxf(v, 0.0f);
+                orow[(size_t)px * 64 + chn] = relu_nan(v);
             }
         }
     }
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void shared_conv_flat_kernel(const float* __re
             if (pp < npix) {
                 const float a = nb ? acc1[r] : acc0[r];
                 const float v = (a + bias) * alpha + beta2;
-                obase[(size_t)pp * 64 + chn] = fmaxf(v, 0.0f);
+                obase[(size_t)pp * 64 + chn] = relu_nan(v);
             }
         }
     }

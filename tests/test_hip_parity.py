@@ -508,6 +508,40 @@ def test_precut_weight_stream_is_bit_identical(N, B):
     assert all(torch.equal(a, b) for a, b in zip(plain2, pre2)) and not torch.equal(pre2[3], pre[3])
 
 
+@pytest.mark.parametrize("B", [3, 70])
+def test_non_finite_inputs_stay_non_finite(B):
+    """Round-2 advisor finding: the fp16 pair kernel fuses ReLU and range scaling into a clamped packed fma, which turns a NaN into 0 and
+    saturates an infinity, and the row maxima it scales by were taken with fmaxf, which drops a NaN: a poisoned frame came out as
+    FINITE numbers where the reference (and the f32 kernels) propagate NaN.  Now the row maxima keep non-finite values and such a
+    track / tile is written as NaN.  Frames next to the poisoned ones are untouched."""
+    import shasta_amd
+    dev = _dev()
+    torch.manual_seed(5)
+    N = 40
+    m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075],
+                                                            out_stride=30), max_obj=N, num_feats=7, num_point=4, in_channels=8)).eval().to(dev)
+    g = torch.Generator().manual_seed(B)
+    bev = torch.relu(torch.randn(B, 48, 48, 64, generator=g)).to(dev)
+    pbev = torch.relu(torch.randn(B, 48, 48, 64, generator=g)).to(dev)
+    det, prev = O.synth_boxes(g, B, N).to(dev), O.synth_boxes(g, B, N).to(dev)
+    for mode in ("f16x2", "f32"):
+        m.arithmetic = mode
+        with torch.no_grad():
+            c1, c2 = m.affinity_from_bev(bev, pbev, det.clone(), prev)
+            bad = bev.clone()
+            bad[1, :, :, 7] = float("nan")        # every gathered row of frame 1 holds a NaN
+            pbad = pbev.clone()
+            pbad[B - 1, :, :, 3] = float("inf")   # every previous-frame row of the last frame holds an infinity (or inf * 0 = NaN)
+            p1, p2 = m.affinity_from_bev(bad, pbad, det.clone(), prev)
+        assert torch.isfinite(c1).all() and torch.isfinite(c2).all()
+        for i in range(B):
+            if i in (1, B - 1):
+                assert not torch.isfinite(p1[i]).any() and not torch.isfinite(p2[i]).any(), (mode, i)
+            else:
+                assert torch.equal(p1[i], c1[i]) and torch.equal(p2[i], c2[i]), (mode, i)
+
+
 def test_anchor_boxes_are_fresh_tensors_and_work_buffers_are_bounded():
     """shasta.py:260-267 leaves newborn / fp / dead_trk / fn on the module as tensors of that forward: a later forward (another
     batch, same size) must not change them.  The work buffers are one set per device (largest batch), not one per batch size."""
