@@ -75,9 +75,8 @@ def _tables(m):
 @pytest.mark.parametrize("name", ["headline_500_7_4", "sharp_500_7_4"])
 def test_headline_size_batches_pin_every_anchor_kernel_on_the_reference_output(name):
     """N=M=500, F=256 (BASELINE.json configs[1]) in batches: frame-pair 0 is the reference's golden frame, the others are
-    synthetic.  Frame-pairs are independent, so (a) frame 0 of a 130-batch (bf16-piece anchor kernel, two weight passes, the
-    second one ragged), of a 64-batch (one 64-item pass), of a 32-batch (f32 MFMA kernel) and of a 1-batch (VALU kernel) must
-    each reproduce the reference: geom = the aug_shape anchors (K = 128 000 first layer, shasta.py:241-244), the aug_dets anchor
+    synthetic.  Frame-pairs are independent, so (a) frame 0 of a 130-batch, of a 100-, 64- and 32-batch (the four batch-block shapes of
+    the fp16 weight stream), of a 16-batch (f32 MFMA kernel) and of a 1-batch (VALU kernel) must each reproduce the reference: geom = the aug_shape anchors (K = 128 000 first layer, shasta.py:241-244), the aug_dets anchor
     boxes, the residual and matched probes / checksums within 1e-5 relative, matched1 / matched2 within 1e-6 (1e-3 and the
     arg-max of every row and column with the sharpened weights); and (b) every frame's result must not depend on the batch it was
     computed in beyond fp32 summation order."""
@@ -111,7 +110,9 @@ def test_headline_size_batches_pin_every_anchor_kernel_on_the_reference_output(n
         return m1.cpu().numpy(), m2.cpu().numpy(), tabs
     full1, full2, full_t = run(slice(0, B))
     runs = {(0, B): (full1, full2, full_t)}
-    for lo, hi in ((0, 64), (0, 32), (0, 1), (129, 130), (64, 130)):
+    # round 3 (pre-cut fp16 weight image, default): 130 -> 256 items per weight pass, 100 -> 128, 64 -> 64, 32 -> 32 items per pass of the
+    # same fp16 kernel; 16 -> the f32 16x16x4 kernel, 1 -> the VALU kernel
+    for lo, hi in ((0, 100), (0, 64), (0, 32), (0, 16), (0, 1), (129, 130), (64, 130)):
         p1, p2, tabs = run(slice(lo, hi))
         runs[(lo, hi)] = (p1, p2, tabs)
         np.testing.assert_allclose(p1, full1[lo:hi], rtol=0, atol=batch_tol)
