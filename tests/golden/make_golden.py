@@ -44,6 +44,9 @@ CONFIGS = [
     # N=M=500 (BASELINE metric size): intermediates as probe rows / columns + float64 checksums of every row and column
     dict(name="headline_500_7_4", max_obj=500, nf=7, np=4, B=1, n_real=None, inter="probe"),
     dict(name="sharp_500_7_4", max_obj=500, nf=7, np=4, B=1, n_real=None, inter="probe", sharp=(5.0, 2.0)),
+    # BASELINE config 3's table shape: the class configurations' network (nf=3, np=5 -> F=320) at the dataset's max_objects = 500
+    # (det3d/datasets/nuscenes/nuscenes.py:66), 120 real rows + zero padding as a crowded frame has them; 1.6 G parameters
+    dict(name="classes_500_3_5_pad", max_obj=500, nf=3, np=5, B=1, n_real=120, inter="probe"),
 ]
 
 

@@ -72,9 +72,9 @@ def _tables(m):
     return {k: v.cpu().numpy() for k, v in m.last_intermediates.items()}
 
 
-@pytest.mark.parametrize("name", ["headline_500_7_4", "sharp_500_7_4"])
+@pytest.mark.parametrize("name", ["headline_500_7_4", "sharp_500_7_4", "classes_500_3_5_pad"])
 def test_headline_size_batches_pin_every_anchor_kernel_on_the_reference_output(name):
-    """N=M=500, F=256 (BASELINE.json configs[1]) in batches: frame-pair 0 is the reference's golden frame, the others are
+    """N=M=500, F=256 (BASELINE.json configs[1]; and F=320, nf=3, padded rows: configs[2]'s table shape) in batches: frame-pair 0 is the reference's golden frame, the others are
     synthetic.  Frame-pairs are independent, so (a) frame 0 of a 130-batch, of a 100-, 64- and 32-batch (the four batch-block shapes of
     the fp16 weight stream), of a 16-batch (f32 MFMA kernel) and of a 1-batch (VALU kernel) must each reproduce the reference: geom = the aug_shape anchors (K = 128 000 first layer, shasta.py:241-244), the aug_dets anchor
     boxes, the residual and matched probes / checksums within 1e-5 relative, matched1 / matched2 within 1e-6 (1e-3 and the
