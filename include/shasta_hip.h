@@ -203,14 +203,16 @@ int shasta_affinity_forward_f32(const shasta_weights* w, const void* packed, int
  * back-projection, as shasta.py:231-239 does) - i.e. all of Shasta.forward behind shared_conv (shasta.py:231-325) in one call.  Same
  * results as shasta_bev_gather_f32 x 2 + shasta_affinity_forward_f32, bit for bit; when the fp16 weight stream follows, the gather
  * also produces the activation row maxima that stream needs, which otherwise take a pass of their own over the tables.
+ * anchor_boxes_out: NULL, or (B, 4, 7): the aug_dets anchor boxes newborn, fp, dead_trk, fn (shasta.py:260-267 leaves them on the
+ * module as fresh tensors; they are also rows N, N+1 of prev_tab / det_tab).
  * h_events4: NULL, or four events from shasta_event_create recorded around the weight-stream kernel [0],[1] and the pair kernel
  * [2],[3] (bench.py's live roofline). */
 int shasta_affinity_from_bev_f32(const shasta_weights* w, const void* packed, int B, const float* bev, const float* prev_bev,
                                  int H, int W, int C, float pc_x0, float pc_y0, float vs_x, float vs_y, float out_stride,
                                  float* feat, float* prev_feat, float* det_boxes, const float* prev_det_boxes, int box_stride,
                                  float* det_tab, float* prev_tab, float* matched1, float* matched2, float* residual_out,
-                                 float* matched_out, void* workspace, size_t workspace_bytes, shasta_stream_t stream,
-                                 void* const* h_events4);
+                                 float* matched_out, float* anchor_boxes_out, void* workspace, size_t workspace_bytes,
+                                 shasta_stream_t stream, void* const* h_events4);
 
 /* Training forward: the same kernels and values as shasta_affinity_forward_f32; additionally keeps what the backward
  * needs and the inference path throws away: residual_out (B, N+2, N+2) and shape_hidden_out (B, 4*H), H = N*F/64, the ReLU

@@ -241,6 +241,7 @@ struct BoxL2Args {
     const float* prev;
     float* det_tab;  // (B, N+2, 8)
     float* prev_tab;
+    float* anchors_out;  // (B, 4, 7) or null: newborn, fp, dead_trk, fn once more, for the caller's own (fresh) tensor
     int HD, N, B, box_stride;
 };
 
@@ -262,7 +263,10 @@ __global__ __launch_bounds__(256) void box_l2_tables_kernel(BoxL2Args a) {
             s = wave_sum(s);
             float v = s + a.bias[mlp][c];
             if (c >= 3 && c < 6) v = fabsf(v);
-            if (lane == 0) tab[c] = v;
+            if (lane == 0) {
+                tab[c] = v;
+                if (a.anchors_out) a.anchors_out[((size_t)b * 4 + mlp) * 7 + c] = v;
+            }
         }
         if (lane == 0) tab[7] = 0.0f;
         return;
@@ -465,7 +469,7 @@ size_t anchor_boxes_workspace_bytes(int B, int N) {
 }
 
 int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes, int box_stride,
-                 float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st) {
+                 float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st, float* anchors_out) {
     const int N = w->max_obj, HD = 7 * N / 32;
     if (B == 0) return SHASTA_OK;
     if (HD > 0) {
@@ -512,6 +516,7 @@ int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* 
     b2.prev = prev_det_boxes;
     b2.det_tab = det_tab;
     b2.prev_tab = prev_tab;
+    b2.anchors_out = anchors_out;
     b2.HD = HD;
     b2.N = N;
     b2.B = B;

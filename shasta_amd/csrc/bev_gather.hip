@@ -27,7 +27,15 @@ __global__ __launch_bounds__(256) void bev_gather_kernel(
     const float* __restrict__ bev, int H, int W, int C, const float* __restrict__ boxes, int N,
     int box_stride, int box_batch_stride, int num_point, float pc_x0, float pc_y0, float vs_x,
     float vs_y, float out_stride_px, float* __restrict__ out, int out_row_stride,
-    int out_batch_stride, int total_points, unsigned* __restrict__ absmax) {
+    int out_batch_stride, int total_points, unsigned* __restrict__ absmax, const float* __restrict__ bev2,
+    const float* __restrict__ boxes2, float* __restrict__ out2, unsigned* __restrict__ absmax2) {
+    // grid.y == 2: both frames of the pair in one launch (second map / box table / feature table / maxima)
+    if (blockIdx.y == 1) {
+        bev = bev2;
+        boxes = boxes2;
+        out = out2;
+        absmax = absmax2;
+    }
     // 16 lanes per point: each lane owns 4 consecutive channels (one 16-byte load per corner), 4 points per wave
     const int wave_raw = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int lane = threadIdx.x & 15;
@@ -158,22 +166,24 @@ int launch_absmax_finalize(const unsigned* slots, unsigned* out, int items, hipS
     return check_launch("absmax_finalize");
 }
 
+// bev2 / boxes2 / out2 / absmax2: null, or the pair's other frame (same shapes and strides), gathered by the same launch
 int launch_bev_gather(const float* bev, int B, int H, int W, int C, const float* boxes, int N, int box_stride, int box_batch_stride,
                       int num_point, float pc_x0, float pc_y0, float vs_x, float vs_y, float out_stride, float* out, int out_row_stride,
-                      int out_batch_stride, unsigned* absmax, hipStream_t st) {
+                      int out_batch_stride, unsigned* absmax, hipStream_t st, const float* bev2 = nullptr, const float* boxes2 = nullptr,
+                      float* out2 = nullptr, unsigned* absmax2 = nullptr) {
     const long total = (long)B * N * num_point;
     if (total == 0) return SHASTA_OK;
     SHASTA_REQUIRE(total < (1L << 30), "bev_gather: too many points");
     const int points_per_block = 16;  // 256 threads, 16 lanes per point
-    const int blocks = cdiv((int)total, points_per_block);
+    const dim3 grid(cdiv((int)total, points_per_block), bev2 ? 2 : 1);
     if (absmax)
-        hipLaunchKernelGGL(bev_gather_kernel<true>, dim3(blocks), dim3(16 * points_per_block), 0, st, bev, H, W, C, boxes, N, box_stride,
+        hipLaunchKernelGGL(bev_gather_kernel<true>, grid, dim3(16 * points_per_block), 0, st, bev, H, W, C, boxes, N, box_stride,
                            box_batch_stride, num_point, pc_x0, pc_y0, vs_x, vs_y, out_stride, out, out_row_stride, out_batch_stride, (int)total,
-                           absmax);
+                           absmax, bev2, boxes2, out2, absmax2);
     else
-        hipLaunchKernelGGL(bev_gather_kernel<false>, dim3(blocks), dim3(16 * points_per_block), 0, st, bev, H, W, C, boxes, N, box_stride,
+        hipLaunchKernelGGL(bev_gather_kernel<false>, grid, dim3(16 * points_per_block), 0, st, bev, H, W, C, boxes, N, box_stride,
                            box_batch_stride, num_point, pc_x0, pc_y0, vs_x, vs_y, out_stride, out, out_row_stride, out_batch_stride, (int)total,
-                           nullptr);
+                           nullptr, bev2, boxes2, out2, nullptr);
     return check_launch("bev_gather");
 }
 

@@ -17,9 +17,10 @@ size_t bev_absmax_slot_bytes(int items);
 int launch_absmax_finalize(const unsigned* slots, unsigned* out, int items, hipStream_t st);
 int launch_bev_gather(const float* bev, int B, int H, int W, int C, const float* boxes, int N, int box_stride, int box_batch_stride,
                       int num_point, float pc_x0, float pc_y0, float vs_x, float vs_y, float out_stride, float* out, int out_row_stride,
-                      int out_batch_stride, unsigned* absmax, hipStream_t st);
+                      int out_batch_stride, unsigned* absmax, hipStream_t st, const float* bev2, const float* boxes2, float* out2,
+                      unsigned* absmax2);
 int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes, int box_stride,
-                 float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st);
+                 float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st, float* anchors_out);
 int pair_residual(const shasta_weights* w, const float* packed, int B, const float* feat, const float* prev_feat,
                   const float* det_tab, const float* prev_tab, float* residual, int ld, void* ws, size_t ws_bytes,
                   hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
@@ -144,7 +145,7 @@ extern "C" int shasta_anchor_boxes_f32(const shasta_weights* w, int B, float* de
         return SHASTA_E_WORKSPACE;
     }
     return anchor_boxes(w, B, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, static_cast<float*>(workspace),
-                        as_stream(stream));
+                        as_stream(stream), nullptr);
 }
 
 extern "C" int shasta_pair_residual_f32(const shasta_weights* w, const void* packed, int B, const float* feat,
@@ -176,6 +177,7 @@ struct BevSource {
     const float *bev, *prev_bev;
     int H, W, C;
     float pc_x0, pc_y0, vs_x, vs_y, out_stride;
+    float* anchor_boxes_out;
 };
 
 static int forward_impl(const shasta_weights* w, const void* packed, int B, float* feat, float* prev_feat,
@@ -215,12 +217,10 @@ static int forward_impl(const shasta_weights* w, const void* packed, int B, floa
             xmax_ready = true;
         }
         const int np = F / src->C;
+        // both frames in one launch (grid.y = 2)
         if ((rc = launch_bev_gather(src->bev, B, src->H, src->W, src->C, det_boxes, N, box_stride, N * box_stride, np, src->pc_x0, src->pc_y0,
-                                    src->vs_x, src->vs_y, src->out_stride, feat, F, T * F, slots, st)))
-            return rc;
-        if ((rc = launch_bev_gather(src->prev_bev, B, src->H, src->W, src->C, prev_det_boxes, N, box_stride, N * box_stride, np, src->pc_x0,
-                                    src->pc_y0, src->vs_x, src->vs_y, src->out_stride, prev_feat, F, T * F,
-                                    slots ? slots + bev_absmax_slot_bytes(B) / sizeof(unsigned) : nullptr, st)))
+                                    src->vs_x, src->vs_y, src->out_stride, feat, F, T * F, slots, st, src->prev_bev, prev_det_boxes, prev_feat,
+                                    slots ? slots + bev_absmax_slot_bytes(B) / sizeof(unsigned) : nullptr)))
             return rc;
         if (slots && (rc = launch_absmax_finalize(slots, anchor_shape_xmax(stage, B, N, F), 2 * B, st))) return rc;
     }
@@ -236,7 +236,8 @@ static int forward_impl(const shasta_weights* w, const void* packed, int B, floa
             return SHASTA_E_LAUNCH;
         }
     }
-    if ((rc = anchor_boxes(w, B, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, static_cast<float*>(stage), st)))
+    if ((rc = anchor_boxes(w, B, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, static_cast<float*>(stage), st,
+                           src ? src->anchor_boxes_out : nullptr)))
         return rc;
     if ((rc = pair_residual(w, pk, B, feat, prev_feat, det_tab, prev_tab, residual, Dp, stage, stage_bytes, st, ev_pair0, ev_pair1)))
         return rc;
@@ -288,14 +289,14 @@ extern "C" int shasta_affinity_from_bev_f32(const shasta_weights* w, const void*
                                             int H, int W, int C, float pc_x0, float pc_y0, float vs_x, float vs_y, float out_stride,
                                             float* feat, float* prev_feat, float* det_boxes, const float* prev_det_boxes, int box_stride,
                                             float* det_tab, float* prev_tab, float* matched1, float* matched2, float* residual_out,
-                                            float* matched_out, void* workspace, size_t workspace_bytes, shasta_stream_t stream,
-                                            void* const* h_events4) {
+                                            float* matched_out, float* anchor_boxes_out, void* workspace, size_t workspace_bytes,
+                                            shasta_stream_t stream, void* const* h_events4) {
     SHASTA_REQUIRE(w && bev && prev_bev, "affinity_from_bev: null pointer");
     SHASTA_REQUIRE(H > 0 && W > 0 && C > 0 && w->feat_dim % C == 0, "affinity_from_bev: feat_dim must be num_point * C");
     const int np = w->feat_dim / C;
     SHASTA_REQUIRE(np == 1 || np == 4 || np == 5, "affinity_from_bev: num_point = feat_dim / C must be 1, 4 or 5");
     SHASTA_REQUIRE(box_stride >= 10, "affinity_from_bev: box rows need [x,y,z,w,l,h,yaw,vx,vy,dt]");
-    const BevSource src{bev, prev_bev, H, W, C, pc_x0, pc_y0, vs_x, vs_y, out_stride};
+    const BevSource src{bev, prev_bev, H, W, C, pc_x0, pc_y0, vs_x, vs_y, out_stride, anchor_boxes_out};
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
     if (h_events4)
         for (int i = 0; i < 4; ++i) {

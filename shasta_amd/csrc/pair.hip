@@ -552,6 +552,9 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     // that leaves 1024 workgroups (two rounds at two workgroups per CU); see launch_pair_f16
     int ny = 1;
     while ((long)B * cdiv(D, dt) * ny < 1024 && cdiv(T, wpb * ny * 2) >= 2 * tpi) ny *= 2;
+    // ... and while the launch does not even hold one workgroup per CU (one small frame-pair: 3 tiles at max_obj 90), down to ONE
+    // iteration per wave: the prologue is repeated, but 24 workgroups finish in a third of the time of 3 (31 -> ~10 us at D = 92)
+    while ((long)B * cdiv(D, dt) * ny < 256 && cdiv(T, wpb * ny * 2) >= tpi) ny *= 2;
     const int tw = cdiv(cdiv(T, wpb * ny), tpi) * tpi;
     const size_t lds = ((size_t)dt * (d.ET + 4) + ((a4_total(F) + 3) & ~3) + (size_t)wpb * 3 * tpi * 256) * sizeof(float);
     dim3 grid(cdiv(D, dt), cdiv(T, wpb * tw), B);

@@ -61,8 +61,8 @@ SYMBOLS = {
     "shasta_aug_shape_aux_f32": (_I, [_WP, _P, _Z, _P]),
     "shasta_forward_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "shasta_affinity_forward_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
-    "shasta_affinity_from_bev_f32": (_I, [_WP, _P, _I, _P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P,
-                                          C.POINTER(C.c_void_p)]),
+    "shasta_affinity_from_bev_f32": (_I, [_WP, _P, _I, _P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z,
+                                          _P, C.POINTER(C.c_void_p)]),
     "shasta_affinity_forward_train_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "shasta_affinity_forward_timed_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P]),
     "shasta_event_create": (_I, [C.POINTER(C.c_void_p)]),

@@ -402,16 +402,20 @@ class Shasta(BaseTrack):
                 raise ValueError("det_boxes and prev_det_boxes must have the same row width")
             x0, y0, vx, vy, stp = self.bev_extractor._geom()
             evs = None if l1_events is None else (C.c_void_p * 4)(*[e.value for e in l1_events[:4]])
+            anch = torch.empty(B, 4, 7, device=dev)  # newborn, fp, dead_trk, fn: a fresh tensor per forward, written by the library
             hip.check(lib.shasta_affinity_from_bev_f32(
                 C.byref(w), hip.ptr(self._packed), B, hip.ptr(bev_nhwc), hip.ptr(prev_bev_nhwc), bev_nhwc.shape[1], bev_nhwc.shape[2],
                 bev_nhwc.shape[3], x0, y0, vx, vy, stp, hip.ptr(bufs["feat"]), hip.ptr(bufs["prev_feat"]), hip.ptr(det_boxes),
                 hip.ptr(prev_det_boxes), det_boxes.shape[2], hip.ptr(bufs["det_tab"]), hip.ptr(bufs["prev_tab"]), hip.ptr(m1), hip.ptr(m2),
-                hip.ptr(res), hip.ptr(mat), hip.ptr(bufs["ws"]), bufs["ws_bytes"], hip.stream_ptr(), evs), "shasta_affinity_from_bev_f32")
-        # shasta.py:260-267 leaves the four anchor boxes on the module as fresh tensors: copy them out of the work buffers
-        # (two small copies), which the next forward overwrites
-        pa, da = bufs["prev_tab"][:, N:, :7].clone(), bufs["det_tab"][:, N:, :7].clone()
-        self.newborn, self.fp = pa[:, 0:1], pa[:, 1:2]
-        self.dead_trk, self.fn = da[:, 0:1], da[:, 1:2]
+                hip.ptr(res), hip.ptr(mat), hip.ptr(anch), hip.ptr(bufs["ws"]), bufs["ws_bytes"], hip.stream_ptr(), evs),
+                "shasta_affinity_from_bev_f32")
+            self.newborn, self.fp, self.dead_trk, self.fn = anch[:, 0:1], anch[:, 1:2], anch[:, 2:3], anch[:, 3:4]
+        if _train_keep is not None:
+            # shasta.py:260-267 leaves the four anchor boxes on the module as fresh tensors: the training entry has no output for them,
+            # so they are copied out of the work buffers (two small copies), which the next forward overwrites
+            pa, da = bufs["prev_tab"][:, N:, :7].clone(), bufs["det_tab"][:, N:, :7].clone()
+            self.newborn, self.fp = pa[:, 0:1], pa[:, 1:2]
+            self.dead_trk, self.fn = da[:, 0:1], da[:, 1:2]
         if self.keep_intermediates:
             self.last_intermediates = dict(feature=bufs["feat"], prev_feature=bufs["prev_feat"], residual=res,
                                            matched=mat, det_tab=bufs["det_tab"], prev_tab=bufs["prev_tab"])

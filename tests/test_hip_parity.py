@@ -454,10 +454,13 @@ def test_fused_from_bev_entry_equals_gather_plus_forward(B, npnt):
     assert torch.equal(det, det2) and torch.equal(im["feature"], feat) and torch.equal(im["prev_feature"], pfeat)
     assert torch.equal(im["residual"], res) and torch.equal(im["matched"], mat) and torch.equal(m1, a1) and torch.equal(m2, a2)
     assert torch.isfinite(m1).all()
+    # the anchor boxes left on the module (shasta.py:260-267) are the library's (B, 4, 7) output = rows N, N+1 of the box tables
+    assert torch.equal(m.newborn[:, 0], ptab[:, N, :7]) and torch.equal(m.fp[:, 0], ptab[:, N + 1, :7])
+    assert torch.equal(m.dead_trk[:, 0], dtab[:, N, :7]) and torch.equal(m.fn[:, 0], dtab[:, N + 1, :7]) and m.newborn.shape == (B, 1, 7)
     # argument checks of the new entry: C must divide feat_dim into 1 / 4 / 5 points
     bad = lib.shasta_affinity_from_bev_f32(C.byref(w), hip.ptr(m._packed), B, hip.ptr(bev), hip.ptr(pbev), hw, hw, 48, -54.0, -54.0, 0.075, 0.075, 30.0,
                                            hip.ptr(feat), hip.ptr(pfeat), hip.ptr(det2), hip.ptr(prev), 11, hip.ptr(dtab), hip.ptr(ptab), hip.ptr(a1),
-                                           hip.ptr(a2), None, None, hip.ptr(ws), wsb, hip.stream_ptr(), None)
+                                           hip.ptr(a2), None, None, None, hip.ptr(ws), wsb, hip.stream_ptr(), None)
     assert bad == -1
 
 
