@@ -141,6 +141,11 @@ typedef struct shasta_linear {
                                               pieces from the companion buffer (shasta_aug_shape_aux_f32 built with this bit: + 4 bytes per
                                               weight resident) instead of cutting the fp32 tensors on the fly; same arithmetic, same results */
 
+#define SHASTA_OPT_F16GRID_PAIR 64 /* with SHASTA_OPT_F16X2_PAIR, from 8192 table rows: the fp16 pieces of the per-pair hidden activations on a
+                                      fixed grid per MLP (22 bits of the tile's largest sum) instead of cut per pair from the fp32 sum:
+                                      a third fewer vector instructions in the pair kernel, errors of the residual 2x (max) / 5x (rms)
+                                      those of the fp32 kernels (about 1e-6 of its range): NOT fp32-equivalent, opt-in */
+
 typedef struct shasta_weights {
     int max_obj;   /* N */
     int num_feats; /* nf: 1..7 */

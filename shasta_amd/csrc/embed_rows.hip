@@ -299,15 +299,35 @@ __global__ __launch_bounds__(64 * ER_WAVES) void embed_rows_kernel(EmbedArgs a) 
             amax[it] = absmax_keep_nan(amax[it], absmax_keep_nan(absmax_keep_nan(fabsf(s[0]), fabsf(s[1])), absmax_keep_nan(fabsf(s[2]), fabsf(s[3]))));
         }
     }
+    // maxima over the 8-lane groups first: at F = 256 (ET = 128, one float4 per thread) they are the column ranges of the three MLPs -
+    // threads 0-7: fuse_shape, 8-23: res_coeff, 24-31: fuse_det -, which the fixed-grid pair kernel scales separately (slots 14, 15)
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1)
+    for (int off = 4; off > 0; off >>= 1)
+#pragma unroll
+        for (int it = 0; it < RPT; ++it) amax[it] = absmax_keep_nan(amax[it], __shfl_xor(amax[it], off, 64));
+    float m_fs[RPT], m_rc[RPT];
+#pragma unroll
+    for (int it = 0; it < RPT; ++it) {
+        const int base = threadIdx.x & 32;  // first lane of this row's 32 threads inside the wave
+        m_fs[it] = __shfl(amax[it], base, 64);
+        m_rc[it] = absmax_keep_nan(__shfl(amax[it], base + 8, 64), __shfl(amax[it], base + 16, 64));
+    }
+#pragma unroll
+    for (int off = 16; off > 4; off >>= 1)
 #pragma unroll
         for (int it = 0; it < RPT; ++it) amax[it] = absmax_keep_nan(amax[it], __shfl_xor(amax[it], off, 64));
     if (q == 0) {
 #pragma unroll
         for (int it = 0; it < RPT; ++it) {
             const int row = g0 + (tid >> 5) + it * 2 * ER_WAVES;
-            if (row < a.M) a.hand[side][(size_t)row * 16 + 13] = amax[it];
+            if (row < a.M) {
+                float* h = a.hand[side] + (size_t)row * 16;
+                h[13] = amax[it];
+                if (d.ET == 128) {  // F = 256
+                    h[14] = m_fs[it];
+                    h[15] = m_rc[it];
+                }
+            }
         }
     }
     ER_STAMP(4);

@@ -205,10 +205,9 @@ __global__ __launch_bounds__(256) void row_prep_kernel(RowPrepArgs a) {
         h[0] = b0;
         h[1] = f32x4{b1[0], b1[1], b1[2], 0.0f};
         h[2] = f32x4{logf(b0[3] + 1e-10f), logf(b1[0] + 1e-10f), logf(b1[1] + 1e-10f), cosf(b1[2])};
-        float* h3 = a.hand[which] + (size_t)row * 16 + 12;  // slot 13 belongs to the row role above
-        h3[0] = sinf(b1[2]);
-        h3[2] = 0.0f;
-        h3[3] = 0.0f;
+        // slots 13 - 15 belong to the row embeddings (embed_rows.hip / the row role above): the row's largest |E| over all columns and,
+        // from the fused kernel at F = 256, over the fuse_shape and res_coeff column ranges
+        a.hand[which][(size_t)row * 16 + 12] = sinf(b1[2]);
         return;
     }
     // ---- column norms ----
@@ -468,7 +467,8 @@ size_t pair_workspace_bytes(int B, int N, int F) {
 
 int pair_f16_pack(const shasta_weights* w, float* out, hipStream_t st);
 int launch_pair_f16(const float* packed, const float* p16, const float* UP, const float* UC, const float* hand_prev,
-                    const float* hand_det, const float* denom, float* residual, int B, int T, int D, int ld, int nf, hipStream_t st);
+                    const float* hand_det, const float* denom, float* residual, int B, int T, int D, int ld, int nf, bool grid,
+                    hipStream_t st);
 int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
                    int N, int K, int act, hipStream_t st);
 int launch_gemm_nt_dual(const float* A0, const float* W0, const float* bias0, float* C0, const float* A1, const float* W1,
@@ -538,7 +538,9 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     if ((w->options & SHASTA_OPT_F16X2_PAIR) && F == 256) {
         // second layers of the three pair MLPs on the f16 matrix path (pair_f16.hip), everything else as below
         if (ev0) (void)hipEventRecord(ev0, st);
-        rc = launch_pair_f16(packed, packed + P.p16, UP, UC, hand_prev, hand_det, denom, residual, B, T, D, ld, nf, st);
+        // SHASTA_OPT_F16GRID_PAIR: the fixed-grid form (needs the per-MLP row maxima that only the fused row-embedding kernel writes)
+        const bool grid = (w->options & SHASTA_OPT_F16GRID_PAIR) != 0 && fused;
+        rc = launch_pair_f16(packed, packed + P.p16, UP, UC, hand_prev, hand_det, denom, residual, B, T, D, ld, nf, grid, st);
         if (ev1) (void)hipEventRecord(ev1, st);
         return rc;
     }

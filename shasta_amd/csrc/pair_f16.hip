@@ -136,7 +136,15 @@ int pair_f16_pack(const shasta_weights* w, float* out, hipStream_t st) {
 // ---- the kernel (F = 256: H1 = 32, R1 = 64, fuse_det 32; H2 = 16, R2 = 16, 8) ---------------------------------------------
 constexpr int PF_TS = 44;  // floats per pair in the transposition tile: 40 + 4 pad (conflict-free b128 reads at stride 44)
 
-template <int WPB>
+// GRID (SHASTA_OPT_F16GRID_PAIR, opt-in): the pieces of h1 are not cut per pair.  UP[t] and UC[d] are cut ONCE per row into two
+// fp16 pieces on a common fixed grid per MLP - high piece an integer, low piece a multiple of 2^-11, after scaling the largest
+// possible |UP| + |UC| of the (workgroup's tracks, detection tile) to at most 2^11 -, so that per pair the pieces of UP + UC are
+// two exact packed adds and its ReLU two packed maxima (h' = max(h, -1), l' = max(l, -h'): for h >= 1 both pieces stay, for h = 0
+// the low piece is clamped at 0, for h <= -1 the two cancel): 256 packed fp16 instructions per track and wave instead of 384
+// conversions / mixes / packed fp32 ops.  The price is accuracy: a fixed grid spends its 22 bits on the LARGEST sum of the tile
+// (tools/pair_quant_sim.py: max / rms error of `residual` 2x / 5x the fp32 kernels', 1e-6 of its range), which is why this is
+// not the default arithmetic.
+template <int WPB, bool GRID>
 __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restrict__ packed, const uint32_t* __restrict__ p16,
                                                        const float* __restrict__ UP, const float* __restrict__ UC,
                                                        const float* __restrict__ hand_prev, const float* __restrict__ hand_det,
@@ -152,6 +160,19 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
     float* s_a4 = s_dynh + 64 * US;                        // [NA4] 4x4x1 operand table (layers 3-4 and the layer-2 biases)
     float* s_up = s_a4 + ((NA4 + 3) & ~3);                 // [WPB][3 slots][256 floats]
     float* s_tr = s_up + WPB * 3 * 256;                    // [WPB][64 pairs][PF_TS]
+    // GRID: the tile holds fp16 pieces instead: [64][GR_ROW] high pieces, then the same of low pieces (in place of s_uc, 1 KB more:
+    // everything behind it moves by GR_EXTRA floats), and every wave has a row of UP pieces: [WPB][2][128 fp16] behind the tiles
+    constexpr int GR_ROW = 136;                            // fp16 per tile row: 128 + 8 pad (272 B)
+    constexpr int GR_EXTRA = GRID ? (2 * 64 * GR_ROW / 2 - 64 * US) : 0;
+    if constexpr (GRID) {
+        s_a4 += GR_EXTRA;
+        s_up += GR_EXTRA;
+        s_tr += GR_EXTRA;
+    }
+    // (all piece storage is written and read as 32-bit words = fp16 pairs: one access type, no type punning through memory)
+    uint32_t* s_uch = reinterpret_cast<uint32_t*>(s_dynh);            // [64][GR_ROW / 2]
+    uint32_t* s_ucl = s_uch + 64 * (GR_ROW / 2);
+    uint32_t* s_upp = reinterpret_cast<uint32_t*>(s_tr + WPB * 64 * PF_TS);  // [WPB][2][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (Placing the 8 detection tiles of a frame-pair on ONE XCD - they all read that frame-pair's UP / hand tables, 265 KB, which with
@@ -161,14 +182,16 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
     const int d = d0 + lane, dcl = min(d, D - 1);
     const PackedLayout P(0, 0, F);
     {
-        const f32x4* src = reinterpret_cast<const f32x4*>(UC);
+        if constexpr (!GRID) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(UC);
 #pragma unroll 4
-        for (int e = tid; e < 64 * (ET / 4); e += 64 * WPB) {
-            const int r = e / (ET / 4), c = e - r * (ET / 4);
-            // float4 c of the row = k step c >> 3, k block (c >> 1) & 3, half c & 1: stored k-block-major, the blocks in the order
-            // 0, 2, 1, 3 (see load_uc: blocks 0 / 1 and 2 / 3 must sit 64 floats apart)
-            const int cp = (((c >> 1) & 1) << 4) | (((c >> 2) & 1) << 3) | ((c >> 3) << 1) | (c & 1);
-            *reinterpret_cast<f32x4*>(&s_uc[r * US + 4 * cp]) = src[((size_t)b * D + min(d0 + r, D - 1)) * (ET / 4) + c];
+            for (int e = tid; e < 64 * (ET / 4); e += 64 * WPB) {
+                const int r = e / (ET / 4), c = e - r * (ET / 4);
+                // float4 c of the row = k step c >> 3, k block (c >> 1) & 3, half c & 1: stored k-block-major, the blocks in the order
+                // 0, 2, 1, 3 (see load_uc: blocks 0 / 1 and 2 / 3 must sit 64 floats apart)
+                const int cp = (((c >> 1) & 1) << 4) | (((c >> 2) & 1) << 3) | ((c >> 3) << 1) | (c & 1);
+                *reinterpret_cast<f32x4*>(&s_uc[r * US + 4 * cp]) = src[((size_t)b * D + min(d0 + r, D - 1)) * (ET / 4) + c];
+            }
         }
         const f32x4* asrc = reinterpret_cast<const f32x4*>(packed + P.a4);
 #pragma unroll 2
@@ -186,6 +209,72 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mc = absmax_keep_nan(mc, __shfl_xor(mc, off, 64));  // a NaN / inf row maximum survives
     const float dnm = denom[(size_t)b * D + dcl];
+    // GRID: one grid per MLP for all tracks of this workgroup and the detections of this tile.  Largest magnitudes per column range
+    // (hand slots: 14 fuse_shape, 15 res_coeff, 13 = all columns, the bound used for fuse_det) of the tile's UC rows and of the
+    // workgroup's UP rows; ge[r] = the exponent that puts their sum into (2^10, 2^11].
+    int ge[3] = {0, 0, 0};
+    bool grid_finite = true;
+    if constexpr (GRID) {
+        float mcr[3], mur[3] = {0.0f, 0.0f, 0.0f};
+        {
+            const float* h = hand_det + ((size_t)b * D + dcl) * 16;
+            mcr[0] = h[14];
+            mcr[1] = h[15];
+            mcr[2] = h[13];
+        }
+        const int tw0 = by * WPB * TW, tw1 = min(T, tw0 + WPB * TW);
+        for (int t = tw0 + tid; t < tw1; t += 64 * WPB) {
+            const float* h = hand_prev + ((size_t)b * T + t) * 16;
+            mur[0] = absmax_keep_nan(mur[0], h[14]);
+            mur[1] = absmax_keep_nan(mur[1], h[15]);
+            mur[2] = absmax_keep_nan(mur[2], h[13]);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                mcr[r] = absmax_keep_nan(mcr[r], __shfl_xor(mcr[r], off, 64));
+                mur[r] = absmax_keep_nan(mur[r], __shfl_xor(mur[r], off, 64));
+            }
+        float* red = s_tr;  // scratch: the transposition tiles are not in use yet
+        if (lane == 0) {
+            red[wid * 3 + 0] = mur[0];
+            red[wid * 3 + 1] = mur[1];
+            red[wid * 3 + 2] = mur[2];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float m = red[r];
+            for (int w = 1; w < WPB; ++w) m = absmax_keep_nan(m, red[w * 3 + r]);
+            // (+ 0.2 %: the two high pieces are rounded to integers separately, their sum must stay below 2048, where fp16 still
+            // holds every integer)
+            const float bound = (m + mcr[r]) * 1.002f;
+            grid_finite = grid_finite && (bound < INFINITY);
+            ge[r] = range_exponent_bits(__float_as_uint(bound)) - 3;
+        }
+        __syncthreads();  // red is read by everyone before the tiles are written
+        // the tile: UC rows cut on the grids
+        const f32x4* src = reinterpret_cast<const f32x4*>(UC);
+        for (int e = tid; e < 64 * (ET / 4); e += 64 * WPB) {
+            const int r = e / (ET / 4), c = e - r * (ET / 4);  // float4 c = columns 4 c .. 4 c + 3: one MLP range
+            const f32x4 v = src[((size_t)b * D + min(d0 + r, D - 1)) * (ET / 4) + c];
+            const int ex = c < 8 ? ge[0] : c < 24 ? ge[1] : ge[2];
+            _Float16 hh[4], ll[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float sv = __builtin_ldexpf(v[q], ex), hi = rintf(sv);
+                hh[q] = (_Float16)hi;
+                ll[q] = (_Float16)(rintf((sv - hi) * 2048.0f) * (1.0f / 2048.0f));
+            }
+            typedef uint32_t pu2 __attribute__((ext_vector_type(2)));
+            typedef _Float16 ph2t __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<pu2*>(s_uch + r * (GR_ROW / 2) + 2 * c) =
+                pu2{__builtin_bit_cast(uint32_t, ph2t{hh[0], hh[1]}), __builtin_bit_cast(uint32_t, ph2t{hh[2], hh[3]})};
+            *reinterpret_cast<pu2*>(s_ucl + r * (GR_ROW / 2) + 2 * c) =
+                pu2{__builtin_bit_cast(uint32_t, ph2t{ll[0], ll[1]}), __builtin_bit_cast(uint32_t, ph2t{ll[2], ll[3]})};
+        }
+    }
     // second-layer weight pieces: 4 fragments x {high, low}, registers for the whole kernel
     pu4 wh[4], wl[4];
 #pragma unroll
@@ -237,31 +326,70 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
                 hp[12 + k] = h3[k];
             }
         }
-        // the track's scale: every h1 of this track and tile is at most max |UP[t]| + max |UC|
-        // Non-finite embeddings: the clamp of the packed fma below turns a NaN into 0 and saturates an infinity at 1, so they would come
-        // out as finite residuals; the row maxima keep them (absmax_keep_nan), and a track whose bound is not finite gets NaN for the
-        // whole tile - more NaNs than the reference's element-wise propagation, never a finite number in their place.
-        const float bound = hp[13] + mc;
-        const bool finite_bound = bound < INFINITY;  // false for NaN and +inf
-        const int e1 = range_exponent_bits(__float_as_uint(bound));
-        // h1 = relu(UP + UC) is formed as clamp01(UC cs + UP cs) with cs = 2^(e1 - 14): every sum is at most 1 after the scaling
-        // (exact, a power of two), so the clamp of one packed fma is the ReLU of two values; the conversion multiplies by 2^14.
-        const float cs = __builtin_ldexpf(1.0f, e1 - 14);
-        const pf2 cs2 = {cs, cs};
+        typedef _Float16 ph2 __attribute__((ext_vector_type(2)));
+        bool finite_bound;
+        int e1 = 0;
+        pf2 cs2 = {0.0f, 0.0f};
         const pf2 c14 = {16384.0f, 16384.0f};
-        // this lane's UP values, scaled: 8 per k step (the same address in the 16 lanes of a k block: LDS broadcast)
-        pf2 upv[16];
+        pf2 upv[GRID ? 1 : 16];   // !GRID: this lane's UP values, scaled
+        pu4 uph[GRID ? 4 : 1], upl[GRID ? 4 : 1];  // GRID: this lane's UP pieces, 8 per k step
+        if constexpr (!GRID) {
+            // the track's scale: every h1 of this track and tile is at most max |UP[t]| + max |UC|
+            // Non-finite embeddings: the clamp of the packed fma below turns a NaN into 0 and saturates an infinity at 1, so they would
+            // come out as finite residuals; the row maxima keep them (absmax_keep_nan), and a track whose bound is not finite gets NaN
+            // for the whole tile - more NaNs than the reference's element-wise propagation, never a finite number in their place.
+            const float bound = hp[13] + mc;
+            finite_bound = bound < INFINITY;  // false for NaN and +inf
+            e1 = range_exponent_bits(__float_as_uint(bound));
+            // h1 = relu(UP + UC) is formed as clamp01(UC cs + UP cs) with cs = 2^(e1 - 14): every sum is at most 1 after the scaling
+            // (exact, a power of two), so the clamp of one packed fma is the ReLU of two values; the conversion multiplies by 2^14.
+            const float cs = __builtin_ldexpf(1.0f, e1 - 14);
+            cs2 = pf2{cs, cs};
+            // this lane's UP values, scaled: 8 per k step (the same address in the 16 lanes of a k block: LDS broadcast)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const f32x4 a = *reinterpret_cast<const lf32x4*>(up + 32 * s + 8 * kb), c = *reinterpret_cast<const lf32x4*>(up + 32 * s + 8 * kb + 4);
-            upv[4 * s] = pf2{a[0], a[1]} * cs2;
-            upv[4 * s + 1] = pf2{a[2], a[3]} * cs2;
-            upv[4 * s + 2] = pf2{c[0], c[1]} * cs2;
-            upv[4 * s + 3] = pf2{c[2], c[3]} * cs2;
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 a = *reinterpret_cast<const lf32x4*>(up + 32 * s + 8 * kb), c = *reinterpret_cast<const lf32x4*>(up + 32 * s + 8 * kb + 4);
+                upv[4 * s] = pf2{a[0], a[1]} * cs2;
+                upv[4 * s + 1] = pf2{a[2], a[3]} * cs2;
+                upv[4 * s + 2] = pf2{c[0], c[1]} * cs2;
+                upv[4 * s + 3] = pf2{c[2], c[3]} * cs2;
+            }
+        } else {
+            finite_bound = grid_finite;
+            // the track's UP row cut on the grids: lane L cuts columns 2 L, 2 L + 1 (L < 16: fuse_shape, < 48: res_coeff, else fuse_det)
+            // into the wave's piece rows; every lane then reads its 8 values per k step back (LDS broadcast within a k block)
+            uint32_t* my_p = s_upp + wid * 128;  // [high 64 words | low 64 words]
+            {
+                typedef __attribute__((address_space(3))) pf2 lpf2;
+                const pf2 v = *reinterpret_cast<const lpf2*>(up + 2 * lane);
+                const int ex = lane < 16 ? ge[0] : lane < 48 ? ge[1] : ge[2];
+                const float s0 = __builtin_ldexpf(v[0], ex), s1 = __builtin_ldexpf(v[1], ex);
+                const float h0 = rintf(s0), h1v = rintf(s1);
+                const ph2 hh = {(_Float16)h0, (_Float16)h1v};
+                const ph2 ll = {(_Float16)(rintf((s0 - h0) * 2048.0f) * (1.0f / 2048.0f)), (_Float16)(rintf((s1 - h1v) * 2048.0f) * (1.0f / 2048.0f))};
+                my_p[lane] = __builtin_bit_cast(uint32_t, hh);
+                my_p[64 + lane] = __builtin_bit_cast(uint32_t, ll);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                uph[s] = *reinterpret_cast<const pu4*>(my_p + 16 * s + 4 * kb);
+                upl[s] = *reinterpret_cast<const pu4*>(my_p + 64 + 16 * s + 4 * kb);
+            }
         }
         // Software pipeline over the four sub-steps: the UC reads of sub-step s+1 are issued before the arithmetic of sub-step s,
         // and the pieces of sub-step s+1 are cut before the MFMAs of sub-step s are issued (they run under the cut of s+1).
         auto load_uc = [&](int sub, f32x4 (&u)[8]) {
+            if constexpr (GRID) {
+                // u[0..3] = the high pieces of the four k steps (8 fp16 each), u[4..7] = the low pieces
+                const uint32_t* hr = s_uch + (16 * sub + p) * (GR_ROW / 2) + 4 * kb;
+                const uint32_t* lr = s_ucl + (16 * sub + p) * (GR_ROW / 2) + 4 * kb;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    u[s] = __builtin_bit_cast(f32x4, *reinterpret_cast<const pu4*>(hr + 16 * s));
+                    u[4 + s] = __builtin_bit_cast(f32x4, *reinterpret_cast<const pu4*>(lr + 16 * s));
+                }
+                return;
+            }
             // A ds_read_b128 serves lanes {0-3, 12-15, 20-23, 24-27}, {4-11, 16-19, 28-31} (and the same + 32) together - not 16
             // consecutive lanes (tools/probes/lds_pattern_probe.hip).  In this layout lane = (p, kb) a group mixes rows p of k blocks
             // kb and kb + 1; with the four k blocks of a step 8 floats apart those fell on each other's banks (every read took 8
@@ -275,6 +403,23 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
             }
         };
         auto cut = [&](const f32x4 (&u)[8], pu4 (&xh)[4], pu4 (&xl)[4]) {
+            if constexpr (GRID) {
+                // pieces of relu(UP + UC): exact packed adds, then h' = max(h, -1), l' = max(l, -h'); on whole 8-halves vectors (the
+                // compiler lowers them to v_pk_add_f16 / v_pk_max_f16 with the negation as an operand modifier; written dword by dword
+                // through bit casts of vector elements hipcc 7.2 computed element 0 only and replicated it)
+                const _Float16 m1 = (_Float16)-1.0f;
+                const ph16x8 neg1 = {m1, m1, m1, m1, m1, m1, m1, m1};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const ph16x8 h = __builtin_bit_cast(ph16x8, u[s]) + __builtin_bit_cast(ph16x8, uph[s]);
+                    const ph16x8 l = __builtin_bit_cast(ph16x8, u[4 + s]) + __builtin_bit_cast(ph16x8, upl[s]);
+                    const ph16x8 h2 = __builtin_elementwise_max(h, neg1);
+                    const ph16x8 l2 = __builtin_elementwise_max(l, -h2);
+                    xh[s] = __builtin_bit_cast(pu4, h2);
+                    xl[s] = __builtin_bit_cast(pu4, l2);
+                }
+                return;
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -345,8 +490,9 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
         const lfloat* arow = (const lfloat*)(unsigned long long)ao;
         const lfloat* abias = (const lfloat*)(unsigned long long)bo;
         (void)abias;
-        const float i_rc = __builtin_ldexpf(1.0f, -(e1 + ew_rc)), i_fs = __builtin_ldexpf(1.0f, -(e1 + ew_fs)),
-                    i_fd = __builtin_ldexpf(1.0f, -(e1 + ew_fd));
+        // exact descaling: one exponent per track (default form) or one per MLP and workgroup (GRID)
+        const float i_rc = __builtin_ldexpf(1.0f, -((GRID ? ge[1] : e1) + ew_rc)), i_fs = __builtin_ldexpf(1.0f, -((GRID ? ge[0] : e1) + ew_fs)),
+                    i_fd = __builtin_ldexpf(1.0f, -((GRID ? ge[2] : e1) + ew_fd));
         f32x4 a_rc2[4], a_fs2[4], a_fd2[2];
         {
             const float* mine = my_tr + lane * PF_TS;
@@ -446,14 +592,21 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
     }
 }
 
-size_t pair_f16_lds_bytes(int wpb) {
+size_t pair_f16_lds_bytes(int wpb, bool grid) {
     constexpr PairDims dm(256);
-    return ((size_t)64 * (dm.ET + 4) + ((a4_total(256) + 3) & ~3) + (size_t)wpb * 3 * 256 + (size_t)wpb * 64 * PF_TS) * sizeof(float);
+    const size_t base = ((size_t)64 * (dm.ET + 4) + ((a4_total(256) + 3) & ~3) + (size_t)wpb * 3 * 256 + (size_t)wpb * 64 * PF_TS) * sizeof(float);
+    // GRID: the fp16 piece tile is 1 KB larger than the fp32 tile, + 512 bytes of UP pieces per wave
+    return base + (grid ? (size_t)(2 * 64 * 136 * 2 - 64 * (dm.ET + 4) * 4) + (size_t)wpb * 512 : 0);
 }
 
 int launch_pair_f16(const float* packed, const float* p16, const float* UP, const float* UC, const float* hand_prev,
-                    const float* hand_det, const float* denom, float* residual, int B, int T, int D, int ld, int nf, hipStream_t st) {
+                    const float* hand_det, const float* denom, float* residual, int B, int T, int D, int ld, int nf, bool grid,
+                    hipStream_t st) {
+#ifdef PAIR_WPB  // probe builds only: waves per workgroup = waves per CU (the LDS allows one workgroup per CU)
+    constexpr int wpb = PAIR_WPB;
+#else
     constexpr int wpb = 8;
+#endif
     // tracks per wave: the T tracks dealt evenly to the 8 ny waves of the ny workgroups of a detection tile, ny the smallest power of two
     // that leaves 512 workgroups (two rounds of the CU array).  A workgroup's prologue - the detection tile and the operand table
     // into LDS behind a barrier - is paid once per 8 tw tracks: 5.42 / 5.23 / 5.11 / 5.05 ms for 8 / 16 / 32 / 64 tracks per wave at
@@ -461,11 +614,17 @@ int launch_pair_f16(const float* packed, const float* p16, const float* UP, cons
     int ny = 1;
     while ((long)B * cdiv(D, 64) * ny < 512 && cdiv(T, wpb * ny * 2) >= 2) ny *= 2;
     const int tw = cdiv(T, wpb * ny);
-    const size_t lds = pair_f16_lds_bytes(wpb);
-    (void)hipFuncSetAttribute((const void*)pair_f16_kernel<wpb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid(cdiv(D, 64), cdiv(T, wpb * tw), B);
-    hipLaunchKernelGGL((pair_f16_kernel<wpb>), grid, dim3(64 * wpb), lds, st, packed, reinterpret_cast<const uint32_t*>(p16), UP, UC,
-                       hand_prev, hand_det, denom, residual, T, D, ld, nf, tw);
+    const size_t lds = pair_f16_lds_bytes(wpb, grid);
+    dim3 grd(cdiv(D, 64), cdiv(T, wpb * tw), B);
+    if (grid) {
+        (void)hipFuncSetAttribute((const void*)pair_f16_kernel<wpb, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((pair_f16_kernel<wpb, true>), grd, dim3(64 * wpb), lds, st, packed, reinterpret_cast<const uint32_t*>(p16), UP, UC,
+                           hand_prev, hand_det, denom, residual, T, D, ld, nf, tw);
+    } else {
+        (void)hipFuncSetAttribute((const void*)pair_f16_kernel<wpb, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((pair_f16_kernel<wpb, false>), grd, dim3(64 * wpb), lds, st, packed, reinterpret_cast<const uint32_t*>(p16), UP, UC,
+                           hand_prev, hand_det, denom, residual, T, D, ld, nf, tw);
+    }
     return check_launch("pair_f16");
 }
 

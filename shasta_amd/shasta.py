@@ -120,6 +120,9 @@ class Shasta(BaseTrack):
         #   "pieces": above 32 frame-pairs per call the aug_shape first layer and, from 8192 table rows, the row-embedding GEMMs
         #            and the aff layers use three exact bf16 pieces per operand, six products per fp32 product;
         #   "f32":   the f32 MFMA kernels everywhere.
+        #   "f16grid" (opt-in, NOT fp32-equivalent): as "f16x2", but at F = 256 and from 8192 table rows the pair kernel takes the fp16
+        #            pieces of its hidden activations from a fixed grid per MLP (22 bits of the tile's largest sum): a third fewer
+        #            vector instructions, errors of `residual` about 2x (max) / 5x (rms) those of the fp32 kernels, 1e-6 of its range.
         self.arithmetic = "f16x2"
         # "f16x2" only: keep the first aug_shape layers ALSO as pre-cut fp16 pieces (+4 bytes per weight resident: 4.1 GB at N=500, built
         # lazily with the row maxima for the first forward of more than 64 frame-pairs) and stream those instead of cutting the fp32
@@ -203,11 +206,12 @@ class Shasta(BaseTrack):
 
         w = hip.Weights()
         w.max_obj, w.num_feats, w.feat_dim = self.max_obj, self.num_feats, self.aug_shape_output
-        if self.arithmetic not in ("pieces", "f32", "f16x2"):
-            raise ValueError("Shasta.arithmetic must be 'pieces', 'f32' or 'f16x2'")
+        if self.arithmetic not in ("pieces", "f32", "f16x2", "f16grid"):
+            raise ValueError("Shasta.arithmetic must be 'pieces', 'f32', 'f16x2' or 'f16grid'")
         w.options = {"pieces": 0, "f32": hip.OPT_F32_WEIGHT_STREAM | hip.OPT_F32_EMBED_GEMM | hip.OPT_F32_AFF,
-                     "f16x2": hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_F16X2_PAIR}[self.arithmetic]
-        if self.arithmetic == "f16x2" and self.precut_weight_stream:
+                     "f16x2": hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_F16X2_PAIR,
+                     "f16grid": hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_F16X2_PAIR | hip.OPT_F16GRID_PAIR}[self.arithmetic]
+        if self.arithmetic in ("f16x2", "f16grid") and self.precut_weight_stream:
             w.options |= hip.OPT_PRECUT_WEIGHT_STREAM
         for i in range(4):
             w.aug_shape[i][0], w.aug_shape[i][1] = lin(self.aug_shape[i][0]), lin(self.aug_shape[i][2])
@@ -244,7 +248,7 @@ class Shasta(BaseTrack):
         the stream; up to 16 the f32 16x16x4 kernel is as fast and needs no activation image).  Training steps (weights change every step) never build the image for it: they keep the kernels that read the fp32
         tensors.  Without a companion the library recomputes the maxima inside every call that needs them."""
         small = self.precut_weight_stream and not training and B >= hip.PRECUT_MIN_BATCH
-        need = self.arithmetic == "f16x2" and (B > 64 or small) and self.max_obj * self.aug_shape_output >= 64
+        need = self.arithmetic in ("f16x2", "f16grid") and (B > 64 or small) and self.max_obj * self.aug_shape_output >= 64
         if not need:
             w.aug_shape_aux = None
             return

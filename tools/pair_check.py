@@ -44,7 +44,7 @@ gc = torch.Generator().manual_seed(4)
 det0, prev = O.synth_boxes(gc, B, N).to(dev), O.synth_boxes(gc, B, N).to(dev)
 model.keep_intermediates = True
 ref = None
-for mode in ("f16x2", "pieces", "f32"):
+for mode in ("f16x2", "pieces", "f32", "f16grid"):
     model.arithmetic = mode
     with torch.no_grad():
         model.affinity_from_bev(bev, pbev, det0.clone(), prev)
