@@ -14,8 +14,9 @@ the elapsed time.
 GPU, started before this process touches the GPU; rank 0's JSON line is the output).  Rank 0 prints ONE JSON line (see
 DESIGN.md "Measurement" for the definition of every field).  On one GPU the same line carries, under `extra`, the other
 operating points SURVEY.md 8(d) asks for, measured by the same process right after the headline run: frame-pairs per step
-1 / 8 / 64 (the reference's eval loop runs batch 1), the strict-f32 and bf16-piece arithmetic at the headline batch, and the
-reference's shipped car configuration (max_obj 90, num_point 5 -> F = 320, num_feats 3).
+1 / 8 / 64 / 512 (the reference's eval loop runs batch 1; 512 was the headline batch of rounds 1 - 2), the strict-f32, bf16-piece and
+opt-in fixed-grid arithmetic at 512 per step, and the reference's shipped car configuration (max_obj 90, num_point 5 -> F = 320,
+num_feats 3).
 """
 import argparse
 import ctypes as C
@@ -395,7 +396,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512, help="frame-pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=1024,
+                    help="frame-pairs per step per GPU (SURVEY.md 8(d): headline = best batch; measured 512: 54.4 k, 768: 56.5 k, 1024: 57.3 k, "
+                         "1536: 55.1 k, 2048: 54.4 k frame-pairs/s on one box - the same joules per frame-pair, the longer kernels hold more power)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline operating point only (no `extra` object)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (no HIP-event roofline)")
@@ -493,7 +496,7 @@ def extras(bench, args):
     B in {1, 8, 64} at the headline size (B = 1 is the reference's eval batch, tools/nusc_shasta/eval.py:96-101: its step time is the
     latency), the other two arithmetic forms at the headline batch (`arithmetic_f32` = strict fp32 products on the f32 MFMA
     instructions), and the shipped car configuration (configs/nusc/car.py:22-39: max_obj 90, num_point 5 -> F = 320, num_feats 3)."""
-    B = args.batch
+    B = min(args.batch, 512)  # the other forms and the car configuration at 512 frame-pairs per step, as in rounds 1 - 2
     ex = {"note": "measured by the same process after the headline run; each entry: W warm-up + K timed steps, barrier + synchronize "
                   "on both sides; rooflines from HIP events on the launch stream as in the headline"}
 
@@ -508,8 +511,8 @@ def extras(bench, args):
             return {"error": "%s: %s" % (type(err).__name__, str(err)[:300]), "frame_pairs_per_step": b, "arithmetic": mode}
 
     sweep = {}
-    for b, k in ((1, 200), (8, 100), (64, 50)):
-        if b <= B:
+    for b, k in ((1, 200), (8, 100), (64, 50), (512, 30)):
+        if b <= args.batch and b != args.batch:
             sweep["b%d" % b] = point(HEADLINE, b, k, args.arithmetic)
     ex["batch_sweep"] = sweep
     for mode in ("f32", "pieces"):

@@ -51,7 +51,7 @@ def pmc(dirs, dst):
 
 if __name__ == "__main__":
     os.makedirs(P, exist_ok=True)
-    for name, dst in (("prof_default", "bench_default_b512"), ("prof_b128", "bench_b128"), ("prof_b64", "bench_b64"), ("prof_b1", "bench_b1"),
+    for name, dst in (("prof_default", "bench_default_b512"), ("prof_b1024", "bench_b1024"), ("prof_b128", "bench_b128"), ("prof_b64", "bench_b64"), ("prof_b1", "bench_b1"),
                       ("prof_pieces", "bench_pieces_b512")):
         src = os.path.join(G, SRC, name, "d_kernel_stats.csv")
         if os.path.exists(src):
@@ -77,7 +77,7 @@ if __name__ == "__main__":
     # HBM bytes per launch of the two heaviest kernels (bench.py: roofline.traffic), FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md)
     rows = list(csv.DictReader(open(os.path.join(P, TAG + "_pmc_summary.csv"))))
     traffic = {}
-    for b in (1, 32, 64, 128, 512):
+    for b in (1, 32, 64, 128, 512, 1024):
         for key, kern in (("batch_%d", "anchor_l1"), ("pair_batch_%d", "::pair_")):
             f = [float(r["mean_value_per_launch"]) for r in rows if r["run"] == "b%d_fetch" % b and kern in r["kernel"] and r["counter"] == "FETCH_SIZE"
                  and int(r["launches"]) > 3]
@@ -86,7 +86,7 @@ if __name__ == "__main__":
             if f and w:
                 traffic[key % b] = int((2 * f[0] + w[0]) * 1024)
     kern_names = {}
-    for b in (1, 32, 64, 128, 512):
+    for b in (1, 32, 64, 128, 512, 1024):
         for key, kern in (("batch_%d", "anchor_l1"), ("pair_batch_%d", "::pair_")):
             names = sorted({r["kernel"] for r in rows if r["run"] == "b%d_fetch" % b and kern in r["kernel"] and int(r["launches"]) > 3})
             if names and (key % b) in traffic:
