@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void box_l2_tables_kernel(BoxL2Args a) {
 
 size_t anchor_split_workspace_bytes(int B, int K);
 bool anchor_split_serves(int B, int K, int x_batch_stride);
-void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, int B, int x_batch_stride, int np, const unsigned* xmax,
+void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, int B, int x_batch_stride, int np, const unsigned* xmax, bool precut,
                     hipStream_t st);
 void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part, int H, int K, int B, int* ks_out, int np,
                             const unsigned* wmax, const void* wimg, hipStream_t st);
@@ -414,7 +414,7 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
         }
         if (!xmax_ready && (rc0 = launch_x_maxima(feat, prev_feat, K, B, a.x_batch_stride, xmax, st))) return rc0;
     }
-    if (split) launch_split_x(feat, prev_feat, xs, K, B, a.x_batch_stride, np, xmax, st);
+    if (split) launch_split_x(feat, prev_feat, xs, K, B, a.x_batch_stride, np, xmax, f16x2 && wimg, st);
     if (ev0) (void)hipEventRecord(ev0, st);
     if (B == 1) launch_l1<1, R>(a, st);
     else if (split) launch_anchor_l1_split(a.W, xs, part, H, K, B, &a.KS, np, wmax, f16x2 ? wimg : nullptr, st);

@@ -144,12 +144,19 @@ constexpr int PF_TS = 44;  // floats per pair in the transposition tile: 40 + 4 
 // conversions / mixes / packed fp32 ops.  The price is accuracy: a fixed grid spends its 22 bits on the LARGEST sum of the tile
 // (tools/pair_quant_sim.py: max / rms error of `residual` 2x / 5x the fp32 kernels', 1e-6 of its range), which is why this is
 // not the default arithmetic.
+#ifdef PAIR_STAMP  // diagnostic build only (tools/pair_clock.py): in-kernel clock = d(s_memtime) / d(s_memrealtime) * 100 MHz per workgroup,
+// and where / when each of its waves ran: per wave {shader cycles, s_memrealtime at its start, at its end, XCC_ID << 32 | HW_ID}
+__device__ unsigned long long g_pair_stamp[4096][8][4];
+#endif
+
 template <int WPB, bool GRID>
 __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restrict__ packed, const uint32_t* __restrict__ p16,
                                                        const float* __restrict__ UP, const float* __restrict__ UC,
                                                        const float* __restrict__ hand_prev, const float* __restrict__ hand_det,
                                                        const float* __restrict__ denom, float* __restrict__ residual, int T,
-                                                       int D, int ld, int nf, int TW) {
+                                                       int D, int ld, int nf, int TWG, int TA, int TB) {
+    // TWG tracks per workgroup: TA to each of the waves 0 .. 3, TB to each of the waves 4 .. 7 (launch_pair_f16: the two waves of a
+    // SIMD do not advance at the same rate)
     constexpr int F = 256;
     constexpr PairDims dm(F);
     constexpr int ET = dm.ET, US = ET + 4;
@@ -175,6 +182,9 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
     uint32_t* s_upp = reinterpret_cast<uint32_t*>(s_tr + WPB * 64 * PF_TS);  // [WPB][2][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PAIR_STAMP
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // (Placing the 8 detection tiles of a frame-pair on ONE XCD - they all read that frame-pair's UP / hand tables, 265 KB, which with
     // the plain order is fetched into eight L2s - was measured: 1.5 % less energy per step, pair kernel 4.21 - 4.30 -> 4.35 ms; not kept.)
     const int b = blockIdx.z, d0 = blockIdx.x * 64;
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
             mcr[1] = h[15];
             mcr[2] = h[13];
         }
-        const int tw0 = by * WPB * TW, tw1 = min(T, tw0 + WPB * TW);
+        const int tw0 = by * TWG, tw1 = min(T, tw0 + TWG);
         for (int t = tw0 + tid; t < tw1; t += 64 * WPB) {
             const float* h = hand_prev + ((size_t)b * T + t) * 16;
             mur[0] = absmax_keep_nan(mur[0], h[14]);
@@ -293,8 +303,8 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
     const int p = lane & 15, kb = lane >> 4;
     float* my_tr = s_tr + wid * (64 * PF_TS);
 
-    const int t_beg = (by * WPB + wid) * TW;
-    const int t_end = min(T, t_beg + TW);
+    const int t_beg = by * TWG + (wid < 4 ? wid * TA : 4 * TA + (wid - 4) * TB);
+    const int t_end = min(min(T, (by + 1) * TWG), t_beg + (wid < 4 ? TA : TB));
     float* my_up = s_up + wid * (3 * 256);
     const bool hp_lane = lane >= ET / 4 && lane < ET / 4 + 4;
     const int up_lane = 4 * min(lane, ET / 4 - 1), hp_off = 4 * (lane - ET / 4);
@@ -590,6 +600,15 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
         const float res = (a_rc3[0][0] * a_fd3[0][0] + a_rc3[0][1] * dist) + a_rc3[0][2] * a_fs4[0][0];
         if (d < D) residual[((size_t)b * T + t) * ld + d] = finite_bound ? res : __builtin_nanf("");
     }
+#ifdef PAIR_STAMP
+    if (lane == 0) {
+        const unsigned slot = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 4095;
+        g_pair_stamp[slot][wid & 7][0] = __builtin_amdgcn_s_memtime() - st0;
+        g_pair_stamp[slot][wid & 7][1] = sr0;
+        g_pair_stamp[slot][wid & 7][2] = __builtin_amdgcn_s_memrealtime();
+        g_pair_stamp[slot][wid & 7][3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+#endif
 }
 
 size_t pair_f16_lds_bytes(int wpb, bool grid) {
@@ -607,25 +626,44 @@ int launch_pair_f16(const float* packed, const float* p16, const float* UP, cons
 #else
     constexpr int wpb = 8;
 #endif
-    // tracks per wave: the T tracks dealt evenly to the 8 ny waves of the ny workgroups of a detection tile, ny the smallest power of two
-    // that leaves 512 workgroups (two rounds of the CU array).  A workgroup's prologue - the detection tile and the operand table
-    // into LDS behind a barrier - is paid once per 8 tw tracks: 5.42 / 5.23 / 5.11 / 5.05 ms for 8 / 16 / 32 / 64 tracks per wave at
-    // 512 frame-pairs (T = 502: 63 per wave, the last wave 61, instead of 64 and 54).
+    // tracks per workgroup: the T tracks dealt evenly to the ny workgroups of a detection tile, ny the smallest power of two that leaves
+    // 512 workgroups (two rounds of the CU array).  A workgroup's prologue - the detection tile and the operand table into LDS behind a
+    // barrier - is paid once per workgroup: 5.42 / 5.23 / 5.11 / 5.05 ms for 8 / 16 / 32 / 64 tracks per wave at 512 frame-pairs.
+    // Tracks per WAVE: the LDS allows one workgroup per CU, so its waves w and w + 4 share a SIMD for the whole kernel, and the SIMD
+    // issues from the older wave first: stamped per wave (tools/pair_clock.py), waves 0 .. 3 ran their tracks at the pace of a wave
+    // that has the SIMD to itself (6 870 cycles per track) while waves 4 .. 7 advanced 0.625 tracks per track of theirs, then finished
+    // alone - the slow way, one wave per SIMD - for the last quarter of the workgroup's time, with the CU's LDS held.  Dealing the
+    // tracks 78 : 48 instead of 63 : 63 lets both finish together.
     int ny = 1;
     while ((long)B * cdiv(D, 64) * ny < 512 && cdiv(T, wpb * ny * 2) >= 2) ny *= 2;
-    const int tw = cdiv(T, wpb * ny);
+    const int twg = cdiv(cdiv(T, ny), wpb) * wpb;  // a multiple of the waves
+#ifndef PAIR_SPLIT_PERMILLE
+#define PAIR_SPLIT_PERMILLE 615  // tracks of a late wave per 1000 of an early one
+#endif
+    int ta = twg / wpb, tb = ta;
+    if (wpb == 8) {
+        const int per_simd = twg / 4;
+        ta = (per_simd * 1000 + (1000 + PAIR_SPLIT_PERMILLE) / 2) / (1000 + PAIR_SPLIT_PERMILLE);  // to nearest
+        tb = per_simd - ta;
+    }
     const size_t lds = pair_f16_lds_bytes(wpb, grid);
-    dim3 grd(cdiv(D, 64), cdiv(T, wpb * tw), B);
+    dim3 grd(cdiv(D, 64), cdiv(T, twg), B);
     if (grid) {
         (void)hipFuncSetAttribute((const void*)pair_f16_kernel<wpb, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((pair_f16_kernel<wpb, true>), grd, dim3(64 * wpb), lds, st, packed, reinterpret_cast<const uint32_t*>(p16), UP, UC,
-                           hand_prev, hand_det, denom, residual, T, D, ld, nf, tw);
+                           hand_prev, hand_det, denom, residual, T, D, ld, nf, twg, ta, tb);
     } else {
         (void)hipFuncSetAttribute((const void*)pair_f16_kernel<wpb, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((pair_f16_kernel<wpb, false>), grd, dim3(64 * wpb), lds, st, packed, reinterpret_cast<const uint32_t*>(p16), UP, UC,
-                           hand_prev, hand_det, denom, residual, T, D, ld, nf, tw);
+                           hand_prev, hand_det, denom, residual, T, D, ld, nf, twg, ta, tb);
     }
     return check_launch("pair_f16");
 }
 
 }  // namespace shasta
+
+#ifdef PAIR_STAMP
+extern "C" __attribute__((visibility("default"))) int shasta_debug_pair_stamp(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(shasta::g_pair_stamp), sizeof(shasta::g_pair_stamp));
+}
+#endif

@@ -1,6 +1,7 @@
 """Build a variant of the library for A/B runs: one source recompiled with extra -D flags, linked with the objects of the
 normal build.  usage: python tools/build_variant.py <name> <source.hip> [-DFLAG ...]  ->  tools/probes/_bin/libshasta_<name>.so
-(load it with SHASTA_HIP_LIB=<path>, see tools/gpu_ab.sh)"""
+(load it with SHASTA_HIP_LIB=<path>, see tools/gpu_ab.sh).  --export-all links without the export map (diagnostic builds that add an
+extern "C" accessor of their own, e.g. -DPAIR_STAMP)."""
 import os
 import subprocess
 import sys
@@ -11,6 +12,8 @@ from shasta_amd import build as B  # noqa: E402
 
 def main():
     name, src, flags = sys.argv[1], sys.argv[2], sys.argv[3:]
+    export_all = "--export-all" in flags
+    flags = [f for f in flags if f != "--export-all"]
     B.build()
     objdir = os.path.join(B.CSRC, "build")
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "_bin")
@@ -20,8 +23,8 @@ def main():
     subprocess.run(cmd, check=True)
     objs = [obj if s == src else os.path.join(objdir, s.replace(".hip", ".o")) for s in B.SOURCES]
     lib = os.path.join(out, "libshasta_%s.so" % name)
-    subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(B.CSRC, "exports.map"),
-                    "-o", lib] + objs, check=True)
+    vs = [] if export_all else ["-Wl,--version-script=" + os.path.join(B.CSRC, "exports.map")]
+    subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + vs + ["-o", lib] + objs, check=True)
     print(lib)
 
 
