@@ -277,6 +277,12 @@ struct A4 {
 // DT = detections per wave: 64 (one track per iteration), or 32 with TWO tracks per iteration (lanes 32..63 take track t + 1): the
 // same instruction stream covers 2 x 32 pairs, so a table of D = 92 rows (the shipped car configuration: max_obj 90) fills 3 x 32
 // lanes-of-work at 96 % instead of 2 x 64 at 72 %, and D = 22 (bus) one tile at 69 % instead of 34 %.
+#ifdef PAIR_STAMP  // diagnostic build only (tools/pair_clock.py, as in pair_f16.hip).  Stamped at N = 500, 512 frame-pairs: two workgroups
+// per CU; a workgroup's waves 4 .. 7 end 133 us after its waves 0 .. 3 (of 700 us), but the other workgroup of the CU fills the
+// SIMDs meanwhile: dealing fewer tracks to the late waves (900 / 850 / 800 per 1000) changed neither this kernel's 5.96 ms nor the car
+// configuration's 0.31 ms, so the tracks stay dealt evenly here.
+__device__ unsigned long long g_pair_stamp[4096][8][4];
+#endif
 template <int F, int WPB, int DT = 64>
 __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __restrict__ packed, const float* __restrict__ UP,
                                                          const float* __restrict__ UC, const float* __restrict__ hand_prev,
@@ -300,6 +306,9 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dlane = lane & (DT - 1), th = lane / DT;  // detection of the tile, track of the iteration
+#ifdef PAIR_STAMP
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int b = blockIdx.z, d0 = blockIdx.x * DT;
     const int d = d0 + dlane, dcl = min(d, D - 1);
     const PackedLayout P(0, 0, F);
@@ -452,6 +461,15 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
         const float res = (a_rc3[0][0] * a_fd3[0][0] + a_rc3[0][1] * dist) + a_rc3[0][2] * a_fs4[0][0];
         if (d < D && tt < t_end) residual[((size_t)b * T + tt) * ld + d] = res;
     }
+#ifdef PAIR_STAMP
+    if (lane == 0) {
+        const unsigned slot = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 4095;
+        g_pair_stamp[slot][wid & 7][0] = __builtin_amdgcn_s_memtime() - st0;
+        g_pair_stamp[slot][wid & 7][1] = sr0;
+        g_pair_stamp[slot][wid & 7][2] = __builtin_amdgcn_s_memrealtime();
+        g_pair_stamp[slot][wid & 7][3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+#endif
 }
 
 size_t pair_workspace_bytes(int B, int N, int F) {
@@ -607,3 +625,9 @@ int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {
 }
 
 }  // namespace shasta
+
+#ifdef PAIR_STAMP
+extern "C" __attribute__((visibility("default"))) int shasta_debug_pair_stamp(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(shasta::g_pair_stamp), sizeof(shasta::g_pair_stamp));
+}
+#endif

@@ -633,7 +633,9 @@ int launch_pair_f16(const float* packed, const float* p16, const float* UP, cons
     // issues from the older wave first: stamped per wave (tools/pair_clock.py), waves 0 .. 3 ran their tracks at the pace of a wave
     // that has the SIMD to itself (6 870 cycles per track) while waves 4 .. 7 advanced 0.625 tracks per track of theirs, then finished
     // alone - the slow way, one wave per SIMD - for the last quarter of the workgroup's time, with the CU's LDS held.  Dealing the
-    // tracks 78 : 48 instead of 63 : 63 lets both finish together.
+    // tracks 78 : 48 instead of 63 : 63 lets both finish together (within 7 us of 234): pair stage 4.41 -> 4.16 ms at 512 frame-pairs;
+    // 55 : 100 and 68 : 100 measured 1 - 2 % behind 61.5 : 100.  (s_setprio by phase - the wave in its lane-per-pair phase first, or
+    // last - with even or uneven tracks: at best equal, 7.71 against 7.65 ms at 1024 frame-pairs; not kept.)
     int ny = 1;
     while ((long)B * cdiv(D, 64) * ny < 512 && cdiv(T, wpb * ny * 2) >= 2) ny *= 2;
     const int twg = cdiv(cdiv(T, ny), wpb) * wpb;  // a multiple of the waves

@@ -3,7 +3,7 @@
 and SHASTA_HIP_LIB=tools/probes/_bin/libshasta_pstamp.so.  Every workgroup stamps s_memtime (shader cycles) and s_memrealtime (100 MHz)
 around itself; clock = d(s_memtime) / d(s_memrealtime) * 100 MHz, median over the 4096 workgroups of the last launch, after 2 s of
 back-to-back launches of (a) the whole forward, (b) the pair stage alone, and (c) one launch after 300 ms of idle.
-usage: pair_clock.py [B]"""
+usage: pair_clock.py [B] [arithmetic]   (arithmetic "pieces": pair_mfma4_kernel, diagnostic build of pair.hip instead)"""
 import ctypes as C
 import os
 import statistics
@@ -24,6 +24,8 @@ with torch.device(dev):
     m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
         max_obj=500, num_feats=7, num_point=4)).eval()
+if len(sys.argv) > 2:
+    m.arithmetic = sys.argv[2]
 lib = hip.load()
 dbg = C.CDLL(os.environ["SHASTA_HIP_LIB"])
 w = m._weights()
@@ -76,6 +78,7 @@ def stamps(label, ms):
     dur = w1 - w0
     hw = a[:, 0, 3]
     cu = ((hw >> np.uint64(32)) & np.uint64(15)) * np.uint64(1 << 16) + (hw & np.uint64(0xff00))  # (XCC, SE, SH, CU)
+    print("    waves of the first workgroup: " + " ".join("w%d simd %d slot %d" % (w, (int(a[0, w, 3]) >> 4) & 3, int(a[0, w, 3]) & 15) for w in range(8)))
     ids, counts = np.unique(cu, return_counts=True)
     gaps = []
     for c in ids:
