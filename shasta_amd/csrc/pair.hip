@@ -114,7 +114,7 @@ __global__ void pack_pair_weights_kernel(PackArgs a) {
 //   threads 0 .. (R1+32)/4-1:  E[row][H1 + j]       += Wbox[j][:nf] . box[:nf]                 (res_coeff.0 box columns)
 //                              E[row][H1 + R1 + j]   = Wbox[R1 + j][:nf] . box[:nf] (+ bias)   (fuse_det.0)
 //  blocks [nrow, nrow + nhand): one thread per table row:
-//                              hand[row] = [box7, 0, log(w+eps), log(l+eps), log(h+eps), cos(yaw), sin(yaw), max |E[row]|, 0, 0]
+//                              hand[row] = [box7 (slots >= num_feats zero), 0, log(w+eps), log(l+eps), log(h+eps), cos(yaw), sin(yaw), max |E[row]|, 0, 0]
 //                              (slot 13, the row's largest embedding magnitude, is written by the first role)
 //  the remaining blocks: col_norm (shasta.py:278-279): d2[t][d] = sum_{k<nf} (prev_k - det_k)^2,
 //   denom[d] = max(||d2[:, d]||_2, 1e-12) (F.normalize acts along dim=1 = tracks); 16 detections x 16 track groups per block,
@@ -202,8 +202,10 @@ __global__ __launch_bounds__(256) void row_prep_kernel(RowPrepArgs a) {
         const f32x4* bp = reinterpret_cast<const f32x4*>(a.tab[which] + (size_t)row * 8);
         const f32x4 b0 = bp[0], b1 = bp[1];
         f32x4* h = reinterpret_cast<f32x4*>(a.hand[which] + (size_t)row * 16);
-        h[0] = b0;
-        h[1] = f32x4{b1[0], b1[1], b1[2], 0.0f};
+        // (box slots >= num_feats are zero in both tables' hand rows: pair_layout.hpp, hand_dist)
+        const int nf = a.nf;
+        h[0] = f32x4{b0[0], nf > 1 ? b0[1] : 0.0f, nf > 2 ? b0[2] : 0.0f, nf > 3 ? b0[3] : 0.0f};
+        h[1] = f32x4{nf > 4 ? b1[0] : 0.0f, nf > 5 ? b1[1] : 0.0f, nf > 6 ? b1[2] : 0.0f, 0.0f};
         h[2] = f32x4{logf(b0[3] + 1e-10f), logf(b1[0] + 1e-10f), logf(b1[1] + 1e-10f), cosf(b1[2])};
         // slots 13 - 15 belong to the row embeddings (embed_rows.hip / the row role above): the row's largest |E| over all columns and,
         // from the fused kernel at F = 256, over the fuse_shape and res_coeff column ranges
@@ -283,8 +285,10 @@ struct A4 {
 // configuration's 0.31 ms, so the tracks stay dealt evenly here.
 __device__ unsigned long long g_pair_stamp[4096][8][4];
 #endif
+// (two workgroups per CU = 4 waves per SIMD need at most 128 registers: stated, because <320, 8, 32> sits at the limit - 126, and 130
+// with two more live values, which cost 7 % of the car configuration's pair kernel when it happened)
 template <int F, int WPB, int DT = 64>
-__global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __restrict__ packed, const float* __restrict__ UP,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4))) void pair_mfma4_kernel(const float* __restrict__ packed, const float* __restrict__ UP,
                                                          const float* __restrict__ UC, const float* __restrict__ hand_prev,
                                                          const float* __restrict__ hand_det, const float* __restrict__ denom,
                                                          float* __restrict__ residual, int T, int D, int ld, int nf,
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
         hd[0] = a[0]; hd[1] = a[1]; hd[2] = a[2]; hd[3] = a[3]; hd[4] = c[0]; hd[5] = c[1]; hd[6] = c[2];
         hd[7] = e[0]; hd[8] = e[1]; hd[9] = e[2]; hd[10] = e[3]; hd[11] = g[0];
     }
-    const float dnm = denom[(size_t)b * D + dcl];
+    const float dnm = denom[(size_t)b * D + dcl], rdn = 1.0f / dnm;
     __syncthreads();
     const float* ucrow = s_uc + dlane * US;
     typedef __attribute__((address_space(3))) float lfloat;
@@ -446,17 +450,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_mfma4_kernel(const float* __res
         layer(A4<F, L_FS4>{}, a_fs3, a_fs4);
 
         // ---- hand-designed residual (shasta.py:277-283) ----
-        float d2 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 7; ++k)
-            if (k < nf) {
-                const float df = hp[k] - hd[k];
-                d2 += df * df;
-            }
-        float r = d2 / dnm;
-        const float dim = (fabsf(hp[8] - hd[7]) + fabsf(hp[9] - hd[8])) + fabsf(hp[10] - hd[9]);
-        const float dcs = hp[11] - hd[10], dsn = hp[12] - hd[11];
-        const float dist = (r + dim) + sqrtf(dcs * dcs + dsn * dsn);
+        const float dist = hand_dist(hp, hd, dnm, rdn);
         // ---- combine (shasta.py:316-319) ----
         const float res = (a_rc3[0][0] * a_fd3[0][0] + a_rc3[0][1] * dist) + a_rc3[0][2] * a_fs4[0][0];
         if (d < D && tt < t_end) residual[((size_t)b * T + tt) * ld + d] = res;

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mc = absmax_keep_nan(mc, __shfl_xor(mc, off, 64));  // a NaN / inf row maximum survives
-    const float dnm = denom[(size_t)b * D + dcl];
+    const float dnm = denom[(size_t)b * D + dcl], rdn = 1.0f / dnm;
     // GRID: one grid per MLP for all tracks of this workgroup and the detections of this tile.  Largest magnitudes per column range
     // (hand slots: 14 fuse_shape, 15 res_coeff, 13 = all columns, the bound used for fuse_det) of the tile's UC rows and of the
     // workgroup's UP rows; ge[r] = the exponent that puts their sum into (2^10, 2^11].
@@ -585,17 +585,7 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
         layer(A4h<F, L_FS4>{}, a_fs3, a_fs4, std::false_type{});
 
         // ---- hand-designed residual (shasta.py:277-283) ----
-        float d2 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 7; ++k)
-            if (k < nf) {
-                const float df = hp[k] - hd[k];
-                d2 += df * df;
-            }
-        float r = d2 / dnm;
-        const float dim = (fabsf(hp[8] - hd[7]) + fabsf(hp[9] - hd[8])) + fabsf(hp[10] - hd[9]);
-        const float dcs = hp[11] - hd[10], dsn = hp[12] - hd[11];
-        const float dist = (r + dim) + sqrtf(dcs * dcs + dsn * dsn);
+        const float dist = hand_dist(hp, hd, dnm, rdn);
         // ---- combine (shasta.py:316-319) ----
         const float res = (a_rc3[0][0] * a_fd3[0][0] + a_rc3[0][1] * dist) + a_rc3[0][2] * a_fs4[0][0];
         if (d < D) residual[((size_t)b * T + t) * ld + d] = finite_bound ? res : __builtin_nanf("");

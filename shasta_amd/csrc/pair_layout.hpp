@@ -104,4 +104,30 @@ struct PackedLayout {
     }
 };
 
+#if defined(__HIPCC__)
+// The hand-designed residual of one pair (det3d/models/tracker/shasta.py:277-283) from the hand rows of its track (hp, 16 floats)
+// and of its detection (hd: slots 0 - 6 and 8 - 12 of that row), the column norm dnm = max(||.||, 1e-12) of the detection and
+// rdn = 1.0f / dnm (IEEE, once per lane).  row_prep writes zeros into the box slots >= num_feats of both rows, so the sum of squares
+// runs over all seven slots in the reference's order (x + 0.0 is exact) without a per-slot select.  The division by the
+// loop-invariant dnm is a multiplication by rdn with one residual correction (q = d2 rdn; q += fma(-q, dnm, d2) rdn: the correctly
+// rounded quotient whenever rdn is the correctly rounded reciprocal - Markstein - in 3 instructions instead of the 11 of the generic
+// IEEE sequence); the square root is the hardware's (1 ulp; its operand comes from this library's own cosf / sinf of the yaws).
+__device__ __forceinline__ float hand_dist(const float (&hp)[16], const float (&hd)[12], float dnm, float rdn) {
+    typedef float hpf2 __attribute__((ext_vector_type(2)));
+    hpf2 d01 = hpf2{hp[0], hp[1]} - hpf2{hd[0], hd[1]}, d23 = hpf2{hp[2], hp[3]} - hpf2{hd[2], hd[3]},
+         d45 = hpf2{hp[4], hp[5]} - hpf2{hd[4], hd[5]};
+    const float d6 = hp[6] - hd[6];
+    d01 *= d01;
+    d23 *= d23;
+    d45 *= d45;
+    const float d2 = (((((d01[0] + d01[1]) + d23[0]) + d23[1]) + d45[0]) + d45[1]) + d6 * d6;
+    const float q = d2 * rdn;
+    const float r = __builtin_fmaf(__builtin_fmaf(-q, dnm, d2), rdn, q);
+    const float dim = (__builtin_fabsf(hp[8] - hd[7]) + __builtin_fabsf(hp[9] - hd[8])) + __builtin_fabsf(hp[10] - hd[9]);
+    hpf2 cs = hpf2{hp[11], hp[12]} - hpf2{hd[10], hd[11]};
+    cs *= cs;
+    return (r + dim) + __builtin_amdgcn_sqrtf(cs[0] + cs[1]);
+}
+#endif
+
 }  // namespace shasta
