@@ -270,6 +270,9 @@ struct AnchorSplitArgs {
 #ifdef SHASTA_L1_STAMP  // diagnostic build only (tools/probes/l1_split_probe.hip): in-kernel clock and cycles per tile
 __device__ unsigned long long g_split_stamp[4096][3];
 #endif
+#ifdef SHASTA_L1_TIMELINE  // diagnostic build only (tools/l1_timeline.py): when and where every workgroup ran
+__device__ unsigned long long g_split_timeline[4096][4];  // {shader cycles, s_memrealtime at start, at end, XCC_ID << 32 | HW_ID}
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vm_split() {
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
         }
     };
 
-#ifdef SHASTA_L1_STAMP
+#if defined(SHASTA_L1_STAMP) || defined(SHASTA_L1_TIMELINE)
     const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // Prologue: fill the ring, take tile 0 into registers.
@@ -512,6 +515,14 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
         g_split_stamp[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - st0;
         g_split_stamp[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - sr0;
         g_split_stamp[blockIdx.x][2] = (unsigned long long)NT;
+    }
+#endif
+#ifdef SHASTA_L1_TIMELINE
+    if (lane == 0 && wid == 0 && blockIdx.x < 4096) {
+        g_split_timeline[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - st0;
+        g_split_timeline[blockIdx.x][1] = sr0;
+        g_split_timeline[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime();
+        g_split_timeline[blockIdx.x][3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
     }
 #endif
     // D[i = weight row][j = batch row]
@@ -643,3 +654,9 @@ void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part
 }
 
 }  // namespace shasta
+
+#ifdef SHASTA_L1_TIMELINE
+extern "C" __attribute__((visibility("default"))) int shasta_debug_l1_timeline(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(shasta::g_split_timeline), sizeof(shasta::g_split_timeline));
+}
+#endif
