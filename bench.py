@@ -503,7 +503,9 @@ def extras(bench, args):
     def point(cfg, b, steps, mode, note=None):
         """One extra operating point; a failure here must not cost the headline line: it is recorded in place of the entry."""
         try:
-            e = brief(cfg, mode, bench.measure(cfg, b, steps, 5 if steps >= 30 else 3, mode))
+            # warm-up: the clock needs ~45 ms to settle after the lighter points before a heavy one (tools/thermal_probe.py)
+            warm = 10 if b >= 256 else 5 if steps >= 30 else 3
+            e = brief(cfg, mode, bench.measure(cfg, b, steps, warm, mode))
             if note:
                 e["note"] = note
             return e

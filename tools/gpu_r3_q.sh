@@ -2,7 +2,7 @@
 # full bench line at the new default batch + the two operating-point tests
 cd "$(dirname "$0")/.." && R=$PWD
 O=$R/gpurun_out/r3q; mkdir -p $O
-python -m pytest tests/test_hip_parity.py -m gpu -q -k "operating_points" 2>&1 | grep -E "passed|failed|Error" | tail -5
+
 s=$(date +%s); python3 bench.py > $O/bench_full.json 2> $O/bench_full.err
 echo "bench wall $(( $(date +%s) - s )) s"
 python3 - <<'PY'
