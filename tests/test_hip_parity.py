@@ -815,6 +815,34 @@ def test_pair_kernels_are_fp32_accurate():
         assert f16["max_abs_err"] <= 1e-5 * f16["ref_scale"]
 
 
+@pytest.mark.parametrize("N,B", [(1, 1), (2, 3), (5, 2), (13, 4), (47, 2), (129, 1), (200, 3)])
+def test_fp16_pair_path_at_odd_table_sizes_matches_oracle(N, B):
+    """pair_f16_kernel (F = 256) deals a workgroup's tracks unevenly to the two waves of a SIMD (launch_pair_f16) and several workgroups
+    share a detection tile when the launch is small: table sizes from 3 rows (one track per early wave, none for most others) through
+    ragged last tiles and last waves, against the CPU oracle on the same seeded inputs; every row of matched1 must keep its arg-max."""
+    import shasta_amd
+    dev = _dev()
+    torch.manual_seed(100 + N)
+    m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075],
+                                                            out_stride=8), max_obj=N, num_feats=7, num_point=4)).eval()
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(N)
+    bev = torch.relu(torch.randn(B, 180, 180, 64, generator=g))
+    pbev = torch.relu(torch.randn(B, 180, 180, 64, generator=g))
+    det, prev = O.synth_boxes(g, B, N), O.synth_boxes(g, B, N)
+    r1, r2 = O.forward_from_bev(w, bev, pbev, det.clone(), prev.clone(), 7, 4)
+    m = m.to(dev)
+    assert m.arithmetic == "f16x2"
+    with torch.no_grad():
+        m1, m2 = m.affinity_from_bev(bev.to(dev), pbev.to(dev), det.to(dev), prev.to(dev))
+    m1, m2 = m1.cpu(), m2.cpu()
+    assert float((m1 - r1).abs().max()) < 1e-5 and float((m2 - r2).abs().max()) < 1e-5
+    top2 = torch.topk(r1, 2, dim=-1).values
+    decided = (top2[..., 0] - top2[..., 1]) > 1e-5
+    assert bool((m1.argmax(-1) == r1.argmax(-1))[decided].all())
+
+
 def test_fp16_form_is_range_safe():
     """The two-piece fp16 weight stream scales every batch row of the activations and every weight row by its own power of two
     (range exponents), so magnitudes far outside fp16's range - activations around 1e6 and 1e-9, weights around 3e4 and 1e-7 in
