@@ -18,10 +18,13 @@ def main():
     objdir = os.path.join(B.CSRC, "build")
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "_bin")
     os.makedirs(out, exist_ok=True)
-    obj = os.path.join(out, "%s_%s.o" % (name, src.replace(".hip", "")))
-    cmd = [B._hipcc()] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + flags + ["-c", os.path.join(B.CSRC, src), "-o", obj]
-    subprocess.run(cmd, check=True)
-    objs = [obj if s == src else os.path.join(objdir, s.replace(".hip", ".o")) for s in B.SOURCES]
+    variant = {}
+    for one in src.split(","):  # several sources (comma-separated) take the same flags
+        obj = os.path.join(out, "%s_%s.o" % (name, one.replace(".hip", "")))
+        cmd = [B._hipcc()] + B.FLAGS + B.EXTRA_FLAGS.get(one, []) + flags + ["-c", os.path.join(B.CSRC, one), "-o", obj]
+        subprocess.run(cmd, check=True)
+        variant[one] = obj
+    objs = [variant.get(s, os.path.join(objdir, s.replace(".hip", ".o"))) for s in B.SOURCES]
     lib = os.path.join(out, "libshasta_%s.so" % name)
     vs = [] if export_all else ["-Wl,--version-script=" + os.path.join(B.CSRC, "exports.map")]
     subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + vs + ["-o", lib] + objs, check=True)
