@@ -455,8 +455,8 @@ def main():
                    "max_obj": N_OBJ, "num_feats": NF, "num_point": NPOINT, "bev_hw": HW,
                    "parallelism": "replica x%d (frame-parallel, no data-path collective)" % world,
                    "hip_graph": bool(args.graph), "precut_weight_stream": not args.no_precut,
-                   "arithmetic": {"f16x2": "fp32 operands in HBM, fp32 accumulation throughout; above 32 frame-pairs per step the first "
-                                           "aug_shape layer (above 64 frame-pairs) and the second layers of the pair MLPs form every fp32 product from three products of "
+                   "arithmetic": {"f16x2": "fp32 operands in HBM, fp32 accumulation throughout; the first aug_shape layer (from 17 frame-pairs per step "
+                                           "with the pre-cut weight image, above 64 without) and the second layers of the pair MLPs form every fp32 product from three products of "
                                            "two range-scaled fp16 pieces per operand (round to nearest; measured max error vs float64: weight "
                                            "stream 5.5e-6 against 7.0e-6 for the f32 MFMA kernel, pair stage 1.8e-6 against 2.3e-6); from 8192 "
                                            "table rows the row-embedding GEMMs and the aff layers use six products of three exact bf16 "
