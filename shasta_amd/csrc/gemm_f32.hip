@@ -114,6 +114,54 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_dual_kernel(GemmNtDual p, int
                        N, K, act);
 }
 
+// Few rows (the row embeddings of one or a few small frame-pairs: 12 workgroups of the kernel above walk ten dependent 32-wide slices,
+// 13 us at max_obj 90, batch 1): the whole K in ONE round of loads.  A workgroup owns a 32 x 32 output tile; its four waves take a
+// quarter of K each - every operand element of the wave straight from global memory into the MFMA layout, all loads in flight at
+// once (lane (r, h) holds row r, elements [KQ/2 * h, KQ/2 * (h + 1)) of the wave's quarter for both operands, so MFMA step s pairs the
+// same k on both sides) - and the four partial tiles are added in wave order through LDS.  K % 32 == 0 and K <= 512 (F = 64 .. 512).
+template <int KQ>  // K / 4: elements per wave
+__global__ __launch_bounds__(256) void gemm_nt_f32_small_dual_kernel(GemmNtDual p, int lda, int ldw, int ldc, int M, int N, int act) {
+    __shared__ float red[4][32][33];
+    constexpr int KH = KQ / 2;  // elements per lane and operand
+    static_assert(KH % 4 == 0, "16-byte loads");
+    const int z = blockIdx.z;
+    const float* A = z ? p.A[1] : p.A[0];
+    const float* W = z ? p.W[1] : p.W[0];
+    const float* bias = z ? p.bias[1] : p.bias[0];
+    float* C = z ? p.C[1] : p.C[0];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const f32x4* ap = reinterpret_cast<const f32x4*>(A + (size_t)min(m0 + r, M - 1) * lda + wid * KQ + h * KH);
+    const f32x4* wp = reinterpret_cast<const f32x4*>(W + (size_t)min(n0 + r, N - 1) * ldw + wid * KQ + h * KH);
+    f32x4 av[KH / 4], wv[KH / 4];
+#pragma unroll
+    for (int i = 0; i < KH / 4; ++i) {
+        av[i] = ap[i];
+        wv[i] = wp[i];
+    }
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < KH / 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j], wv[i][j], acc, 0, 0, 0);
+    // accumulator map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[wid][(q & 3) + 8 * (q >> 2) + 4 * h][r] = acc[q];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, row = e >> 5, col = e & 31;
+        if (m0 + row < M && n0 + col < N) {
+            float v = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+            if (bias) v += bias[n0 + col];
+            if (act == 1) v = relu_nan(v);
+            else if (act == 2) v = fabsf(v);
+            C[(size_t)(m0 + row) * ldc + n0 + col] = v;
+        }
+    }
+}
+
 int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
                    int N, int K, int act, hipStream_t st) {
     if (M == 0 || N == 0) return SHASTA_OK;
@@ -173,6 +221,15 @@ int launch_gemm_nt_dual(const float* A0, const float* W0, const float* bias0, fl
         return launch_gemm_nt(A1, lda, W1, ldw, bias1, C1, ldc, M, N, K, act, st);
     }
     GemmNtDual p{{A0, A1}, {W0, W1}, {bias0, bias1}, {C0, C1}};
+    // while the 64 x 64 tiles leave most of the chip idle: the one-shot kernel (four times the workgroups, one load latency)
+    if (2 * cdiv(N, BN) * cdiv(M, BM) <= 128 && (K == 64 || K == 256 || K == 320 || K == 512)) {
+        const dim3 grid(cdiv(N, 32), cdiv(M, 32), 2);
+        if (K == 64) hipLaunchKernelGGL(gemm_nt_f32_small_dual_kernel<16>, grid, dim3(256), 0, st, p, lda, ldw, ldc, M, N, act);
+        else if (K == 256) hipLaunchKernelGGL(gemm_nt_f32_small_dual_kernel<64>, grid, dim3(256), 0, st, p, lda, ldw, ldc, M, N, act);
+        else if (K == 320) hipLaunchKernelGGL(gemm_nt_f32_small_dual_kernel<80>, grid, dim3(256), 0, st, p, lda, ldw, ldc, M, N, act);
+        else hipLaunchKernelGGL(gemm_nt_f32_small_dual_kernel<128>, grid, dim3(256), 0, st, p, lda, ldw, ldc, M, N, act);
+        return check_launch("gemm_nt_f32_small_dual");
+    }
     hipLaunchKernelGGL(gemm_nt_f32_dual_kernel, dim3(cdiv(N, BN), cdiv(M, BM), 2), dim3(256), 0, st, p, lda, ldw, ldc, M, N, K, act);
     return check_launch("gemm_nt_f32_dual");
 }
