@@ -248,9 +248,8 @@ struct BoxL2Args {
 // the 4x7 anchor outputs, back-projection (shasta.py:270) and the (N+2, 8) box tables (shasta.py:273-274; column 7 is
 // padding and written as 0).
 // grid (B, 1 + ceil(N / 256)): block y == 0 computes the anchors, blocks y >= 1 copy / back-project 256 table rows each.
-__global__ __launch_bounds__(256) void box_l2_tables_kernel(BoxL2Args a) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (blockIdx.y == 0) {
+__device__ __forceinline__ void box_l2_tables_role(const BoxL2Args& a, int b, int y, int tid) {
+    if (y == 0) {
         // wave `mlp` computes the 7 outputs of aug_dets[mlp].2, lanes across the hidden units
         const int mlp = tid >> 6, lane = tid & 63;
         const float* h = a.hid + ((size_t)b * 4 + mlp) * a.HD;
@@ -271,7 +270,7 @@ __global__ __launch_bounds__(256) void box_l2_tables_kernel(BoxL2Args a) {
         if (lane == 0) tab[7] = 0.0f;
         return;
     }
-    const int n = (blockIdx.y - 1) * 256 + tid;
+    const int n = (y - 1) * 256 + tid;
     if (n < a.N) {
         float* d = a.det + ((size_t)b * a.N + n) * a.box_stride;
         const float* p = a.prev + ((size_t)b * a.N + n) * a.box_stride;
@@ -291,6 +290,69 @@ __global__ __launch_bounds__(256) void box_l2_tables_kernel(BoxL2Args a) {
         pr[7] = 0.0f;
     }
 }
+
+__global__ __launch_bounds__(256) void box_l2_tables_kernel(BoxL2Args a) { box_l2_tables_role(a, blockIdx.x, blockIdx.y, threadIdx.x); }
+
+// Small batches (one or a few frame-pairs: every launch costs ~4.5 us of a 115 us step at max_obj 90): everything behind the weight
+// stream in ONE launch instead of three (anchor_hidden, anchor_l2, box_l2_tables).  Workgroups [0, nbox): the roles of
+// box_l2_tables_kernel (b = blk / ybox, y = blk % ybox).  The others: one (batch item, MLP, 16 output features) of the second
+// aug_shape layer each - the workgroup first forms that MLP's hidden activations relu(b1 + sum_ks part) in LDS (fixed order, as
+// anchor_hidden_kernel; re-formed by every workgroup of the MLP: KS * H floats from L2), then every wave takes four output features
+// with the lane / wave_sum order of anchor_l2_kernel, so the results are bit-identical to the three-launch form.
+struct AnchorTailArgs {
+    AnchorL2Args l2;
+    BoxL2Args box;
+    const float* part;   // (KS, B, 4H) split-K partials of the first layer
+    const float* b1[4];  // aug_shape.i.0.bias
+    int KS, nbox, ybox, jblocks;
+};
+__global__ __launch_bounds__(256) void anchor_tail_small_kernel(AnchorTailArgs a) {
+    extern __shared__ float s_hid[];
+    const int tid = threadIdx.x;
+    int blk = blockIdx.x;
+    if (blk < a.nbox) {
+        box_l2_tables_role(a.box, blk / a.ybox, blk % a.ybox, tid);
+        return;
+    }
+    blk -= a.nbox;
+    const int H = a.l2.H, F = a.l2.F, B = a.l2.B;
+    const int jb = blk % a.jblocks, mlp = (blk / a.jblocks) & 3, b = blk / (4 * a.jblocks);
+    const size_t total = (size_t)B * 4 * H;
+    const float* bias1 = a.b1[mlp];
+    for (int i = tid; i < H; i += 256) {
+        const float* p = a.part + (size_t)b * 4 * H + (size_t)mlp * H + i;
+        float s = p[0];
+        int ks = 1;
+        for (; ks + 8 <= a.KS; ks += 8) {  // eight partials in flight, added in order
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(ks + q) * total];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; ks < a.KS; ++ks) s += p[(size_t)ks * total];
+        s_hid[i] = relu_nan(s + bias1[i]);
+    }
+    __syncthreads();
+    const int lane = tid & 63, j0 = jb * 16 + (tid >> 6) * 4;
+    const float* w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = a.l2.W[mlp] + (size_t)min(j0 + q, F - 1) * H;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 2
+    for (int i = lane; i < H; i += 64) {
+        const float hv = s_hid[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = fmaf(w[q][i], hv, s[q]);
+    }
+    float* tab = ((mlp < 2) ? a.l2.prev_feat : a.l2.feat) + ((size_t)b * (a.l2.N + 2) + a.l2.N + (mlp & 1)) * F;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float v = wave_sum(s[q]);
+        if (lane == 0 && j0 + q < F) tab[j0 + q] = fabsf(v + a.l2.bias[mlp][j0 + q]);
+    }
+}
+constexpr int ANCHOR_TAIL_FUSED_MAX_B = 8;
 
 size_t anchor_split_workspace_bytes(int B, int K);
 bool anchor_split_serves(int B, int K, int x_batch_stride);
@@ -364,8 +426,9 @@ unsigned* anchor_shape_xmax_slots(void* ws, int B, int N, int F) {
                                        align_up((size_t)4 * H * sizeof(int), 256));
 }
 
-int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes,
-                 hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const unsigned* wmax, bool xmax_ready) {
+// tail: the deferred box roles of anchor_boxes_impl; when given (small batches) everything behind the first layer goes into ONE launch
+static int anchor_shape_impl(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes, hipStream_t st,
+                             hipEvent_t ev0, hipEvent_t ev1, const unsigned* wmax, bool xmax_ready, const BoxL2Args* tail) {
     const int N = w->max_obj, F = w->feat_dim;
     const int K = N * F, H = K / 64;
     if (ws_bytes < anchor_shape_workspace_bytes(B, N, F)) {
@@ -423,6 +486,33 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     int rc = check_launch("anchor_l1");
     if (rc) return rc;
     const int total = B * 4 * H;
+    if (tail) {
+        if (f16x2) {
+            set_error_msg("anchor_shape: the fused tail serves the f32 weight-stream kernels only");
+            return SHASTA_E_ARG;
+        }
+        AnchorTailArgs t;
+        for (int i = 0; i < 4; ++i) {
+            t.l2.W[i] = w->aug_shape[i][1].weight;
+            t.l2.bias[i] = w->aug_shape[i][1].bias;
+            t.b1[i] = w->aug_shape[i][0].bias;
+        }
+        t.l2.hidden = nullptr;
+        t.l2.feat = feat;
+        t.l2.prev_feat = prev_feat;
+        t.l2.H = H;
+        t.l2.F = F;
+        t.l2.N = N;
+        t.l2.B = B;
+        t.box = *tail;
+        t.part = part;
+        t.KS = a.KS;
+        t.ybox = 1 + cdiv(N, 256);
+        t.nbox = B * t.ybox;
+        t.jblocks = cdiv(F, 16);
+        hipLaunchKernelGGL(anchor_tail_small_kernel, dim3(t.nbox + B * 4 * t.jblocks), dim3(256), (size_t)H * sizeof(float), st, t);
+        return check_launch("anchor_tail_small");
+    }
     hipLaunchKernelGGL(anchor_hidden_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, part,
                        w->aug_shape[0][0].bias, w->aug_shape[1][0].bias, w->aug_shape[2][0].bias,
                        w->aug_shape[3][0].bias, hidden, H, B, a.KS, f16x2 ? xmax : nullptr, wmax);
@@ -462,14 +552,19 @@ int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, 
     else hipLaunchKernelGGL(anchor_l2_kernel<8>, dim3(cdiv(cdiv(B, 8) * 4 * F, 4)), dim3(256), 0, st, l2);
     return check_launch("anchor_l2");
 }
+int anchor_shape(const shasta_weights* w, int B, float* feat, float* prev_feat, void* ws, size_t ws_bytes,
+                 hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const unsigned* wmax, bool xmax_ready) {
+    return anchor_shape_impl(w, B, feat, prev_feat, ws, ws_bytes, st, ev0, ev1, wmax, xmax_ready, nullptr);
+}
 
 // [hidden (B, 4, HD)][packed box rows (2, B, ceil4(7N)) for the GEMM form]
 size_t anchor_boxes_workspace_bytes(int B, int N) {
     return align_up((size_t)B * 4 * max(1, 7 * N / 32) * sizeof(float), 256) + align_up((size_t)2 * B * ((7 * N + 3) / 4 * 4) * sizeof(float), 256);
 }
 
-int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes, int box_stride,
-                 float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st, float* anchors_out) {
+// defer: when given, the second layers / back-projection / tables are not launched but described there (anchor_shape_impl's tail)
+static int anchor_boxes_impl(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes, int box_stride,
+                             float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st, float* anchors_out, BoxL2Args* defer) {
     const int N = w->max_obj, HD = 7 * N / 32;
     if (B == 0) return SHASTA_OK;
     if (HD > 0) {
@@ -521,8 +616,36 @@ int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* 
     b2.N = N;
     b2.B = B;
     b2.box_stride = box_stride;
+    if (defer) {
+        *defer = b2;
+        return SHASTA_OK;
+    }
     hipLaunchKernelGGL(box_l2_tables_kernel, dim3(B, 1 + cdiv(N, 256)), dim3(256), 0, st, b2);
     return check_launch("box_l2_tables");
+}
+int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes, int box_stride,
+                 float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st, float* anchors_out) {
+    return anchor_boxes_impl(w, B, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, hid_ws, st, anchors_out, nullptr);
+}
+
+// Both anchor stages of a small batch (forward_impl): the first box layers (they read the boxes before the back-projection), the
+// first aug_shape layer, then anchor_tail_small_kernel.  ws: anchor_shape's workspace followed by anchor_boxes'.
+bool anchor_stage_fused_serves(const shasta_weights* w, int B) {
+    return B >= 1 && B <= ANCHOR_TAIL_FUSED_MAX_B && (size_t)w->max_obj * w->feat_dim / 64 * sizeof(float) <= 48 * 1024;
+}
+int anchor_stage_fused(const shasta_weights* w, int B, float* feat, float* prev_feat, float* det_boxes, const float* prev_det_boxes,
+                       int box_stride, float* det_tab, float* prev_tab, void* ws, size_t ws_bytes, hipStream_t st, hipEvent_t ev0,
+                       hipEvent_t ev1, const unsigned* wmax, bool xmax_ready, float* anchors_out) {
+    const size_t shape_bytes = anchor_shape_workspace_bytes(B, w->max_obj, w->feat_dim);
+    if (ws_bytes < shape_bytes + anchor_boxes_workspace_bytes(B, w->max_obj)) {
+        set_error_msg("anchor stages: workspace too small");
+        return SHASTA_E_WORKSPACE;
+    }
+    BoxL2Args tail;
+    int rc = anchor_boxes_impl(w, B, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab,
+                               reinterpret_cast<float*>(static_cast<char*>(ws) + shape_bytes), st, anchors_out, &tail);
+    if (rc) return rc;
+    return anchor_shape_impl(w, B, feat, prev_feat, ws, shape_bytes, st, ev0, ev1, wmax, xmax_ready, &tail);
 }
 
 }  // namespace shasta

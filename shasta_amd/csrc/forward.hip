@@ -21,6 +21,10 @@ int launch_bev_gather(const float* bev, int B, int H, int W, int C, const float*
                       unsigned* absmax2);
 int anchor_boxes(const shasta_weights* w, int B, float* det_boxes, const float* prev_det_boxes, int box_stride,
                  float* det_tab, float* prev_tab, float* hid_ws, hipStream_t st, float* anchors_out);
+bool anchor_stage_fused_serves(const shasta_weights* w, int B);
+int anchor_stage_fused(const shasta_weights* w, int B, float* feat, float* prev_feat, float* det_boxes, const float* prev_det_boxes,
+                       int box_stride, float* det_tab, float* prev_tab, void* ws, size_t ws_bytes, hipStream_t st, hipEvent_t ev0,
+                       hipEvent_t ev1, const unsigned* wmax, bool xmax_ready, float* anchors_out);
 int pair_residual(const shasta_weights* w, const float* packed, int B, const float* feat, const float* prev_feat,
                   const float* det_tab, const float* prev_tab, float* residual, int ld, void* ws, size_t ws_bytes,
                   hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
@@ -64,8 +68,9 @@ struct FwdWs {
         pair = pair_workspace_bytes(B, N, F);
         aff = aff_workspace_bytes(B, N);
         residual = align_up((size_t)B * T * Dp * sizeof(float), 256);
-        // anchor / pair / aff scratch is live one stage at a time -> shared region
-        size_t stage = anchor > pair ? anchor : pair;
+        // anchor / pair / aff scratch is live one stage at a time -> shared region (the two anchor stages side by side: small batches run
+        // them interleaved, anchor_stage_fused)
+        size_t stage = anchor + boxes > pair ? anchor + boxes : pair;
         stage = stage > aff ? stage : aff;
         stage = stage > boxes ? stage : boxes;
         total = stage + residual;
@@ -224,21 +229,28 @@ static int forward_impl(const shasta_weights* w, const void* packed, int B, floa
             return rc;
         if (slots && (rc = launch_absmax_finalize(slots, anchor_shape_xmax(stage, B, N, F), 2 * B, st))) return rc;
     }
-    // row maxima of the first-layer weights (fp16 form of the weight stream): the caller's companion buffer, or recomputed per call
-    if ((rc = anchor_shape(w, B, feat, prev_feat, stage, stage_bytes, st, ev0, ev1, static_cast<const unsigned*>(w->aug_shape_aux), xmax_ready)))
-        return rc;
-    if (shape_hidden_out) {  // training: the backward re-uses the hidden activations instead of re-streaming the weights
-        const size_t H = (size_t)N * F / 64;
-        hipError_t e = hipMemcpyAsync(shape_hidden_out, anchor_shape_hidden(stage, B, N, F), (size_t)B * 4 * H * sizeof(float),
-                                      hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) {
-            set_error("forward: copy anchor hidden", e);
-            return SHASTA_E_LAUNCH;
+    if (!shape_hidden_out && anchor_stage_fused_serves(w, B) && !anchor_shape_uses_xmax(w, B)) {
+        // one or a few frame-pairs: three launches less (the training path wants the hidden activations materialised: the long form)
+        if ((rc = anchor_stage_fused(w, B, feat, prev_feat, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, stage, stage_bytes, st, ev0,
+                                     ev1, static_cast<const unsigned*>(w->aug_shape_aux), xmax_ready, src ? src->anchor_boxes_out : nullptr)))
+            return rc;
+    } else {
+        // row maxima of the first-layer weights (fp16 form of the weight stream): the caller's companion buffer, or recomputed per call
+        if ((rc = anchor_shape(w, B, feat, prev_feat, stage, stage_bytes, st, ev0, ev1, static_cast<const unsigned*>(w->aug_shape_aux), xmax_ready)))
+            return rc;
+        if (shape_hidden_out) {  // training: the backward re-uses the hidden activations instead of re-streaming the weights
+            const size_t H = (size_t)N * F / 64;
+            hipError_t e = hipMemcpyAsync(shape_hidden_out, anchor_shape_hidden(stage, B, N, F), (size_t)B * 4 * H * sizeof(float),
+                                          hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) {
+                set_error("forward: copy anchor hidden", e);
+                return SHASTA_E_LAUNCH;
+            }
         }
+        if ((rc = anchor_boxes(w, B, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, static_cast<float*>(stage), st,
+                               src ? src->anchor_boxes_out : nullptr)))
+            return rc;
     }
-    if ((rc = anchor_boxes(w, B, det_boxes, prev_det_boxes, box_stride, det_tab, prev_tab, static_cast<float*>(stage), st,
-                           src ? src->anchor_boxes_out : nullptr)))
-        return rc;
     if ((rc = pair_residual(w, pk, B, feat, prev_feat, det_tab, prev_tab, residual, Dp, stage, stage_bytes, st, ev_pair0, ev_pair1)))
         return rc;
     if (residual_out) {
