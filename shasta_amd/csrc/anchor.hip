@@ -378,6 +378,8 @@ int launch_anchor_l1_mfma(const float* const W[4], const float* feat, const floa
                           int B, int x_batch_stride, int* ks_out, hipStream_t st);
 int launch_gemm_nt_quad(const float* const A[4], const float* const W[4], const float* const bias[4], float* const C[4], int lda,
                         int ldw, int ldc, int M, int N, int K, int act, hipStream_t st);
+bool gemm_nt_quad_direct_ok(const float* const A[4], const float* const W[4], int lda, int ldw, int K);
+constexpr int GEMM_DIRECT_MIN_B = 256;  // below, the VALU kernels of the small batches are as fast as the direct skinny GEMM (gemm_f32.hip)
 
 template <int BT, int R>
 static void launch_l1(const AnchorL1Args& a, hipStream_t st) {
@@ -530,9 +532,10 @@ static int anchor_shape_impl(const shasta_weights* w, int B, float* feat, float*
     l2.F = F;
     l2.N = N;
     l2.B = B;
-    if (B >= 256) {  // (measured: the four GEMMs take 80 - 100 us whatever the batch, the VALU kernel 39 us at 64 frame-pairs, 238 at 512)
-        // a plain GEMM per MLP from here on: (B, H) x (F, H)^T on the matrix cores, |.| and the table row as the epilogue's
-        // target (row N + (i & 1) of prev_feat for newborn / fp, of feat for dead_trk / fn; leading dimension = one batch item)
+    {
+        // a plain GEMM per MLP: (B, H) x (F, H)^T on the matrix cores, |.| and the table row as the epilogue's target (row N + (i & 1) of
+        // prev_feat for newborn / fp, of feat for dead_trk / fn; leading dimension = one batch item).  From 256 frame-pairs always (the
+        // 64 x 64 tiles take 80 - 100 us whatever the batch, the direct form 50 us, the VALU kernel below 39 us at 64 frame-pairs, 238 at 512).
         const float* A[4];
         const float* W2[4];
         const float* b2[4];
@@ -543,7 +546,8 @@ static int anchor_shape_impl(const shasta_weights* w, int B, float* feat, float*
             b2[i] = l2.bias[i];
             C[i] = ((i < 2) ? prev_feat : feat) + (size_t)(N + (i & 1)) * F;
         }
-        return launch_gemm_nt_quad(A, W2, b2, C, 4 * H, H, (N + 2) * F, B, F, H, 2, st);
+        if (B >= 256 || (B >= GEMM_DIRECT_MIN_B && gemm_nt_quad_direct_ok(A, W2, 4 * H, H, H)))
+            return launch_gemm_nt_quad(A, W2, b2, C, 4 * H, H, (N + 2) * F, B, F, H, 2, st);
     }
     // small batches: no duplicated activation loads (BT = batch items that share one weight row read)
     if (B == 1) hipLaunchKernelGGL(anchor_l2_kernel<1>, dim3(cdiv(B * 4 * F, 4)), dim3(256), 0, st, l2);
@@ -580,8 +584,11 @@ static int anchor_boxes_impl(const shasta_weights* w, int B, float* det_boxes, c
         a.N = N;
         a.B = B;
         a.box_stride = box_stride;
-        if (B >= 256) {
-            const int ldx = (7 * N + 3) / 4 * 4;
+        const int ldx = (7 * N + 3) / 4 * 4;
+        const float* W1d[4] = {a.W[0], a.W[1], a.W[2], a.W[3]};
+        // (the packed box rows x7 are 16-byte aligned rows of ldx floats; the weights' rows are when 7 N % 4 == 0)
+        const bool direct = B >= GEMM_DIRECT_MIN_B && gemm_nt_quad_direct_ok(W1d, W1d, ldx, 7 * N, 7 * N);
+        if (B >= 256 || direct) {
             float* x7 = reinterpret_cast<float*>(reinterpret_cast<char*>(hid_ws) + align_up((size_t)B * 4 * HD * sizeof(float), 256));
             hipLaunchKernelGGL(box_pack7_kernel, dim3(cdiv(ldx, 256), B, 2), dim3(256), 0, st, det_boxes, prev_det_boxes, x7, B, N, box_stride, ldx);
             int rc = check_launch("box_pack7");

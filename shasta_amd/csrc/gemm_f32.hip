@@ -191,6 +191,80 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_quad_kernel(GemmNtQuad p, int
     gemm_nt_tile<VEC>(As, Ws, p.A[z], lda, p.W[z], ldw, p.bias[z], p.C[z], ldc, M, N, K, act);
 }
 
+// Skinny problems with a long K (the second aug_shape layers: M = batch, N = F, K = N F / 64; the first aug_dets layers: K = 7 N): the
+// 64 x 64 tiles above are 16 .. 128 workgroups that walk K in 60 .. 110 dependent slices, 80 - 100 us whatever the batch.  Here a
+// workgroup owns a 32 x 32 tile and walks K in chunks of 128: its four waves take 32 consecutive k of every chunk each, operands go
+// straight from global memory (L2) into the MFMA layout - lane (r, h) holds row r, 16 consecutive k, for both operands -, the next
+// chunk's loads are in flight under the 16 MFMAs of this one, no LDS and no barrier until the four partial tiles are added in wave
+// order at the end.  Preconditions (launch_gemm_nt_quad checks them): K % 4 == 0, 16-byte aligned operand rows.  Measured at
+// N = 500: 50 us against 94 us for the 64 x 64 tiles at 512 rows; at 64 rows 36 - 41 us, no better than the VALU kernels of the small
+// batches (anchor.hip: 37 - 40 us), which therefore stay below 256 rows.
+#ifndef SHASTA_GEMM_DIRECT
+#define SHASTA_GEMM_DIRECT 1
+#endif
+__global__ __launch_bounds__(256) void gemm_nt_f32_direct_quad_kernel(GemmNtQuad p, int lda, int ldw, int ldc, int M, int N, int K, int act) {
+    __shared__ float red[4][32][33];
+    const int z = blockIdx.z;
+    const float* A = p.A[z];
+    const float* W = p.W[z];
+    const float* bias = p.bias[z];
+    float* C = p.C[z];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const float* ap = A + (size_t)min(m0 + r, M - 1) * lda + wid * 32 + h * 16;
+    const float* wp = W + (size_t)min(n0 + r, N - 1) * ldw + wid * 32 + h * 16;
+    const int kl = wid * 32 + h * 16;  // this lane's first k inside a chunk
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    // (two chunks per wave in flight; four measured the same: 50.1 against 51.5 us at 512 rows, K = 2000 / 3500)
+    constexpr int NB = 2;
+    f32x4 av[NB][4], wv[NB][4];
+    auto load = [&](int c, f32x4 (&a4)[4], f32x4 (&w4)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = c * 128 + kl + 4 * i < K;
+            a4[i] = in ? *reinterpret_cast<const f32x4*>(ap + (size_t)c * 128 + 4 * i) : zero;
+            w4[i] = in ? *reinterpret_cast<const f32x4*>(wp + (size_t)c * 128 + 4 * i) : zero;
+        }
+    };
+    const int nc = (K + 127) / 128;
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < NB - 1; ++b)
+        if (b < nc) load(b, av[b], wv[b]);
+    for (int c = 0; c < nc; c += NB) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (c + b >= nc) break;
+            if (c + b + NB - 1 < nc) load(c + b + NB - 1, av[(b + NB - 1) % NB], wv[(b + NB - 1) % NB]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b][i][j], wv[b][i][j], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[wid][(q & 3) + 8 * (q >> 2) + 4 * h][r] = acc[q];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, row = e >> 5, col = e & 31;
+        if (m0 + row < M && n0 + col < N) {
+            float v = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+            if (bias) v += bias[n0 + col];
+            if (act == 1) v = relu_nan(v);
+            else if (act == 2) v = fabsf(v);
+            C[(size_t)(m0 + row) * ldc + n0 + col] = v;
+        }
+    }
+}
+
+// true when launch_gemm_nt_quad will take the direct form for these operands
+bool gemm_nt_quad_direct_ok(const float* const A[4], const float* const W[4], int lda, int ldw, int K) {
+    bool ok = SHASTA_GEMM_DIRECT && lda % 4 == 0 && ldw % 4 == 0 && K % 4 == 0 && K >= 512;
+    for (int i = 0; i < 4; ++i) ok = ok && (((uintptr_t)A[i] | (uintptr_t)W[i]) % 16 == 0);
+    return ok;
+}
 int launch_gemm_nt_quad(const float* const A[4], const float* const W[4], const float* const bias[4], float* const C[4], int lda,
                         int ldw, int ldc, int M, int N, int K, int act, hipStream_t st) {
     if (M == 0 || N == 0) return SHASTA_OK;
@@ -202,6 +276,10 @@ int launch_gemm_nt_quad(const float* const A[4], const float* const W[4], const 
         p.bias[i] = bias[i];
         p.C[i] = C[i];
         vec = vec && (((uintptr_t)A[i] | (uintptr_t)W[i]) % 16 == 0);
+    }
+    if (SHASTA_GEMM_DIRECT && vec && K % 4 == 0 && K >= 512) {  // skinny, long K: the direct form
+        hipLaunchKernelGGL(gemm_nt_f32_direct_quad_kernel, dim3(cdiv(N, 32), cdiv(M, 32), 4), dim3(256), 0, st, p, lda, ldw, ldc, M, N, K, act);
+        return check_launch("gemm_nt_f32_direct_quad");
     }
     dim3 grid(cdiv(N, BN), cdiv(M, BM), 4);
     if (vec) hipLaunchKernelGGL(gemm_nt_f32_quad_kernel<true>, grid, dim3(256), 0, st, p, lda, ldw, ldc, M, N, K, act);
