@@ -220,6 +220,11 @@ class Bench:
         det0, prev = self.boxes(cfg)
         det0, prev, bev, pbev = det0[:B], prev[:B], self.bev[:B], self.pbev[:B]
         det = det0.clone()
+        # one-time set-up (the packed small weights, the companion image of the first aug_shape layers: 4 GB of allocation and one pass
+        # over the weights) belongs in front of the warm-up steps, not inside the first of them
+        w = model._weights()
+        model._ensure_packed(w, self.dev)
+        model._ensure_aux(w, B, self.dev)
         evs = []  # per step: (L1 start, L1 stop, pair start, pair stop)
         for _ in range(steps):
             four = tuple(C.c_void_p() for _ in range(4))
