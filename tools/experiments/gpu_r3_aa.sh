@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.." && R=$PWD
+cd "$(dirname "$0")/../.." && R=$PWD
 for round in 1 2; do
 python3 tools/two_pipelines.py --mode single --batch 1024 --steps 40 2>/dev/null | tail -1
 python3 tools/two_pipelines.py --mode plain --pipes 2 --batch 512 --steps 40 --offset-ms 0 2>/dev/null | tail -1

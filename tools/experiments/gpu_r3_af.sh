@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.." && R=$PWD
+cd "$(dirname "$0")/../.." && R=$PWD
 python -m pytest tests/test_hip_parity.py -m gpu -q -x 2>&1 | grep -E "passed|failed|Error|assert" | tail -6
 python3 tools/car_b1.py 1 300 2>&1 | grep "car B"
 python3 tools/car_b1.py 8 300 2>&1 | grep "car B"

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.." && R=$PWD
+cd "$(dirname "$0")/../.." && R=$PWD
 O=$R/gpurun_out/r3ai; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for b in 64 512; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.." && R=$PWD
+cd "$(dirname "$0")/../.." && R=$PWD
 s=$(date +%s); python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/driver_like.json 2> gpurun_out/driver_like.err; echo "rc=$? wall $(( $(date +%s) - s )) s"
 python3 - <<'PY'
 import json

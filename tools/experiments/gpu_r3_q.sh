@@ -1,6 +1,6 @@
 #!/bin/bash
 # full bench line at the new default batch + the two operating-point tests
-cd "$(dirname "$0")/.." && R=$PWD
+cd "$(dirname "$0")/../.." && R=$PWD
 O=$R/gpurun_out/r3q; mkdir -p $O
 
 s=$(date +%s); python3 bench.py > $O/bench_full.json 2> $O/bench_full.err

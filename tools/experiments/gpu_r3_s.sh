@@ -1,6 +1,6 @@
 #!/bin/bash
 # weight stream on v_mfma_f32_16x16x32_f16 (default build) against the 32x32x16 form (variant s32): parity tests, then A/B at 512 / 1024 / 64
-cd "$(dirname "$0")/.." && R=$PWD
+cd "$(dirname "$0")/../.." && R=$PWD
 python -m pytest tests/test_hip_parity.py -m gpu -q -x -k "precut or batch or operating_points or anchor" 2>&1 | grep -E "passed|failed|Error|assert" | tail -8
 AB_STEPS=40 bash tools/gpu_ab.sh r3s shasta_amd/csrc/libshasta_hip.so tools/probes/_bin/libshasta_s32.so
 for b in 512 64 32; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.." && R=$PWD
+cd "$(dirname "$0")/../.." && R=$PWD
 python -m pytest tests/test_hip_parity.py -m gpu -q -x -k "pair or arithmetic" 2>&1 | grep -E "passed|failed|Error|assert" | tail -4
 for round in 1 2; do
 for lib in shasta_amd/csrc/libshasta_hip.so tools/probes/_bin/libshasta_p4s900.so tools/probes/_bin/libshasta_p4s850.so tools/probes/_bin/libshasta_p4s800.so; do

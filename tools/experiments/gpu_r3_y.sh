@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.." && R=$PWD
+cd "$(dirname "$0")/../.." && R=$PWD
 python -m pytest tests/test_hip_parity.py -m gpu -q -x -k "pair or forward or arithmetic or golden" 2>&1 | grep -E "passed|failed|Error|assert" | tail -4
 for round in 1 2; do for lib in shasta_amd/csrc/libshasta_hip.so tools/probes/_bin/libshasta_prev.so; do
   SHASTA_HIP_LIB=$R/$lib python3 - <<PY 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids"
