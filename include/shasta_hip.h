@@ -118,6 +118,33 @@ int shasta_shared_conv_pack_f32(const float* weight, const float* bias, const fl
 int shasta_shared_conv_f32(const float* x, const float* x_prev, int B, int in_channels, int H, int W,
                            const void* packed, float* out, float* out_prev, shasta_stream_t stream);
 
+/* K0 on the fp16 matrix path, one launch for up to 8 class heads (the per-class models of tools/nusc_shasta/eval.py:86-101,
+ * official_val.sh each hold their own shared_conv.0 / .1 and convolve the SAME neck output): fp32 maps in, fp32 NHWC maps out, fp32
+ * accumulation; every fp32 product is formed from three products of two range-scaled, round-to-nearest fp16 pieces per operand (the
+ * SHASTA_OPT_F16X2_* arithmetic: one power-of-two scale per output channel, fixed at pack time, and one per image, taken from a
+ * max-reduction pass over the map inside the call).  The map is read from HBM once for all heads.
+ *
+ *  shasta_shared_conv_f16x2_supported : 1 when the fp16 kernel serves (in_channels, H, W): in_channels % 16 == 0 and a map at most
+ *          187 columns wide (the staged tile of 256 pixels + one image row either side must fit 640 LDS slots); other shapes stay
+ *          on shasta_shared_conv_f32
+ *  packed : `heads` images of shasta_shared_conv_f16x2_packed_bytes(Cin) bytes, `head_stride_bytes` apart (multiple of 16), each
+ *           written by shasta_shared_conv_pack_f16x2 from that head's six tensors; re-pack when one of them changes
+ *  x, x_prev : (B, Cin, H, W) fp32 NCHW, 16-byte aligned; x_prev / h_out_prev NULL together to skip the previous frame
+ *  h_out, h_out_prev : HOST arrays of `heads` device pointers, each (B, H, W, 64) fp32 NHWC
+ *  workspace : shasta_shared_conv_multi_workspace_bytes(B) bytes (the image maxima)
+ * Non-finite inputs: an image that holds an Inf or a NaN is cut with scale 1; where torch would give an Inf the result is a NaN. */
+int shasta_shared_conv_f16x2_supported(int in_channels, int H, int W);
+size_t shasta_shared_conv_f16x2_packed_bytes(int in_channels);
+int shasta_shared_conv_pack_f16x2(const float* weight, const float* bias, const float* bn_weight,
+                                  const float* bn_bias, const float* bn_mean, const float* bn_var,
+                                  float bn_eps, int in_channels, void* packed, size_t packed_bytes,
+                                  shasta_stream_t stream);
+size_t shasta_shared_conv_multi_workspace_bytes(int B);
+int shasta_shared_conv_multi_f32(const float* x, const float* x_prev, int B, int in_channels, int H, int W,
+                                 const void* packed, size_t head_stride_bytes, int heads, float* const* h_out,
+                                 float* const* h_out_prev, void* workspace, size_t workspace_bytes,
+                                 shasta_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Weights of the affinity network, raw nn.Linear layout (out_features, in_features) row major,
  * exactly the tensors of the reference state_dict (det3d/models/tracker/shasta.py:49-106).

@@ -1,0 +1,429 @@
+// K0 on the fp16 matrix path: shared_conv of the affinity network (det3d/models/tracker/shasta.py:42-47, applied :223-228)
+//   Conv2d(Cin -> 64, 3x3, padding 1, bias) -> BatchNorm2d(64) in eval mode -> ReLU -> permute to NHWC
+// with fp32 operands in HBM, fp32 accumulation and every fp32 product formed from THREE fp16 products (the two-piece form of the
+// weight stream, anchor_split.hip):  a 2^e = a_h + a_l,  a_h = fp16(a 2^e),  a_l = fp16(a 2^e - a_h), both rounded to nearest;
+// w x = w_l x_h + w_h x_l + w_h x_h (the dropped w_l x_l is below 2^-22 |w x|).  2^e is an exact power of two - one per OUTPUT CHANNEL for
+// the weights (pack time), one per IMAGE for the activations (a max-reduction pass over the map, conv16_absmax_kernel) - that puts
+// the largest magnitude into (2^13, 2^14]; the epilogue scales the sums back exactly.  v_mfma_f32_32x32x16_f16 forms 16x the
+// products per cycle of v_mfma_f32_32x32x2_f32, so the 38.2 GFLOP of a frame pair have a 0.046 ms matrix floor instead of 0.24 ms.
+//
+// Implicit GEMM: M = pixels, N = 64 output channels (two 32-wide blocks), K = 9 taps x Cin, walked in chunks of 16 input channels
+// (one k-step of 16 = one tap of one chunk; lane half h of an operand fragment holds channels 8h .. 8h+7).
+// A workgroup (8 waves) owns 256 CONSECUTIVE pixels of the flattened image (254 workgroups per 180 x 180 map, no padding waste),
+// wave w the 32 pixels 32w .. 32w+31 and both channel blocks (2 accumulators).  Per chunk:
+//  * input tile: exactly the flat pixel range the 256 pixels touch (one image row + one pixel either side) is loaded with
+//    16-byte loads along the pixel axis (a lane = 4 pixels x 8 channels), cut ONCE into its fp16 pieces on the VALU and written
+//    to LDS as [piece][channel octet][padded pixel slot][8 fp16]: an operand fragment of a tap is one ds_read_b128 per lane at
+//    (a per-lane base) + (a compile-time offset), lane-linear, i.e. conflict-free.  Slots are numbered as in an image whose rows
+//    have one padding column either side: the padding slots are zeroed once and never written, so the x-boundary of the
+//    convolution costs nothing in the loop (the y-boundary: rows outside the image are never written either).
+//  * weights: pre-cut at pack time into the fragment order [chunk][tap][channel block][piece][lane][8 fp16] (36 KB per chunk) and
+//    copied straight into LDS by LDS-DMA (global_load_lds_dwordx4), shared by the eight waves.
+//  Both tiles are double buffered; one barrier per chunk.  The two waves of a SIMD (w, w+4) cut their share of the next input
+//  tile at different points of the chunk, so that one of them always feeds the matrix pipe.
+// Several class heads (the seven per-class models of tools/nusc_shasta, official_val.sh) run in ONE launch: blockIdx -> (tile, head)
+// with the heads of a tile next to each other on one XCD, so the map is read from HBM once and 6 of 7 tile reads hit that L2.
+#include "common.hpp"
+
+#pragma clang diagnostic ignored "-Winline-asm"
+#include <type_traits>
+
+namespace shasta {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t w32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int C16_TILE = 256;                  // pixels per workgroup
+constexpr int C16_NSLOT = 640;                 // padded pixel slots of one staged tile (W = 180 needs 626)
+constexpr int C16_PLANE = C16_NSLOT * 16;      // bytes of one [slot][8 fp16] plane
+constexpr int C16_INBUF = 4 * C16_PLANE;       // [piece 2][octet 2] planes
+constexpr int C16_WBUF = 9 * 2 * 2 * 1024;     // [tap 9][channel block 2][piece 2] fragments of 1 KB
+constexpr int C16_TRASH = 2 * C16_WBUF + 2 * C16_INBUF;  // 1 KB behind the tiles: where lanes without a valid pixel store
+constexpr int C16_LDS = C16_TRASH + 1024;      // 156 672 bytes: one workgroup per CU
+constexpr int C16_MAXH = 8;                    // class heads per launch
+constexpr int C16_PARAMS = 256;                // floats behind the fragments: alpha[64], beta'[64], bias[64], 2^-e[64]
+
+__device__ __forceinline__ void cut2(float a, _Float16& h, _Float16& l) {
+    h = (_Float16)a;
+    l = (_Float16)(a - (float)h);
+}
+// a pointer the compiler should keep in scalar registers (operands of the LDS-DMA asm)
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ uint32_t pack2h(_Float16 even, _Float16 odd) {
+    const h16x2 v = {even, odd};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// ---- pack: one workgroup per output channel --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv16_pack_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mean, const float* __restrict__ var, float eps, int Cin,
+                                                          char* __restrict__ out) {
+    __shared__ float red[4];
+    const int n = blockIdx.x, tid = threadIdx.x, K = Cin * 9;
+    const float* wn = w + (size_t)n * K;
+    float m = 0.0f;
+    for (int i = tid; i < K; i += 256) m = absmax_keep_nan(m, fabsf(wn[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = absmax_keep_nan(m, __shfl_xor(m, off, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = absmax_keep_nan(absmax_keep_nan(red[0], red[1]), absmax_keep_nan(red[2], red[3]));
+    const int e = range_exponent_bits(__float_as_uint(m));
+    const int nchunk = Cin / 16, nb = n >> 5, nl = n & 31;
+    for (int it = tid; it < nchunk * 18; it += 256) {
+        const int c = it / 18, r = it - c * 18, tap = r >> 1, h = r & 1;
+        w32x4 hi, lo;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            _Float16 h0, l0, h1, l1;
+            cut2(__builtin_ldexpf(wn[(16 * c + 8 * h + 2 * jj) * 9 + tap], e), h0, l0);
+            cut2(__builtin_ldexpf(wn[(16 * c + 8 * h + 2 * jj + 1) * 9 + tap], e), h1, l1);
+            hi[jj] = pack2h(h0, h1);
+            lo[jj] = pack2h(l0, l1);
+        }
+        char* f = out + (size_t)c * C16_WBUF + ((tap * 2 + nb) * 2) * 1024 + (h * 32 + nl) * 16;
+        *reinterpret_cast<w32x4*>(f) = hi;
+        *reinterpret_cast<w32x4*>(f + 1024) = lo;
+    }
+    if (tid == 0) {
+        float* par = reinterpret_cast<float*>(out + (size_t)nchunk * C16_WBUF);
+        const float invstd = 1.0f / sqrtf(var[n] + eps);
+        const float alpha = invstd * gamma[n];
+        par[n] = alpha;
+        par[64 + n] = beta[n] - mean[n] * alpha;
+        par[128 + n] = bias[n];
+        par[192 + n] = __builtin_ldexpf(1.0f, -e);
+    }
+}
+
+// ---- largest magnitude of every image: grid (slices, images); out[image] must be zero on entry ----------------------------------------
+__global__ __launch_bounds__(256) void conv16_absmax_kernel(const float* __restrict__ xa, const float* __restrict__ xb, long per_image, int B,
+                                                            unsigned* __restrict__ out) {
+    __shared__ float red[4];
+    const int z = blockIdx.y;
+    const float* x = (z >= B ? xb + (size_t)(z - B) * per_image : xa + (size_t)z * per_image);
+    const long n4 = per_image / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
+    const long beg = blockIdx.x * per, end = min(n4, beg + per);
+    const f32x4* p = reinterpret_cast<const f32x4*>(x);
+    float m = 0.0f;
+    for (long i = beg + threadIdx.x; i < end; i += 256) {
+        const f32x4 v = p[i];
+        m = absmax_keep_nan(absmax_keep_nan(m, absmax_keep_nan(fabsf(v[0]), fabsf(v[1]))), absmax_keep_nan(fabsf(v[2]), fabsf(v[3])));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = absmax_keep_nan(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(out + z, __float_as_uint(absmax_keep_nan(absmax_keep_nan(red[0], red[1]), absmax_keep_nan(red[2], red[3]))));
+}
+
+struct Conv16Args {
+    const float* x[2];              // current / previous neck outputs (B, Cin, H, W)
+    float* out[2][C16_MAXH];        // per head: (B, H, W, 64)
+    const char* packed;             // heads x head_stride bytes
+    size_t head_stride;
+    const unsigned* xmax;           // [nmaps] bit patterns of the image maxima
+    int B, Cin, H, W, heads, tiles_per_map, ntiles, tiles_per_xcd, vec_ok;
+};
+
+// VEC: H * W is a multiple of 4, so a lane's four consecutive flat pixels (first index a multiple of 4) are inside the image together
+// or not at all and every channel row is 16-byte aligned: one 16-byte load per channel; otherwise four 4-byte loads.
+template <bool VEC>
+__global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // block -> (tile, head): blocks 8 apart share an XCD; an XCD takes a contiguous range of tiles (neighbours share halo rows in
+    // its L2) and runs the heads of a tile back to back
+    const int xl = blockIdx.x & 7, bslot = blockIdx.x >> 3;
+    const int head = bslot % a.heads, tl = bslot / a.heads;
+    const int t = xl * a.tiles_per_xcd + tl;
+    if (t >= a.ntiles) return;
+    const int z = t / a.tiles_per_map, tile = t - z * a.tiles_per_map;
+    const bool second = z >= a.B;
+    const int b = second ? z - a.B : z;
+    const int W = a.W, WT = W + 2, npix = a.H * W, Cin = a.Cin;
+    const float* xin = (second ? a.x[1] : a.x[0]) + (size_t)b * Cin * npix;
+    float* out = (second ? a.out[1][head] : a.out[0][head]) + (size_t)b * npix * 64;
+    const char* wsrc = a.packed + (size_t)head * a.head_stride;
+    const int eimg = range_exponent_bits(a.xmax[z]);
+    const int p0 = tile * C16_TILE;
+    const int y0 = p0 / W, x0 = p0 - y0 * W;
+    const int first = (y0 - 1) * WT + x0;  // padded index (y * WT + x + 1) of pixel (y0 - 1, x0 - 1) = slot 0
+    char* const in_lds = lds + 2 * C16_WBUF;
+
+    // zero both input buffers once: padding slots and rows outside the image are never written afterwards
+    {
+        const w32x4 zz = {0u, 0u, 0u, 0u};
+        for (int i = tid; i < 2 * C16_INBUF / 16; i += 512) reinterpret_cast<w32x4*>(in_lds)[i] = zz;
+    }
+
+    // staging role of this lane: 4 consecutive flat pixels x 8 channels (one octet) of every chunk
+    const int p_last = min(p0 + C16_TILE, npix) - 1;
+    const int qa = (p0 - W - 1) & ~3;          // first staged flat pixel, a multiple of 4 (may be negative)
+    const int nq = ((p_last + W + 1 - qa) >> 2) + 1;
+    const int QW = (nq + 7) >> 3;              // quads per wave (the host guarantees QW <= 32)
+    const int oct = lane >= QW ? 1 : 0;
+    const int qi = wv * QW + lane - oct * QW;
+    const bool st_lane = lane < 2 * QW && qi < nq;
+    const int q = qa + 4 * qi;
+    int st_addr[4];   // LDS byte offset (inside an input buffer) of the four pixels; -1: not staged (stored to the trash slot)
+    unsigned ld_off[4];  // element offset of channel 0 of the octet inside a chunk; always a valid address
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int qq = q + k;
+        const bool ok = st_lane && qq >= 0 && qq < npix;
+        const int yy = ok ? qq / W : 0, xx = qq - yy * W;
+        const int s = yy * WT + xx + 1 - first;
+        st_addr[k] = (ok && s >= 0 && s < C16_NSLOT) ? oct * C16_PLANE + s * 16 : -1;
+        ld_off[k] = (unsigned)(oct * 8 * npix + (ok ? qq : 0));
+    }
+    if (VEC) ld_off[0] = (unsigned)(oct * 8 * npix + min(max(q, 0), npix - 4));
+    const float scale = __builtin_ldexpf(1.0f, eimg);
+
+    f32x4 r[8];
+    auto load_chunk = [&](int ch) {
+        const float* xc = xin + (size_t)ch * 16 * npix;  // wave-uniform
+        if (VEC) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = *reinterpret_cast<const f32x4*>(xc + (ld_off[0] + (unsigned)(j * npix)));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[j][k] = xc[ld_off[k] + (unsigned)(j * npix)];
+        }
+    };
+    const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds);
+    const uint32_t dma_off = (uint32_t)(lane * 16);
+    // the 36 fragments of a chunk are dealt to the eight waves: wave w copies fragments w, w + 8, ... (five for w < 4, else four)
+    auto dma_weights = [&](int ch, int buf, auto ndma) {
+        const char* src = wsrc + (size_t)ch * C16_WBUF + wv * 1024;
+        const uint32_t dst0 = lds0 + (uint32_t)(buf * C16_WBUF + wv * 1024);
+        const uint32_t off = dma_off;  // (a generic lambda does not capture a variable named only in an asm operand)
+#pragma unroll
+        for (int j = 0; j < decltype(ndma)::value; ++j) {
+            const char* base = uniform_ptr(src + j * 8192);
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)(j * 8192));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory", "m0");
+        }
+    };
+    auto cut_store = [&](int buf) {
+        const int ib = 2 * C16_WBUF + buf * C16_INBUF, trash = C16_TRASH + lane * 16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            w32x4 hi, lo;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                _Float16 h0, l0, h1, l1;
+                cut2(r[2 * jj][k] * scale, h0, l0);
+                cut2(r[2 * jj + 1][k] * scale, h1, l1);
+                hi[jj] = pack2h(h0, h1);
+                lo[jj] = pack2h(l0, l1);
+            }
+            *reinterpret_cast<w32x4*>(lds + (st_addr[k] >= 0 ? ib + st_addr[k] : trash)) = hi;
+            *reinterpret_cast<w32x4*>(lds + (st_addr[k] >= 0 ? ib + st_addr[k] + 2 * C16_PLANE : trash)) = lo;
+        }
+    };
+
+    // operand addresses of this lane
+    const int li = lane & 31, h = lane >> 5;
+    const int p = min(p0 + 32 * wv + li, npix - 1);
+    const int py = p / W, px = p - py * W;
+    const int sc = py * WT + px + 1 - first;  // slot of the pixel itself (>= WT + 1)
+    int a_row[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) a_row[dy] = h * C16_PLANE + (sc + (dy - 1) * WT - 1) * 16;  // tap (dy, dx = 0); dx adds 16 bytes each
+    const int b_lane = lane * 16;
+
+    f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    struct Frag {
+        h16x8 ah, al, b0h, b0l, b1h, b1l;
+    };
+    auto read_tap = [&](int buf, int tap, Frag& f) {
+        const char* ib = in_lds + buf * C16_INBUF;
+        const char* wb = lds + buf * C16_WBUF + b_lane;
+        const int dy = tap / 3, dx = tap % 3;
+        f.ah = *reinterpret_cast<const h16x8*>(ib + a_row[dy] + dx * 16);
+        f.al = *reinterpret_cast<const h16x8*>(ib + a_row[dy] + dx * 16 + 2 * C16_PLANE);
+        f.b0h = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 0) * 1024);
+        f.b0l = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 1) * 1024);
+        f.b1h = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 2) * 1024);
+        f.b1l = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 3) * 1024);
+    };
+    auto mma_tap = [&](const Frag& f) {  // piece products, small to large
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.b0h, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.b1h, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.b0l, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.b1l, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.b0h, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.b1h, acc1, 0, 0, 0);
+    };
+
+    const int nchunk = Cin / 16;
+    if (wv < 4) dma_weights(0, 0, std::integral_constant<int, 5>{});
+    else dma_weights(0, 0, std::integral_constant<int, 4>{});
+    load_chunk(0);
+    __syncthreads();  // the zero fill is complete
+    cut_store(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // One chunk: stage chunk ch + 1 (the last trip stages the last chunk once more, into the buffer nobody reads again: no branch in
+    // the loop), multiply chunk ch: the fragments of tap t + 1 are read while tap t is multiplied.  The two waves of a SIMD (w, w + 4)
+    // cut their share of the next tile at different points of the chunk.
+    auto chunk = [&](int ch, auto cut_after, auto ndma) {
+        constexpr int CUT = decltype(cut_after)::value;
+        const int cur = ch & 1, nxt = min(ch + 1, nchunk - 1);
+        dma_weights(nxt, cur ^ 1, ndma);
+        load_chunk(nxt);
+        Frag fa, fb;
+        read_tap(cur, 0, fa);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap += 2) {
+            if (tap + 1 < 9) read_tap(cur, tap + 1, fb);
+            mma_tap(fa);
+            if (tap + 1 == CUT) cut_store(cur ^ 1);
+            if (tap + 1 < 9) {
+                if (tap + 2 < 9) read_tap(cur, tap + 2, fa);
+                mma_tap(fb);
+                if (tap + 2 == CUT) cut_store(cur ^ 1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    if (wv < 4) {
+#pragma unroll 1
+        for (int ch = 0; ch < nchunk; ++ch) chunk(ch, std::integral_constant<int, 2>{}, std::integral_constant<int, 5>{});
+    } else {
+#pragma unroll 1
+        for (int ch = 0; ch < nchunk; ++ch) chunk(ch, std::integral_constant<int, 6>{}, std::integral_constant<int, 4>{});
+    }
+
+    // epilogue: D[pixel][channel]: lane = channel (32 nb + li), pixel = (r & 3) + 8 (r >> 2) + 4 h of the wave's 32
+    if (p0 + 32 * wv >= npix) return;
+    const float* par = reinterpret_cast<const float*>(wsrc + (size_t)nchunk * C16_WBUF);
+    const float back = __builtin_ldexpf(1.0f, -eimg);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int chn = 32 * nb + li;
+        const float alpha = par[chn], beta2 = par[64 + chn], bias = par[128 + chn], un = par[192 + chn] * back;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int pp = p0 + 32 * wv + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+            if (pp < npix) {
+                const float s = (nb ? acc1[rr] : acc0[rr]) * un;
+                const float v = (s + bias) * alpha + beta2;
+                out[(size_t)pp * 64 + chn] = relu_nan(v);
+            }
+        }
+    }
+}
+
+// slots one staged tile needs at this map width (see the kernel: np + 2 WT + 2 + 2 x row wraps)
+static int conv16_slots(int H, int W) {
+    const int np = min(C16_TILE, H * W);
+    const int wraps = (W - 1 + np - 1) / W;
+    return np + 2 * (W + 2) + 2 + 2 * wraps;
+}
+
+}  // namespace shasta
+
+using namespace shasta;
+
+extern "C" int shasta_shared_conv_f16x2_supported(int in_channels, int H, int W) {
+    if (in_channels <= 0 || in_channels % 16 || H <= 0 || W <= 0) return 0;
+    if ((long)in_channels * H * W >= (1L << 31)) return 0;
+    if (conv16_slots(H, W) > C16_NSLOT) return 0;
+    const int nq = (min(C16_TILE, H * W) + 2 * W + 2 + 3) / 4 + 1;
+    return (nq + 7) / 8 <= 32;
+}
+
+extern "C" size_t shasta_shared_conv_f16x2_packed_bytes(int in_channels) {
+    if (in_channels <= 0 || in_channels % 16) return 0;
+    return (size_t)(in_channels / 16) * C16_WBUF + C16_PARAMS * sizeof(float);
+}
+
+extern "C" int shasta_shared_conv_pack_f16x2(const float* weight, const float* bias, const float* bn_weight, const float* bn_bias,
+                                             const float* bn_mean, const float* bn_var, float bn_eps, int in_channels, void* packed,
+                                             size_t packed_bytes, shasta_stream_t stream) {
+    SHASTA_REQUIRE(weight && bias && bn_weight && bn_bias && bn_mean && bn_var && packed, "shared_conv_pack_f16x2: null pointer");
+    SHASTA_REQUIRE(in_channels > 0 && in_channels % 16 == 0, "shared_conv_pack_f16x2: in_channels must be a multiple of 16");
+    SHASTA_REQUIRE((uintptr_t)packed % 16 == 0, "shared_conv_pack_f16x2: packed buffer must be 16-byte aligned");
+    if (packed_bytes < shasta_shared_conv_f16x2_packed_bytes(in_channels)) {
+        set_error_msg("shared_conv_pack_f16x2: packed buffer too small");
+        return SHASTA_E_WORKSPACE;
+    }
+    hipLaunchKernelGGL(conv16_pack_kernel, dim3(64), dim3(256), 0, as_stream(stream), weight, bias, bn_weight, bn_bias, bn_mean, bn_var,
+                       bn_eps, in_channels, static_cast<char*>(packed));
+    return check_launch("shared_conv_pack_f16x2");
+}
+
+extern "C" size_t shasta_shared_conv_multi_workspace_bytes(int B) { return B <= 0 ? 0 : align_up((size_t)2 * B * sizeof(unsigned), 256); }
+
+extern "C" int shasta_shared_conv_multi_f32(const float* x, const float* x_prev, int B, int in_channels, int H, int W, const void* packed,
+                                            size_t head_stride_bytes, int heads, float* const* h_out, float* const* h_out_prev,
+                                            void* workspace, size_t workspace_bytes, shasta_stream_t stream) {
+    SHASTA_REQUIRE(x && packed && h_out, "shared_conv_multi: null pointer");
+    SHASTA_REQUIRE((x_prev == nullptr) == (h_out_prev == nullptr), "shared_conv_multi: x_prev and h_out_prev go together");
+    SHASTA_REQUIRE(heads >= 1 && heads <= C16_MAXH, "shared_conv_multi: 1 to 8 heads per call");
+    SHASTA_REQUIRE(B >= 0 && H > 0 && W > 0, "shared_conv_multi: bad size");
+    SHASTA_REQUIRE(shasta_shared_conv_f16x2_supported(in_channels, H, W),
+                   "shared_conv_multi: shape not served by the fp16 kernel (in_channels % 16, map width; see shasta_shared_conv_f16x2_supported)");
+    SHASTA_REQUIRE((uintptr_t)packed % 16 == 0 && head_stride_bytes % 16 == 0, "shared_conv_multi: packed buffer / head stride must be 16-byte aligned");
+    SHASTA_REQUIRE(head_stride_bytes >= shasta_shared_conv_f16x2_packed_bytes(in_channels) || heads == 1, "shared_conv_multi: head stride too small");
+    SHASTA_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)x_prev % 16 == 0, "shared_conv_multi: maps must be 16-byte aligned");
+    if (B == 0) return SHASTA_OK;
+    SHASTA_REQUIRE(workspace, "shared_conv_multi: null workspace");
+    if (workspace_bytes < shasta_shared_conv_multi_workspace_bytes(B)) {
+        set_error_msg("shared_conv_multi: workspace too small");
+        return SHASTA_E_WORKSPACE;
+    }
+    hipStream_t st = as_stream(stream);
+    const int nmaps = x_prev ? 2 * B : B;
+    const long per_image = (long)in_channels * H * W;
+    unsigned* xmax = static_cast<unsigned*>(workspace);
+    if (hipMemsetAsync(xmax, 0, (size_t)nmaps * sizeof(unsigned), st) != hipSuccess) return SHASTA_E_LAUNCH;
+    int slices = 1;
+    while (slices < 1024 && slices * nmaps < 2048 && per_image / (slices * 2) >= 16384) slices *= 2;
+    hipLaunchKernelGGL(conv16_absmax_kernel, dim3(slices, nmaps), dim3(256), 0, st, x, x_prev, per_image, B, xmax);
+    int rc = check_launch("shared_conv_multi (image maxima)");
+    if (rc != SHASTA_OK) return rc;
+
+    Conv16Args a;
+    a.x[0] = x;
+    a.x[1] = x_prev;
+    for (int i = 0; i < C16_MAXH; ++i) {
+        a.out[0][i] = i < heads ? h_out[i] : nullptr;
+        a.out[1][i] = (i < heads && h_out_prev) ? h_out_prev[i] : nullptr;
+        if (i < heads) SHASTA_REQUIRE(a.out[0][i] && (!h_out_prev || a.out[1][i]), "shared_conv_multi: null output pointer");
+    }
+    a.packed = static_cast<const char*>(packed);
+    a.head_stride = head_stride_bytes;
+    a.xmax = xmax;
+    a.B = B;
+    a.Cin = in_channels;
+    a.H = H;
+    a.W = W;
+    a.heads = heads;
+    a.tiles_per_map = cdiv(H * W, C16_TILE);
+    a.ntiles = a.tiles_per_map * nmaps;
+    a.tiles_per_xcd = cdiv(a.ntiles, 8);
+    a.vec_ok = (H * W) % 4 == 0;
+    if (a.vec_ok) {
+        (void)hipFuncSetAttribute((const void*)shared_conv_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS);
+        hipLaunchKernelGGL(shared_conv_f16_kernel<true>, dim3(8 * a.tiles_per_xcd * heads), dim3(512), C16_LDS, st, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)shared_conv_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS);
+        hipLaunchKernelGGL(shared_conv_f16_kernel<false>, dim3(8 * a.tiles_per_xcd * heads), dim3(512), C16_LDS, st, a);
+    }
+    return check_launch("shared_conv_f16");
+}

@@ -9,7 +9,7 @@ import os
 
 import torch
 
-ABI_VERSION = 7  # must equal shasta_abi_version() of the loaded library
+ABI_VERSION = 8  # must equal shasta_abi_version() of the loaded library
 # SHASTA_HIP_LIB: load another build of the same ABI (A/B timing of kernel variants on one box)
 _LIB_PATH = os.environ.get("SHASTA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libshasta_hip.so")
 _lib = None
@@ -56,6 +56,11 @@ SYMBOLS = {
     "shasta_shared_conv_packed_bytes": (_Z, [_I]),
     "shasta_shared_conv_pack_f32": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _P, _Z, _P]),
     "shasta_shared_conv_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "shasta_shared_conv_f16x2_supported": (_I, [_I, _I, _I]),
+    "shasta_shared_conv_f16x2_packed_bytes": (_Z, [_I]),
+    "shasta_shared_conv_pack_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _P, _Z, _P]),
+    "shasta_shared_conv_multi_workspace_bytes": (_Z, [_I]),
+    "shasta_shared_conv_multi_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _Z, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, _Z, _P]),
     "shasta_packed_bytes": (_Z, [_I, _I, _I]),
     "shasta_pack_weights_f32": (_I, [_WP, _P, _Z, _P]),
     "shasta_aug_shape_aux_bytes": (_Z, [_I, _I, _I]),

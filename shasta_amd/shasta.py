@@ -110,6 +110,7 @@ class Shasta(BaseTrack):
         self._aux_key = None
         self._conv_packed = None
         self._conv_key = None
+        self._conv_bank = None
         self._wstruct = None
         self._bufs = {}
         self._graph_bufs = []
@@ -289,7 +290,9 @@ class Shasta(BaseTrack):
 
     def shared_conv_nhwc(self, bev_map, prev_bev_map=None):
         """shasta.py:223-228: relu(bn(conv3x3(map))) -> NHWC for the current (and, in the same launch, the previous) neck
-        output, by the hand-written implicit-GEMM kernel (csrc/shared_conv.hip).  Eval-mode BatchNorm (running
+        output, by the hand-written implicit-GEMM kernels: csrc/shared_conv_f16.hip (arithmetic "f16x2" / "f16grid": fp32 products
+        from two fp16 pieces per operand; maps up to 187 columns wide) or csrc/shared_conv.hip (strict f32 MFMA: "f32", "pieces",
+        wider maps).  Eval-mode BatchNorm (running
         statistics) only: in train() mode the module's own nn.Sequential is used so that batch statistics behave like
         the reference.  Returns one tensor, or a pair when prev_bev_map is given."""
         conv, bn = self.shared_conv[0], self.shared_conv[1]
@@ -303,6 +306,13 @@ class Shasta(BaseTrack):
             # on are the reference's own differentiable nn.Sequential; the hand-written kernel is the inference operator.
             outs = [self.shared_conv(t).permute(0, 2, 3, 1).contiguous() for t in maps]
             return outs[0] if prev_bev_map is None else tuple(outs)
+        if self.arithmetic in ("f16x2", "f16grid"):  # products from two fp16 pieces per operand (csrc/shared_conv_f16.hip)
+            if self._conv_bank is None:
+                from .shared_conv import SharedConvBank
+                self._conv_bank = SharedConvBank([self])
+            if self._conv_bank.supported(bev_map.shape[2], bev_map.shape[3]):
+                res = self._conv_bank(bev_map, prev_bev_map)
+                return res[0] if prev_bev_map is None else (res[0][0], res[1][0])
         if conv.in_channels % 8 != 0:  # the kernel's K chunks are 8 channels wide: zero-pad the channel axis (exact)
             return self._shared_conv_padded(bev_map, prev_bev_map)
         lib = hip.load()
