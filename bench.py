@@ -540,7 +540,75 @@ def extras(bench, args):
     car["config"] = "max_obj 90, num_point 5 (F = 320), num_feats 3: configs/nusc/car.py:22-39 of the reference; 180 x 180 x 64 BEV maps"
     ex["car_90_320_3"] = car
     bench.model(HEADLINE).arithmetic = args.arithmetic
+    for name, fn in (("shared_conv", extra_shared_conv),):
+        try:
+            fn(bench, args, ex)
+        except Exception as err:  # noqa: BLE001
+            ex[name] = {"error": "%s: %s" % (type(err).__name__, str(err)[:300])}
     return ex
+
+
+def timed_ms(torch, fn, iters, warm=3):
+    """mean wall time of fn() in ms over `iters` calls, synchronised on both sides, after `warm` untimed calls"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def extra_shared_conv(bench, args, ex):
+    """K0 (SURVEY.md 8(f)-1, det3d/models/tracker/shasta.py:42-47,223-228): the 3x3 512 -> 64 convolution + BN + ReLU -> NHWC that a real
+    nuScenes forward starts with, both maps of a frame pair per launch.  Arithmetic "f16x2" (csrc/shared_conv_f16.hip, incl. its
+    max-reduction pass over the maps), strict "f32" (csrc/shared_conv.hip), MIOpen (the module's own nn.Sequential) beside them, and all
+    seven class heads in one launch.  `from_neck_b1`: the shipped car configuration from the neck output (conv + rows 4-16), batch 1."""
+    torch, dev = bench.torch, bench.dev
+    from shasta_amd.shared_conv import SharedConvBank
+    flop_pair = 2 * 2 * HW * HW * 64 * 512 * 9  # both maps
+    car = bench.model(CAR)
+    heads = [car]
+    for i in range(6):
+        torch.manual_seed(100 + i)
+        with torch.device(dev):
+            heads.append(bench.shasta.build_simp_track(dict(
+                type="Shasta", reader=None, backbone=None, neck=None,
+                bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
+                max_obj=4, num_feats=3, num_point=5)).eval())
+    bank = SharedConvBank(heads)
+    sc = {"note": "ms per call of B frame pairs (two (B,512,180,180) fp32 maps -> two (B,180,180,64) NHWC maps); tflops = fp32-equivalent "
+                  "(38.2 GFLOP per frame pair and head); f16x2 includes the max-reduction pass over the maps"}
+    with torch.no_grad():
+        for B in (1, 8):
+            x = torch.relu(torch.randn(B, 512, HW, HW, device=dev, generator=bench.gen))
+            xp = torch.relu(torch.randn(B, 512, HW, HW, device=dev, generator=bench.gen))
+            e = {}
+            for mode in ("f16x2", "f32"):
+                car.arithmetic = mode
+                ms = timed_ms(torch, lambda: car.shared_conv_nhwc(x, xp), 30 if B == 1 else 10)
+                e[mode] = {"ms": ms, "ms_per_frame_pair": ms / B, "tflops": B * flop_pair / ms / 1e9}
+            ms = timed_ms(torch, lambda: (car.shared_conv(x).permute(0, 2, 3, 1).contiguous(), car.shared_conv(xp).permute(0, 2, 3, 1).contiguous()),
+                          30 if B == 1 else 10)
+            e["miopen"] = {"ms": ms, "ms_per_frame_pair": ms / B, "tflops": B * flop_pair / ms / 1e9}
+            ms = timed_ms(torch, lambda: bank(x, xp), 20 if B == 1 else 5)
+            e["f16x2_7_heads"] = {"ms": ms, "ms_per_frame_pair_per_head": ms / B / 7, "tflops": 7 * B * flop_pair / ms / 1e9}
+            e["f16x2_over_miopen"] = e["miopen"]["ms"] / e["f16x2"]["ms"]
+            sc["b%d" % B] = e
+            if B == 1:
+                car.arithmetic = args.arithmetic
+                det0, prev = bench.boxes(CAR)
+                det0, prev = det0[:1], prev[:1]
+
+                def fwd():
+                    return car(dict(det_boxes=det0.clone(), prev_det_boxes=prev, bev_map=x, prev_bev_map=xp), train_mode=False)
+                ms = timed_ms(torch, fwd, 50, warm=5)
+                ex["car_90_320_3"]["from_neck_b1"] = {"ms_per_step": ms, "frame_pairs_per_s": 1e3 / ms, "arithmetic": args.arithmetic,
+                                                       "note": "Shasta.forward from the neck outputs: shared_conv (both maps) + rows 4-16, one frame pair"}
+            del x, xp
+    car.arithmetic = args.arithmetic
+    ex["shared_conv"] = sc
 
 
 def _pmc_traffic(B, kernel, running):

@@ -129,7 +129,7 @@ int shasta_shared_conv_f32(const float* x, const float* x_prev, int B, int in_ch
  *          on shasta_shared_conv_f32
  *  packed : `heads` images of shasta_shared_conv_f16x2_packed_bytes(Cin) bytes, `head_stride_bytes` apart (multiple of 16), each
  *           written by shasta_shared_conv_pack_f16x2 from that head's six tensors; re-pack when one of them changes
- *  x, x_prev : (B, Cin, H, W) fp32 NCHW, 16-byte aligned; x_prev / h_out_prev NULL together to skip the previous frame
+ *  x, x_prev : (B, Cin, H, W) fp32 NCHW; x_prev / h_out_prev NULL together to skip the previous frame
  *  h_out, h_out_prev : HOST arrays of `heads` device pointers, each (B, H, W, 64) fp32 NHWC
  *  workspace : shasta_shared_conv_multi_workspace_bytes(B) bytes (the image maxima)
  * Non-finite inputs: an image that holds an Inf or a NaN is cut with scale 1; where torch would give an Inf the result is a NaN. */

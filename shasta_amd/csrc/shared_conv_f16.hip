@@ -11,8 +11,8 @@
 // (one k-step of 16 = one tap of one chunk; lane half h of an operand fragment holds channels 8h .. 8h+7).
 // A workgroup (8 waves) owns 256 CONSECUTIVE pixels of the flattened image (254 workgroups per 180 x 180 map, no padding waste),
 // wave w the 32 pixels 32w .. 32w+31 and both channel blocks (2 accumulators).  Per chunk:
-//  * input tile: exactly the flat pixel range the 256 pixels touch (one image row + one pixel either side) is loaded with
-//    16-byte loads along the pixel axis (a lane = 4 pixels x 8 channels), cut ONCE into its fp16 pieces on the VALU and written
+//  * input tile: exactly the flat pixel range the 256 pixels touch (one image row + one pixel either side) is loaded along the
+//    pixel axis (a lane = 1 pixel x 8 channels, three such items per lane), cut ONCE into its fp16 pieces on the VALU and written
 //    to LDS as [piece][channel octet][padded pixel slot][8 fp16]: an operand fragment of a tap is one ds_read_b128 per lane at
 //    (a per-lane base) + (a compile-time offset), lane-linear, i.e. conflict-free.  Slots are numbered as in an image whose rows
 //    have one padding column either side: the padding slots are zeroed once and never written, so the x-boundary of the
@@ -41,6 +41,7 @@ constexpr int C16_INBUF = 4 * C16_PLANE;       // [piece 2][octet 2] planes
 constexpr int C16_WBUF = 9 * 2 * 2 * 1024;     // [tap 9][channel block 2][piece 2] fragments of 1 KB
 constexpr int C16_TRASH = 2 * C16_WBUF + 2 * C16_INBUF;  // 1 KB behind the tiles: where lanes without a valid pixel store
 constexpr int C16_LDS = C16_TRASH + 1024;      // 156 672 bytes: one workgroup per CU
+constexpr int C16_NIT = 3;                    // staged (pixel, octet) items per lane and chunk
 constexpr int C16_MAXH = 8;                    // class heads per launch
 constexpr int C16_PARAMS = 256;                // floats behind the fragments: alpha[64], beta'[64], bias[64], 2^-e[64]
 
@@ -53,6 +54,19 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+// x - h, exact in fp32, with h = the low / high half of a packed fp16 pair read as an fp16 operand (v_fma_mix_f32); the results go
+// through a compiler-generated conversion before anything else reads them (hazard rule of pair_f16.hip)
+typedef float c16f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float c16_res_lo(float x, uint32_t hpk) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(hpk));
+    return r;
+}
+__device__ __forceinline__ float c16_res_hi(float x, uint32_t hpk) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(hpk));
+    return r;
 }
 __device__ __forceinline__ uint32_t pack2h(_Float16 even, _Float16 odd) {
     const h16x2 v = {even, odd};
@@ -130,12 +144,9 @@ struct Conv16Args {
     const char* packed;             // heads x head_stride bytes
     size_t head_stride;
     const unsigned* xmax;           // [nmaps] bit patterns of the image maxima
-    int B, Cin, H, W, heads, tiles_per_map, ntiles, tiles_per_xcd, vec_ok;
+    int B, Cin, H, W, heads, tiles_per_map, ntiles, tiles_per_xcd;
 };
 
-// VEC: H * W is a multiple of 4, so a lane's four consecutive flat pixels (first index a multiple of 4) are inside the image together
-// or not at all and every channel row is 16-byte aligned: one 16-byte load per channel; otherwise four 4-byte loads.
-template <bool VEC>
 __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -165,40 +176,37 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
         for (int i = tid; i < 2 * C16_INBUF / 16; i += 512) reinterpret_cast<w32x4*>(in_lds)[i] = zz;
     }
 
-    // staging role of this lane: 4 consecutive flat pixels x 8 channels (one octet) of every chunk
+    // staging roles of this lane: three (pixel, channel octet) items of every chunk.  The flat pixel range the tile touches is dealt in
+    // blocks of 64 consecutive pixels, first all blocks of octet 0, then those of octet 1; block 8 i + w goes to wave w as its item i:
+    // consecutive lanes = consecutive pixels, so the 4-byte loads of a channel row are whole 256-byte lines and the 16-byte LDS stores
+    // of a piece are lane-linear (a lane holding FOUR consecutive pixels would store 64 bytes apart: a 4-way bank conflict on every store)
     const int p_last = min(p0 + C16_TILE, npix) - 1;
-    const int qa = (p0 - W - 1) & ~3;          // first staged flat pixel, a multiple of 4 (may be negative)
-    const int nq = ((p_last + W + 1 - qa) >> 2) + 1;
-    const int QW = (nq + 7) >> 3;              // quads per wave (the host guarantees QW <= 32)
-    const int oct = lane >= QW ? 1 : 0;
-    const int qi = wv * QW + lane - oct * QW;
-    const bool st_lane = lane < 2 * QW && qi < nq;
-    const int q = qa + 4 * qi;
-    int st_addr[4];   // LDS byte offset (inside an input buffer) of the four pixels; -1: not staged (stored to the trash slot)
-    unsigned ld_off[4];  // element offset of channel 0 of the octet inside a chunk; always a valid address
+    const int qs = p0 - W - 1, qe = p_last + W + 1;   // first / last flat pixel a tap of this tile reads (may lie outside the image)
+    const int nblk = (qe - qs + 64) >> 6;             // 64-pixel blocks per octet (the host guarantees 2 nblk <= 24)
+    int st_addr[C16_NIT];      // LDS byte offset inside an input buffer; -1: not staged (stored to the trash slot)
+    unsigned ld_off[C16_NIT];  // byte offset of channel 0 of the octet inside a chunk; always a valid address
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int qq = q + k;
-        const bool ok = st_lane && qq >= 0 && qq < npix;
-        const int yy = ok ? qq / W : 0, xx = qq - yy * W;
-        const int s = yy * WT + xx + 1 - first;
-        st_addr[k] = (ok && s >= 0 && s < C16_NSLOT) ? oct * C16_PLANE + s * 16 : -1;
-        ld_off[k] = (unsigned)(oct * 8 * npix + (ok ? qq : 0));
+    for (int it = 0; it < C16_NIT; ++it) {
+        const int blk = it * 8 + wv;
+        const int oct = blk >= nblk ? 1 : 0;
+        const int q = qs + 64 * (blk - oct * nblk) + lane;
+        const bool ok = blk < 2 * nblk && q >= 0 && q < npix && q <= qe;
+        const int yy = ok ? q / W : 0, xx = q - yy * W;
+        const int sl = yy * WT + xx + 1 - first;
+        st_addr[it] = (ok && sl < C16_NSLOT) ? oct * C16_PLANE + sl * 16 : -1;
+        ld_off[it] = 4u * (unsigned)(oct * 8 * npix + (ok ? q : 0));
     }
-    if (VEC) ld_off[0] = (unsigned)(oct * 8 * npix + min(max(q, 0), npix - 4));
     const float scale = __builtin_ldexpf(1.0f, eimg);
+    const c16f2 scale2 = {scale, scale};
 
-    f32x4 r[8];
+    float r[C16_NIT][8];
     auto load_chunk = [&](int ch) {
-        const float* xc = xin + (size_t)ch * 16 * npix;  // wave-uniform
-        if (VEC) {
+        const char* xc = reinterpret_cast<const char*>(xin + (size_t)ch * 16 * npix);  // wave-uniform: scalar base + 32-bit lane offset
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = *reinterpret_cast<const f32x4*>(xc + (ld_off[0] + (unsigned)(j * npix)));
-        } else {
+        for (int j = 0; j < 8; ++j) {
+            const char* xj = xc + (size_t)j * npix * 4;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) r[j][k] = xc[ld_off[k] + (unsigned)(j * npix)];
+            for (int it = 0; it < C16_NIT; ++it) r[it][j] = *reinterpret_cast<const float*>(xj + ld_off[it]);
         }
     };
     const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds);
@@ -218,18 +226,17 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
     auto cut_store = [&](int buf) {
         const int ib = 2 * C16_WBUF + buf * C16_INBUF, trash = C16_TRASH + lane * 16;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int it = 0; it < C16_NIT; ++it) {
             w32x4 hi, lo;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                _Float16 h0, l0, h1, l1;
-                cut2(r[2 * jj][k] * scale, h0, l0);
-                cut2(r[2 * jj + 1][k] * scale, h1, l1);
-                hi[jj] = pack2h(h0, h1);
-                lo[jj] = pack2h(l0, l1);
+            for (int jj = 0; jj < 4; ++jj) {  // 2.5 vector instructions per value: packed scale, packed convert, two exact residuals, packed convert
+                const c16f2 sv = c16f2{r[it][2 * jj], r[it][2 * jj + 1]} * scale2;
+                const uint32_t hp = pack2h((_Float16)sv[0], (_Float16)sv[1]);
+                hi[jj] = hp;
+                lo[jj] = pack2h((_Float16)c16_res_lo(sv[0], hp), (_Float16)c16_res_hi(sv[1], hp));
             }
-            *reinterpret_cast<w32x4*>(lds + (st_addr[k] >= 0 ? ib + st_addr[k] : trash)) = hi;
-            *reinterpret_cast<w32x4*>(lds + (st_addr[k] >= 0 ? ib + st_addr[k] + 2 * C16_PLANE : trash)) = lo;
+            *reinterpret_cast<w32x4*>(lds + (st_addr[it] >= 0 ? ib + st_addr[it] : trash)) = hi;
+            *reinterpret_cast<w32x4*>(lds + (st_addr[it] >= 0 ? ib + st_addr[it] + 2 * C16_PLANE : trash)) = lo;
         }
     };
 
@@ -260,6 +267,10 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
         f.b1l = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 3) * 1024);
     };
     auto mma_tap = [&](const Frag& f) {  // piece products, small to large
+#ifdef C16_ABL_NO_MFMA  // ablation build (tools/build_variant.py): everything but the matrix instructions; results are wrong
+        asm volatile("" ::"v"(f.ah), "v"(f.al), "v"(f.b0h), "v"(f.b0l), "v"(f.b1h), "v"(f.b1l));
+        return;
+#endif
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.b0h, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.b1h, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.b0l, acc0, 0, 0, 0);
@@ -269,44 +280,77 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
     };
 
     const int nchunk = Cin / 16;
+    constexpr int NLD = 8 * C16_NIT;  // global loads of one staged chunk per lane
     if (wv < 4) dma_weights(0, 0, std::integral_constant<int, 5>{});
     else dma_weights(0, 0, std::integral_constant<int, 4>{});
     load_chunk(0);
     __syncthreads();  // the zero fill is complete
     cut_store(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // One chunk: stage chunk ch + 1 (the last trip stages the last chunk once more, into the buffer nobody reads again: no branch in
-    // the loop), multiply chunk ch: the fragments of tap t + 1 are read while tap t is multiplied.  The two waves of a SIMD (w, w + 4)
-    // cut their share of the next tile at different points of the chunk.
+    load_chunk(min(1, nchunk - 1));
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD) : "memory");  // the weight fragments of chunk 0 (older than the loads) have landed
+    __builtin_amdgcn_s_barrier();
+    // One chunk.  On entry LDS holds chunk ch (tile + weights) and the registers r[] the raw tile of chunk ch + 1, on its way since the
+    // middle of the previous trip: it is cut into the other buffer after CUT taps, and the loads of chunk ch + 2 follow at once, so a
+    // load has a whole trip to land.  The last trips stage the last chunk again, into the buffer nobody reads any more: no branch in
+    // the loop.  The fragments of tap t + 1 are read while tap t is multiplied.  The two waves of a SIMD (w, w + 4) cut at different
+    // points of the trip.  vmcnt at the end: everything but the NLD loads just issued, i.e. the LDS-DMA of the next weights.
     auto chunk = [&](int ch, auto cut_after, auto ndma) {
         constexpr int CUT = decltype(cut_after)::value;
-        const int cur = ch & 1, nxt = min(ch + 1, nchunk - 1);
+        const int cur = ch & 1, nxt = min(ch + 1, nchunk - 1), nx2 = min(ch + 2, nchunk - 1);
+#ifndef C16_ABL_NO_DMA
         dma_weights(nxt, cur ^ 1, ndma);
-        load_chunk(nxt);
+#endif
         Frag fa, fb;
         read_tap(cur, 0, fa);
 #pragma unroll
         for (int tap = 0; tap < 9; tap += 2) {
             if (tap + 1 < 9) read_tap(cur, tap + 1, fb);
             mma_tap(fa);
-            if (tap + 1 == CUT) cut_store(cur ^ 1);
+            if (tap + 1 == CUT) {
+                __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise lifts the cut - and its wait for the loads - to the top of the trip)
+#ifndef C16_ABL_NO_STAGE
+                cut_store(cur ^ 1);
+                load_chunk(nx2);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (tap + 1 < 9) {
                 if (tap + 2 < 9) read_tap(cur, tap + 2, fa);
                 mma_tap(fb);
-                if (tap + 2 == CUT) cut_store(cur ^ 1);
+                if (tap + 2 == CUT) {
+                    __builtin_amdgcn_sched_barrier(0);
+#ifndef C16_ABL_NO_STAGE
+                    cut_store(cur ^ 1);
+                    load_chunk(nx2);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+#ifdef C16_ABL_NO_STAGE
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD) : "memory");
+#endif
+#ifndef C16_ABL_NO_BARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
+        asm volatile("" ::: "memory");
     };
+#ifndef C16_CUT_A
+#define C16_CUT_A 2
+#endif
+#ifndef C16_CUT_B
+#define C16_CUT_B 6
+#endif
     if (wv < 4) {
 #pragma unroll 1
-        for (int ch = 0; ch < nchunk; ++ch) chunk(ch, std::integral_constant<int, 2>{}, std::integral_constant<int, 5>{});
+        for (int ch = 0; ch < nchunk; ++ch) chunk(ch, std::integral_constant<int, C16_CUT_A>{}, std::integral_constant<int, 5>{});
     } else {
 #pragma unroll 1
-        for (int ch = 0; ch < nchunk; ++ch) chunk(ch, std::integral_constant<int, 6>{}, std::integral_constant<int, 4>{});
+        for (int ch = 0; ch < nchunk; ++ch) chunk(ch, std::integral_constant<int, C16_CUT_B>{}, std::integral_constant<int, 4>{});
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged-again last chunk: nothing may be in flight when the wave ends
 
     // epilogue: D[pixel][channel]: lane = channel (32 nb + li), pixel = (r & 3) + 8 (r >> 2) + 4 h of the wave's 32
     if (p0 + 32 * wv >= npix) return;
@@ -343,8 +387,7 @@ extern "C" int shasta_shared_conv_f16x2_supported(int in_channels, int H, int W)
     if (in_channels <= 0 || in_channels % 16 || H <= 0 || W <= 0) return 0;
     if ((long)in_channels * H * W >= (1L << 31)) return 0;
     if (conv16_slots(H, W) > C16_NSLOT) return 0;
-    const int nq = (min(C16_TILE, H * W) + 2 * W + 2 + 3) / 4 + 1;
-    return (nq + 7) / 8 <= 32;
+    return 2 * ((min(C16_TILE, H * W) + 2 * W + 2 + 63) / 64) <= 8 * C16_NIT;
 }
 
 extern "C" size_t shasta_shared_conv_f16x2_packed_bytes(int in_channels) {
@@ -380,7 +423,6 @@ extern "C" int shasta_shared_conv_multi_f32(const float* x, const float* x_prev,
                    "shared_conv_multi: shape not served by the fp16 kernel (in_channels % 16, map width; see shasta_shared_conv_f16x2_supported)");
     SHASTA_REQUIRE((uintptr_t)packed % 16 == 0 && head_stride_bytes % 16 == 0, "shared_conv_multi: packed buffer / head stride must be 16-byte aligned");
     SHASTA_REQUIRE(head_stride_bytes >= shasta_shared_conv_f16x2_packed_bytes(in_channels) || heads == 1, "shared_conv_multi: head stride too small");
-    SHASTA_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)x_prev % 16 == 0, "shared_conv_multi: maps must be 16-byte aligned");
     if (B == 0) return SHASTA_OK;
     SHASTA_REQUIRE(workspace, "shared_conv_multi: null workspace");
     if (workspace_bytes < shasta_shared_conv_multi_workspace_bytes(B)) {
@@ -417,13 +459,7 @@ extern "C" int shasta_shared_conv_multi_f32(const float* x, const float* x_prev,
     a.tiles_per_map = cdiv(H * W, C16_TILE);
     a.ntiles = a.tiles_per_map * nmaps;
     a.tiles_per_xcd = cdiv(a.ntiles, 8);
-    a.vec_ok = (H * W) % 4 == 0;
-    if (a.vec_ok) {
-        (void)hipFuncSetAttribute((const void*)shared_conv_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS);
-        hipLaunchKernelGGL(shared_conv_f16_kernel<true>, dim3(8 * a.tiles_per_xcd * heads), dim3(512), C16_LDS, st, a);
-    } else {
-        (void)hipFuncSetAttribute((const void*)shared_conv_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS);
-        hipLaunchKernelGGL(shared_conv_f16_kernel<false>, dim3(8 * a.tiles_per_xcd * heads), dim3(512), C16_LDS, st, a);
-    }
+    (void)hipFuncSetAttribute((const void*)shared_conv_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS);
+    hipLaunchKernelGGL(shared_conv_f16_kernel, dim3(8 * a.tiles_per_xcd * heads), dim3(512), C16_LDS, st, a);
     return check_launch("shared_conv_f16");
 }

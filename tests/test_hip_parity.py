@@ -260,11 +260,13 @@ def test_forward_with_shared_conv_on_device():
     np.testing.assert_allclose(m2.cpu().numpy(), z["m2"], rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("arith", ["f16x2", "f32"])
 @pytest.mark.parametrize("B,cin,H,W", [(1, 512, 180, 180), (2, 8, 24, 24), (1, 16, 7, 45), (3, 64, 33, 70), (1, 8, 9, 200), (2, 8, 5, 240),
-                                        (1, 16, 6, 256), (1, 8, 4, 300)])
-def test_shared_conv_vs_oracle(B, cin, H, W):
+                                        (1, 16, 6, 256), (1, 8, 4, 300), (2, 32, 3, 187), (1, 48, 200, 2), (1, 16, 1, 1)])
+def test_shared_conv_vs_oracle(B, cin, H, W, arith):
     """K0 against the oracle (conv2d + eval batch_norm + relu -> NHWC); K = 9*Cin sequential fp32 accumulation differs from
-    oneDNN's blocked order by ~1e-6 relative."""
+    oneDNN's blocked order by ~1e-6 relative.  Both arithmetics: "f16x2" = csrc/shared_conv_f16.hip where it serves the shape (maps up
+    to 187 columns; channels zero-padded to a multiple of 16), "f32" = the f32 MFMA kernel of csrc/shared_conv.hip."""
     import shasta_amd
     dev = _dev()
     torch.manual_seed(3)
@@ -282,11 +284,99 @@ def test_shared_conv_vs_oracle(B, cin, H, W):
     x = torch.relu(torch.randn(B, cin, H, W, generator=g))
     ref = O.shared_conv_nhwc(w, x)
     m = m.to(dev)
+    m.arithmetic = arith
     with torch.no_grad():
         got = m.shared_conv_nhwc(x.to(dev))
     assert got.shape == ref.shape
     scale = float(ref.abs().max())
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5 * max(1.0, scale))
+
+
+def _conv_models(n, cin, seed0=20):
+    import shasta_amd
+    ms = []
+    for i in range(n):
+        torch.manual_seed(seed0 + i)
+        m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                             bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
+                                             max_obj=4, num_feats=7, num_point=5, in_channels=cin)).eval()
+        with torch.no_grad():
+            m.shared_conv[1].running_mean.copy_(torch.randn(64) * 0.3)
+            m.shared_conv[1].running_var.copy_(torch.rand(64) + 0.5)
+            m.shared_conv[1].weight.copy_(torch.rand(64) + 0.5)
+            m.shared_conv[1].bias.copy_(torch.randn(64) * 0.2)
+        ms.append(m)
+    return ms
+
+
+@pytest.mark.parametrize("heads,B,cin,H,W", [(7, 1, 64, 40, 180), (3, 2, 24, 9, 37), (8, 1, 16, 5, 7), (2, 1, 512, 180, 180)])
+def test_shared_conv_bank_equals_the_single_heads_and_the_oracle(heads, B, cin, H, W):
+    """shasta_shared_conv_multi_f32: the class heads of tools/nusc_shasta/eval.py:86-101 in one launch.  Every head's output is
+    bit-identical to that model's own shared_conv_nhwc (same kernel, heads = 1) and within the K0 tolerance of the oracle; the
+    packed images follow a change of a head's tensors."""
+    from shasta_amd.shared_conv import SharedConvBank
+    dev = _dev()
+    ms = _conv_models(heads, cin)
+    ws = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in ms]
+    g = torch.Generator().manual_seed(6)
+    x, xp = torch.relu(torch.randn(B, cin, H, W, generator=g)), torch.relu(torch.randn(B, cin, H, W, generator=g))
+    ms = [m.to(dev) for m in ms]
+    bank = SharedConvBank(ms)
+    with torch.no_grad():
+        outs, outs_p = bank(x.to(dev), xp.to(dev))
+        only = bank(x.to(dev))
+        for i, m in enumerate(ms):
+            y, yp = m.shared_conv_nhwc(x.to(dev), xp.to(dev))
+            assert torch.equal(y, outs[i]) and torch.equal(yp, outs_p[i]) and torch.equal(only[i], outs[i])
+            if i < 3:
+                ref, refp = O.shared_conv_nhwc(ws[i], x), O.shared_conv_nhwc(ws[i], xp)
+                tol = 2e-5 * max(1.0, float(ref.abs().max()))
+                np.testing.assert_allclose(outs[i].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=tol)
+                np.testing.assert_allclose(outs_p[i].cpu().numpy(), refp.numpy(), rtol=1e-4, atol=tol)
+        ms[1].shared_conv[0].weight.mul_(1.5)  # in place: the version counter moves, the bank re-packs
+        again = bank(x.to(dev))
+        assert torch.equal(again[0], outs[0]) and not torch.equal(again[1], outs[1])
+        w1 = {k: v.detach().cpu().clone() for k, v in ms[1].state_dict().items()}
+        ref1 = O.shared_conv_nhwc(w1, x)
+        np.testing.assert_allclose(again[1].cpu().numpy(), ref1.numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(ref1.abs().max())))
+
+
+@pytest.mark.parametrize("kind", ["tiny", "huge", "spike", "mixed_images", "wide_weights"])
+def test_shared_conv_fp16_form_is_range_safe(kind):
+    """The fp16 form scales every image by one power of two (its largest magnitude) and every output channel's weights by another:
+    maps of magnitude 1e-6 or 1e5, one 1e4 spike in an otherwise O(1) map, two images of very different scale in one batch and
+    weights whose rows differ by 2^20 all stay within twice the strict-f32 kernel's error against float64."""
+    dev = _dev()
+    m = _conv_models(1, 64, seed0=31)[0].to(dev)
+    g = torch.Generator(device=dev).manual_seed(8)
+    x = torch.relu(torch.randn(2, 64, 40, 90, device=dev, generator=g))
+    if kind == "tiny":
+        x = x * 1e-6
+    elif kind == "huge":
+        x = x * 1e5
+    elif kind == "spike":
+        x[0, 3, 7, 11] = 1e4
+        x[1, 60, 39, 89] = -1e4
+    elif kind == "mixed_images":
+        x[0] *= 1e-4
+        x[1] *= 1e3
+    else:
+        with torch.no_grad():
+            m.shared_conv[0].weight.mul_(torch.exp2(torch.linspace(-10, 10, 64, device=dev)).view(64, 1, 1, 1))
+    conv, bn = m.shared_conv[0], m.shared_conv[1]
+    with torch.no_grad():
+        y64 = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        y64 = (y64 - bn.running_mean.double()[None, :, None, None]) / torch.sqrt(bn.running_var.double() + bn.eps)[None, :, None, None]
+        y64 = torch.relu(y64 * bn.weight.double()[None, :, None, None] + bn.bias.double()[None, :, None, None]).permute(0, 2, 3, 1)
+        err = {}
+        for arith in ("f32", "f16x2"):
+            m.arithmetic = arith
+            y = m.shared_conv_nhwc(x)
+            # per (image, channel) scale: the error is relative to what that channel of that image holds
+            den = y64.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-30)
+            err[arith] = float(((y.double() - y64).abs() / den).max())
+    assert err["f16x2"] <= 2 * err["f32"] + 1e-7, err
+    assert err["f16x2"] < 2e-5, err
 
 
 @pytest.mark.parametrize("B,N,n_real,npnt,hw,stride", [(2, 37, None, 5, 180, 8), (1, 500, None, 4, 180, 8),

@@ -10,7 +10,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import shasta_amd  # noqa: E402
 from shasta_amd.shared_conv import SharedConvBank  # noqa: E402
 
