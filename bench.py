@@ -454,13 +454,13 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": r["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.arithmetic == "f32" else "f32 (%s products)" % args.arithmetic, "data": "synthetic",
         "config": {"workload": "synthetic N=M=500, F=256 (num_point=4, C=64), nf=7 affinity forward from HBM-resident "
                                "NHWC BEV features (SURVEY 8a rows 4-16)", "frame_pairs_per_step_per_gpu": B,
                    "max_obj": N_OBJ, "num_feats": NF, "num_point": NPOINT, "bev_hw": HW,
                    "parallelism": "replica x%d (frame-parallel, no data-path collective)" % world,
                    "hip_graph": bool(args.graph), "precut_weight_stream": not args.no_precut,
-                   "arithmetic": {"f16x2": "fp32 operands in HBM, fp32 accumulation throughout; the first aug_shape layer (from 17 frame-pairs per step "
+                   "arithmetic": args.arithmetic + ": " + {"f16x2": "fp32 operands in HBM, fp32 accumulation throughout; the first aug_shape layer (from 17 frame-pairs per step "
                                            "with the pre-cut weight image, above 64 without) and the second layers of the pair MLPs form every fp32 product from three products of "
                                            "two range-scaled fp16 pieces per operand (round to nearest; measured max error vs float64: weight "
                                            "stream 5.5e-6 against 7.0e-6 for the f32 MFMA kernel, pair stage 1.8e-6 against 2.3e-6); from 8192 "
@@ -540,7 +540,17 @@ def extras(bench, args):
     car["config"] = "max_obj 90, num_point 5 (F = 320), num_feats 3: configs/nusc/car.py:22-39 of the reference; 180 x 180 x 64 BEV maps"
     ex["car_90_320_3"] = car
     bench.model(HEADLINE).arithmetic = args.arithmetic
-    for name, fn in (("shared_conv", extra_shared_conv),):
+    n5 = {}
+    cfg5 = dict(max_obj=N_OBJ, num_feats=3, num_point=5)
+    for b, k in ((1, 100), (64, 30), (B, 10)):
+        if b <= B:
+            n5["b%d" % b] = point(cfg5, b, k, args.arithmetic)
+    n5["config"] = "max_obj 500, num_point 5 (F = 320), num_feats 3: BASELINE config 3's table shape (all 7 classes, N,M <= 500, configs/nusc/*.py)"
+    ex["n500_f320_nf3"] = n5
+    bench.models.pop(tuple(sorted(cfg5.items())), None)  # 6.4 GB of weights + their companion image: released before the next extras
+    torch = bench.torch
+    torch.cuda.empty_cache()
+    for name, fn in (("shared_conv", extra_shared_conv), ("voxelize", extra_voxelize), ("train_step", extra_train_step)):
         try:
             fn(bench, args, ex)
         except Exception as err:  # noqa: BLE001
@@ -558,6 +568,97 @@ def timed_ms(torch, fn, iters, warm=3):
         fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / iters * 1e3
+
+
+def extra_voxelize(bench, args, ex):
+    """K1 (SURVEY.md 8(a) rows 1-2, det3d/ops/point_cloud/point_cloud_ops.py:112-184 + voxel_encoder.py:18-28): hard voxelisation + per-voxel
+    mean of one nuScenes-sized cloud (3e5 points, 10 sweeps: loading.py:128-148), the configuration of configs/nusc/car.py:120-125.
+    Algorithmic bytes: the points read once, the (V, 10, 5) voxels + coordinates + counts + means written once."""
+    import numpy as np
+    torch, dev = bench.torch, bench.dev
+    from shasta_amd.voxel_generator import points_to_voxel_device
+    VS, RG = np.array([0.075, 0.075, 0.2], np.float32), np.array([-54, -54, -5, 54, 54, 3], np.float32)
+    rng = np.random.default_rng(0)
+    P = 300000
+    pts = np.zeros((P, 5), np.float32)
+    r = np.abs(rng.normal(0, 18, size=P)).astype(np.float32)
+    th = rng.uniform(0, 2 * np.pi, size=P).astype(np.float32)
+    pts[:, 0], pts[:, 1] = r * np.cos(th), r * np.sin(th)
+    pts[:, 2] = rng.normal(-1.5, 0.6, size=P)
+    pts[:, 3] = rng.uniform(0, 255, size=P)
+    d = torch.from_numpy(pts).to(dev)
+    out = points_to_voxel_device(d, VS, RG, 10, 160000, with_mean=True)
+    V = int(out[0].shape[0])
+    ms = timed_ms(torch, lambda: points_to_voxel_device(d, VS, RG, 10, 160000, with_mean=True), 20)
+    alg = P * 5 * 4 + V * (10 * 5 * 4 + 3 * 4 + 4 + 5 * 4)
+    e = {"points": P, "voxels": V, "ms": ms, "note": "one call incl. output allocation and the host read of the voxel count",
+         "algorithmic_bytes": alg, "algorithmic_gbs": alg / ms / 1e6, "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS, "clouds_per_s": 1e3 / ms}
+    if not args.no_cpu_baseline:
+        from oracle import voxelize_oracle as VO  # the checker's C twin of the serial reference loop, timed on one host core
+        VO.points_to_voxel(pts, VS, RG, 10, 160000)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            VO.points_to_voxel(pts, VS, RG, 10, 160000, with_mean=True)
+        e["cpu_oracle_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+        e["cpu_oracle"] = "oracle/voxelize_oracle.c (restatement of the reference's numba loop), 1 thread"
+    ex["voxelize"] = e
+
+
+def extra_train_step(bench, args, ex):
+    """Row 19 / BASELINE config 5 (tools/nusc_shasta/train.py:198-218): forward + masked NLL + HIP backward + fused Adam of the affinity
+    network on one GPU, synthetic batch; fp32 and Shasta.train_precision = "bf16".  Split by torch events on the launch stream."""
+    torch, dev = bench.torch, bench.dev
+    from shasta_amd import training
+    ts = {"note": "ms per step = forward (rows 4-16) + loss + backward + Adam; frame-pairs/s = B / step; fwd / bwd / adam from events on the stream"}
+    for (cfg, B, steps) in ((CAR, 16, 10), (CAR, 64, 6), (HEADLINE, 8, 3)):
+        for prec in ("fp32", "bf16"):
+            key = "n%d_b%d_%s" % (cfg["max_obj"], B, prec)
+            try:
+                torch.manual_seed(0)
+                with torch.device(dev):
+                    model = bench.shasta.build_simp_track(dict(
+                        type="Shasta", reader=None, backbone=None, neck=None,
+                        bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8), **cfg)).train()
+                model.train_precision = prec
+                params = training.affinity_params(model)
+                opt = training.FusedAdam(params, lr=1e-4)
+                N = cfg["max_obj"]
+                det0, prev = bench.boxes(cfg)
+                det0, prev, bev, pbev = det0[:B], prev[:B], bench.bev[:B], bench.pbev[:B]
+                gt = (torch.rand(B, N + 2, N + 2, device=dev, generator=bench.gen) < 0.02).float()
+                gt[:, 0, 0] = 1
+                evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+
+                def one(ev=None):
+                    opt.zero_grad(set_to_none=True)
+                    if ev:
+                        ev[0].record()
+                    m1, m2 = training.affinity_train(model, bev, pbev, det0.clone(), prev.clone())
+                    loss = training.affinity_loss(m1, m2, gt)
+                    if ev:
+                        ev[1].record()
+                    loss.backward()
+                    if ev:
+                        ev[2].record()
+                    opt.step()
+                    if ev:
+                        ev[3].record()
+                for _ in range(2):
+                    one()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    one(evs[i])
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / steps * 1e3
+                ts[key] = {"ms_per_step": ms, "frame_pairs_per_s": B / ms * 1e3,
+                           "fwd_ms": sum(e[0].elapsed_time(e[1]) for e in evs) / steps, "bwd_ms": sum(e[1].elapsed_time(e[2]) for e in evs) / steps,
+                           "adam_ms": sum(e[2].elapsed_time(e[3]) for e in evs) / steps}
+                del model, params, opt
+                torch.cuda.empty_cache()
+            except Exception as err:  # noqa: BLE001
+                ts[key] = {"error": "%s: %s" % (type(err).__name__, str(err)[:200])}
+    ex["train_step"] = ts
 
 
 def extra_shared_conv(bench, args, ex):
