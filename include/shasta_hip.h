@@ -185,6 +185,8 @@ typedef struct shasta_weights {
     shasta_linear res_coeff[3];    /* res_coeff.{0,2,4}:    2F+2nf->32+F/8->8+F/32->3   */
     shasta_linear aff[6];          /* aff.{0,2,4,6,8,10}:   N+2->128->64->32->64->128->N+2 */
     const void* aug_shape_aux;     /* shasta_aug_shape_aux_f32 output for the CURRENT aug_shape.{i}.0.weight, or NULL */
+    size_t aug_shape_aux_bytes;    /* its size: every call that takes the struct rejects (SHASTA_E_ARG) a companion smaller than
+                                      shasta_aug_shape_aux_bytes(max_obj, feat_dim, options), e.g. one built without the PRECUT bit */
 } shasta_weights;
 
 /* Packed (kernel-ready) copy of the SMALL weights: MFMA fragments of the pair MLPs (fuse_shape, fuse_det, res_coeff),

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void bev_gather_kernel(
                 v = __fadd_rn(v, __fmul_rn(c[q], wc));
                 v = __fadd_rn(v, __fmul_rn(d[q], wd));
                 r[q] = v;
-                if (ABSMAX) amax = fmaxf(amax, fabsf(v));
+                if (ABSMAX) amax = absmax_keep_nan(amax, fabsf(v));
             }
             if (live) reinterpret_cast<f32x4*>(o)[c4] = r;
         }
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void bev_gather_kernel(
             v = __fadd_rn(v, __fmul_rn(Ib[ch], wb));
             v = __fadd_rn(v, __fmul_rn(Ic[ch], wc));
             v = __fadd_rn(v, __fmul_rn(Id[ch], wd));
-            if (ABSMAX) amax = fmaxf(amax, fabsf(v));
+            if (ABSMAX) amax = absmax_keep_nan(amax, fabsf(v));
             if (live) o[ch] = v;
         }
     }
@@ -133,16 +133,16 @@ __global__ __launch_bounds__(256) void bev_gather_kernel(
         // 16 lanes -> one value per point -> (normally) one per wave, posted into one of ABSMAX_SLOTS cache lines of the batch item
         // (consecutive waves take consecutive lines): every wave of a batch item hitting ONE address serialises on a single L2
         // channel - measured: one atomic per 16-point block 211 -> 267 us per call, a read-then-atomic per wave 2.0 ms.  No LDS, no
-        // barrier.  The consumer reduces the lines (absmax_finalize_kernel).  fmaxf drops a NaN; a NaN / inf in the tables then
-        // shows up in the products themselves.
+        // barrier.  The consumer reduces the lines (absmax_finalize_kernel).  absmax_keep_nan: a NaN / inf survives in the
+        // maximum exactly as in the stand-alone row_max / row_prep passes (the bit-for-bit claim of shasta_affinity_from_bev_f32).
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 16));
+        for (int off = 8; off > 0; off >>= 1) amax = absmax_keep_nan(amax, __shfl_xor(amax, off, 16));
         if (!live) amax = 0.0f;
         const int slot = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (ABSMAX_SLOTS - 1);
         const int b_first = __shfl(b, 0, 64), b_last = __shfl(b, 48, 64);  // batch items are non-decreasing along the wave's four points
         if (b_first == b_last) {
-            amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
-            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            amax = absmax_keep_nan(amax, __shfl_xor(amax, 16, 64));
+            amax = absmax_keep_nan(amax, __shfl_xor(amax, 32, 64));
             if ((threadIdx.x & 63) == 0) atomicMax(absmax + ((size_t)b * ABSMAX_SLOTS + slot) * 32, __float_as_uint(amax));
         } else if (lane == 0) {
             atomicMax(absmax + ((size_t)b * ABSMAX_SLOTS + slot) * 32, __float_as_uint(amax));

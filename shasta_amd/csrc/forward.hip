@@ -56,6 +56,11 @@ static int check_weights(const shasta_weights* w) {
     for (int i = 0; i < 6; ++i) SHASTA_REQUIRE(w->aff[i].weight && w->aff[i].bias, "aff weights missing");
     for (int i = 0; i < 4; ++i)
         SHASTA_REQUIRE((uintptr_t)w->aug_shape[i][0].weight % 16 == 0, "aug_shape.*.0.weight must be 16-byte aligned");
+    // a companion buffer must have been built with the SAME options (the pre-cut image sits behind the maxima only when it was
+    // built with SHASTA_OPT_PRECUT_WEIGHT_STREAM): its size says so
+    SHASTA_REQUIRE(!w->aug_shape_aux || w->aug_shape_aux_bytes >= shasta_aug_shape_aux_bytes(w->max_obj, w->feat_dim, w->options),
+                   "aug_shape_aux: companion buffer smaller than shasta_aug_shape_aux_bytes(max_obj, feat_dim, options) - built without "
+                   "SHASTA_OPT_PRECUT_WEIGHT_STREAM? (set shasta_weights.aug_shape_aux_bytes)");
     return SHASTA_OK;
 }
 

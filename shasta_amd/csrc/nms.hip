@@ -175,6 +175,7 @@ extern "C" int shasta_boxes_bev_f32(const float* boxes_a, int num_a, const float
     SHASTA_REQUIRE(num_a >= 0 && num_b >= 0 && mode >= 0 && mode <= 2, "boxes_bev: bad argument");
     if (num_a == 0 || num_b == 0) return SHASTA_OK;
     SHASTA_REQUIRE(boxes_a && boxes_b && out, "boxes_bev: null pointer");
+    SHASTA_REQUIRE(num_a <= 4 * 65535, "boxes_bev: at most 262140 rows (boxes_a) per call");
     hipLaunchKernelGGL(boxes_bev_kernel, dim3(cdiv(num_b, 64), cdiv(num_a, 4)), dim3(256), 0, as_stream(stream), boxes_a, num_a, boxes_b,
                        num_b, mode, out);
     return check_launch("boxes_bev");
@@ -187,20 +188,20 @@ extern "C" size_t shasta_nms_workspace_bytes(int num_boxes) {
 
 static int nms_impl(bool axis_aligned, const float* boxes_sorted, int num_boxes, float thresh, void* workspace, size_t workspace_bytes,
                     int32_t* keep, int32_t* num_keep, shasta_stream_t stream) {
-    SHASTA_REQUIRE(keep && num_keep && num_boxes >= 0, "nms_rotated: bad argument");
-    SHASTA_REQUIRE(num_boxes <= 64 * 64 * NMS_MAX_WORDS_PER_LANE, "nms_rotated: at most 32768 boxes");
+    SHASTA_REQUIRE(keep && num_keep && num_boxes >= 0, axis_aligned ? "nms_normal: bad argument" : "nms_rotated: bad argument");
+    SHASTA_REQUIRE(num_boxes <= 64 * 64 * NMS_MAX_WORDS_PER_LANE, axis_aligned ? "nms_normal: at most 32768 boxes" : "nms_rotated: at most 32768 boxes");
     hipStream_t st = as_stream(stream);
     if (num_boxes == 0) {
         hipError_t e = hipMemsetAsync(num_keep, 0, sizeof(int32_t), st);
         if (e != hipSuccess) {
-            set_error("nms_rotated: memset", e);
+            set_error(axis_aligned ? "nms_normal: memset" : "nms_rotated: memset", e);
             return SHASTA_E_LAUNCH;
         }
         return SHASTA_OK;
     }
-    SHASTA_REQUIRE(boxes_sorted && workspace, "nms_rotated: null pointer");
+    SHASTA_REQUIRE(boxes_sorted && workspace, axis_aligned ? "nms_normal: null pointer" : "nms_rotated: null pointer");
     if (workspace_bytes < shasta_nms_workspace_bytes(num_boxes)) {
-        set_error_msg("nms_rotated: workspace too small");
+        set_error_msg(axis_aligned ? "nms_normal: workspace too small" : "nms_rotated: workspace too small");
         return SHASTA_E_WORKSPACE;
     }
     const int words = cdiv(num_boxes, 64);

@@ -37,7 +37,7 @@ class Weights(C.Structure):
     _fields_ = [("max_obj", C.c_int), ("num_feats", C.c_int), ("feat_dim", C.c_int), ("options", C.c_int),
                 ("aug_shape", (Linear * 2) * 4), ("aug_dets", (Linear * 2) * 4),
                 ("fuse_shape", Linear * 4), ("fuse_det", Linear * 3), ("res_coeff", Linear * 3),
-                ("aff", Linear * 6), ("aug_shape_aux", C.c_void_p)]
+                ("aff", Linear * 6), ("aug_shape_aux", C.c_void_p), ("aug_shape_aux_bytes", C.c_size_t)]
 
 
 # every symbol include/shasta_hip.h declares: name -> (restype, argtypes)

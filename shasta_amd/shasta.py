@@ -12,12 +12,37 @@ the C ABI (include/shasta_hip.h).  There is no PyTorch/CPU fallback: without the
 tensors, forward raises.
 """
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
 
 from . import builder, hip
 from .registry import TRACK
+
+
+# ---- pointer-cache invalidation: torch calls these hooks whenever a Parameter / sub-module is (re-)registered on ANY module ---------
+_OWNER = weakref.WeakKeyDictionary()  # sub-module of a Shasta -> weakref to that Shasta
+_HOOKED = []
+
+
+def _on_register(module, name, value):
+    ref = _OWNER.get(module)
+    owner = ref() if ref is not None else None
+    if owner is not None:
+        owner._wstruct = None
+    return None
+
+
+def _watch(model):
+    """(Re-)enrol every sub-module of `model`; install the two global hooks once."""
+    if not _HOOKED:
+        from torch.nn.modules import module as M
+        _HOOKED.append(M.register_module_parameter_registration_hook(_on_register))
+        _HOOKED.append(M.register_module_module_registration_hook(_on_register))
+    ref = weakref.ref(model)
+    for sub in model.modules():
+        _OWNER[sub] = ref
 
 
 class BaseTrack(nn.Module):
@@ -112,6 +137,7 @@ class Shasta(BaseTrack):
         self._conv_key = None
         self._conv_bank = None
         self._wstruct = None
+        self._plist = None
         self._bufs = {}
         self._graph_bufs = []
         # How fp32 products are formed on the matrix cores (shasta_weights.options, include/shasta_hip.h); fp32 operands in HBM and
@@ -180,22 +206,45 @@ class Shasta(BaseTrack):
         return [p for m in mods for p in (m.weight, m.bias)]
 
     def _apply(self, fn, *a, **k):  # .to() / .cuda() / .float(): parameter storage moves -> drop pointer caches
-        self._wstruct = None
+        self.invalidate_weights_cache()
         return super()._apply(fn, *a, **k)
 
+    def invalidate_weights_cache(self):
+        """Forget every kernel-side copy / pointer table derived from the parameters (the shasta_weights struct, the packed small
+        weights, the companion of the aug_shape first layers incl. its pre-cut fp16 image, the packed shared_conv): the next forward
+        rebuilds them.  The caches follow parameter re-assignment, moves, optimizer steps and load_state_dict by themselves (pointer +
+        version checks); call this after writing parameter memory in a way that bumps no version counter (`p.data.copy_()`, a raw-pointer
+        write from another library)."""
+        self._wstruct = None
+        self._plist = None
+        self._packed_key = None
+        self._aux_key = None
+        self._conv_key = None
+        if getattr(self, "_conv_bank", None) is not None:
+            self._conv_bank._key = None
+
     def _weights(self):
-        """shasta_weights struct over the live parameter storage (no copies).  Cached: building it walks 64 tensors, which
-        is a visible part of a forward at small configurations; optimizer steps and load_state_dict update the storage in
-        place, moves go through _apply, and a re-assigned parameter is caught by the pointer probe over one tensor per block."""
-        probe = tuple(t.data_ptr() for t in (self.aug_shape[0][0].weight, self.aug_shape[3][2].weight, self.aug_dets[0][0].weight,
-                                             self.fuse_shape[0].weight, self.fuse_det[0].weight, self.res_coeff[0].weight,
-                                             self.aff[0].weight, self.aff[10].weight)) + (self.arithmetic, self.precut_weight_stream)
+        """shasta_weights struct over the live parameter storage (no copies).  Cached, because building it walks 34 modules - a visible
+        part of a forward at small configurations.  It is re-validated on every call by the data pointers of ALL its tensors (6 us: the
+        Parameter objects themselves are cached, which catches `p.data = ...`), and a parameter or sub-module that is REPLACED
+        (`m.aff[4].weight = nn.Parameter(...)`, pruning / parametrisation utilities, `m.aff[4] = nn.Linear(...)`) drops the cache through
+        torch's registration hooks (_watch).  Optimizer steps and load_state_dict write in place; moves go through _apply."""
+        plist = getattr(self, "_plist", None)
         ws = getattr(self, "_wstruct", None)
-        if ws is not None and ws[1] == probe:
-            return ws[0]
+        if ws is not None and plist is not None:
+            probe = tuple(p.data_ptr() for p in plist) + (self.arithmetic, self.precut_weight_stream)
+            if ws[1] == probe:
+                return ws[0]
         w = self._build_weights()
-        self._wstruct = (w, probe)
+        _watch(self)
+        self._plist = [p for m in self._linear_modules() for p in (m.weight, m.bias)]
+        self._wstruct = (w, tuple(p.data_ptr() for p in self._plist) + (self.arithmetic, self.precut_weight_stream))
         return w
+
+    def _linear_modules(self):
+        return ([self.aug_shape[i][j] for i in range(4) for j in (0, 2)] + [self.aug_dets[i][j] for i in range(4) for j in (0, 2)] +
+                [self.fuse_shape[k] for k in (0, 2, 4, 6)] + [self.fuse_det[k] for k in (0, 2, 4)] + [self.res_coeff[k] for k in (0, 2, 4)] +
+                [self.aff[k] for k in (0, 2, 4, 6, 8, 10)])
 
     def _build_weights(self):
         def lin(m):
@@ -246,12 +295,12 @@ class Shasta(BaseTrack):
         forward that takes the fp16 weight stream - and again only after one of the four matrices changed (an optimizer step bumps
         their versions).  The fp16 stream serves more than 64 frame-pairs per call; with the pre-cut image also every inference call
         of at least 17 (its loop then holds nothing but DMA, LDS reads and MFMAs: 32 / 64 items per weight pass run at the speed of
-        the stream; up to 16 the f32 16x16x4 kernel is as fast and needs no activation image).  Training steps (weights change every step) never build the image for it: they keep the kernels that read the fp32
-        tensors.  Without a companion the library recomputes the maxima inside every call that needs them."""
+        the stream; up to 16 the f32 16x16x4 kernel is as fast and needs no activation image).  Training steps (weights change every step) never build the image: affinity_from_bev clears the PRECUT bit for
+        them, so they keep the kernels that read the fp32 tensors and only the row maxima are rebuilt.  Without a companion the library recomputes the maxima inside every call that needs them."""
         small = self.precut_weight_stream and not training and B >= hip.PRECUT_MIN_BATCH
         need = self.arithmetic in ("f16x2", "f16grid") and (B > 64 or small) and self.max_obj * self.aug_shape_output >= 64
         if not need:
-            w.aug_shape_aux = None
+            w.aug_shape_aux, w.aug_shape_aux_bytes = None, 0
             return
         key = tuple((self.aug_shape[i][0].weight.data_ptr(), self.aug_shape[i][0].weight._version) for i in range(4)) + (w.options,)
         if self._aux is None or self._aux_key != key or self._aux.device != device:
@@ -259,10 +308,10 @@ class Shasta(BaseTrack):
             nbytes = lib.shasta_aug_shape_aux_bytes(self.max_obj, self.aug_shape_output, w.options)
             self._aux = None
             self._aux = torch.empty(nbytes // 4, dtype=torch.int32, device=device)
-            w.aug_shape_aux = None
+            w.aug_shape_aux, w.aug_shape_aux_bytes = None, 0
             hip.check(lib.shasta_aug_shape_aux_f32(C.byref(w), hip.ptr(self._aux), nbytes, hip.stream_ptr()), "shasta_aug_shape_aux_f32")
             self._aux_key = key
-        w.aug_shape_aux = self._aux.data_ptr()
+        w.aug_shape_aux, w.aug_shape_aux_bytes = self._aux.data_ptr(), self._aux.numel() * 4
 
     def _work_buffers(self, B, device):
         """Feature / box tables and the stage workspace.  ONE set per device, sized for the largest batch seen so far and
@@ -384,6 +433,11 @@ class Shasta(BaseTrack):
         if B == 0:  # nothing to launch
             return torch.empty(0, N, N + 2, device=dev), torch.empty(0, N + 2, N, device=dev)
         w = self._weights()
+        if _train_keep is not None and (w.options & hip.OPT_PRECUT_WEIGHT_STREAM):
+            # training steps change the weights every step: they keep the kernels that read the fp32 tensors (a private copy of the
+            # struct without the bit, so that no 4 GB piece image is rebuilt per step only to be streamed once)
+            w = hip.Weights.from_buffer_copy(w)
+            w.options &= ~hip.OPT_PRECUT_WEIGHT_STREAM
         self._ensure_packed(w, dev)
         self._ensure_aux(w, B, dev, training=_train_keep is not None)
         bufs = self._work_buffers(B, dev)

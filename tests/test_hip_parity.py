@@ -722,6 +722,77 @@ def test_anchor_boxes_are_fresh_tensors_and_work_buffers_are_bounded():
     assert len(m._bufs) == 1 and next(iter(m._bufs.values()))["B"] == c["B"]
 
 
+def test_weight_pointer_cache_follows_reassigned_and_rewritten_parameters():
+    """Shasta._weights() caches a struct of 68 raw device pointers.  A parameter that is re-assigned (`m.aff[4].weight = nn.Parameter`),
+    a sub-module that is replaced, a `.data = ` swap and a pruned weight are all seen by the next forward (only 8 of the
+    tensors were probed); invalidate_weights_cache() covers writes that bump no version counter."""
+    dev = _dev()
+    z, c, m, bev, pbev, det, prev = _case("small_32_7_4")
+    with torch.no_grad():
+        f, pf = O.shared_conv_nhwc({k: v.detach().clone() for k, v in m.state_dict().items()}, bev).to(dev), \
+            O.shared_conv_nhwc({k: v.detach().clone() for k, v in m.state_dict().items()}, pbev).to(dev)
+    m = m.to(dev)
+    nf, npnt = c["num_feats"], c["num_point"]
+
+    def run():
+        with torch.no_grad():
+            return m.affinity_from_bev(f, pf, det.to(dev).clone(), prev.to(dev).clone())
+
+    def oracle():
+        w = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        return O.forward_from_bev(w, f.cpu(), pf.cpu(), det.clone(), prev.clone(), nf, npnt)
+
+    def check(what):
+        m1, m2 = run()
+        r1, r2 = oracle()
+        assert float((m1.cpu() - r1).abs().max()) < TOL and float((m2.cpu() - r2).abs().max()) < TOL, what
+
+    check("baseline")
+    base = run()[0].clone()
+    g = torch.Generator().manual_seed(3)
+    m.aff[4].weight = torch.nn.Parameter((torch.randn(64, 32, generator=g) * 0.3).to(dev))  # un-probed tensor of round 3
+    assert not torch.equal(run()[0], base)
+    check("re-assigned aff[4].weight")
+    m.res_coeff[2] = torch.nn.Linear(m.res_coeff[2].in_features, m.res_coeff[2].out_features).to(dev)
+    check("replaced res_coeff[2]")
+    m.fuse_det[2].bias.data = (torch.randn(8, generator=g)).to(dev)
+    check(".data swap of fuse_det[2].bias")
+    with torch.no_grad():
+        before = run()[0].clone()
+        m.aug_dets[1][2].weight.data.mul_(3.0)  # in place through .data: the pointer is the same, the aug_dets tensors are read in place
+        check("in-place write through .data")
+        m.fuse_shape[0].weight.data.mul_(1.5)  # a PACKED tensor written without a version bump: needs the explicit call
+        m.invalidate_weights_cache()
+        check("invalidate_weights_cache after a silent write")
+        assert not torch.equal(run()[0], before)
+
+
+def test_companion_buffer_size_is_checked():
+    """a forward with SHASTA_OPT_PRECUT_WEIGHT_STREAM and a companion built WITHOUT that bit used to read the piece image past
+    the end of the buffer; shasta_weights now carries the companion's size and the call is rejected."""
+    from shasta_amd import hip
+    dev = _dev()
+    z, c, m, bev, pbev, det, prev = _case("small_32_7_4")
+    m = m.to(dev)
+    lib = hip.load()
+    w = hip.Weights.from_buffer_copy(m._weights())
+    w.options = hip.OPT_F16X2_WEIGHT_STREAM
+    small = lib.shasta_aug_shape_aux_bytes(m.max_obj, m.aug_shape_output, w.options)
+    aux = torch.zeros(small // 4, dtype=torch.int32, device=dev)
+    w.aug_shape_aux, w.aug_shape_aux_bytes = None, 0
+    hip.check(lib.shasta_aug_shape_aux_f32(C.byref(w), hip.ptr(aux), small, hip.stream_ptr()), "aux")
+    w.aug_shape_aux, w.aug_shape_aux_bytes = aux.data_ptr(), small
+    B, N, F = 20, m.max_obj, m.aug_shape_output
+    feat, pfeat = torch.rand(B, N + 2, F, device=dev), torch.rand(B, N + 2, F, device=dev)
+    wsb = lib.shasta_forward_workspace_bytes(B, N, m.num_feats, F)
+    ws = torch.empty(wsb // 4 + 1, device=dev)
+    assert lib.shasta_anchor_shape_f32(C.byref(w), B, hip.ptr(feat), hip.ptr(pfeat), hip.ptr(ws), wsb, hip.stream_ptr()) == 0
+    w.options |= hip.OPT_PRECUT_WEIGHT_STREAM  # the companion was built without the image
+    rc = lib.shasta_anchor_shape_f32(C.byref(w), B, hip.ptr(feat), hip.ptr(pfeat), hip.ptr(ws), wsb, hip.stream_ptr())
+    assert rc == -1 and b"aug_shape_aux" in lib.shasta_last_error()
+    torch.cuda.synchronize()
+
+
 def test_shared_conv_pads_odd_channel_counts_and_never_leaves_the_hip_kernel_in_inference():
     """in_channels that is not a multiple of the kernel's 8-channel K chunk runs the SAME HIP kernel on zero-padded channels
     (no MIOpen fallback); eval() with autograd on (frozen-BN fine-tuning) takes the differentiable module instead."""
