@@ -787,7 +787,8 @@ def dry_run(args, rank, world):
     assert int(t.item()) == world and args.gpus == world
     if rank == 0:
         print(json.dumps({"metric": "affinity frame-pairs/sec at N=M=500, F=256", "value": None, "unit": "frame-pairs/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "max_over_ranks": t.item()}), flush=True)
+                          "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "dry_run": True,
+                          "max_over_ranks": t.item()}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -35,8 +35,11 @@ def split_paths(root, split="val", det="cp"):
 
 def write_synthetic_split(root, n_scenes=3, frames_per_scene=6, seed=0, split="val", det="cp", objects=None, dt=0.5,
                           drop=0.12, clutter=2):
-    """Writes the files listed above; returns (paths dict, scenes: list of (scene name, [tokens in time order]))."""
+    """Writes the files listed above; returns (paths dict, scenes: list of (scene name, [tokens in time order])).
+    frames_per_scene: one length for every scene, or one length per scene (nuScenes scenes are about 40 key frames, not all equal)."""
     rng = np.random.default_rng(seed)
+    lengths = [int(frames_per_scene)] * n_scenes if np.isscalar(frames_per_scene) else [int(v) for v in frames_per_scene]
+    assert len(lengths) == n_scenes and min(lengths) >= 1
     objects = dict(DEFAULT_OBJECTS if objects is None else objects)
     p = split_paths(root, split, det)
     os.makedirs(p["det_path"], exist_ok=True)
@@ -44,7 +47,7 @@ def write_synthetic_split(root, n_scenes=3, frames_per_scene=6, seed=0, split="v
     frame_info, frames_meta, scenes = {}, [], []
     t0 = 1_500_000_000_000_000
     for s in range(n_scenes):
-        tokens = [hashlib.md5(("%d/%d/%d" % (seed, s, f)).encode()).hexdigest() for f in range(frames_per_scene)]
+        tokens = [hashlib.md5(("%d/%d/%d" % (seed, s, f)).encode()).hexdigest() for f in range(lengths[s])]
         scenes.append(("scene-%04d" % s, tokens))
         objs = []
         for name, n in objects.items():

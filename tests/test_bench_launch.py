@@ -28,6 +28,15 @@ def test_bench_gpus_2_typed_as_is_starts_its_own_ranks():
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["max_over_ranks"] == 2.0 and lines[0]["steps"] == 3
 
 
+def test_bench_gpus_8_dry_run_is_one_line_from_eight_ranks():
+    """The node size the driver scales to: 8 self-launched ranks rendezvous on 127.0.0.1, barrier, reduce the MAX, rank 0 prints."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["max_over_ranks"] == 8.0 and lines[0]["scaling"] == "weak"
+
+
 def test_bench_under_torch_distributed_run():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],

@@ -26,7 +26,7 @@ def _worker(rank, world, port, q):
         p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
     params.append(torch.nn.Parameter(torch.zeros(2)))  # no gradient: skipped
     allreduce_gradients(params, bucket_bytes=64 * 1024)  # forces several buckets
-    ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params[:4]))
+    ok = all(torch.allclose(p.grad, torch.full_like(p, (world + 1) / 2 * (i + 1))) for i, p in enumerate(params[:4]))
     ok = ok and params[4].grad is None
     # low-rank factor exchange: gathering the rank-B factors and one product over world*B rows == the all-reduced average of
     # the local outer products; a tensor flagged as already global is skipped by allreduce_gradients (and the flag is cleared)
@@ -44,21 +44,40 @@ def _worker(rank, world, port, q):
     p._shasta_grad_is_global = True
     allreduce_gradients([p])
     ok = ok and torch.equal(p.grad, torch.full((4,), float(rank))) and p._shasta_grad_is_global is False
+    # ragged local batches are refused on EVERY rank (the factor all-gather needs equal chunks), equal ones pass
+    from shasta_amd import hip
+    from shasta_amd.training import _check_equal_local_batch
+    _check_equal_local_batch(4, world, None, torch.device("cpu"))
+    try:
+        _check_equal_local_batch(4 if rank != world - 1 else 3, world, None, torch.device("cpu"))
+        ok = False
+    except hip.ShastaHipError as e:
+        ok = ok and "same local batch" in str(e)
     q.put((rank, ok))
     dist.destroy_process_group()
 
 
-def test_allreduce_gradients_two_ranks():
+def _run_allreduce(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]
+
+
+def test_allreduce_gradients_two_ranks():
+    _run_allreduce(2)
+
+
+def test_allreduce_gradients_factor_gather_and_ragged_refusal_eight_ranks():
+    """world 8 = the node size of BASELINE configs 4-5: bucketed averaging, the low-rank factor all-gather and the ragged-batch
+    refusal behave as with two ranks."""
+    _run_allreduce(8)
 
 
 def _train_worker(rank, world, port, q):
@@ -70,7 +89,7 @@ def _train_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from shasta_amd.sync_bn import convert_syncbn_model
     from shasta_amd.training import allreduce_gradients
-    model, bev, pbev, det, prev, gt = _ddp_case()
+    model, bev, pbev, det, prev, gt = _ddp_case(2 * world)
     convert_syncbn_model(model)
     model.train()
     sl = slice(rank * 2, rank * 2 + 2)
@@ -85,20 +104,20 @@ def _train_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def _ddp_case():
+def _ddp_case(B=4):
     import shasta_amd
     from oracle import shasta_oracle as O
     torch.manual_seed(4)
     model = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
                                              bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075],
                                                                 out_stride=8), max_obj=6, num_feats=3, num_point=4, in_channels=8))
-    bev, pbev, det, prev = O.synth_case(4, 6, 5, 8, 24, 24, 11)
+    bev, pbev, det, prev = O.synth_case(B, 6, 5, 8, 24, 24, 11)
     span = 24 * 8 * 0.075
     for t in (det, prev):
         t[:, :, 0] = (t[:, :, 0] % (span * 0.8)) - 54 + 0.1 * span
         t[:, :, 1] = (t[:, :, 1] % (span * 0.8)) - 54 + 0.1 * span
     g = torch.Generator().manual_seed(5)
-    gt = (torch.rand(4, 8, 8, generator=g) < 0.2).float()
+    gt = (torch.rand(B, 8, 8, generator=g) < 0.2).float()
     gt[:, 0, 0] = 1.0
     gt[:2, 1, 1] = 1.0  # different normalisers on the two ranks
     return model, bev, pbev, det, prev, gt
@@ -115,18 +134,26 @@ def _oracle_loss(model, bev, pbev, det, prev, gt):
 
 
 def test_two_rank_train_step_equals_the_single_process_step():
-    """BASELINE config 5's shape on 2 gloo ranks: 2 x (B/2) with SyncBN + averaged gradients == what apex SyncBN + DDP compute,
-    i.e. the gradient of the MEAN of the per-rank losses with BatchNorm statistics of the whole batch; running statistics too."""
+    _train_step_equals_single(2)
+
+
+def test_eight_rank_train_step_equals_the_single_process_step():
+    _train_step_equals_single(8)
+
+
+def _train_step_equals_single(world):
+    """BASELINE config 5's shape on `world` gloo ranks: world x 2 frame pairs with SyncBN + averaged gradients == what apex SyncBN + DDP
+    compute, i.e. the gradient of the MEAN of the per-rank losses with BatchNorm statistics of the whole batch; running statistics too."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in procs)
+    res = dict(q.get(timeout=600) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    model, bev, pbev, det, prev, gt = _ddp_case()
+    model, bev, pbev, det, prev, gt = _ddp_case(2 * world)
     model.train()
     # single process: both halves through ONE BatchNorm call each (statistics of all 4 maps), mean of the two per-rank losses
     from oracle import shasta_oracle as O
@@ -135,21 +162,21 @@ def test_two_rank_train_step_equals_the_single_process_step():
     a = model.shared_conv(bev).permute(0, 2, 3, 1).contiguous()
     b = model.shared_conv(pbev).permute(0, 2, 3, 1).contiguous()
     loss = 0
-    for r in range(2):
+    for r in range(world):
         sl = slice(2 * r, 2 * r + 2)
         m1, m2 = O.forward_from_bev(w, a[sl], b[sl], det[sl].clone(), prev[sl].clone(), 3, 4, grad=True)
-        loss = loss + O.affinity_loss(m1, m2, gt[sl]) / 2
+        loss = loss + O.affinity_loss(m1, m2, gt[sl]) / world
     loss.backward()
     want = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     assert set(want) <= set(res[0]) and len(want) > 60
     for n, g in want.items():
-        for r in range(2):
+        for r in range(world):
             scale = max(float(g.abs().max()), 1e-8)
             assert float((torch.from_numpy(res[r][n]) - g).abs().max()) <= 2e-4 * scale + 1e-7, (n, r)
     # note: the two BatchNorm calls per step (current and previous map) each update the running statistics, like the reference
     for k, ref in (("__running_mean", model.shared_conv[1].running_mean), ("__running_var", model.shared_conv[1].running_var)):
         assert torch.allclose(torch.from_numpy(res[0][k]), ref, rtol=1e-4, atol=1e-6), k
-        assert torch.equal(torch.from_numpy(res[0][k]), torch.from_numpy(res[1][k]))
+        assert all(torch.equal(torch.from_numpy(res[0][k]), torch.from_numpy(res[r][k])) for r in range(1, world))
 
 
 def _syncbn_worker(rank, world, port, q):
