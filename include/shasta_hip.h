@@ -206,6 +206,18 @@ int shasta_pack_weights_f32(const shasta_weights* w, void* packed, size_t packed
 size_t shasta_aug_shape_aux_bytes(int max_obj, int feat_dim, int options);
 int shasta_aug_shape_aux_f32(const shasta_weights* w, void* aux, size_t aux_bytes, shasta_stream_t stream);
 
+/* Range guard of the two-piece fp16 weight stream.  That form is block floating point: ONE power-of-two scale per weight row puts the
+ * row's largest magnitude into (2^13, 2^14], so every weight is represented with an ABSOLUTE error of at most 2^-38 of the row maximum.
+ * That is below fp32's own per-element rounding (2^-24 relative) as long as the elements that carry the row are within 2^14 of its
+ * maximum.  shasta_aug_shape_aux_f32 therefore also records, per row, max|w| / mean|w| of the row's OTHER entries; this call returns the largest over the
+ * 4 * N*F/64 rows (and its row, MLP-major) to the HOST - it synchronises `stream` - so that the caller can take the fp16 form only
+ * when the figure is at most SHASTA_F16X2_MAX_ROW_RATIO and fall back to the exact bf16-piece form (options without
+ * SHASTA_OPT_F16X2_WEIGHT_STREAM) otherwise.  Default uniform init: ~2; Gaussian rows: ~6; log-normal (sigma 2) rows: ~1e3; a row with
+ * one entry 2^20 x the others: ~1e5 (refused).  A NaN figure means non-finite weights. */
+#define SHASTA_F16X2_MAX_ROW_RATIO 16384.0f
+int shasta_aug_shape_aux_row_ratio(int max_obj, int feat_dim, const void* aux, size_t aux_bytes, float* h_max_ratio, int* h_row,
+                                   shasta_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * K3-K6  affinity forward after the gather: Shasta.forward, det3d/models/tracker/shasta.py:240-325
  *   anchors (aug_shape :241-247, aug_dets :260-267), back-projection (:270, IN PLACE on

@@ -361,7 +361,7 @@ void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, 
 void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part, int H, int K, int B, int* ks_out, int np,
                             const unsigned* wmax, const void* wimg, hipStream_t st);
 int launch_x_maxima(const float* feat, const float* prev_feat, int K, int B, int x_batch_stride, unsigned* xmax, hipStream_t st);
-int launch_w_maxima(const float* const W[4], int H, int K, unsigned* wmax, hipStream_t st);
+int launch_w_maxima(const float* const W[4], int H, int K, unsigned* wmax, float* sumabs, hipStream_t st);
 
 
 // [split-K partials, worst-case KS = 64][hidden (B, 4H)][bf16 activation image of anchor_split.hip, batches > 32 only]
@@ -399,7 +399,7 @@ static const void* precut_image(const shasta_weights* w) {
     const int K = w->max_obj * w->feat_dim, H = K / 64;
     const bool on = (w->options & SHASTA_OPT_F16X2_WEIGHT_STREAM) && (w->options & SHASTA_OPT_PRECUT_WEIGHT_STREAM) &&
                     !(w->options & SHASTA_OPT_F32_WEIGHT_STREAM) && w->aug_shape_aux && K % 32 == 0 && H > 0;
-    return on ? static_cast<const char*>(w->aug_shape_aux) + align_up((size_t)4 * H * sizeof(unsigned), 256) : nullptr;
+    return on ? static_cast<const char*>(w->aug_shape_aux) + aux_image_offset((size_t)H) : nullptr;
 }
 // from how many frame-pairs per call the pre-cut fp16 stream replaces the f32 MFMA / bf16-piece kernels of the smaller batches.
 // Measured per step at N=500 (with / without): 2: 0.828 / 0.769 ms, 8: 0.922 / 0.878, 16: 1.019 / 1.006 (the 16x16x4 f32 kernel
@@ -474,7 +474,7 @@ static int anchor_shape_impl(const shasta_weights* w, int B, float* feat, float*
         int rc0;
         if (!wmax) {  // stage entry point without a packed buffer: one extra pass over the weights into the workspace
             unsigned* wm = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(xmax) + align_up((size_t)2 * B * sizeof(int), 256));
-            if ((rc0 = launch_w_maxima(a.W, H, K, wm, st))) return rc0;
+            if ((rc0 = launch_w_maxima(a.W, H, K, wm, nullptr, st))) return rc0;
             wmax = wm;
         }
         if (!xmax_ready && (rc0 = launch_x_maxima(feat, prev_feat, K, B, a.x_batch_stride, xmax, st))) return rc0;

@@ -56,6 +56,7 @@ struct RowMaxArgs {
     long stride;     // floats between consecutive rows of one source
     int rows, len;   // rows per source, floats per row
     unsigned* out;   // [source][rows]
+    float* sumabs;   // [source][rows] sum of |x| of every row (zero on entry), or null
 };
 __global__ __launch_bounds__(256) void row_max_kernel(RowMaxArgs a) {
     __shared__ float red[4];
@@ -63,16 +64,64 @@ __global__ __launch_bounds__(256) void row_max_kernel(RowMaxArgs a) {
     const int n4 = a.len / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
     const int beg = blockIdx.x * per, end = min(n4, beg + per);
     const f32x4* p = reinterpret_cast<const f32x4*>(a.base[src] + (size_t)row * a.stride);
-    float m = 0.0f;
+    float m = 0.0f, sa = 0.0f;
     for (int i = beg + threadIdx.x; i < end; i += 256) {
         const f32x4 v = __builtin_nontemporal_load(p + i);
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        sa += (fabsf(v[0]) + fabsf(v[1])) + (fabsf(v[2]) + fabsf(v[3]));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) atomicMax(a.out + src * a.rows + row, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+    if (a.sumabs) {  // a statistic for the range guard (aux_ratio_kernel), not an operand: float atomics in any order are fine
+        sa = wave_sum(sa);
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.sumabs + src * a.rows + row, sa);
+    }
+}
+
+// largest (row maximum) / (mean |w| of the row's other entries) over all 4 H rows -> summary[0], its row -> summary[1]; one workgroup
+__global__ __launch_bounds__(256) void aux_ratio_kernel(const unsigned* __restrict__ wmax, const float* __restrict__ sumabs, int rows, int K,
+                                                        float* __restrict__ summary) {
+    __shared__ float rbest[4];
+    __shared__ int ibest[4];
+    float best = 0.0f;
+    int where = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        // the row's largest entry against the mean magnitude of the OTHER K - 1 (with the maximum inside the mean a single huge entry
+        // would hide behind itself); an all-zero row has nothing to lose; a row whose other entries vanish against the maximum in the
+        // fp32 sum (or are exactly zero) is refused
+        const float mx = __uint_as_float(wmax[r]), sa = sumabs[r], rest = sa - mx;
+        const float ratio = !(mx > 0.0f) || K < 2 ? (mx == mx ? 0.0f : mx) : rest > sa * 1e-6f ? mx * (float)(K - 1) / rest : INFINITY;
+        if (!(ratio <= best)) {  // a NaN ratio (non-finite weights) wins
+            best = ratio;
+            where = r;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int ow = __shfl_xor(where, off, 64);
+        if (!(ob <= best)) {
+            best = ob;
+            where = ow;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        rbest[threadIdx.x >> 6] = best;
+        ibest[threadIdx.x >> 6] = where;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (!(rbest[w] <= best)) {
+                best = rbest[w];
+                where = ibest[w];
+            }
+        summary[0] = best;
+        summary[1] = (float)where;
+    }
 }
 
 static int row_max_chunks(int rows, int sources, int len) {  // enough workgroups to fill the chip, at least 16 KB per workgroup
@@ -91,20 +140,27 @@ int launch_x_maxima(const float* feat, const float* prev_feat, int K, int B, int
     r.rows = B;
     r.len = K;
     r.out = xmax;
+    r.sumabs = nullptr;
     hipLaunchKernelGGL(row_max_kernel, dim3(row_max_chunks(B, 2, K), B, 2), dim3(256), 0, st, r);
     return check_launch("row_max (activations)");
 }
 // maxima of the 4 x H weight rows of the aug_shape first layers (pack time): wmax[4][H]
-int launch_w_maxima(const float* const W[4], int H, int K, unsigned* wmax, hipStream_t st) {
+// sumabs (optional): [4][H] floats + 16 floats of summary behind them (the stats section of the companion buffer, common.hpp)
+int launch_w_maxima(const float* const W[4], int H, int K, unsigned* wmax, float* sumabs, hipStream_t st) {
     if (hipMemsetAsync(wmax, 0, (size_t)4 * H * sizeof(unsigned), st) != hipSuccess) return SHASTA_E_LAUNCH;
+    if (sumabs && hipMemsetAsync(sumabs, 0, ((size_t)4 * H + 16) * sizeof(float), st) != hipSuccess) return SHASTA_E_LAUNCH;
     RowMaxArgs r;
     for (int i = 0; i < 4; ++i) r.base[i] = W[i];
     r.stride = K;
     r.rows = H;
     r.len = K;
     r.out = wmax;
+    r.sumabs = sumabs;
     hipLaunchKernelGGL(row_max_kernel, dim3(row_max_chunks(H, 4, K), H, 4), dim3(256), 0, st, r);
-    return check_launch("row_max (weights)");
+    int rc = check_launch("row_max (weights)");
+    if (rc || !sumabs) return rc;
+    hipLaunchKernelGGL(aux_ratio_kernel, dim3(1), dim3(256), 0, st, wmax, sumabs, 4 * H, K, sumabs + (size_t)4 * H);
+    return check_launch("aux_ratio");
 }
 
 // Two-piece fp16 form (NP = 2): a * 2^e = h + l + err with h = fp16(a 2^e) and l = fp16(a 2^e - h), both rounded to nearest:

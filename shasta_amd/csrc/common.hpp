@@ -61,6 +61,15 @@ __device__ __forceinline__ float absmax_keep_nan(float a, float b) { return __ui
 // operand, i.e. turn a NaN into 0 and every later layer into finite numbers)
 __device__ __forceinline__ float relu_nan(float x) { return __builtin_elementwise_maximum(x, 0.0f); }
 
+// Layout of the companion buffer of the four aug_shape first-layer matrices (shasta_aug_shape_aux_f32), H = rows per matrix:
+//   [0, A)      4 H uint32: bit patterns of the row maxima                       A = align256(16 H)
+//   [A, A + S)  4 H fp32: sum of |w| of every row, then 16 floats of summary (aux_ratio_kernel: [0] = largest max / mean|w| over all
+//               rows, [1] = its row)                                             S = align256(16 H + 64)
+//   [A + S, ..) the pre-cut fp16 piece image (only with SHASTA_OPT_PRECUT_WEIGHT_STREAM)
+inline size_t aux_maxima_bytes(size_t H) { return align_up(4 * H * sizeof(unsigned), 256); }
+inline size_t aux_stats_bytes(size_t H) { return align_up(4 * H * sizeof(float) + 64, 256); }
+inline size_t aux_image_offset(size_t H) { return aux_maxima_bytes(H) + aux_stats_bytes(H); }
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -31,7 +31,7 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
 int aff_softmax(const shasta_weights* w, const float* packed, int B, const float* residual, int ld, float* m1,
                 float* m2, float* matched_out, void* ws, size_t ws_bytes, hipStream_t st);
 int pack_weights(const shasta_weights* w, float* packed, hipStream_t st);
-int launch_w_maxima(const float* const W[4], int H, int K, unsigned* wmax, hipStream_t st);
+int launch_w_maxima(const float* const W[4], int H, int K, unsigned* wmax, float* sumabs, hipStream_t st);
 size_t precut_image_bytes(int H, int K);
 int launch_precut_weights(const float* const W[4], const unsigned* wmax, void* img, int H, int K, hipStream_t st);
 
@@ -105,7 +105,7 @@ extern "C" int shasta_pack_weights_f32(const shasta_weights* w, void* packed, si
 
 extern "C" size_t shasta_aug_shape_aux_bytes(int max_obj, int feat_dim, int options) {
     const size_t H = (size_t)max_obj * feat_dim / 64;
-    size_t n = align_up((size_t)4 * H * sizeof(unsigned), 256);
+    size_t n = aux_image_offset(H);  // row maxima + row statistics (common.hpp)
     if (options & SHASTA_OPT_PRECUT_WEIGHT_STREAM) n += precut_image_bytes((int)H, max_obj * feat_dim);
     return n;
 }
@@ -121,11 +121,29 @@ extern "C" int shasta_aug_shape_aux_f32(const shasta_weights* w, void* aux, size
     const float* W[4];
     for (int i = 0; i < 4; ++i) W[i] = w->aug_shape[i][0].weight;
     const int K = w->max_obj * w->feat_dim, H = K / 64;
-    if ((rc = launch_w_maxima(W, H, K, static_cast<unsigned*>(aux), as_stream(stream)))) return rc;
+    float* stats = reinterpret_cast<float*>(static_cast<char*>(aux) + aux_maxima_bytes((size_t)H));
+    if ((rc = launch_w_maxima(W, H, K, static_cast<unsigned*>(aux), stats, as_stream(stream)))) return rc;
     if ((w->options & SHASTA_OPT_PRECUT_WEIGHT_STREAM) && precut_image_bytes(H, K))
-        rc = launch_precut_weights(W, static_cast<const unsigned*>(aux), static_cast<char*>(aux) + align_up((size_t)4 * H * sizeof(unsigned), 256),
-                                   H, K, as_stream(stream));
+        rc = launch_precut_weights(W, static_cast<const unsigned*>(aux), static_cast<char*>(aux) + aux_image_offset((size_t)H), H, K, as_stream(stream));
     return rc;
+}
+
+extern "C" int shasta_aug_shape_aux_row_ratio(int max_obj, int feat_dim, const void* aux, size_t aux_bytes, float* h_max_ratio, int* h_row,
+                                              shasta_stream_t stream) {
+    SHASTA_REQUIRE(aux && h_max_ratio && max_obj >= 1 && feat_dim >= 1, "aug_shape_aux_row_ratio: bad argument");
+    const size_t H = (size_t)max_obj * feat_dim / 64;
+    SHASTA_REQUIRE(aux_bytes >= aux_image_offset(H), "aug_shape_aux_row_ratio: not a companion buffer of this shape");
+    float s[2];
+    const char* src = static_cast<const char*>(aux) + aux_maxima_bytes(H) + 4 * H * sizeof(float);
+    hipError_t e = hipMemcpyAsync(s, src, sizeof(s), hipMemcpyDeviceToHost, as_stream(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
+    if (e != hipSuccess) {
+        set_error("aug_shape_aux_row_ratio", e);
+        return SHASTA_E_LAUNCH;
+    }
+    *h_max_ratio = s[0];
+    if (h_row) *h_row = (int)s[1];
+    return SHASTA_OK;
 }
 
 extern "C" size_t shasta_forward_workspace_bytes(int B, int max_obj, int num_feats, int feat_dim) {

@@ -26,6 +26,7 @@ OPT_F16X2_WEIGHT_STREAM = 8
 OPT_F16X2_PAIR = 16
 OPT_PRECUT_WEIGHT_STREAM = 32
 OPT_F16GRID_PAIR = 64
+F16X2_MAX_ROW_RATIO = 16384.0  # SHASTA_F16X2_MAX_ROW_RATIO
 PRECUT_MIN_BATCH = 17  # csrc/anchor.hip: from this many frame-pairs per call the pre-cut fp16 weight stream serves the call
 
 
@@ -65,6 +66,7 @@ SYMBOLS = {
     "shasta_pack_weights_f32": (_I, [_WP, _P, _Z, _P]),
     "shasta_aug_shape_aux_bytes": (_Z, [_I, _I, _I]),
     "shasta_aug_shape_aux_f32": (_I, [_WP, _P, _Z, _P]),
+    "shasta_aug_shape_aux_row_ratio": (_I, [_I, _I, _P, _Z, C.POINTER(C.c_float), C.POINTER(C.c_int), _P]),
     "shasta_forward_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "shasta_affinity_forward_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "shasta_affinity_from_bev_f32": (_I, [_WP, _P, _I, _P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z,

@@ -133,6 +133,8 @@ class Shasta(BaseTrack):
         self._packed_key = None
         self._aux = None
         self._aux_key = None
+        self._guard_key = None      # weight set (pointers, versions) for which the range guard refused the fp16 weight stream
+        self.f16x2_guard = None     # what _ensure_aux measured and decided, once a companion has been built
         self._conv_packed = None
         self._conv_key = None
         self._conv_bank = None
@@ -219,6 +221,7 @@ class Shasta(BaseTrack):
         self._plist = None
         self._packed_key = None
         self._aux_key = None
+        self._guard_key = None
         self._conv_key = None
         if getattr(self, "_conv_bank", None) is not None:
             self._conv_bank._key = None
@@ -246,6 +249,17 @@ class Shasta(BaseTrack):
                 [self.fuse_shape[k] for k in (0, 2, 4, 6)] + [self.fuse_det[k] for k in (0, 2, 4)] + [self.res_coeff[k] for k in (0, 2, 4)] +
                 [self.aff[k] for k in (0, 2, 4, 6, 8, 10)])
 
+    def _options(self):
+        """shasta_weights.options of Shasta.arithmetic / precut_weight_stream (before the range guard of _ensure_aux)."""
+        if self.arithmetic not in ("pieces", "f32", "f16x2", "f16grid"):
+            raise ValueError("Shasta.arithmetic must be 'pieces', 'f32', 'f16x2' or 'f16grid'")
+        o = {"pieces": 0, "f32": hip.OPT_F32_WEIGHT_STREAM | hip.OPT_F32_EMBED_GEMM | hip.OPT_F32_AFF,
+             "f16x2": hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_F16X2_PAIR,
+             "f16grid": hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_F16X2_PAIR | hip.OPT_F16GRID_PAIR}[self.arithmetic]
+        if self.arithmetic in ("f16x2", "f16grid") and self.precut_weight_stream:
+            o |= hip.OPT_PRECUT_WEIGHT_STREAM
+        return o
+
     def _build_weights(self):
         def lin(m):
             for p in (m.weight, m.bias):
@@ -256,13 +270,7 @@ class Shasta(BaseTrack):
 
         w = hip.Weights()
         w.max_obj, w.num_feats, w.feat_dim = self.max_obj, self.num_feats, self.aug_shape_output
-        if self.arithmetic not in ("pieces", "f32", "f16x2", "f16grid"):
-            raise ValueError("Shasta.arithmetic must be 'pieces', 'f32', 'f16x2' or 'f16grid'")
-        w.options = {"pieces": 0, "f32": hip.OPT_F32_WEIGHT_STREAM | hip.OPT_F32_EMBED_GEMM | hip.OPT_F32_AFF,
-                     "f16x2": hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_F16X2_PAIR,
-                     "f16grid": hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_F16X2_PAIR | hip.OPT_F16GRID_PAIR}[self.arithmetic]
-        if self.arithmetic in ("f16x2", "f16grid") and self.precut_weight_stream:
-            w.options |= hip.OPT_PRECUT_WEIGHT_STREAM
+        w.options = self._options()
         for i in range(4):
             w.aug_shape[i][0], w.aug_shape[i][1] = lin(self.aug_shape[i][0]), lin(self.aug_shape[i][2])
             w.aug_dets[i][0], w.aug_dets[i][1] = lin(self.aug_dets[i][0]), lin(self.aug_dets[i][2])
@@ -296,13 +304,25 @@ class Shasta(BaseTrack):
         their versions).  The fp16 stream serves more than 64 frame-pairs per call; with the pre-cut image also every inference call
         of at least 17 (its loop then holds nothing but DMA, LDS reads and MFMAs: 32 / 64 items per weight pass run at the speed of
         the stream; up to 16 the f32 16x16x4 kernel is as fast and needs no activation image).  Training steps (weights change every step) never build the image: affinity_from_bev clears the PRECUT bit for
-        them, so they keep the kernels that read the fp32 tensors and only the row maxima are rebuilt.  Without a companion the library recomputes the maxima inside every call that needs them."""
-        small = self.precut_weight_stream and not training and B >= hip.PRECUT_MIN_BATCH
-        need = self.arithmetic in ("f16x2", "f16grid") and (B > 64 or small) and self.max_obj * self.aug_shape_output >= 64
+        them, so they keep the kernels that read the fp32 tensors and only the row maxima are rebuilt.  Without a companion the library recomputes the maxima inside every call that needs them.
+
+        Range guard (inference): the same pass records every row's max|w| / mean|w|; when the largest of them exceeds
+        hip.F16X2_MAX_ROW_RATIO (a row that one fp16 scale cannot represent to fp32 accuracy, include/shasta_hip.h) the weight stream of
+        THIS weight set falls back to the exact bf16-piece form.  `self.f16x2_guard` says what was measured and decided."""
+        wkey = tuple((self.aug_shape[i][0].weight.data_ptr(), self.aug_shape[i][0].weight._version) for i in range(4))
+        fp16_bits = hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_PRECUT_WEIGHT_STREAM
+        if self._guard_key is not None and self._guard_key != wkey:  # other weights: decide again
+            self._guard_key = None
+            if not training:
+                w.options = self._options()
+        if self._guard_key == wkey and self._guard_key is not None:
+            w.options &= ~fp16_bits
+        small = bool(w.options & hip.OPT_PRECUT_WEIGHT_STREAM) and not training and B >= hip.PRECUT_MIN_BATCH
+        need = bool(w.options & hip.OPT_F16X2_WEIGHT_STREAM) and (B > 64 or small) and self.max_obj * self.aug_shape_output >= 64
         if not need:
             w.aug_shape_aux, w.aug_shape_aux_bytes = None, 0
             return
-        key = tuple((self.aug_shape[i][0].weight.data_ptr(), self.aug_shape[i][0].weight._version) for i in range(4)) + (w.options,)
+        key = wkey + (w.options,)
         if self._aux is None or self._aux_key != key or self._aux.device != device:
             lib = hip.load()
             nbytes = lib.shasta_aug_shape_aux_bytes(self.max_obj, self.aug_shape_output, w.options)
@@ -311,6 +331,21 @@ class Shasta(BaseTrack):
             w.aug_shape_aux, w.aug_shape_aux_bytes = None, 0
             hip.check(lib.shasta_aug_shape_aux_f32(C.byref(w), hip.ptr(self._aux), nbytes, hip.stream_ptr()), "shasta_aug_shape_aux_f32")
             self._aux_key = key
+            if not training and not torch.cuda.is_current_stream_capturing():  # one host read per weight set (never per step)
+                ratio, row = C.c_float(), C.c_int()
+                hip.check(lib.shasta_aug_shape_aux_row_ratio(self.max_obj, self.aug_shape_output, hip.ptr(self._aux), nbytes, C.byref(ratio),
+                                                             C.byref(row), hip.stream_ptr()), "shasta_aug_shape_aux_row_ratio")
+                tripped = not (ratio.value <= hip.F16X2_MAX_ROW_RATIO)  # a NaN trips it
+                self.f16x2_guard = dict(max_row_ratio=ratio.value, row=row.value, threshold=hip.F16X2_MAX_ROW_RATIO, tripped=tripped,
+                                        weight_stream="pieces" if tripped else "f16x2")
+                if tripped:
+                    print("shasta_amd: aug_shape first-layer row %d has max|w| / mean|w| = %.3g > %g: the fp16 weight stream is not "
+                          "fp32-accurate for it, using the bf16-piece form for this weight set" % (row.value, ratio.value, hip.F16X2_MAX_ROW_RATIO))
+                    self._guard_key = wkey
+                    self._aux, self._aux_key = None, None
+                    w.options &= ~fp16_bits
+                    w.aug_shape_aux, w.aug_shape_aux_bytes = None, 0
+                    return
         w.aug_shape_aux, w.aug_shape_aux_bytes = self._aux.data_ptr(), self._aux.numel() * 4
 
     def _work_buffers(self, B, device):

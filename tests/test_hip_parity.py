@@ -72,7 +72,7 @@ def _tables(m):
     return {k: v.cpu().numpy() for k, v in m.last_intermediates.items()}
 
 
-@pytest.mark.parametrize("name", ["headline_500_7_4", "sharp_500_7_4", "classes_500_3_5_pad"])
+@pytest.mark.parametrize("name", ["headline_500_7_4", "sharp_500_7_4", "classes_500_3_5_pad", "mod_500_7_4", "heavy_500_7_4"])
 def test_headline_size_batches_pin_every_anchor_kernel_on_the_reference_output(name):
     """N=M=500, F=256 (BASELINE.json configs[1]; and F=320, nf=3, padded rows: configs[2]'s table shape) in batches: frame-pair 0 is the reference's golden frame, the others are
     synthetic.  Frame-pairs are independent, so (a) frame 0 of a 130-batch, of a 100-, 64- and 32-batch (the four batch-block shapes of
@@ -99,7 +99,9 @@ def test_headline_size_batches_pin_every_anchor_kernel_on_the_reference_output(n
     prevs = O.synth_boxes(gc, B, N, None).to(dev)
     dets[0], prevs[0] = det[0].to(dev), prev[0].to(dev)
     sharp = c["sharp"] is not None
-    batch_tol = 2e-3 if sharp else 1e-6  # two HIP results, each within M_ATOL_SHARP / M_ATOL of the reference
+    moderate = "matol" in z.files  # logits O(10): the results of two batch sizes differ like default-init ones (measured 1e-7)
+    batch_tol = 2e-6 if moderate else 2e-3 if sharp else 1e-6  # two HIP results, each within M_ATOL_SHARP / M_ATOL of the reference
+    decided_min = 0.9 if moderate else 0.99
 
     def run(idx):
         ex = dict(det_boxes=dets[idx].clone(), prev_det_boxes=prevs[idx].clone(), bev_feature=f[idx].contiguous(),
@@ -119,9 +121,9 @@ def test_headline_size_batches_pin_every_anchor_kernel_on_the_reference_output(n
         np.testing.assert_allclose(p2, full2[lo:hi], rtol=0, atol=batch_tol)
         if sharp:  # the synthetic frames may hold near-ties: arg-max must agree wherever the top-2 margin exceeds the tolerance
             same, decided = row_argmax_agreement(p1, full1[lo:hi], 4 * batch_tol)
-            assert same[decided].all() and decided.mean() > 0.99
+            assert same[decided].all() and decided.mean() > decided_min
             same, decided = row_argmax_agreement(np.swapaxes(p2, 1, 2), np.swapaxes(full2[lo:hi], 1, 2), 4 * batch_tol)
-            assert same[decided].all() and decided.mean() > 0.99
+            assert same[decided].all() and decided.mean() > decided_min
     for (lo, hi), (p1, p2, tabs) in runs.items():
         if lo != 0:
             continue  # the golden frame, through this batch size's anchor kernel
@@ -732,7 +734,7 @@ def test_weight_pointer_cache_follows_reassigned_and_rewritten_parameters():
         f, pf = O.shared_conv_nhwc({k: v.detach().clone() for k, v in m.state_dict().items()}, bev).to(dev), \
             O.shared_conv_nhwc({k: v.detach().clone() for k, v in m.state_dict().items()}, pbev).to(dev)
     m = m.to(dev)
-    nf, npnt = c["num_feats"], c["num_point"]
+    nf, npnt = c["nf"], c["np"]
 
     def run():
         with torch.no_grad():
@@ -750,7 +752,7 @@ def test_weight_pointer_cache_follows_reassigned_and_rewritten_parameters():
     check("baseline")
     base = run()[0].clone()
     g = torch.Generator().manual_seed(3)
-    m.aff[4].weight = torch.nn.Parameter((torch.randn(64, 32, generator=g) * 0.3).to(dev))  # un-probed tensor of round 3
+    m.aff[4].weight = torch.nn.Parameter((torch.randn(tuple(m.aff[4].weight.shape), generator=g) * 0.3).to(dev))  # un-probed tensor of round 3
     assert not torch.equal(run()[0], base)
     check("re-assigned aff[4].weight")
     m.res_coeff[2] = torch.nn.Linear(m.res_coeff[2].in_features, m.res_coeff[2].out_features).to(dev)
@@ -1002,6 +1004,82 @@ def test_fp16_pair_path_at_odd_table_sizes_matches_oracle(N, B):
     top2 = torch.topk(r1, 2, dim=-1).values
     decided = (top2[..., 0] - top2[..., 1]) > 1e-5
     assert bool((m1.argmax(-1) == r1.argmax(-1))[decided].all())
+
+
+@pytest.mark.parametrize("kind", ["lognormal_rows", "activation_spike", "one_outlier_2p20", "gaussian"])
+def test_fp16_weight_stream_with_outliers_inside_a_row(kind):
+    """the fp16 form spends ONE power of two per weight row / per batch row of activations, and every accuracy
+    figure so far was on PyTorch's uniform init.  Here, against float64, with the strict-f32 kernel beside it (bound: twice its error):
+      lognormal_rows   - weights x exp(2 z) (largest entry ~1e3 x the row's mean magnitude): the fp16 form still serves, guard quiet
+      activation_spike - one 1e4 entry in every otherwise O(1) activation row (hidden units where the spike's product does not dominate
+                         are the ones that could lose bits)
+      one_outlier_2p20 - one weight 2^20 x the row's typical magnitude, aligned with a ZERO activation: everything the row computes comes
+                         from entries 2^-20 of its maximum - the case a single fp16 scale cannot represent; the range guard must
+                         refuse the fp16 form (f16x2_guard['tripped']) and the bf16-piece form must keep fp32 accuracy
+      gaussian         - control."""
+    import shasta_amd
+    from shasta_amd import hip
+    dev = _dev()
+    torch.manual_seed(5)
+    N, B = 40, 70
+    m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075],
+                                                            out_stride=8), max_obj=N, num_feats=7, num_point=4, in_channels=8)).eval().to(dev)
+    K, H = N * 256, N * 4
+    g = torch.Generator(device=dev).manual_seed(3)
+    feat = torch.rand(B, N + 2, 256, device=dev, generator=g)
+    pfeat = torch.rand(B, N + 2, 256, device=dev, generator=g)
+    with torch.no_grad():
+        for i in range(4):
+            wmat = m.aug_shape[i][0].weight
+            if kind == "lognormal_rows":
+                wmat.mul_(torch.exp(2.0 * torch.randn(H, K, device=dev, generator=g)))
+            elif kind == "gaussian":
+                wmat.copy_(torch.randn(H, K, device=dev, generator=g) * 0.01)
+            elif kind == "one_outlier_2p20":
+                col = 256 * 3 + 17 + i
+                wmat[:, col] = wmat.abs().mean() * 2.0 ** 20
+        if kind == "one_outlier_2p20":
+            for t in (feat, pfeat):
+                for i in range(4):
+                    t.view(B, -1)[:, 256 * 3 + 17 + i] = 0.0  # the outliers meet zeros
+        if kind == "activation_spike":
+            for t in (feat, pfeat):
+                t.view(B, -1)[torch.arange(B), torch.randint(0, K, (B,), device=dev, generator=g)] = 1e4
+    lib = hip.load()
+    hid = {}
+    for mode in ("f16x2", "f32"):
+        m.arithmetic = mode
+        m.invalidate_weights_cache()
+        w = m._weights()
+        m._ensure_packed(w, dev)
+        m._ensure_aux(w, B, dev)
+        if mode == "f16x2":
+            assert m.f16x2_guard is not None and m.f16x2_guard["tripped"] == (kind == "one_outlier_2p20"), m.f16x2_guard
+            if kind == "lognormal_rows":
+                assert 50 < m.f16x2_guard["max_row_ratio"] < hip.F16X2_MAX_ROW_RATIO, m.f16x2_guard
+            assert bool(w.options & hip.OPT_F16X2_WEIGHT_STREAM) == (kind != "one_outlier_2p20")
+        wsb = lib.shasta_forward_workspace_bytes(B, N, 7, 256)
+        ws = torch.zeros(wsb // 4 + 1, device=dev)
+        f1, f2 = feat.clone(), pfeat.clone()
+        keep_res = torch.empty(B, N + 2, N + 2, device=dev)
+        keep_hid = torch.empty(B, 4 * H, device=dev)
+        det = O.synth_boxes(torch.Generator().manual_seed(1), B, N).to(dev)
+        tabs = torch.empty(B, N + 2, 8, device=dev), torch.empty(B, N + 2, 8, device=dev)
+        m1, m2 = torch.empty(B, N, N + 2, device=dev), torch.empty(B, N + 2, N, device=dev)
+        hip.check(lib.shasta_affinity_forward_train_f32(C.byref(w), hip.ptr(m._packed), B, hip.ptr(f1), hip.ptr(f2), hip.ptr(det), hip.ptr(det.clone()),
+                                                        11, hip.ptr(tabs[0]), hip.ptr(tabs[1]), hip.ptr(m1), hip.ptr(m2), hip.ptr(keep_res),
+                                                        hip.ptr(keep_hid), hip.ptr(ws), wsb, hip.stream_ptr()), "forward_train")
+        torch.cuda.synchronize()
+        hid[mode] = keep_hid.double()
+    x_cur, x_prev = feat[:, :N].reshape(B, K).double(), pfeat[:, :N].reshape(B, K).double()
+    ref = torch.cat([torch.relu((x_cur if i < 2 else x_prev) @ m.aug_shape[i][0].weight.double().t() + m.aug_shape[i][0].bias.double())
+                     for i in range(4)], dim=1)
+    # error of every hidden unit relative to the magnitude of what it sums: sum_k |w_k x_k| (float64), per batch row the worst unit
+    mag = torch.cat([(x_cur if i < 2 else x_prev).abs() @ m.aug_shape[i][0].weight.double().abs().t() for i in range(4)], dim=1).clamp_min(1e-300)
+    err = {mode: float(((hid[mode] - ref).abs() / mag).max()) for mode in hid}
+    assert err["f16x2"] <= 2.0 * err["f32"] + 2e-8, (kind, err, m.f16x2_guard)
+    assert err["f32"] < 1e-5, err
 
 
 def test_fp16_form_is_range_safe():
@@ -1266,3 +1344,17 @@ def test_device_decode_flags_match_host_decode():
         got = Dm.decode_frame_from_flags(pc[b], ps[b], df[b], ds[b], c2, p2, "tok", 0.5)
         assert got[1] == ref[1] and got[2] == ref[2], b
         assert got[0] == ref[0], b
+
+
+def test_zz_argmax_agreement_report(capsys):
+    """Un-masked arg-max agreement of the default-init goldens seen by this session (reported: these outputs are flat, a differing row
+    is a tie inside the reference's own rounding; the sharpened and the moderately sharp goldens ASSERT every arg-max)."""
+    from tests import helpers
+    rows = sum(r["rows"] for r in helpers.ARGMAX_AGREEMENT)
+    cols = sum(r["cols"] for r in helpers.ARGMAX_AGREEMENT)
+    with capsys.disabled():
+        if rows:
+            print("\n[arg-max agreement, default-init goldens, no margin mask] rows %d / %d = %.5f, columns %d / %d = %.5f (%d comparisons)"
+                  % (sum(r["rows_same"] for r in helpers.ARGMAX_AGREEMENT), rows, sum(r["rows_same"] for r in helpers.ARGMAX_AGREEMENT) / rows,
+                     sum(r["cols_same"] for r in helpers.ARGMAX_AGREEMENT), cols, sum(r["cols_same"] for r in helpers.ARGMAX_AGREEMENT) / cols,
+                     len(helpers.ARGMAX_AGREEMENT)))
