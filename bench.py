@@ -550,7 +550,8 @@ def extras(bench, args):
     bench.models.pop(tuple(sorted(cfg5.items())), None)  # 6.4 GB of weights + their companion image: released before the next extras
     torch = bench.torch
     torch.cuda.empty_cache()
-    for name, fn in (("shared_conv", extra_shared_conv), ("voxelize", extra_voxelize), ("train_step", extra_train_step)):
+    for name, fn in (("shared_conv", extra_shared_conv), ("voxelize", extra_voxelize), ("train_step", extra_train_step),
+                     ("pipeline", extra_pipeline)):
         try:
             fn(bench, args, ex)
         except Exception as err:  # noqa: BLE001
@@ -659,6 +660,61 @@ def extra_train_step(bench, args, ex):
             except Exception as err:  # noqa: BLE001
                 ts[key] = {"error": "%s: %s" % (type(err).__name__, str(err)[:200])}
     ex["train_step"] = ts
+
+
+def extra_pipeline(bench, args, ex):
+    """BASELINE configs 2-4 as one chain on a synthetic split (20 scenes x 40 frames, all seven class models, N = 20 .. 90, F = 320,
+    nf = 3): per-frame files -> loader -> neck maps (device stand-in for the out-of-scope backbone) -> shared_conv of all class heads in
+    one launch -> per-class affinity forward -> device decode -> merge -> PubTrackerMerged (shasta_amd.pipeline.run_split;
+    tools/nusc_shasta/eval.py:96-181, merge_results.py:37-59, pub_test.py:88-162).  Frames/s of the whole chain, the per-stage split
+    (device synchronised at every stage boundary, so a little slower than the un-instrumented total), and the reference-style
+    frame-by-frame chain on the host (oracle/pipeline_oracle.py, features instead of neck maps: no K0 on the host side)."""
+    import shutil
+    import tempfile
+    torch, dev = bench.torch, bench.dev
+    from shasta_amd import pipeline, scenes
+    root = tempfile.mkdtemp(prefix="shasta_split_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        n_scenes, n_frames = 20, 40
+        paths, sc = scenes.write_synthetic_split(root, n_scenes=n_scenes, frames_per_scene=n_frames, seed=3)
+        models = {n: pipeline.build_class_model(n, dev, seed=1) for n in pipeline.CLASS_CONFIGS}
+        for m in models.values():
+            m.arithmetic = args.arithmetic
+        neck = scenes.TokenNeck()
+        wpaths, wsc = scenes.write_synthetic_split(os.path.join(root, "warm"), n_scenes=2, frames_per_scene=n_frames, seed=5)
+        pipeline.run_split(models, wpaths, wsc, neck, dev, batch_pairs=n_frames)  # warm-up: weight packs, allocator
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipeline.run_split(models, paths, sc, neck, dev, batch_pairs=n_frames)
+        torch.cuda.synchronize()
+        total = time.perf_counter() - t0
+        timer = pipeline.StageTimer(sync=True)
+        pipeline.run_split(models, paths, sc, neck, dev, batch_pairs=n_frames, timer=timer)
+        st = timer.seconds
+        n = n_scenes * n_frames
+        k0 = st.get("maps: shared_conv, all class heads (K0)", 0.0)
+        fwd = st.get("h2d + forward + decode kernel", 0.0)
+        standin = st.get("maps: neck outputs (stand-in for backbone + neck)", 0.0)
+        e = {"frames": n, "classes": 7, "frames_per_run": n_frames, "seconds": total, "frames_per_s": n / total,
+             "class_frame_pairs_per_s": 7 * n / total, "stages_s": {k: round(v, 4) for k, v in st.items()},
+             "forward_only_frames_per_s": n / (k0 + fwd) if k0 + fwd > 0 else None,
+             "chain_over_forward_only": ((k0 + fwd) / (sum(st.values()) - standin)) if st else None,
+             "note": "chain_over_forward_only = (K0 + per-class forward) / (all stages except the device stand-in for the backbone), from the "
+                     "synchronised pass; the loader runs on a prefetch thread, so its stage is the wait that is left"}
+        if not args.no_cpu_baseline:
+            from oracle import pipeline_oracle as PO
+            small_root = os.path.join(root, "small")
+            spaths, ssc = scenes.write_synthetic_split(small_root, n_scenes=1, frames_per_scene=4, seed=4)
+            W = {nm: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for nm, m in models.items()}
+            t0 = time.perf_counter()
+            PO.run_split(W, pipeline.CLASS_CONFIGS, spaths, ssc, scenes.TokenBev())
+            dt = time.perf_counter() - t0
+            e["cpu_oracle_chain"] = {"frames": 4, "seconds": dt, "frames_per_s": 4 / dt, "threads": torch.get_num_threads(),
+                                     "note": "oracle/pipeline_oracle.py: one frame pair at a time per class, torch-CPU forward from NHWC "
+                                             "features (the host side never runs K0), reference-style decode loop and tracker"}
+        ex["pipeline"] = e
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def extra_shared_conv(bench, args, ex):

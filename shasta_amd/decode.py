@@ -54,25 +54,32 @@ def decode_frame(matched1, matched2, cls_det_boxes, prev_cls_det_boxes, token, t
     return annos, dead_prev, keep_dets
 
 
-def decode_flags_device(matched1, matched2, n_prev, n_cur):
-    """Batched decisions of the decode loop on the GPU (csrc/decode.hip): returns CPU numpy arrays
-    (prev_class (B,N), prev_score (B,N), det_flags (B,N), det_score (B,N)) after ONE device->host copy per array."""
-    import ctypes as C  # noqa: F401
-
+def decode_flags_launch(matched1, matched2, n_prev, n_cur):
+    """The decode kernel for a batch, asynchronous: returns ONE device int32 tensor (4, B, N) = [prev_class, prev_score bits, det_flags,
+    det_score bits] (a single device->host copy fetches all four decision arrays; decode_flags_unpack splits it)."""
     from . import hip
     lib = hip.load()
     B, N = matched1.shape[0], matched1.shape[1]
     dev = matched1.device
-    npv = torch.as_tensor(n_prev, dtype=torch.int32).to(dev).contiguous()
-    ncv = torch.as_tensor(n_cur, dtype=torch.int32).to(dev).contiguous()
-    pc = torch.empty(B, N, dtype=torch.int32, device=dev)
-    ps = torch.empty(B, N, dtype=torch.float32, device=dev)
-    df = torch.empty(B, N, dtype=torch.int32, device=dev)
-    ds = torch.empty(B, N, dtype=torch.float32, device=dev)
-    hip.check(lib.shasta_decode_flags_f32(hip.ptr(matched1.contiguous()), hip.ptr(matched2.contiguous()), hip.ptr(npv), hip.ptr(ncv),
-                                          B, N, hip.ptr(pc), hip.ptr(ps), hip.ptr(df), hip.ptr(ds), hip.stream_ptr()),
-              "shasta_decode_flags_f32")
-    return pc.cpu().numpy(), ps.cpu().numpy(), df.cpu().numpy(), ds.cpu().numpy()
+    counts = torch.tensor([list(n_prev), list(n_cur)], dtype=torch.int32)
+    counts = (counts.pin_memory() if dev.type == "cuda" else counts).to(dev, non_blocking=True)
+    buf = torch.empty(4, B, N, dtype=torch.int32, device=dev)
+    hip.check(lib.shasta_decode_flags_f32(hip.ptr(matched1.contiguous()), hip.ptr(matched2.contiguous()), hip.ptr(counts[0]), hip.ptr(counts[1]),
+                                          B, N, hip.ptr(buf[0]), hip.ptr(buf[1].view(torch.float32)), hip.ptr(buf[2]),
+                                          hip.ptr(buf[3].view(torch.float32)), hip.stream_ptr()), "shasta_decode_flags_f32")
+    return buf
+
+
+def decode_flags_unpack(host_buf):
+    """(4, B, N) int32 host tensor of decode_flags_launch -> numpy (prev_class, prev_score, det_flags, det_score)."""
+    a = host_buf.numpy()
+    return a[0], a[1].view(np.float32), a[2], a[3].view(np.float32)
+
+
+def decode_flags_device(matched1, matched2, n_prev, n_cur):
+    """Batched decisions of the decode loop on the GPU (csrc/decode.hip): returns CPU numpy arrays
+    (prev_class (B,N), prev_score (B,N), det_flags (B,N), det_score (B,N)) after ONE device->host copy."""
+    return decode_flags_unpack(decode_flags_launch(matched1, matched2, n_prev, n_cur).cpu())
 
 
 def decode_frame_from_flags(prev_class, prev_score, det_flags, det_score, cls_det_boxes, prev_cls_det_boxes, token, time_lag):
@@ -124,14 +131,20 @@ class AffinityDecoder:
         self.results[token] = annos
         return annos
 
-    def add_batch(self, matched1, matched2, processed_batch, on_device=True):
+    def add_batch(self, matched1, matched2, processed_batch, on_device=True, flags=None, lags=None):
         """Every frame pair of a batch (any number of frames x classes).  on_device: the per-row / per-column decisions of the
-        whole batch come from ONE launch of the decode kernel and one device->host copy per decision array; otherwise the
-        matrices are copied to the host once and the restated reference loop runs per frame."""
-        B = matched1.shape[0]
+        whole batch come from ONE launch of the decode kernel and ONE device->host copy; otherwise the matrices are copied to the
+        host once and the restated reference loop runs per frame.  flags: the decisions already on the host (decode_flags_unpack of
+        a copy the caller made for several batches at once), lags: prev_det_boxes[:, 0, 9] from the host side of the batch - with
+        both given this call touches no device memory."""
         cls_all, prev_all = processed_batch["cls_det_boxes"], processed_batch["prev_cls_det_boxes"]
-        lags = processed_batch["prev_det_boxes"][:, 0, 9].detach().float().cpu().numpy()
-        if on_device:
+        B = len(cls_all)
+        if lags is None:
+            lags = processed_batch["prev_det_boxes"][:, 0, 9].detach().float().cpu().numpy()
+        if flags is not None:
+            pc, ps, df, ds = flags
+            on_device = True
+        elif on_device:
             pc, ps, df, ds = decode_flags_device(matched1, matched2, [len(p) for p in prev_all], [len(c) for c in cls_all])
         else:
             m1h, m2h = matched1.detach().cpu().numpy(), matched2.detach().cpu().numpy()

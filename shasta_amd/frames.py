@@ -149,6 +149,71 @@ class FramePairs:
         return out
 
 
+class SharedFrames:
+    """`FramePairs.load` for SEVERAL detection classes over the same frames: every per-frame file is read and parsed once (the
+    reference's per-class eval runs re-read both files of a frame twice per class, as current and as previous frame), the quaternion ->
+    yaw conversion is done once per detection, and the rows of a class are assembled from the cached values.  `load(name, token)`
+    returns exactly what `FramePairs(det_type=[name], max_objects=max_objects[name], test_mode=True).load(token)` returns - the same
+    float64 rows, fresh class dicts (the decode mutates them) - as tests/test_frames.py checks on the synthetic split."""
+
+    def __init__(self, det_path, cls_info_path, frame_info_path, max_objects, rng=_random, cache=256):
+        self.det_path, self.cls_info_path, self.max_objects, self.rng, self.cache = det_path, cls_info_path, dict(max_objects), rng, cache
+        with open(frame_info_path) as f:
+            self.frame_info = json.load(f)
+        self._parsed = {}
+
+    def _frame(self, token):
+        fr = self._parsed.get(token)
+        if fr is None:
+            if len(self._parsed) >= self.cache:
+                self._parsed.pop(next(iter(self._parsed)))
+            with open(os.path.join(self.det_path, token + ".json")) as f:
+                boxes = json.load(f)
+            with open(os.path.join(self.cls_info_path, token + ".json")) as f:
+                cls_info = json.load(f)
+            by_class = {}
+            base = []
+            for i, (b, ci) in enumerate(zip(boxes, cls_info)):
+                by_class.setdefault(ci["detection_name"], []).append(i)
+                base.append([float(b[0]), float(b[1]), float(b[2]), float(b[3]), float(b[4]), float(b[5]), quaternion_yaw(b[6:10]),
+                             float(b[10]), float(b[11]), 0.0, float(ci["detection_score"])])
+            fr = self._parsed[token] = (len(boxes), base, cls_info, by_class)
+        return fr
+
+    def _rows(self, name, token, time_diff):
+        N = self.max_objects[name]
+        nbox, base, cls_info, by_class = self._frame(token)
+        rows = np.zeros((N, 11))
+        if nbox == 0:
+            return rows, list(range(N)), [], 0
+        keep = list(by_class.get(name, ()))
+        if len(keep) > N:
+            pick = self.rng.sample(range(len(keep)), N)
+            pick.sort()
+            keep = [keep[i] for i in pick]
+        if keep:
+            r = np.array([base[i] for i in keep])
+            r[:, 9] = time_diff
+            rows[:len(keep)] = r
+        # fresh dicts: decode.decode_frame writes flags / scores into them and moves `translation` of a propagated box in place
+        kept_cls = [dict(cls_info[i], translation=list(cls_info[i]["translation"])) for i in keep]
+        return rows, keep, kept_cls, len(keep)
+
+    def load(self, name, token, known_tokens=None):
+        fi = self.frame_info[token]
+        prev_token = fi["prev"]
+        if known_tokens is not None and prev_token not in known_tokens:
+            prev_token = ""
+        N = self.max_objects[name]
+        time_diff = 1e-6 * fi["timestamp"] - 1e-6 * fi["prev_timestamp"] if "prev_timestamp" in fi else 0.0
+        prev_rows, prev_cls, n_prev = np.zeros((N, 11)), [], 0
+        if prev_token != "":
+            prev_rows, _, prev_cls, n_prev = self._rows(name, prev_token, time_diff)
+        rows, _, cls, n = self._rows(name, token, time_diff)
+        return dict(token=token, prev_token=prev_token, prev_det_boxes=prev_rows, prev_cls_det_boxes=prev_cls, num_prev_det_boxes=n_prev,
+                    det_boxes=rows, cls_det_boxes=cls, num_det_boxes=n)
+
+
 def collate_pairs(samples, device=None):
     """Stack loaded frame pairs into the batch the model consumes (det3d/torchie/parallel/collate.py keeps these keys as
     stacked float tensors; example_to_device casts to fp32): det_boxes / prev_det_boxes (B, max_obj, 11) fp32, gt

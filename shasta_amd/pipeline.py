@@ -12,9 +12,11 @@ sharded over the ranks (one process per GPU, replica.shard_scenes) and only the 
 the centre-distance / greedy kernel per frame index.  The spconv backbone and the neck are out of scope (SURVEY.md section 2 rows
 10-11): `bev` is any callable token -> (H, W, C) NHWC feature map after shared_conv (`scenes.TokenBev` for the synthetic split).
 """
+import contextlib
 import copy
 import json
 import os
+import time
 
 import torch
 
@@ -25,6 +27,29 @@ from .train_track import track_batch_processor
 # configs/nusc/<class>.py:26-29,66-71: table size per class; every shipped config has num_feats=3, num_point=5 (F=320)
 CLASS_CONFIGS = {"bicycle": 50, "bus": 20, "car": 90, "motorcycle": 50, "pedestrian": 90, "trailer": 60, "truck": 60}
 META = {"use_camera": False, "use_lidar": True, "use_radar": False, "use_map": False, "use_external": False}
+
+
+class StageTimer:
+    """Wall time per stage of the chain (bench.py `extra.pipeline`): `with timer.stage("forward"): ...`; with sync=True the device is
+    synchronised on both sides of a stage, so that asynchronous launches are charged to the stage that issued them."""
+
+    def __init__(self, sync=True):
+        self.sync, self.seconds = sync, {}
+
+    @contextlib.contextmanager
+    def stage(self, name):
+        if self.sync and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        try:
+            yield
+        finally:
+            if self.sync and torch.cuda.is_available():
+                torch.cuda.synchronize()
+            self.seconds[name] = self.seconds.get(name, 0.0) + time.perf_counter() - t0
+
+
+_NO_TIMER = StageTimer(sync=False)
 
 
 def class_model_cfg(name, num_feats=3, num_point=5):
@@ -46,7 +71,7 @@ def build_class_model(name, device, checkpoint=None, seed=0, **kw):
     return model.to(device)
 
 
-def eval_class(model, name, paths, tokens, bev, device, known_tokens=None, batch_pairs=32, decode_on_device=True, forward=None):
+def eval_class(model, name, paths, tokens, bev, device, known_tokens=None, batch_pairs=32, decode_on_device=True, forward=None, timer=None):
     """eval.py:96-181 for one class over `tokens` (in time order inside every scene).  Returns the AffinityDecoder (not finalized:
     the `dead` post-pass needs the whole split, replica.gather_decoded / finalize do it).  `forward`: replaces the device model
     call - the tests pass the CPU oracle here to obtain the reference-side result of the same chain."""
@@ -54,18 +79,23 @@ def eval_class(model, name, paths, tokens, bev, device, known_tokens=None, batch
                            max_objects=CLASS_CONFIGS[name], test_mode=True)
     known = set(ds.frame_info.keys()) if known_tokens is None else set(known_tokens)
     dec = decode.AffinityDecoder()
+    timer = _NO_TIMER if timer is None else timer
     for i in range(0, len(tokens), batch_pairs):
-        samples = [ds.load(t, known_tokens=known) for t in tokens[i:i + batch_pairs]]
-        batch = frames.collate_pairs(samples)
-        batch["bev_feature"] = torch.stack([bev(s["token"]) for s in samples])
-        batch["prev_bev_feature"] = torch.stack([bev(s["prev_token"] or s["token"]) for s in samples])  # nuscenes.py:399-406
+        with timer.stage("loader + collate"):
+            samples = [ds.load(t, known_tokens=known) for t in tokens[i:i + batch_pairs]]
+            batch = frames.collate_pairs(samples)
+        with timer.stage("bev maps"):
+            batch["bev_feature"] = torch.stack([bev(s["token"]) for s in samples])
+            batch["prev_bev_feature"] = torch.stack([bev(s["prev_token"] or s["token"]) for s in samples])  # nuscenes.py:399-406
         if forward is not None:
             m1, m2, example = forward(batch)
             dec.add_batch(m1, m2, example, on_device=False)
             continue
-        with torch.no_grad():
-            m1, m2, example = track_batch_processor(model, batch, train_mode=False, local_rank=device.index or 0)
-        dec.add_batch(m1, m2, example, on_device=decode_on_device)
+        with timer.stage("h2d + forward"):
+            with torch.no_grad():
+                m1, m2, example = track_batch_processor(model, batch, train_mode=False, local_rank=device.index or 0)
+        with timer.stage("decode"):
+            dec.add_batch(m1, m2, example, on_device=decode_on_device)
     return dec
 
 
@@ -128,30 +158,88 @@ def run_tracking(predictions, frames_meta, max_age=4, hungarian=False, merged=Tr
     return annos
 
 
+def _scene_runs(scenes, mine, known, frame_info, batch_pairs):
+    """The frames of this rank's scenes cut into runs of at most batch_pairs CONSECUTIVE frames of one scene.  A run is a list of
+    (token, prev token or ""); inside a run the previous frame of element i is element i - 1, so one stack of maps
+    [prev of the first, frame 0, frame 1, ...] serves the whole run: current maps = stack[1:], previous maps = stack[:-1] (views)."""
+    for name, toks in scenes:
+        if name not in mine:
+            continue
+        for i in range(0, len(toks), batch_pairs):
+            run = []
+            for t in toks[i:i + batch_pairs]:
+                prev = frame_info[t]["prev"]
+                run.append((t, prev if prev in known else ""))
+            assert all(run[j][1] == run[j - 1][0] for j in range(1, len(run))), "frames of a scene must be listed in time order"
+            yield run
+
+
+def _run_features(bev, models, names, run, device, bank_cache, timer=_NO_TIMER):
+    """NHWC feature maps of the run's frames for every class: {class: (len(run) + 1, H, W, C) device tensor}; row 0 is the previous frame
+    of the run's first frame (that frame itself at a scene start, nuscenes.py:399-406).  Three kinds of `bev`:
+      * has `neck_batch(tokens, device)` -> (n, Cin, H, W) neck outputs on the device: every class head's shared_conv runs in ONE launch
+        over them (shared_conv.SharedConvBank), once per frame - the reference convolves every frame twice per class;
+      * has `device_batch(tokens, device)` -> (n, H, W, C) features on the device, shared by all classes;
+      * a plain callable token -> (H, W, C) CPU tensor (tests: the CPU oracle must see the same bytes): stacked, copied once per run."""
+    toks = [run[0][1] or run[0][0]] + [t for t, _ in run]
+    if hasattr(bev, "neck_batch"):
+        if "bank" not in bank_cache:
+            from .shared_conv import SharedConvBank
+            bank_cache["bank"] = SharedConvBank([models[n] for n in names])
+        with timer.stage("maps: neck outputs (stand-in for backbone + neck)"):
+            x = bev.neck_batch(toks, device)
+        with timer.stage("maps: shared_conv, all class heads (K0)"):
+            with torch.no_grad():
+                outs = bank_cache["bank"](x)
+        return dict(zip(names, outs))
+    with timer.stage("maps: features (stand-in for backbone + neck + shared_conv)"):
+        if hasattr(bev, "device_batch"):
+            f = bev.device_batch(toks, device)
+        else:
+            f = torch.stack([bev(t) for t in toks])
+            f = (f.pin_memory() if device.type == "cuda" else f).to(device, non_blocking=True)
+    return {n: f for n in names}
+
+
 def run_split(models, paths, scenes, bev, device, work_dir=None, split="val", max_age=4, batch_pairs=32, decode_on_device=True,
-              rank=0, world=1, group=None, forward_override=None, tracker_on_device=True):
+              rank=0, world=1, group=None, forward_override=None, tracker_on_device=True, timer=None, prefetch=True):
     """Configs 2-4 end to end.  models: {class name: Shasta on `device`}; scenes: [(scene name, [tokens])] of the WHOLE split.
     Scenes are sharded over `world` ranks; rank 0 returns (per-class cp dicts, merged dict, tracking dict) and, with work_dir,
     writes <class>/cp_<split>.json, merged_cp_<split>.json and tracking_result.json like the reference CLIs; other ranks
     return None.  forward_override ({class name: callable(batch) -> (m1, m2, example)}) and tracker_on_device=False exist for the
-    CPU tests of the sharding / gather / merge logic (gloo, no GPU in the build container); the product path leaves them alone."""
+    CPU tests of the sharding / gather / merge logic (gloo, no GPU in the build container); the product path leaves them alone.
+
+    Device path, frame-major: the reference runs one CLI per class over the whole split (eval.py), re-reading every frame's files and
+    re-convolving its maps per class.  Here a run of up to batch_pairs consecutive frames of one scene is loaded ONCE for all classes
+    (frames.SharedFrames, on a prefetch thread while the device works on the previous run), its maps are produced once per frame
+    (_run_features), every class's forward and decode kernel are launched back to back, and ONE synchronisation per run brings all
+    classes' decisions to the host.  Same per-class results as the class-major chain (tests/test_pipeline.py)."""
     mine = set(replica.shard_scenes([(n, len(t)) for n, t in scenes], rank, world))
     tokens = [t for n, toks in scenes if n in mine for t in toks]
     all_tokens = [t for _, toks in scenes for t in toks]
     per_class = {}
-    for name in NUSCENES_TRACKING_NAMES:
-        if name not in models:
-            continue
-        dec = eval_class(models[name], name, paths, tokens, bev, device, known_tokens=all_tokens, batch_pairs=batch_pairs,
-                         decode_on_device=decode_on_device, forward=None if forward_override is None else forward_override[name])
-        per_class[name] = replica.gather_decoded(dec, dst=0, group=group)
+    timer = _NO_TIMER if timer is None else timer
+    names = [n for n in NUSCENES_TRACKING_NAMES if n in models]
+    if forward_override is not None:
+        for name in names:
+            dec = eval_class(models[name], name, paths, tokens, bev, device, known_tokens=all_tokens, batch_pairs=batch_pairs,
+                             decode_on_device=decode_on_device, forward=forward_override[name], timer=timer)
+            per_class[name] = replica.gather_decoded(dec, dst=0, group=group)
+    else:
+        decs = _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, batch_pairs, decode_on_device, timer, prefetch)
+        for name in names:
+            per_class[name] = replica.gather_decoded(decs[name], dst=0, group=group)
     if rank != 0:
         return None
-    merged = merge_results(per_class)
-    with open(paths["frames_meta_path"]) as f:
-        meta = json.load(f)["frames"]
+    with timer.stage("merge"):
+        merged = merge_results(per_class)
+        with open(paths["frames_meta_path"]) as f:
+            meta = json.load(f)["frames"]
     if tracker_on_device:
-        tracking = run_tracking(copy.deepcopy(merged["results"]), meta, max_age=max_age)
+        with timer.stage("tracker"):
+            # the tracker writes top-level keys into the detection dicts (ct, tracking, tracking_id, age, ...) and never into their lists:
+            # a shallow copy per dict keeps `merged` as decoded (a deepcopy of the split was a third of the tracker's time)
+            tracking = run_tracking({tok: [dict(d) for d in annos] for tok, annos in merged["results"].items()}, meta, max_age=max_age)
     else:
         tracking = None
     if work_dir is not None:
@@ -165,3 +253,62 @@ def run_split(models, paths, scenes, bev, device, work_dir=None, split="val", ma
             with open(os.path.join(work_dir, "tracking_result.json"), "w") as f:
                 json.dump(tracking, f)
     return per_class, merged, tracking
+
+
+def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, batch_pairs, decode_on_device, timer, prefetch):
+    from concurrent.futures import ThreadPoolExecutor
+    loader = frames.SharedFrames(paths["det_path"], paths["cls_info_path"], paths["frame_info_path"], {n: CLASS_CONFIGS[n] for n in names})
+    known = set(all_tokens)
+    decs = {n: decode.AffinityDecoder() for n in names}
+    cuda = device.type == "cuda"
+
+    def load(run):
+        out = {}
+        for n in names:
+            samples = [loader.load(n, t, known_tokens=known) for t, _ in run]
+            b = frames.collate_pairs(samples)
+            if cuda:
+                b["det_boxes"], b["prev_det_boxes"] = b["det_boxes"].pin_memory(), b["prev_det_boxes"].pin_memory()
+            b["_lags"] = b["prev_det_boxes"][:, 0, 9].numpy().copy()
+            out[n] = b
+        return out
+
+    runs = list(_scene_runs(scenes, mine, known, loader.frame_info, batch_pairs))
+    pool = ThreadPoolExecutor(max_workers=1) if (prefetch and len(runs) > 1) else None
+    bank_cache = {}
+    nxt = pool.submit(load, runs[0]) if pool and runs else None
+    for i, run in enumerate(runs):
+        with timer.stage("loader + collate (wait)"):
+            batches = nxt.result() if pool else load(run)
+            if pool and i + 1 < len(runs):
+                nxt = pool.submit(load, runs[i + 1])
+        feats = _run_features(bev, models, names, run, device, bank_cache, timer)
+        pending = []
+        with timer.stage("h2d + forward + decode kernel"):
+            for n in names:
+                b = batches[n]
+                ex = dict(b)
+                ex.pop("_lags")
+                ex["det_boxes"] = b["det_boxes"].to(device, non_blocking=True)
+                ex["prev_det_boxes"] = b["prev_det_boxes"].to(device, non_blocking=True)
+                ex["bev_feature"], ex["prev_bev_feature"] = feats[n][1:], feats[n][:-1]
+                with torch.no_grad():
+                    m1, m2, ex = models[n](ex, train_mode=False)
+                if decode_on_device:
+                    buf = decode.decode_flags_launch(m1, m2, [len(p) for p in b["prev_cls_det_boxes"]], [len(c) for c in b["cls_det_boxes"]])
+                    host = torch.empty(buf.shape, dtype=buf.dtype, pin_memory=cuda)
+                    host.copy_(buf, non_blocking=True)
+                    pending.append((n, b, host, None, None))
+                else:
+                    pending.append((n, b, None, m1, m2))
+            if cuda:
+                torch.cuda.current_stream().synchronize()  # the ONE wait of this run
+        with timer.stage("decode (host)"):
+            for n, b, host, m1, m2 in pending:
+                if host is not None:
+                    decs[n].add_batch(None, None, b, flags=decode.decode_flags_unpack(host), lags=b["_lags"])
+                else:
+                    decs[n].add_batch(m1, m2, b, on_device=False, lags=b["_lags"])
+    if pool:
+        pool.shutdown()
+    return decs

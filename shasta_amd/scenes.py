@@ -114,3 +114,22 @@ class TokenBev:
             g = torch.Generator().manual_seed((int(hashlib.md5(token.encode()).hexdigest()[:12], 16) + self.seed) % (2 ** 31))
             self._cache[token] = torch.relu(torch.randn(self.hw, self.hw, self.channels, generator=g))
         return self._cache[token]
+
+
+class TokenNeck:
+    """Stand-in for `neck(backbone(voxels))` of a frame (the (Cin, H, W) map shared_conv reads, shasta.py:223): a deterministic function
+    of the frame token, generated ON the device (a seeded device generator per token), so that a timed chain holds no host-side
+    stand-in work.  `neck_batch(tokens, device)` -> (n, Cin, H, W) fp32."""
+
+    def __init__(self, hw=180, channels=512, seed=0):
+        self.hw, self.channels, self.seed = hw, channels, seed
+        self._gen = {}
+
+    def neck_batch(self, tokens, device):
+        import torch
+        g = self._gen.setdefault(str(device), torch.Generator(device=device))
+        out = torch.empty(len(tokens), self.channels, self.hw, self.hw, device=device)
+        for i, t in enumerate(tokens):
+            g.manual_seed((int(hashlib.md5(t.encode()).hexdigest()[:12], 16) + self.seed) % (2 ** 31))
+            out[i].normal_(generator=g)
+        return torch.relu_(out)
