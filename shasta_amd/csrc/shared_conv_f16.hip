@@ -35,12 +35,11 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t w32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C16_TILE = 256;                  // pixels per workgroup
-constexpr int C16_NSLOT = 640;                 // padded pixel slots of one staged tile (W = 180 needs 626)
+constexpr int C16_NSLOT = 640;                 // padded pixel slots of one staged tile (W = 180 needs 626) incl. the 8 trash slots at the end
 constexpr int C16_PLANE = C16_NSLOT * 16;      // bytes of one [slot][8 fp16] plane
 constexpr int C16_INBUF = 4 * C16_PLANE;       // [piece 2][octet 2] planes
 constexpr int C16_WBUF = 9 * 2 * 2 * 1024;     // [tap 9][channel block 2][piece 2] fragments of 1 KB
-constexpr int C16_TRASH = 2 * C16_WBUF + 2 * C16_INBUF;  // 1 KB behind the tiles: where lanes without a valid pixel store
-constexpr int C16_LDS = C16_TRASH + 1024;      // 156 672 bytes: one workgroup per CU
+constexpr int C16_LDS = 2 * C16_WBUF + 2 * C16_INBUF;  // 155 648 bytes: one workgroup per CU
 constexpr int C16_NIT = 3;                    // staged (pixel, octet) items per lane and chunk
 constexpr int C16_MAXH = 8;                    // class heads per launch
 constexpr int C16_PARAMS = 256;                // floats behind the fragments: alpha[64], beta'[64], bias[64], 2^-e[64]
@@ -183,36 +182,61 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
     const int p_last = min(p0 + C16_TILE, npix) - 1;
     const int qs = p0 - W - 1, qe = p_last + W + 1;   // first / last flat pixel a tap of this tile reads (may lie outside the image)
     const int nblk = (qe - qs + 64) >> 6;             // 64-pixel blocks per octet (the host guarantees 2 nblk <= 24)
-    int st_addr[C16_NIT];      // LDS byte offset inside an input buffer; -1: not staged (stored to the trash slot)
+    int st_addr[C16_NIT];      // LDS byte offset inside an input buffer (octet plane + slot); lanes without a pixel to stage point at one
+                               // of the eight trash slots C16_NSLOT - 8 .. - 1 of their octet plane, which no tap ever reads
     unsigned ld_off[C16_NIT];  // byte offset of channel 0 of the octet inside a chunk; always a valid address
+    bool item_live[C16_NIT];   // wave-uniform: this wave's item holds pixels at all (its cut and stores are skipped otherwise)
 #pragma unroll
     for (int it = 0; it < C16_NIT; ++it) {
         const int blk = it * 8 + wv;
         const int oct = blk >= nblk ? 1 : 0;
         const int q = qs + 64 * (blk - oct * nblk) + lane;
-        const bool ok = blk < 2 * nblk && q >= 0 && q < npix && q <= qe;
+        item_live[it] = blk < 2 * nblk;
+        const bool ok = item_live[it] && q >= 0 && q < npix && q <= qe;
         const int yy = ok ? q / W : 0, xx = q - yy * W;
         const int sl = yy * WT + xx + 1 - first;
-        st_addr[it] = (ok && sl < C16_NSLOT) ? oct * C16_PLANE + sl * 16 : -1;
+        st_addr[it] = (min(oct, 1) * C16_PLANE) + ((ok && sl >= 0 && sl < C16_NSLOT - 8) ? sl : C16_NSLOT - 8 + (lane & 7)) * 16;  // (sl < 0: the pixel left of the halo when the tile starts a row)
         ld_off[it] = 4u * (unsigned)(oct * 8 * npix + (ok ? q : 0));
     }
     const float scale = __builtin_ldexpf(1.0f, eimg);
     const c16f2 scale2 = {scale, scale};
 
+    // The raw tile travels in registers for a whole trip.  Its loads are inline asm: hipcc builds a 64-bit vector address per load
+    // otherwise (24 v_lshl_add_u64 per trip - vector instructions of a wave take issue slots from its SIMD partner's matrix
+    // instructions), and the waits below can then be exact: the compiler knows nothing of these loads, every s_waitcnt vmcnt is ours.
     float r[C16_NIT][8];
-    auto load_chunk = [&](int ch) {
-        const char* xc = reinterpret_cast<const char*>(xin + (size_t)ch * 16 * npix);  // wave-uniform: scalar base + 32-bit lane offset
+    auto load_chunk = [&](int ch) __attribute__((always_inline)) {
+        const char* xc = reinterpret_cast<const char*>(xin + (size_t)ch * 16 * npix);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const char* xj = xc + (size_t)j * npix * 4;
+            const char* xj = uniform_ptr(xc + (size_t)j * npix * 4);
 #pragma unroll
-            for (int it = 0; it < C16_NIT; ++it) r[it][j] = *reinterpret_cast<const float*>(xj + ld_off[it]);
+            for (int it = 0; it < C16_NIT; ++it) {
+#ifdef C16_DBG_CLOADS
+                r[it][j] = *reinterpret_cast<const float*>(xj + ld_off[it]);
+#else
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(r[it][j]) : "v"(ld_off[it]), "s"(xj) : "memory");
+#endif
+            }
         }
+    };
+    // wait until at most `left` of this wave's youngest vector-memory operations are in flight, and tie r[] to the wait so that
+    // nothing reads a register before it has landed
+    auto wait_tile = [&](auto left) __attribute__((always_inline)) {
+#if defined(C16_DBG_WAIT0) || defined(C16_DBG_CLOADS)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[0][3]), "+v"(r[0][4]), "+v"(r[0][5]), "+v"(r[0][6]), "+v"(r[0][7])
+                     : "n"(decltype(left)::value));
+#pragma unroll
+        for (int it = 1; it < C16_NIT; ++it)
+            asm volatile("" : "+v"(r[it][0]), "+v"(r[it][1]), "+v"(r[it][2]), "+v"(r[it][3]), "+v"(r[it][4]), "+v"(r[it][5]), "+v"(r[it][6]), "+v"(r[it][7]));
     };
     const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds);
     const uint32_t dma_off = (uint32_t)(lane * 16);
     // the 36 fragments of a chunk are dealt to the eight waves: wave w copies fragments w, w + 8, ... (five for w < 4, else four)
-    auto dma_weights = [&](int ch, int buf, auto ndma) {
+    auto dma_weights = [&](int ch, int buf, auto ndma) __attribute__((always_inline)) {
         const char* src = wsrc + (size_t)ch * C16_WBUF + wv * 1024;
         const uint32_t dst0 = lds0 + (uint32_t)(buf * C16_WBUF + wv * 1024);
         const uint32_t off = dma_off;  // (a generic lambda does not capture a variable named only in an asm operand)
@@ -223,10 +247,13 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory", "m0");
         }
     };
-    auto cut_store = [&](int buf) {
-        const int ib = 2 * C16_WBUF + buf * C16_INBUF, trash = C16_TRASH + lane * 16;
+    auto cut_store = [&](auto bufc) __attribute__((always_inline)) {
+        constexpr int IB = 2 * C16_WBUF + decltype(bufc)::value * C16_INBUF;
 #pragma unroll
         for (int it = 0; it < C16_NIT; ++it) {
+#ifndef C16_DBG_NOSKIP
+            if (!item_live[it]) continue;  // wave-uniform
+#endif
             w32x4 hi, lo;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {  // 2.5 vector instructions per value: packed scale, packed convert, two exact residuals, packed convert
@@ -235,8 +262,8 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
                 hi[jj] = hp;
                 lo[jj] = pack2h((_Float16)c16_res_lo(sv[0], hp), (_Float16)c16_res_hi(sv[1], hp));
             }
-            *reinterpret_cast<w32x4*>(lds + (st_addr[it] >= 0 ? ib + st_addr[it] : trash)) = hi;
-            *reinterpret_cast<w32x4*>(lds + (st_addr[it] >= 0 ? ib + st_addr[it] + 2 * C16_PLANE : trash)) = lo;
+            *reinterpret_cast<w32x4*>(lds + IB + st_addr[it]) = hi;
+            *reinterpret_cast<w32x4*>(lds + IB + 2 * C16_PLANE + st_addr[it]) = lo;
         }
     };
 
@@ -255,9 +282,9 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
     struct Frag {
         h16x8 ah, al, b0h, b0l, b1h, b1l;
     };
-    auto read_tap = [&](int buf, int tap, Frag& f) {
-        const char* ib = in_lds + buf * C16_INBUF;
-        const char* wb = lds + buf * C16_WBUF + b_lane;
+    auto read_tap = [&](auto bufc, int tap, Frag& f) __attribute__((always_inline)) {
+        const char* ib = in_lds + decltype(bufc)::value * C16_INBUF;
+        const char* wb = lds + decltype(bufc)::value * C16_WBUF + b_lane;
         const int dy = tap / 3, dx = tap % 3;
         f.ah = *reinterpret_cast<const h16x8*>(ib + a_row[dy] + dx * 16);
         f.al = *reinterpret_cast<const h16x8*>(ib + a_row[dy] + dx * 16 + 2 * C16_PLANE);
@@ -266,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
         f.b1h = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 2) * 1024);
         f.b1l = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 3) * 1024);
     };
-    auto mma_tap = [&](const Frag& f) {  // piece products, small to large
+    auto mma_tap = [&](const Frag& f) __attribute__((always_inline)) {  // piece products, small to large
 #ifdef C16_ABL_NO_MFMA  // ablation build (tools/build_variant.py): everything but the matrix instructions; results are wrong
         asm volatile("" ::"v"(f.ah), "v"(f.al), "v"(f.b0h), "v"(f.b0l), "v"(f.b1h), "v"(f.b1l));
         return;
@@ -281,46 +308,58 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
 
     const int nchunk = Cin / 16;
     constexpr int NLD = 8 * C16_NIT;  // global loads of one staged chunk per lane
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
     if (wv < 4) dma_weights(0, 0, std::integral_constant<int, 5>{});
     else dma_weights(0, 0, std::integral_constant<int, 4>{});
     load_chunk(0);
     __syncthreads();  // the zero fill is complete
-    cut_store(0);
+    wait_tile(std::integral_constant<int, 0>{});
+    cut_store(B0{});
     load_chunk(min(1, nchunk - 1));
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD) : "memory");  // the weight fragments of chunk 0 (older than the loads) have landed
+    // Everything has landed before the loop is entered, the second tile included: the compiler thinks an asm load's result is there
+    // at once and may COPY it (it does, into the loop's registers, right behind this barrier) - a copy of a register whose load is
+    // still in flight reads stale data.  Inside the loop the loads write the loop-carried registers themselves (checked in the ISA;
+    // tests/test_hip_parity.py::test_shared_conv_vs_oracle fails loudly if a compiler ever changes that).
+    wait_tile(std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // One chunk.  On entry LDS holds chunk ch (tile + weights) and the registers r[] the raw tile of chunk ch + 1, on its way since the
     // middle of the previous trip: it is cut into the other buffer after CUT taps, and the loads of chunk ch + 2 follow at once, so a
     // load has a whole trip to land.  The last trips stage the last chunk again, into the buffer nobody reads any more: no branch in
     // the loop.  The fragments of tap t + 1 are read while tap t is multiplied.  The two waves of a SIMD (w, w + 4) cut at different
-    // points of the trip.  vmcnt at the end: everything but the NLD loads just issued, i.e. the LDS-DMA of the next weights.
-    auto chunk = [&](int ch, auto cut_after, auto ndma) {
-        constexpr int CUT = decltype(cut_after)::value;
-        const int cur = ch & 1, nxt = min(ch + 1, nchunk - 1), nx2 = min(ch + 2, nchunk - 1);
+    // points of the trip.  Waits: before the cut everything but this trip's LDS-DMA (the loads are older), at the end everything but
+    // the NLD loads just issued (the LDS-DMA is older).  Buffer parity is a compile-time constant (two trips per loop iteration).
+    auto chunk = [&](int ch, auto bufc, auto cut_after, auto ndma) __attribute__((always_inline)) {
+        constexpr int CUT = decltype(cut_after)::value, CUR = decltype(bufc)::value;
+        using NXT = std::integral_constant<int, CUR ^ 1>;
+        const int nxt = min(ch + 1, nchunk - 1), nx2 = min(ch + 2, nchunk - 1);
 #ifndef C16_ABL_NO_DMA
-        dma_weights(nxt, cur ^ 1, ndma);
+        dma_weights(nxt, CUR ^ 1, ndma);
 #endif
         Frag fa, fb;
-        read_tap(cur, 0, fa);
+        read_tap(bufc, 0, fa);
 #pragma unroll
         for (int tap = 0; tap < 9; tap += 2) {
-            if (tap + 1 < 9) read_tap(cur, tap + 1, fb);
+            if (tap + 1 < 9) read_tap(bufc, tap + 1, fb);
             mma_tap(fa);
             if (tap + 1 == CUT) {
                 __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise lifts the cut - and its wait for the loads - to the top of the trip)
 #ifndef C16_ABL_NO_STAGE
-                cut_store(cur ^ 1);
+                wait_tile(ndma);
+                cut_store(NXT{});
                 load_chunk(nx2);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (tap + 1 < 9) {
-                if (tap + 2 < 9) read_tap(cur, tap + 2, fa);
+                if (tap + 2 < 9) read_tap(bufc, tap + 2, fa);
                 mma_tap(fb);
                 if (tap + 2 == CUT) {
                     __builtin_amdgcn_sched_barrier(0);
 #ifndef C16_ABL_NO_STAGE
-                    cut_store(cur ^ 1);
+                    wait_tile(ndma);
+                    cut_store(NXT{});
                     load_chunk(nx2);
 #endif
                     __builtin_amdgcn_sched_barrier(0);
@@ -330,7 +369,11 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
 #ifdef C16_ABL_NO_STAGE
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #else
+#if defined(C16_DBG_WAIT0) || defined(C16_DBG_CLOADS)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD) : "memory");
+#endif
 #endif
 #ifndef C16_ABL_NO_BARRIER
         __builtin_amdgcn_s_barrier();
@@ -343,13 +386,17 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
 #ifndef C16_CUT_B
 #define C16_CUT_B 6
 #endif
-    if (wv < 4) {
+    auto all_chunks = [&](auto cut_after, auto ndma) __attribute__((always_inline)) {
+        int ch = 0;
 #pragma unroll 1
-        for (int ch = 0; ch < nchunk; ++ch) chunk(ch, std::integral_constant<int, C16_CUT_A>{}, std::integral_constant<int, 5>{});
-    } else {
-#pragma unroll 1
-        for (int ch = 0; ch < nchunk; ++ch) chunk(ch, std::integral_constant<int, C16_CUT_B>{}, std::integral_constant<int, 4>{});
-    }
+        for (; ch + 1 < nchunk; ch += 2) {
+            chunk(ch, B0{}, cut_after, ndma);
+            chunk(ch + 1, B1{}, cut_after, ndma);
+        }
+        if (ch < nchunk) chunk(ch, B0{}, cut_after, ndma);
+    };
+    if (wv < 4) all_chunks(std::integral_constant<int, C16_CUT_A>{}, std::integral_constant<int, 5>{});
+    else all_chunks(std::integral_constant<int, C16_CUT_B>{}, std::integral_constant<int, 4>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged-again last chunk: nothing may be in flight when the wave ends
 
     // epilogue: D[pixel][channel]: lane = channel (32 nb + li), pixel = (r & 3) + 8 (r >> 2) + 4 h of the wave's 32
@@ -386,7 +433,7 @@ using namespace shasta;
 extern "C" int shasta_shared_conv_f16x2_supported(int in_channels, int H, int W) {
     if (in_channels <= 0 || in_channels % 16 || H <= 0 || W <= 0) return 0;
     if ((long)in_channels * H * W >= (1L << 31)) return 0;
-    if (conv16_slots(H, W) > C16_NSLOT) return 0;
+    if (conv16_slots(H, W) > C16_NSLOT - 8) return 0;
     return 2 * ((min(C16_TILE, H * W) + 2 * W + 2 + 63) / 64) <= 8 * C16_NIT;
 }
 
