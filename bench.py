@@ -700,7 +700,7 @@ def extra_pipeline(bench, args, ex):
              "forward_only_frames_per_s": n / (k0 + fwd) if k0 + fwd > 0 else None,
              "chain_over_forward_only": ((k0 + fwd) / (sum(st.values()) - standin)) if st else None,
              "note": "chain_over_forward_only = (K0 + per-class forward) / (all stages except the device stand-in for the backbone), from the "
-                     "synchronised pass; the loader runs on a prefetch thread, so its stage is the wait that is left"}
+                     "synchronised pass"}
         if not args.no_cpu_baseline:
             from oracle import pipeline_oracle as PO
             small_root = os.path.join(root, "small")

@@ -202,7 +202,7 @@ def _run_features(bev, models, names, run, device, bank_cache, timer=_NO_TIMER):
 
 
 def run_split(models, paths, scenes, bev, device, work_dir=None, split="val", max_age=4, batch_pairs=32, decode_on_device=True,
-              rank=0, world=1, group=None, forward_override=None, tracker_on_device=True, timer=None, prefetch=True):
+              rank=0, world=1, group=None, forward_override=None, tracker_on_device=True, timer=None, prefetch=False):
     """Configs 2-4 end to end.  models: {class name: Shasta on `device`}; scenes: [(scene name, [tokens])] of the WHOLE split.
     Scenes are sharded over `world` ranks; rank 0 returns (per-class cp dicts, merged dict, tracking dict) and, with work_dir,
     writes <class>/cp_<split>.json, merged_cp_<split>.json and tracking_result.json like the reference CLIs; other ranks
@@ -211,9 +211,9 @@ def run_split(models, paths, scenes, bev, device, work_dir=None, split="val", ma
 
     Device path, frame-major: the reference runs one CLI per class over the whole split (eval.py), re-reading every frame's files and
     re-convolving its maps per class.  Here a run of up to batch_pairs consecutive frames of one scene is loaded ONCE for all classes
-    (frames.SharedFrames, on a prefetch thread while the device works on the previous run), its maps are produced once per frame
-    (_run_features), every class's forward and decode kernel are launched back to back, and ONE synchronisation per run brings all
-    classes' decisions to the host.  Same per-class results as the class-major chain (tests/test_pipeline.py)."""
+    (frames.SharedFrames), its maps are produced once per frame
+    (_run_features), every class's forward and decode kernel are launched back to back, and ONE event wait per run brings all
+    classes' decisions to the host - after the next run has been queued, so the device works while the host decodes and loads.  Same per-class results as the class-major chain (tests/test_pipeline.py)."""
     mine = set(replica.shard_scenes([(n, len(t)) for n, t in scenes], rank, world))
     tokens = [t for n, toks in scenes if n in mine for t in toks]
     all_tokens = [t for _, toks in scenes for t in toks]
@@ -255,60 +255,114 @@ def run_split(models, paths, scenes, bev, device, work_dir=None, split="val", ma
     return per_class, merged, tracking
 
 
+# ---- loader side of the frame-major chain ---------------------------------------------------------------------------------------------
+_LOADER = {}
+
+
+def _loader_init(det_path, cls_info_path, frame_info_path, max_objects, known):
+    _LOADER["frames"] = frames.SharedFrames(det_path, cls_info_path, frame_info_path, max_objects)
+    _LOADER["known"] = set(known)
+    _LOADER["names"] = list(max_objects)
+
+
+def _loader_run(run):
+    """All classes' samples of one run as plain numpy / list data."""
+    import numpy as np
+    sf, known, out = _LOADER["frames"], _LOADER["known"], {}
+    for n in _LOADER["names"]:
+        samples = [sf.load(n, t, known_tokens=known) for t, _ in run]
+        out[n] = dict(det_boxes=np.stack([s["det_boxes"] for s in samples]).astype(np.float32),
+                      prev_det_boxes=np.stack([s["prev_det_boxes"] for s in samples]).astype(np.float32),
+                      num_det_boxes=[s["num_det_boxes"] for s in samples], num_prev_det_boxes=[s["num_prev_det_boxes"] for s in samples],
+                      cls_det_boxes=[s["cls_det_boxes"] for s in samples], prev_cls_det_boxes=[s["prev_cls_det_boxes"] for s in samples],
+                      metadata=[dict(token=s["token"]) for s in samples],
+                      prev_metadata=[dict(token=s["prev_token"] or s["token"]) for s in samples])  # frames.collate_pairs
+    return out
+
+
 def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, batch_pairs, decode_on_device, timer, prefetch):
+    """prefetch: False / None (default) - the loader runs in line, between the launches of one run and the host half of the previous one
+    (the device is busy with the queued run meanwhile); True - one loader thread.  Measured on the 20 x 40 split: in line 653 - 701
+    frames/s, thread 526 - 632 (parsing is pure Python: the thread takes the GIL from the launches), two or four spawned loader
+    processes 248 - 303 (their start-up - importing torch - costs more than the 0.6 - 1.6 s of parsing they take over at this size)."""
     from concurrent.futures import ThreadPoolExecutor
-    loader = frames.SharedFrames(paths["det_path"], paths["cls_info_path"], paths["frame_info_path"], {n: CLASS_CONFIGS[n] for n in names})
-    known = set(all_tokens)
+    max_obj = {n: CLASS_CONFIGS[n] for n in names}
+    init = (paths["det_path"], paths["cls_info_path"], paths["frame_info_path"], max_obj, list(all_tokens))
+    _loader_init(*init)
+    known = _LOADER["known"]
     decs = {n: decode.AffinityDecoder() for n in names}
     cuda = device.type == "cuda"
+    runs = list(_scene_runs(scenes, mine, known, _LOADER["frames"].frame_info, batch_pairs))
+    if not runs:
+        return decs
+    pool = None
+    if prefetch and len(runs) > 1:
+        pool = ThreadPoolExecutor(max_workers=1)
+        futs = [pool.submit(_loader_run, runs[0])]
 
-    def load(run):
-        out = {}
-        for n in names:
-            samples = [loader.load(n, t, known_tokens=known) for t, _ in run]
-            b = frames.collate_pairs(samples)
-            if cuda:
-                b["det_boxes"], b["prev_det_boxes"] = b["det_boxes"].pin_memory(), b["prev_det_boxes"].pin_memory()
+        def _threaded():
+            for i in range(len(runs)):
+                if i + 1 < len(runs):
+                    futs.append(pool.submit(_loader_run, runs[i + 1]))
+                yield futs[i].result()
+        stream_of_batches = _threaded()
+    else:
+        stream_of_batches = (_loader_run(r) for r in runs)
+
+    def tensors(raw):
+        for b in raw.values():
+            for k in ("det_boxes", "prev_det_boxes"):
+                t = torch.from_numpy(b[k])
+                b[k] = t.pin_memory() if cuda else t
             b["_lags"] = b["prev_det_boxes"][:, 0, 9].numpy().copy()
-            out[n] = b
-        return out
+        return raw
 
-    runs = list(_scene_runs(scenes, mine, known, loader.frame_info, batch_pairs))
-    pool = ThreadPoolExecutor(max_workers=1) if (prefetch and len(runs) > 1) else None
+    def finish(pending, ev):
+        if ev is not None:
+            ev.synchronize()  # this run's decision copies have landed (the next run's launches are already queued behind them)
+        for n, b, host, m1, m2 in pending:
+            if host is not None:
+                decs[n].add_batch(None, None, b, flags=decode.decode_flags_unpack(host), lags=b["_lags"])
+            else:
+                decs[n].add_batch(m1, m2, b, on_device=False, lags=b["_lags"])
+
     bank_cache = {}
-    nxt = pool.submit(load, runs[0]) if pool and runs else None
-    for i, run in enumerate(runs):
-        with timer.stage("loader + collate (wait)"):
-            batches = nxt.result() if pool else load(run)
-            if pool and i + 1 < len(runs):
-                nxt = pool.submit(load, runs[i + 1])
-        feats = _run_features(bev, models, names, run, device, bank_cache, timer)
-        pending = []
-        with timer.stage("h2d + forward + decode kernel"):
-            for n in names:
-                b = batches[n]
-                ex = dict(b)
-                ex.pop("_lags")
-                ex["det_boxes"] = b["det_boxes"].to(device, non_blocking=True)
-                ex["prev_det_boxes"] = b["prev_det_boxes"].to(device, non_blocking=True)
-                ex["bev_feature"], ex["prev_bev_feature"] = feats[n][1:], feats[n][:-1]
-                with torch.no_grad():
-                    m1, m2, ex = models[n](ex, train_mode=False)
-                if decode_on_device:
-                    buf = decode.decode_flags_launch(m1, m2, [len(p) for p in b["prev_cls_det_boxes"]], [len(c) for c in b["cls_det_boxes"]])
-                    host = torch.empty(buf.shape, dtype=buf.dtype, pin_memory=cuda)
-                    host.copy_(buf, non_blocking=True)
-                    pending.append((n, b, host, None, None))
-                else:
-                    pending.append((n, b, None, m1, m2))
-            if cuda:
-                torch.cuda.current_stream().synchronize()  # the ONE wait of this run
+    waiting = None
+    try:
+        for run in runs:
+            with timer.stage("loader + collate (wait)"):
+                batches = tensors(next(stream_of_batches))
+            feats = _run_features(bev, models, names, run, device, bank_cache, timer)
+            pending = []
+            with timer.stage("h2d + forward + decode kernel"):
+                for n in names:
+                    b = batches[n]
+                    ex = {k: v for k, v in b.items() if k != "_lags"}
+                    ex["det_boxes"] = b["det_boxes"].to(device, non_blocking=True)
+                    ex["prev_det_boxes"] = b["prev_det_boxes"].to(device, non_blocking=True)
+                    ex["bev_feature"], ex["prev_bev_feature"] = feats[n][1:], feats[n][:-1]
+                    with torch.no_grad():
+                        m1, m2, ex = models[n](ex, train_mode=False)
+                    if decode_on_device:
+                        buf = decode.decode_flags_launch(m1, m2, [len(p) for p in b["prev_cls_det_boxes"]], [len(c) for c in b["cls_det_boxes"]])
+                        host = torch.empty(buf.shape, dtype=buf.dtype, pin_memory=cuda)
+                        host.copy_(buf, non_blocking=True)
+                        pending.append((n, b, host, None, None))
+                    else:
+                        pending.append((n, b, None, m1, m2))
+                ev = None
+                if cuda:
+                    ev = torch.cuda.Event()
+                    ev.record()
+            # the host half of the PREVIOUS run is done while the device works on this one: one event wait per run, no stream-wide stall
+            with timer.stage("decode (host)"):
+                if waiting is not None:
+                    finish(*waiting)
+                waiting = (pending, ev)
         with timer.stage("decode (host)"):
-            for n, b, host, m1, m2 in pending:
-                if host is not None:
-                    decs[n].add_batch(None, None, b, flags=decode.decode_flags_unpack(host), lags=b["_lags"])
-                else:
-                    decs[n].add_batch(m1, m2, b, on_device=False, lags=b["_lags"])
-    if pool:
-        pool.shutdown()
+            if waiting is not None:
+                finish(*waiting)
+    finally:
+        if pool:
+            pool.shutdown()
     return decs

@@ -12,28 +12,34 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from shasta_amd import pipeline, scenes  # noqa: E402
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--scenes", type=int, default=20)
-ap.add_argument("--frames", type=int, default=40)
-ap.add_argument("--batch", type=int, default=32)
-ap.add_argument("--maps", choices=["neck", "features"], default="neck", help="neck: (512,180,180) maps on the device + K0 for all heads; features: TokenBev (CPU stand-in)")
-ap.add_argument("--sync", type=int, default=1)
-a = ap.parse_args()
-dev = torch.device("cuda", 0)
-root = tempfile.mkdtemp(prefix="shasta_split_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-t0 = time.perf_counter()
-paths, sc = scenes.write_synthetic_split(root, n_scenes=a.scenes, frames_per_scene=a.frames, seed=3)
-print("split written in %.2f s: %d frames" % (time.perf_counter() - t0, a.scenes * a.frames), flush=True)
-models = {n: pipeline.build_class_model(n, dev, seed=1) for n in pipeline.CLASS_CONFIGS}
-bev = scenes.TokenNeck() if a.maps == "neck" else scenes.TokenBev()
-kw = {}
-for rep in range(2):
-    timer = pipeline.StageTimer(sync=bool(a.sync))
-    torch.cuda.synchronize()
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scenes", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=40)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--maps", choices=["neck", "features"], default="neck", help="neck: (512,180,180) maps on the device + K0 for all heads; features: TokenBev (CPU stand-in)")
+    ap.add_argument("--sync", type=int, default=1)
+    ap.add_argument("--prefetch", default="none", help="none | thread")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    root = tempfile.mkdtemp(prefix="shasta_split_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     t0 = time.perf_counter()
-    res = pipeline.run_split(models, paths, sc, bev, dev, batch_pairs=a.batch, timer=timer, **kw)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    n = a.scenes * a.frames
-    print(json.dumps({"rep": rep, "frames": n, "seconds": dt, "frames_per_s": n / dt, "class_frame_pairs_per_s": 7 * n / dt,
-                      "stages": {k: round(v, 4) for k, v in timer.seconds.items()}}), flush=True)
+    paths, sc = scenes.write_synthetic_split(root, n_scenes=a.scenes, frames_per_scene=a.frames, seed=3)
+    print("split written in %.2f s: %d frames" % (time.perf_counter() - t0, a.scenes * a.frames), flush=True)
+    models = {n: pipeline.build_class_model(n, dev, seed=1) for n in pipeline.CLASS_CONFIGS}
+    bev = scenes.TokenNeck() if a.maps == "neck" else scenes.TokenBev()
+    kw = dict(prefetch=a.prefetch == "thread")
+    for rep in range(3):
+        timer = pipeline.StageTimer(sync=bool(a.sync))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = pipeline.run_split(models, paths, sc, bev, dev, batch_pairs=a.batch, timer=timer, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n = a.scenes * a.frames
+        print(json.dumps({"rep": rep, "frames": n, "seconds": dt, "frames_per_s": n / dt, "class_frame_pairs_per_s": 7 * n / dt,
+                          "stages": {k: round(v, 4) for k, v in timer.seconds.items()}}), flush=True)
+
+
+if __name__ == "__main__":  # (loader processes are spawned: they import this module again)
+    main()
