@@ -6,31 +6,37 @@ O=$R/gpurun_out/${1:-final}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err   # the driver's line: headline + extra.{batch_sweep, arithmetic_*, car_90_320_3} + cpu_baseline
-python3 $R/bench.py --batch 512 --no-precut --no-cpu-baseline --no-extras > $O/bench_noprecut.json 2> /dev/null
-for b in 1 32 64 128 256 512; do
+for b in 1 64 128 512; do
   python3 $R/bench.py --batch $b --no-cpu-baseline --no-extras > $O/bench_b$b.json 2> /dev/null
 done
 python3 $R/bench.py --batch 512 --arithmetic pieces --no-cpu-baseline --no-extras > $O/bench_pieces.json 2> /dev/null
 python3 $R/bench.py --batch 512 --arithmetic f32 --no-cpu-baseline --no-extras --steps 20 > $O/bench_f32.json 2> /dev/null
-python3 $R/bench.py --batch 2048 --no-cpu-baseline --no-extras --steps 12 > $O/bench_b2048.json 2> /dev/null
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 $R/bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_torchrun.json 2> $O/bench_torchrun.err
 python3 $R/tools/l1_split_check.py --max-obj 500 --batch 64 128 256 512 --steps 10 --arithmetic f16x2 > $O/l1_check_f16x2.json 2> /dev/null
-python3 $R/tools/l1_split_check.py --max-obj 500 --batch 64 128 256 512 --steps 10 --arithmetic pieces > $O/l1_check_pieces.json 2> /dev/null
 python3 $R/tools/l1_split_check.py --max-obj 500 --batch 64 128 256 512 --steps 10 --arithmetic f32 > $O/l1_check_f32.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o d -- python3 $R/bench.py --batch 512 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/prof_default.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1024 -o d -- python3 $R/bench.py --batch 1024 --steps 12 --warmup 3 --no-cpu-baseline --no-extras > $O/prof_b1024.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1 -o d -- python3 $R/bench.py --batch 1 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/prof_b1.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b64 -o d -- python3 $R/bench.py --batch 64 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/prof_b64.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b128 -o d -- python3 $R/bench.py --batch 128 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/prof_b128.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_pieces -o d -- python3 $R/bench.py --batch 512 --arithmetic pieces --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/prof_pieces.log 2>&1
+# K0 (round 4): accuracy + timing against MIOpen, kernel stats and counters of the fp16 kernel at 8 frame pairs (one head, seven heads)
+(cd $R && python3 tools/conv_check.py --batches 1,8 > $O/conv_check.jsonl 2> /dev/null)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_conv_b8 -o d -- python3 $R/tools/conv_only.py --batch 8 --iters 10 > $O/prof_conv_b8.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_conv_b8_heads7 -o d -- python3 $R/tools/conv_only.py --batch 8 --iters 6 --heads 7 > $O/prof_conv_b8_heads7.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_convmfma_b8 -o p -- python3 $R/tools/conv_only.py --batch 8 --iters 4 > $O/pmc_convmfma_b8.log 2>&1
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_convlds_b8 -o p -- python3 $R/tools/conv_only.py --batch 8 --iters 4 > $O/pmc_convlds_b8.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_convfetch_b8 -o p -- python3 $R/tools/conv_only.py --batch 8 --iters 4 > $O/pmc_convfetch_b8.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_convwrite_b8 -o p -- python3 $R/tools/conv_only.py --batch 8 --iters 4 > $O/pmc_convwrite_b8.log 2>&1
+# the configs 2-4 chain (round 4)
+(cd $R && timeout 300 python3 tools/time_pipeline.py --scenes 20 --frames 40 --batch 40 --sync 1 > $O/pipeline_sync.log 2>&1; timeout 300 python3 tools/time_pipeline.py --scenes 20 --frames 40 --batch 40 --sync 0 > $O/pipeline.log 2>&1)
 for b in 1 128 512 1024; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_b$b -o p -- python3 $R/bench.py --batch $b --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_fetch_b$b.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_b$b -o p -- python3 $R/bench.py --batch $b --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_write_b$b.log 2>&1
 done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_b1024 -o p -- python3 $R/bench.py --batch 1024 --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_mfma_b1024.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_b512 -o p -- python3 $R/bench.py --batch 512 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_mfma_b512.log 2>&1
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum --kernel-trace --output-format csv -d $O/pmc_rdreq_b512 -o p -- python3 $R/bench.py --batch 512 --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_rdreq_b512.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $O/pmc_hit_b512 -o p -- python3 $R/bench.py --batch 512 --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_hit_b512.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_valu_b512 -o p -- python3 $R/bench.py --batch 512 --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_valu_b512.log 2>&1
 (cd $R && python3 tools/stage_power.py 512 2 > $O/stage_power.log 2>&1)
-grep -h '^{' $O/bench_default.json $O/bench_b1.json $O/bench_b32.json $O/bench_b64.json $O/bench_b128.json $O/bench_b256.json $O/bench_b512.json $O/bench_noprecut.json $O/bench_pieces.json $O/bench_f32.json $O/bench_b2048.json $O/bench_torchrun.json | cut -c1-230
+grep -h '^{' $O/bench_default.json $O/bench_b1.json $O/bench_b64.json $O/bench_b128.json $O/bench_b512.json $O/bench_pieces.json $O/bench_f32.json $O/bench_torchrun.json | cut -c1-230
+grep time $O/conv_check.jsonl | cut -c1-200; tail -1 $O/pipeline.log | cut -c1-400
 ls $O

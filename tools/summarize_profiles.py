@@ -52,7 +52,7 @@ def pmc(dirs, dst):
 if __name__ == "__main__":
     os.makedirs(P, exist_ok=True)
     for name, dst in (("prof_default", "bench_default_b512"), ("prof_b1024", "bench_b1024"), ("prof_b128", "bench_b128"), ("prof_b64", "bench_b64"), ("prof_b1", "bench_b1"),
-                      ("prof_pieces", "bench_pieces_b512")):
+                      ("prof_pieces", "bench_pieces_b512"), ("prof_conv_b8", "shared_conv_b8"), ("prof_conv_b8_heads7", "shared_conv_b8_heads7")):
         src = os.path.join(G, SRC, name, "d_kernel_stats.csv")
         if os.path.exists(src):
             kernel_stats(src, os.path.join(P, "%s_kernel_stats_%s.csv" % (TAG, dst)))
@@ -71,6 +71,9 @@ if __name__ == "__main__":
             lines = [l for l in open(os.path.join(G, SRC, f)) if l.startswith("{")]
             if lines:
                 json.dump(json.loads(lines[-1]), open(os.path.join(P, TAG + "_stage_power.json"), "w"), indent=1)
+        if f in ("conv_check.jsonl", "pipeline.log", "pipeline_sync.log"):
+            rows = [json.loads(l) for l in open(os.path.join(G, SRC, f)) if l.startswith("{")]
+            json.dump(rows, open(os.path.join(P, TAG + "_" + f.split(".")[0] + ".json"), "w"), indent=1)
         if f.startswith("l1_check_") and f.endswith(".json"):
             rows = [json.loads(l) for l in open(os.path.join(G, SRC, f)) if l.startswith("{")]
             json.dump(rows, open(os.path.join(P, TAG + "_" + f), "w"), indent=1)
@@ -102,8 +105,7 @@ if __name__ == "__main__":
     for f in sorted(os.listdir(P)):
         if f.startswith(TAG + "_bench_") and f.endswith(".json"):
             d = json.load(open(os.path.join(P, f)))
-            if d.get("config", {}).get("arithmetic", "").startswith("fp32 operands in HBM, fp32 accumulation throughout; above 32 frame-pairs per step the first aug_shape layer (above 64") \
-                    and d.get("config", {}).get("precut_weight_stream", True):
+            if d.get("config", {}).get("arithmetic", "").startswith("f16x2") and d.get("config", {}).get("precut_weight_stream", True):
                 b = d["config"]["frame_pairs_per_step_per_gpu"]
                 for key in ("roofline", "roofline_second"):
                     k = ("pair_batch_%d" if d[key]["kernel"].startswith("pair") else "batch_%d") % b
