@@ -40,7 +40,6 @@ constexpr int C16_PLANE = C16_NSLOT * 16;      // bytes of one [slot][8 fp16] pl
 constexpr int C16_INBUF = 4 * C16_PLANE;       // [piece 2][octet 2] planes
 constexpr int C16_WBUF = 9 * 2 * 2 * 1024;     // [tap 9][channel block 2][piece 2] fragments of 1 KB
 constexpr int C16_LDS = 2 * C16_WBUF + 2 * C16_INBUF;  // 155 648 bytes: one workgroup per CU
-constexpr int C16_NIT = 3;                    // staged (pixel, octet) items per lane and chunk
 constexpr int C16_MAXH = 8;                    // class heads per launch
 constexpr int C16_PARAMS = 256;                // floats behind the fragments: alpha[64], beta'[64], bias[64], 2^-e[64]
 
@@ -146,7 +145,14 @@ struct Conv16Args {
     int B, Cin, H, W, heads, tiles_per_map, ntiles, tiles_per_xcd;
 };
 
-__global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
+// PB = 32-pixel blocks per wave.  PB = 1: 8 waves (two per SIMD), each 32 pixels x 64 channels.  PB = 2: 4 waves (one per SIMD, up to 512
+// registers), each 64 pixels x 64 channels: every weight fragment read from LDS feeds two pixel blocks (0.67 instead of 1 ds_read_b128
+// per MFMA) and no other wave's vector instructions compete with a wave's matrix instructions for issue slots.
+template <int PB>
+__global__ __launch_bounds__(512 / PB, PB == 1 ? 2 : 1) void shared_conv_f16_kernel(Conv16Args a) {
+    constexpr int NW = 8 / PB;            // waves per workgroup
+    constexpr int NIT = 24 / NW;          // staged (64-pixel block, octet) items per lane and chunk: up to 24 blocks over the waves
+    constexpr int NDMA_LO = (36 + NW - 1) / NW, NDMA_HI = 36 / NW;  // weight fragments per wave: the first waves take one more when 36 % NW != 0
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
     // zero both input buffers once: padding slots and rows outside the image are never written afterwards
     {
         const w32x4 zz = {0u, 0u, 0u, 0u};
-        for (int i = tid; i < 2 * C16_INBUF / 16; i += 512) reinterpret_cast<w32x4*>(in_lds)[i] = zz;
+        for (int i = tid; i < 2 * C16_INBUF / 16; i += 64 * NW) reinterpret_cast<w32x4*>(in_lds)[i] = zz;
     }
 
     // staging roles of this lane: three (pixel, channel octet) items of every chunk.  The flat pixel range the tile touches is dealt in
@@ -182,13 +188,13 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
     const int p_last = min(p0 + C16_TILE, npix) - 1;
     const int qs = p0 - W - 1, qe = p_last + W + 1;   // first / last flat pixel a tap of this tile reads (may lie outside the image)
     const int nblk = (qe - qs + 64) >> 6;             // 64-pixel blocks per octet (the host guarantees 2 nblk <= 24)
-    int st_addr[C16_NIT];      // LDS byte offset inside an input buffer (octet plane + slot); lanes without a pixel to stage point at one
+    int st_addr[NIT];      // LDS byte offset inside an input buffer (octet plane + slot); lanes without a pixel to stage point at one
                                // of the eight trash slots C16_NSLOT - 8 .. - 1 of their octet plane, which no tap ever reads
-    unsigned ld_off[C16_NIT];  // byte offset of channel 0 of the octet inside a chunk; always a valid address
-    bool item_live[C16_NIT];   // wave-uniform: this wave's item holds pixels at all (its cut and stores are skipped otherwise)
+    unsigned ld_off[NIT];  // byte offset of channel 0 of the octet inside a chunk; always a valid address
+    bool item_live[NIT];   // wave-uniform: this wave's item holds pixels at all (its cut and stores are skipped otherwise)
 #pragma unroll
-    for (int it = 0; it < C16_NIT; ++it) {
-        const int blk = it * 8 + wv;
+    for (int it = 0; it < NIT; ++it) {
+        const int blk = it * NW + wv;
         const int oct = blk >= nblk ? 1 : 0;
         const int q = qs + 64 * (blk - oct * nblk) + lane;
         item_live[it] = blk < 2 * nblk;
@@ -204,14 +210,14 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
     // The raw tile travels in registers for a whole trip.  Its loads are inline asm: hipcc builds a 64-bit vector address per load
     // otherwise (24 v_lshl_add_u64 per trip - vector instructions of a wave take issue slots from its SIMD partner's matrix
     // instructions), and the waits below can then be exact: the compiler knows nothing of these loads, every s_waitcnt vmcnt is ours.
-    float r[C16_NIT][8];
+    float r[NIT][8];
     auto load_chunk = [&](int ch) __attribute__((always_inline)) {
         const char* xc = reinterpret_cast<const char*>(xin + (size_t)ch * 16 * npix);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const char* xj = uniform_ptr(xc + (size_t)j * npix * 4);
 #pragma unroll
-            for (int it = 0; it < C16_NIT; ++it) {
+            for (int it = 0; it < NIT; ++it) {
 #ifdef C16_DBG_CLOADS
                 r[it][j] = *reinterpret_cast<const float*>(xj + ld_off[it]);
 #else
@@ -230,27 +236,27 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
                      : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[0][3]), "+v"(r[0][4]), "+v"(r[0][5]), "+v"(r[0][6]), "+v"(r[0][7])
                      : "n"(decltype(left)::value));
 #pragma unroll
-        for (int it = 1; it < C16_NIT; ++it)
+        for (int it = 1; it < NIT; ++it)
             asm volatile("" : "+v"(r[it][0]), "+v"(r[it][1]), "+v"(r[it][2]), "+v"(r[it][3]), "+v"(r[it][4]), "+v"(r[it][5]), "+v"(r[it][6]), "+v"(r[it][7]));
     };
     const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds);
     const uint32_t dma_off = (uint32_t)(lane * 16);
-    // the 36 fragments of a chunk are dealt to the eight waves: wave w copies fragments w, w + 8, ... (five for w < 4, else four)
+    // the 36 fragments of a chunk are dealt to the NW waves: wave w copies fragments w, w + NW, ...
     auto dma_weights = [&](int ch, int buf, auto ndma) __attribute__((always_inline)) {
         const char* src = wsrc + (size_t)ch * C16_WBUF + wv * 1024;
         const uint32_t dst0 = lds0 + (uint32_t)(buf * C16_WBUF + wv * 1024);
         const uint32_t off = dma_off;  // (a generic lambda does not capture a variable named only in an asm operand)
 #pragma unroll
         for (int j = 0; j < decltype(ndma)::value; ++j) {
-            const char* base = uniform_ptr(src + j * 8192);
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)(j * 8192));
+            const char* base = uniform_ptr(src + j * (NW * 1024));
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)(j * (NW * 1024)));
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory", "m0");
         }
     };
     auto cut_store = [&](auto bufc) __attribute__((always_inline)) {
         constexpr int IB = 2 * C16_WBUF + decltype(bufc)::value * C16_INBUF;
 #pragma unroll
-        for (int it = 0; it < C16_NIT; ++it) {
+        for (int it = 0; it < NIT; ++it) {
 #ifndef C16_DBG_NOSKIP
             if (!item_live[it]) continue;  // wave-uniform
 #endif
@@ -267,27 +273,35 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
         }
     };
 
-    // operand addresses of this lane
+    // operand addresses of this lane: pixel block pb of this wave = pixels (32 PB) w + 32 pb + (lane & 31)
     const int li = lane & 31, h = lane >> 5;
-    const int p = min(p0 + 32 * wv + li, npix - 1);
-    const int py = p / W, px = p - py * W;
-    const int sc = py * WT + px + 1 - first;  // slot of the pixel itself (>= WT + 1)
-    int a_row[3];
+    int a_row[PB][3];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) a_row[dy] = h * C16_PLANE + (sc + (dy - 1) * WT - 1) * 16;  // tap (dy, dx = 0); dx adds 16 bytes each
+    for (int pb = 0; pb < PB; ++pb) {
+        const int p = min(p0 + 32 * (PB * wv + pb) + li, npix - 1);
+        const int py = p / W, px = p - py * W;
+        const int sc = py * WT + px + 1 - first;  // slot of the pixel itself (>= WT + 1)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) a_row[pb][dy] = h * C16_PLANE + (sc + (dy - 1) * WT - 1) * 16;  // tap (dy, dx = 0); dx adds 16 bytes each
+    }
     const int b_lane = lane * 16;
 
-    f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f32x16 acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc[PB][2];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) acc[pb][0] = acc[pb][1] = zero16;
     struct Frag {
-        h16x8 ah, al, b0h, b0l, b1h, b1l;
+        h16x8 ah[PB], al[PB], b0h, b0l, b1h, b1l;
     };
     auto read_tap = [&](auto bufc, int tap, Frag& f) __attribute__((always_inline)) {
         const char* ib = in_lds + decltype(bufc)::value * C16_INBUF;
         const char* wb = lds + decltype(bufc)::value * C16_WBUF + b_lane;
         const int dy = tap / 3, dx = tap % 3;
-        f.ah = *reinterpret_cast<const h16x8*>(ib + a_row[dy] + dx * 16);
-        f.al = *reinterpret_cast<const h16x8*>(ib + a_row[dy] + dx * 16 + 2 * C16_PLANE);
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            f.ah[pb] = *reinterpret_cast<const h16x8*>(ib + a_row[pb][dy] + dx * 16);
+            f.al[pb] = *reinterpret_cast<const h16x8*>(ib + a_row[pb][dy] + dx * 16 + 2 * C16_PLANE);
+        }
         f.b0h = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 0) * 1024);
         f.b0l = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 1) * 1024);
         f.b1h = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 2) * 1024);
@@ -295,23 +309,34 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
     };
     auto mma_tap = [&](const Frag& f) __attribute__((always_inline)) {  // piece products, small to large
 #ifdef C16_ABL_NO_MFMA  // ablation build (tools/build_variant.py): everything but the matrix instructions; results are wrong
-        asm volatile("" ::"v"(f.ah), "v"(f.al), "v"(f.b0h), "v"(f.b0l), "v"(f.b1h), "v"(f.b1l));
+        asm volatile("" ::"v"(f.ah[0]), "v"(f.al[0]), "v"(f.b0h), "v"(f.b0l), "v"(f.b1h), "v"(f.b1l));
         return;
 #endif
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.b0h, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.b1h, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.b0l, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.b1l, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.b0h, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.b1h, acc1, 0, 0, 0);
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            acc[pb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[pb], f.b0h, acc[pb][0], 0, 0, 0);
+            acc[pb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[pb], f.b1h, acc[pb][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            acc[pb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[pb], f.b0l, acc[pb][0], 0, 0, 0);
+            acc[pb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[pb], f.b1l, acc[pb][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            acc[pb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[pb], f.b0h, acc[pb][0], 0, 0, 0);
+            acc[pb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[pb], f.b1h, acc[pb][1], 0, 0, 0);
+        }
     };
 
     const int nchunk = Cin / 16;
-    constexpr int NLD = 8 * C16_NIT;  // global loads of one staged chunk per lane
+    constexpr int NLD = 8 * NIT;  // global loads of one staged chunk per lane
+    static_assert(NLD + NDMA_LO <= 63, "vmcnt is 6 bits");
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
-    if (wv < 4) dma_weights(0, 0, std::integral_constant<int, 5>{});
-    else dma_weights(0, 0, std::integral_constant<int, 4>{});
+    constexpr int NSPLIT = 36 % NW == 0 ? NW / 2 : 36 % NW;  // waves below it: NDMA_LO fragments and the early cut; the others NDMA_HI, late cut
+    if (wv < NSPLIT) dma_weights(0, 0, std::integral_constant<int, NDMA_LO>{});
+    else dma_weights(0, 0, std::integral_constant<int, NDMA_HI>{});
     load_chunk(0);
     __syncthreads();  // the zero fill is complete
     wait_tile(std::integral_constant<int, 0>{});
@@ -395,25 +420,29 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16_kernel(Conv16Args a) {
         }
         if (ch < nchunk) chunk(ch, B0{}, cut_after, ndma);
     };
-    if (wv < 4) all_chunks(std::integral_constant<int, C16_CUT_A>{}, std::integral_constant<int, 5>{});
-    else all_chunks(std::integral_constant<int, C16_CUT_B>{}, std::integral_constant<int, 4>{});
+    if (wv < NSPLIT) all_chunks(std::integral_constant<int, C16_CUT_A>{}, std::integral_constant<int, NDMA_LO>{});
+    else all_chunks(std::integral_constant<int, C16_CUT_B>{}, std::integral_constant<int, NDMA_HI>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged-again last chunk: nothing may be in flight when the wave ends
 
-    // epilogue: D[pixel][channel]: lane = channel (32 nb + li), pixel = (r & 3) + 8 (r >> 2) + 4 h of the wave's 32
-    if (p0 + 32 * wv >= npix) return;
+    // epilogue: D[pixel][channel]: lane = channel (32 nb + li), pixel = (r & 3) + 8 (r >> 2) + 4 h of the block's 32
     const float* par = reinterpret_cast<const float*>(wsrc + (size_t)nchunk * C16_WBUF);
     const float back = __builtin_ldexpf(1.0f, -eimg);
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int chn = 32 * nb + li;
-        const float alpha = par[chn], beta2 = par[64 + chn], bias = par[128 + chn], un = par[192 + chn] * back;
+    for (int pb = 0; pb < PB; ++pb) {
+        const int pblk = p0 + 32 * (PB * wv + pb);
+        if (pblk >= npix) continue;  // wave-uniform
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            const int pp = p0 + 32 * wv + (rr & 3) + 8 * (rr >> 2) + 4 * h;
-            if (pp < npix) {
-                const float s = (nb ? acc1[rr] : acc0[rr]) * un;
-                const float v = (s + bias) * alpha + beta2;
-                out[(size_t)pp * 64 + chn] = relu_nan(v);
+        for (int nb = 0; nb < 2; ++nb) {
+            const int chn = 32 * nb + li;
+            const float alpha = par[chn], beta2 = par[64 + chn], bias = par[128 + chn], un = par[192 + chn] * back;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int pp = pblk + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+                if (pp < npix) {
+                    const float sv = acc[pb][nb][rr] * un;
+                    const float v = (sv + bias) * alpha + beta2;
+                    out[(size_t)pp * 64 + chn] = relu_nan(v);
+                }
             }
         }
     }
@@ -434,7 +463,7 @@ extern "C" int shasta_shared_conv_f16x2_supported(int in_channels, int H, int W)
     if (in_channels <= 0 || in_channels % 16 || H <= 0 || W <= 0) return 0;
     if ((long)in_channels * H * W >= (1L << 31)) return 0;
     if (conv16_slots(H, W) > C16_NSLOT - 8) return 0;
-    return 2 * ((min(C16_TILE, H * W) + 2 * W + 2 + 63) / 64) <= 8 * C16_NIT;
+    return 2 * ((min(C16_TILE, H * W) + 2 * W + 2 + 63) / 64) <= 24;
 }
 
 extern "C" size_t shasta_shared_conv_f16x2_packed_bytes(int in_channels) {
@@ -506,7 +535,10 @@ extern "C" int shasta_shared_conv_multi_f32(const float* x, const float* x_prev,
     a.tiles_per_map = cdiv(H * W, C16_TILE);
     a.ntiles = a.tiles_per_map * nmaps;
     a.tiles_per_xcd = cdiv(a.ntiles, 8);
-    (void)hipFuncSetAttribute((const void*)shared_conv_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS);
-    hipLaunchKernelGGL(shared_conv_f16_kernel, dim3(8 * a.tiles_per_xcd * heads), dim3(512), C16_LDS, st, a);
+#ifndef C16_PB
+#define C16_PB 1
+#endif
+    (void)hipFuncSetAttribute((const void*)shared_conv_f16_kernel<C16_PB>, hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS);
+    hipLaunchKernelGGL(shared_conv_f16_kernel<C16_PB>, dim3(8 * a.tiles_per_xcd * heads), dim3(512 / C16_PB), C16_LDS, st, a);
     return check_launch("shared_conv_f16");
 }

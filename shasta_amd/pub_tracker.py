@@ -217,20 +217,28 @@ class PubTrackerMerged(object):
         self.tracks = []
 
     def _prepare(self, results, time_lag):
-        """Per class: (class name, detections, tracks of that class, arrays of the distance step or None)."""
+        """Per class: (class name, detections, tracks of that class, arrays of the distance step or None).  One pass over the frame's
+        detections groups them by class and one array operation per class forms every detection's `ct` / `tracking` (the values of
+        pub_tracker_merged.py:92-99, element for element; the per-detection arrays are rows of the class arrays)."""
+        by_class = {}
+        for d in results:
+            by_class.setdefault(d["detection_name"], []).append(d)
+        tracks_by_class = {}
+        for t in self.tracks:
+            tracks_by_class.setdefault(t["detection_name"], []).append(t)
         per_class = []
-        for name in NUSCENES_TRACKING_NAMES:
-            dets = [d for d in results if d["detection_name"] == name]
-            for d in dets:
-                d["ct"] = np.array(d["translation"][:2])
-                d["tracking"] = np.array(d["velocity"][:2]) * -1 * time_lag
-                d["label_preds"] = NUSCENES_TRACKING_NAMES.index(d["detection_name"])
-            if len(dets) == 0:  # pub_tracker_merged.py:101-102: nothing of this class in the frame -> its tracks are dropped
+        for label, name in enumerate(NUSCENES_TRACKING_NAMES):
+            dets = by_class.get(name)
+            if not dets:  # pub_tracker_merged.py:101-102: nothing of this class in the frame -> its tracks are dropped
                 continue
-            tracks = [t for t in self.tracks if t["detection_name"] == name]
-            det_xy = np.array([d["ct"] + d["tracking"].astype(np.float32) for d in dets], np.float32)
-            det_cls = np.array([d["label_preds"] for d in dets], np.int32)
-            gate = np.array([self.NUSCENE_CLS_VELOCITY_ERROR[d["detection_name"]] for d in dets], np.float32)
+            ct = np.array([d["translation"][:2] for d in dets])
+            trk = np.array([d["velocity"][:2] for d in dets]) * -1 * time_lag
+            for i, d in enumerate(dets):
+                d["ct"], d["tracking"], d["label_preds"] = ct[i], trk[i], label
+            tracks = tracks_by_class.get(name, [])
+            det_xy = (ct + trk.astype(np.float32)).astype(np.float32)
+            det_cls = np.full(len(dets), label, np.int32)
+            gate = np.full(len(dets), self.NUSCENE_CLS_VELOCITY_ERROR[name], np.float32)
             trk_xy = np.array([t["ct"] for t in tracks], np.float32)
             trk_cls = np.array([t["label_preds"] for t in tracks], np.int32)
             per_class.append((name, dets, tracks, det_xy, trk_xy, det_cls, trk_cls, gate))
