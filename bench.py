@@ -692,16 +692,15 @@ def extra_pipeline(bench, args, ex):
         pipeline.run_split(models, paths, sc, neck, dev, batch_pairs=n_frames, timer=timer)
         st = timer.seconds
         n = n_scenes * n_frames
-        k0 = st.get("maps: shared_conv, all class heads (K0)", 0.0)
-        fwd = st.get("h2d + forward + decode kernel", 0.0)
-        standin = st.get("maps: neck outputs (stand-in for backbone + neck)", 0.0)
+        fwd_s = pipeline.forward_only_seconds(models, paths, sc, neck, dev, batch_pairs=n_frames)
         e = {"frames": n, "classes": 7, "frames_per_run": n_frames, "seconds": total, "frames_per_s": n / total,
-             "class_frame_pairs_per_s": 7 * n / total, "stages_s": {k: round(v, 4) for k, v in st.items()},
-             "forward_only_frames_per_s": n / (k0 + fwd) if k0 + fwd > 0 else None,
-             "chain_over_forward_only": (n / total) / (n / (k0 + fwd)) if k0 + fwd > 0 else None,
-             "note": "chain_over_forward_only = frames/s of the whole chain (un-instrumented pass) / frames/s of K0 + the per-class forwards "
-                     "alone (their synchronised stage times); what separates the two is host Python: parsing the per-frame json files and "
-                     "the tracker's bookkeeping"}
+             "class_frame_pairs_per_s": 7 * n / total,
+             "stages_s": {k: round(v, 4) for k, v in st.items()},
+             "forward_only_s": fwd_s, "forward_only_frames_per_s": n / fwd_s, "chain_over_forward_only": fwd_s / total,
+             "note": "frames_per_s: whole chain; forward_only = device time (HIP events) of K0 for all heads + the seven class forwards + decode kernels over the same "
+                     "runs, nothing else; chain_over_forward_only = their ratio.  What separates the two is host Python: building the class "
+                     "dicts from the per-frame json files, the decode lists and the tracker's bookkeeping.  stages_s: a separate pass with the "
+                     "device synchronised at every stage boundary (slower than the un-instrumented total)"}
         if not args.no_cpu_baseline:
             from oracle import pipeline_oracle as PO
             small_root = os.path.join(root, "small")

@@ -82,8 +82,9 @@ def decode_flags_device(matched1, matched2, n_prev, n_cur):
     return decode_flags_unpack(decode_flags_launch(matched1, matched2, n_prev, n_cur).cpu())
 
 
-def decode_frame_from_flags(prev_class, prev_score, det_flags, det_score, cls_det_boxes, prev_cls_det_boxes, token, time_lag):
-    """Same result as decode_frame, built from the device decisions of one frame (rows of decode_flags_device)."""
+def decode_frame_from_flags(prev_class, prev_score, det_flags, det_score, cls_det_boxes, prev_cls_det_boxes, token, time_lag, copy_fn=False):
+    """Same result as decode_frame, built from the device decisions of one frame (rows of decode_flags_device).  copy_fn: a propagated
+    (false-negative) box of the previous frame is copied before it is moved and flagged, so prev_cls_det_boxes may hold shared dicts."""
     annos, fn_annos, dead_prev, keep_dets = [], [], [], []
     for n in range(len(prev_cls_det_boxes)):
         c = int(prev_class[n])
@@ -91,6 +92,8 @@ def decode_frame_from_flags(prev_class, prev_score, det_flags, det_score, cls_de
             dead_prev.append(n)
         elif c == 2:
             box = prev_cls_det_boxes[n]
+            if copy_fn:
+                box = dict(box, translation=list(box["translation"]))
             box["translation"][:2] = [t + time_lag * v for t, v in zip(box["translation"][:2], box["velocity"])]
             box["FN"] = True
             box["token"] = token
@@ -131,7 +134,7 @@ class AffinityDecoder:
         self.results[token] = annos
         return annos
 
-    def add_batch(self, matched1, matched2, processed_batch, on_device=True, flags=None, lags=None):
+    def add_batch(self, matched1, matched2, processed_batch, on_device=True, flags=None, lags=None, copy_fn=False):
         """Every frame pair of a batch (any number of frames x classes).  on_device: the per-row / per-column decisions of the
         whole batch come from ONE launch of the decode kernel and ONE device->host copy; otherwise the matrices are copied to the
         host once and the restated reference loop runs per frame.  flags: the decisions already on the host (decode_flags_unpack of
@@ -154,7 +157,7 @@ class AffinityDecoder:
             cls, prev_cls = cls_all[b], prev_all[b]
             time_lag = float(lags[b]) if len(prev_cls) else 0.0
             if on_device:
-                annos, dead_prev, keep = decode_frame_from_flags(pc[b], ps[b], df[b], ds[b], cls, prev_cls, token, time_lag)
+                annos, dead_prev, keep = decode_frame_from_flags(pc[b], ps[b], df[b], ds[b], cls, prev_cls, token, time_lag, copy_fn=copy_fn)
             else:
                 annos, dead_prev, keep = decode_frame(m1h[b], m2h[b], cls, prev_cls, token, time_lag)
             if len(prev_cls):

@@ -15,7 +15,10 @@ detections, dead-track / false-positive ratios) draws from `rng` in the same ord
 import json
 import math
 import os
+import pickle
 import random as _random
+import subprocess
+import sys
 
 import numpy as np
 
@@ -149,6 +152,84 @@ class FramePairs:
         return out
 
 
+def parse_frame(det_path, cls_info_path, token):
+    """Both files of a frame, read and parsed once: (number of detections, (n, 11) float64 rows [x, y, z, w, l, h, yaw, vx, vy, 0, score]
+    (box rows with column 9 - the time difference - left open), the class dicts, {class name: indices of its detections})."""
+    with open(os.path.join(det_path, token + ".json")) as f:
+        boxes = json.load(f)
+    with open(os.path.join(cls_info_path, token + ".json")) as f:
+        cls_info = json.load(f)
+    by_class = {}
+    for i, ci in enumerate(cls_info):
+        by_class.setdefault(ci["detection_name"], []).append(i)
+    base = np.zeros((len(boxes), 11))
+    if len(boxes):
+        # quaternion_yaw for all rows at once: the same float64 operations in the same order (products, sums, sqrt and quotients
+        # are exactly rounded in numpy as in Python); atan2 stays math.atan2 (numpy's may be a vector-library version)
+        b = np.array(boxes, dtype=np.float64).reshape(len(boxes), -1)
+        w, x, y, z = b[:, 6], b[:, 7], b[:, 8], b[:, 9]
+        n = np.sqrt(w * w + x * x + y * y + z * z)
+        n = np.where(n > 0.0, n, 1.0)
+        w, x, y, z = w / n, x / n, y / n, z / n
+        sn, cs = 2.0 * (x * y + w * z), 1.0 - 2.0 * (y * y + z * z)
+        base[:, 0:6] = b[:, 0:6]
+        base[:, 6] = [math.atan2(p, q) for p, q in zip(sn.tolist(), cs.tolist())]
+        base[:, 7:9] = b[:, 10:12]
+        base[:, 10] = [float(ci["detection_score"]) for ci in cls_info]
+    return len(boxes), base, cls_info, by_class
+
+
+class ParseWorkers:
+    """Child processes that read and parse frame files (parse_frame) ahead of the chain: the JSON decoding is the largest host term of
+    configs 2-4 and cannot share the interpreter with the kernel launches (a thread takes the GIL from them).  Each child runs THIS FILE
+    as a script (`python -I frames.py --parse-worker ...`: numpy and json only - a child that imported the package would spend longer
+    importing torch than the parsing it takes over) and answers pickled token lists on its stdin with pickled lists of parse_frame
+    tuples on its stdout, in order.  request(i, tokens) / result(i) address child i % workers; close() ends them."""
+
+    def __init__(self, det_path, cls_info_path, workers=3):
+        cmd = [sys.executable, "-I", os.path.abspath(__file__), "--parse-worker", det_path, cls_info_path]
+        self.procs = [subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE) for _ in range(max(1, int(workers)))]
+
+    def request(self, i, tokens):
+        p = self.procs[i % len(self.procs)]
+        pickle.dump(list(tokens), p.stdin, protocol=pickle.HIGHEST_PROTOCOL)
+        p.stdin.flush()
+
+    def result(self, i):
+        p = self.procs[i % len(self.procs)]
+        try:
+            return pickle.load(p.stdout)
+        except EOFError:
+            raise RuntimeError("frame parse worker exited with code %s" % p.wait())
+
+    def close(self):
+        for p in self.procs:
+            try:
+                p.stdin.close()
+            except OSError:
+                pass
+        for p in self.procs:
+            p.stdout.close()
+            p.wait()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def _serve_parse_worker(det_path, cls_info_path):
+    inp, out = sys.stdin.buffer, sys.stdout.buffer
+    while True:
+        try:
+            tokens = pickle.load(inp)
+        except EOFError:
+            return
+        pickle.dump([parse_frame(det_path, cls_info_path, t) for t in tokens], out, protocol=pickle.HIGHEST_PROTOCOL)
+        out.flush()
+
+
 class SharedFrames:
     """`FramePairs.load` for SEVERAL detection classes over the same frames: every per-frame file is read and parsed once (the
     reference's per-class eval runs re-read both files of a frame twice per class, as current and as previous frame), the quaternion ->
@@ -165,24 +246,19 @@ class SharedFrames:
     def _frame(self, token):
         fr = self._parsed.get(token)
         if fr is None:
-            if len(self._parsed) >= self.cache:
-                self._parsed.pop(next(iter(self._parsed)))
-            with open(os.path.join(self.det_path, token + ".json")) as f:
-                boxes = json.load(f)
-            with open(os.path.join(self.cls_info_path, token + ".json")) as f:
-                cls_info = json.load(f)
-            by_class = {}
-            base = []
-            for i, (b, ci) in enumerate(zip(boxes, cls_info)):
-                by_class.setdefault(ci["detection_name"], []).append(i)
-                base.append([float(b[0]), float(b[1]), float(b[2]), float(b[3]), float(b[4]), float(b[5]), quaternion_yaw(b[6:10]),
-                             float(b[10]), float(b[11]), 0.0, float(ci["detection_score"])])
-            fr = self._parsed[token] = (len(boxes), base, cls_info, by_class)
+            fr = self.adopt(token, parse_frame(self.det_path, self.cls_info_path, token))
+        return fr
+
+    def adopt(self, token, parsed):
+        """Puts a parsed frame (parse_frame's tuple, e.g. from a ParseWorkers child) into the cache."""
+        if len(self._parsed) >= self.cache:
+            self._parsed.pop(next(iter(self._parsed)))
+        fr = self._parsed[token] = tuple(parsed) + ({},)
         return fr
 
     def _rows(self, name, token, time_diff):
         N = self.max_objects[name]
-        nbox, base, cls_info, by_class = self._frame(token)
+        nbox, base, cls_info, by_class, _ = self._frame(token)
         rows = np.zeros((N, 11))
         if nbox == 0:
             return rows, list(range(N)), [], 0
@@ -192,12 +268,62 @@ class SharedFrames:
             pick.sort()
             keep = [keep[i] for i in pick]
         if keep:
-            r = np.array([base[i] for i in keep])
+            r = base[keep]
             r[:, 9] = time_diff
             rows[:len(keep)] = r
         # fresh dicts: decode.decode_frame writes flags / scores into them and moves `translation` of a propagated box in place
         kept_cls = [dict(cls_info[i], translation=list(cls_info[i]["translation"])) for i in keep]
         return rows, keep, kept_cls, len(keep)
+
+    def _class_rows(self, name, token):
+        """(indices of the class's detections in the frame, their (k, 11) float64 rows with column 9 = 0), cached with the frame."""
+        fr = self._frame(token)
+        hit = fr[4].get(name)
+        if hit is None:
+            keep = fr[3].get(name, [])
+            hit = fr[4][name] = (keep, fr[1][keep])
+        return hit
+
+    def load_run(self, name, run, share_prev=False):
+        """Every frame pair of a run of consecutive frames ([(token, prev token or "")], pipeline._scene_runs) for one class, as the stacked
+        batch `collate_pairs([load(name, t) for t in run])` gives (same fp32 rows, same class dicts), without building each frame twice
+        (as current frame and as the next one's previous frame): the rows of a (frame, class) are assembled once and written straight into
+        the (n, max_obj, 11) fp32 stacks.  share_prev: the previous frame's class dicts are the cached ones, NOT fresh copies - for a
+        consumer that copies before it writes (decode.decode_frame_from_flags(copy_fn=True)); the current frame's dicts are always fresh.
+        Returns None when a frame holds more than max_obj detections of the class (random sub-sampling: use `load`)."""
+        N, n = self.max_objects[name], len(run)
+        det, prev = np.zeros((n, N, 11), np.float32), np.zeros((n, N, 11), np.float32)
+        out = dict(det_boxes=det, prev_det_boxes=prev, num_det_boxes=[], num_prev_det_boxes=[], cls_det_boxes=[], prev_cls_det_boxes=[],
+                   metadata=[], prev_metadata=[])
+        for i, (token, prev_token) in enumerate(run):
+            fi = self.frame_info[token]
+            time_diff = 1e-6 * fi["timestamp"] - 1e-6 * fi["prev_timestamp"] if "prev_timestamp" in fi else 0.0
+            keep, rows = self._class_rows(name, token)
+            k = len(keep)
+            if k > N:
+                return None
+            cls_info = self._frame(token)[2]
+            if k:
+                det[i, :k] = rows
+                det[i, :k, 9] = time_diff
+            out["cls_det_boxes"].append([dict(cls_info[j], translation=list(cls_info[j]["translation"])) for j in keep])
+            out["num_det_boxes"].append(k)
+            kp, prev_cls = 0, []
+            if prev_token != "":
+                pkeep, prows = self._class_rows(name, prev_token)
+                kp = len(pkeep)
+                if kp > N:
+                    return None
+                pinfo = self._frame(prev_token)[2]
+                if kp:
+                    prev[i, :kp] = prows
+                    prev[i, :kp, 9] = time_diff
+                prev_cls = [pinfo[j] for j in pkeep] if share_prev else [dict(pinfo[j], translation=list(pinfo[j]["translation"])) for j in pkeep]
+            out["prev_cls_det_boxes"].append(prev_cls)
+            out["num_prev_det_boxes"].append(kp)
+            out["metadata"].append(dict(token=token))
+            out["prev_metadata"].append(dict(token=prev_token or token))
+        return out
 
     def load(self, name, token, known_tokens=None):
         fi = self.frame_info[token]
@@ -236,3 +362,8 @@ def collate_pairs(samples, device=None):
             if k in batch:
                 batch[k] = batch[k].pin_memory().to(device, non_blocking=True) if device.type == "cuda" else batch[k].to(device)
     return batch
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 4 and sys.argv[1] == "--parse-worker":
+        _serve_parse_worker(sys.argv[2], sys.argv[3])

@@ -202,7 +202,7 @@ def _run_features(bev, models, names, run, device, bank_cache, timer=_NO_TIMER):
 
 
 def run_split(models, paths, scenes, bev, device, work_dir=None, split="val", max_age=4, batch_pairs=32, decode_on_device=True,
-              rank=0, world=1, group=None, forward_override=None, tracker_on_device=True, timer=None, prefetch=False):
+              rank=0, world=1, group=None, forward_override=None, tracker_on_device=True, timer=None, prefetch=None):
     """Configs 2-4 end to end.  models: {class name: Shasta on `device`}; scenes: [(scene name, [tokens])] of the WHOLE split.
     Scenes are sharded over `world` ranks; rank 0 returns (per-class cp dicts, merged dict, tracking dict) and, with work_dir,
     writes <class>/cp_<split>.json, merged_cp_<split>.json and tracking_result.json like the reference CLIs; other ranks
@@ -255,6 +255,39 @@ def run_split(models, paths, scenes, bev, device, work_dir=None, split="val", ma
     return per_class, merged, tracking
 
 
+def forward_only_seconds(models, paths, scenes, bev, device, batch_pairs=32):
+    """Device time of the chain's forward alone at the chain's batching: for every run of the split, shared_conv of all class heads,
+    every class's affinity forward and the decode kernel, bracketed by HIP events on the launch stream (the stand-in that produces the
+    neck outputs is outside the bracket, the loader runs before it, nothing is decoded or tracked).  The yardstick `run_split`'s
+    frames/s is compared with in bench.py's `extra.pipeline`."""
+    names = [n for n in NUSCENES_TRACKING_NAMES if n in models]
+    all_tokens = [t for _, toks in scenes for t in toks]
+    _loader_init(paths["det_path"], paths["cls_info_path"], paths["frame_info_path"], {n: CLASS_CONFIGS[n] for n in names}, all_tokens)
+    runs = list(_scene_runs(scenes, {n for n, _ in scenes}, _LOADER["known"], _LOADER["frames"].frame_info, batch_pairs))
+    bank_cache, spans = {}, []
+    for run in runs:
+        batches = _loader_run(run, True)
+        dev_in = {n: (torch.from_numpy(b["det_boxes"]).to(device), torch.from_numpy(b["prev_det_boxes"]).to(device)) for n, b in batches.items()}
+        toks = [run[0][1] or run[0][0]] + [t for t, _ in run]
+        x = bev.neck_batch(toks, device)
+        if "bank" not in bank_cache:
+            from .shared_conv import SharedConvBank
+            bank_cache["bank"] = SharedConvBank([models[n] for n in names])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        with torch.no_grad():
+            feats = dict(zip(names, bank_cache["bank"](x)))
+            for n in names:
+                b = batches[n]
+                ex = dict(b, det_boxes=dev_in[n][0], prev_det_boxes=dev_in[n][1], bev_feature=feats[n][1:], prev_bev_feature=feats[n][:-1])
+                m1, m2, _ = models[n](ex, train_mode=False)
+                decode.decode_flags_launch(m1, m2, [len(p) for p in b["prev_cls_det_boxes"]], [len(c) for c in b["cls_det_boxes"]])
+        e1.record()
+        spans.append((e0, e1))
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in spans) * 1e-3
+
+
 # ---- loader side of the frame-major chain ---------------------------------------------------------------------------------------------
 _LOADER = {}
 
@@ -265,27 +298,32 @@ def _loader_init(det_path, cls_info_path, frame_info_path, max_objects, known):
     _LOADER["names"] = list(max_objects)
 
 
-def _loader_run(run):
-    """All classes' samples of one run as plain numpy / list data."""
+def _loader_run(run, share_prev=False):
+    """All classes' samples of one run as plain numpy / list data (frames.collate_pairs' keys)."""
     import numpy as np
     sf, known, out = _LOADER["frames"], _LOADER["known"], {}
     for n in _LOADER["names"]:
-        samples = [sf.load(n, t, known_tokens=known) for t, _ in run]
+        fast = sf.load_run(n, run, share_prev=share_prev)
+        if fast is not None:
+            out[n] = fast
+            continue
+        samples = [sf.load(n, t, known_tokens=known) for t, _ in run]  # a frame with more than max_obj detections of the class
         out[n] = dict(det_boxes=np.stack([s["det_boxes"] for s in samples]).astype(np.float32),
                       prev_det_boxes=np.stack([s["prev_det_boxes"] for s in samples]).astype(np.float32),
                       num_det_boxes=[s["num_det_boxes"] for s in samples], num_prev_det_boxes=[s["num_prev_det_boxes"] for s in samples],
                       cls_det_boxes=[s["cls_det_boxes"] for s in samples], prev_cls_det_boxes=[s["prev_cls_det_boxes"] for s in samples],
                       metadata=[dict(token=s["token"]) for s in samples],
-                      prev_metadata=[dict(token=s["prev_token"] or s["token"]) for s in samples])  # frames.collate_pairs
+                      prev_metadata=[dict(token=s["prev_token"] or s["token"]) for s in samples])
     return out
 
 
 def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, batch_pairs, decode_on_device, timer, prefetch):
-    """prefetch: False / None (default) - the loader runs in line, between the launches of one run and the host half of the previous one
-    (the device is busy with the queued run meanwhile); True - one loader thread.  Measured on the 20 x 40 split: in line 653 - 701
-    frames/s, thread 526 - 632 (parsing is pure Python: the thread takes the GIL from the launches), two or four spawned loader
-    processes 248 - 303 (their start-up - importing torch - costs more than the 0.6 - 1.6 s of parsing they take over at this size)."""
-    from concurrent.futures import ThreadPoolExecutor
+    """prefetch: number of frame-parse worker processes (frames.ParseWorkers); 0 / False / None (default) - every file is parsed in line,
+    between the launches of one run and the host half of an earlier one.  Measured on the 20 x 40 split (MI355X box, 256 host cores):
+    in line 800 - 867 frames/s; 2 / 3 / 4 parse workers 650 - 840 / 700 - 717 / 617 - 682 (each child needs ~0.2 s to start and its
+    answers have to be unpickled here: at 800 frames that costs more than the 0.2 s of json decoding it takes over; a split of several
+    thousand frames amortises it); a loader THREAD 526 - 632 (parsing is pure Python: the thread takes the GIL from the launches);
+    multiprocessing pools 248 - 303 (every child imports the main module and torch)."""
     max_obj = {n: CLASS_CONFIGS[n] for n in names}
     init = (paths["det_path"], paths["cls_info_path"], paths["frame_info_path"], max_obj, list(all_tokens))
     _loader_init(*init)
@@ -295,19 +333,26 @@ def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, ba
     runs = list(_scene_runs(scenes, mine, known, _LOADER["frames"].frame_info, batch_pairs))
     if not runs:
         return decs
-    pool = None
-    if prefetch and len(runs) > 1:
-        pool = ThreadPoolExecutor(max_workers=1)
-        futs = [pool.submit(_loader_run, runs[0])]
+    share = bool(decode_on_device)  # the device-decision decode copies a previous-frame box before it writes to it
+    prefetch = 3 if prefetch is True else int(prefetch or 0)
+    pool = frames.ParseWorkers(paths["det_path"], paths["cls_info_path"], workers=prefetch) if prefetch else None
 
-        def _threaded():
-            for i in range(len(runs)):
-                if i + 1 < len(runs):
-                    futs.append(pool.submit(_loader_run, runs[i + 1]))
-                yield futs[i].result()
-        stream_of_batches = _threaded()
-    else:
-        stream_of_batches = (_loader_run(r) for r in runs)
+    def run_tokens(run):
+        return ([run[0][1]] if run[0][1] else []) + [t for t, _ in run]
+
+    def batches_in_order():
+        ahead = 2 * prefetch
+        if pool:
+            for i in range(min(ahead, len(runs))):
+                pool.request(i, run_tokens(runs[i]))
+        for i, r in enumerate(runs):
+            if pool:
+                for t, fr in zip(run_tokens(r), pool.result(i)):
+                    _LOADER["frames"].adopt(t, fr)
+                if i + ahead < len(runs):
+                    pool.request(i + ahead, run_tokens(runs[i + ahead]))
+            yield _loader_run(r, share)
+    stream_of_batches = batches_in_order()
 
     def tensors(raw):
         for b in raw.values():
@@ -322,12 +367,12 @@ def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, ba
             ev.synchronize()  # this run's decision copies have landed (the next run's launches are already queued behind them)
         for n, b, host, m1, m2 in pending:
             if host is not None:
-                decs[n].add_batch(None, None, b, flags=decode.decode_flags_unpack(host), lags=b["_lags"])
+                decs[n].add_batch(None, None, b, flags=decode.decode_flags_unpack(host), lags=b["_lags"], copy_fn=share)
             else:
                 decs[n].add_batch(m1, m2, b, on_device=False, lags=b["_lags"])
 
     bank_cache = {}
-    waiting = None
+    waiting = []  # runs whose launches are queued and whose decisions have not been read yet
     try:
         for run in runs:
             with timer.stage("loader + collate (wait)"):
@@ -356,13 +401,13 @@ def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, ba
                     ev.record()
             # the host half of the PREVIOUS run is done while the device works on this one: one event wait per run, no stream-wide stall
             with timer.stage("decode (host)"):
-                if waiting is not None:
-                    finish(*waiting)
-                waiting = (pending, ev)
+                waiting.append((pending, ev))
+                if len(waiting) > 1:  # (two runs in flight were measured: the event waits vanish, the total does not move)
+                    finish(*waiting.pop(0))
         with timer.stage("decode (host)"):
-            if waiting is not None:
-                finish(*waiting)
+            for w in waiting:
+                finish(*w)
     finally:
         if pool:
-            pool.shutdown()
+            pool.close()
     return decs
