@@ -163,7 +163,7 @@ typedef struct shasta_linear {
 #define SHASTA_OPT_F32_AFF 4           /* the six aff layers on v_mfma_f32_16x16x4_f32 for every row count */
 #define SHASTA_OPT_F16X2_WEIGHT_STREAM 8 /* aug_shape first layer above 64 frame-pairs from two range-scaled fp16 pieces per operand
                                             (round to nearest, three products per fp32 product) instead of three bf16 pieces (six) */
-#define SHASTA_OPT_F16X2_PAIR 16         /* second layers of the three pair MLPs in the same two-piece fp16 form (feat_dim 256) */
+#define SHASTA_OPT_F16X2_PAIR 16         /* second layers of the three pair MLPs in the same two-piece fp16 form (feat_dim 256: 16x16x32 tiles, 320: 32x32x16 tiles) */
 #define SHASTA_OPT_PRECUT_WEIGHT_STREAM 32 /* with SHASTA_OPT_F16X2_WEIGHT_STREAM: stream the aug_shape first-layer weights as pre-cut fp16
                                               pieces from the companion buffer (shasta_aug_shape_aux_f32 built with this bit: + 4 bytes per
                                               weight resident) instead of cutting the fp32 tensors on the fly; same arithmetic, same results */

@@ -481,6 +481,10 @@ int pair_f16_pack(const shasta_weights* w, float* out, hipStream_t st);
 int launch_pair_f16(const float* packed, const float* p16, const float* UP, const float* UC, const float* hand_prev,
                     const float* hand_det, const float* denom, float* residual, int B, int T, int D, int ld, int nf, bool grid,
                     hipStream_t st);
+bool pair_f16w_serves(int F);
+int pair_f16w_pack(const shasta_weights* w, float* out, hipStream_t st);
+int launch_pair_f16w(const float* packed, const float* p16, const float* UP, const float* UC, const float* hand_prev,
+                     const float* hand_det, const float* denom, float* residual, int B, int T, int D, int ld, int F, hipStream_t st);
 int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
                    int N, int K, int act, hipStream_t st);
 int launch_gemm_nt_dual(const float* A0, const float* W0, const float* bias0, float* C0, const float* A1, const float* W1,
@@ -556,6 +560,13 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
         if (ev1) (void)hipEventRecord(ev1, st);
         return rc;
     }
+    if ((w->options & SHASTA_OPT_F16X2_PAIR) && pair_f16w_serves(F)) {
+        // F = 320 (every shipped class configuration): the same arithmetic on 32-wide tiles (pair_f16w.hip)
+        if (ev0) (void)hipEventRecord(ev0, st);
+        rc = launch_pair_f16w(packed, packed + P.p16w, UP, UC, hand_prev, hand_det, denom, residual, B, T, D, ld, F, st);
+        if (ev1) (void)hipEventRecord(ev1, st);
+        return rc;
+    }
     // lane = pair, 4x4x1 MFMA.  The 8 waves of a workgroup share one 64-detection UC tile and take different track ranges
     // (two workgroups per CU by LDS, 113 VGPRs in the VGPR MFMA form: 4 waves per SIMD).
     constexpr int wpb = 8;
@@ -614,6 +625,7 @@ int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {
     const PackedLayout P(w->max_obj, w->num_feats, w->feat_dim);
     if ((rc = aff_pieces_pack(w, packed + P.affp, st))) return rc;
     if (w->feat_dim == 256 && (rc = pair_f16_pack(w, packed + P.p16, st))) return rc;
+    if (pair_f16w_serves(w->feat_dim) && (rc = pair_f16w_pack(w, packed + P.p16w, st))) return rc;
     if (embed_rows_serves(w->feat_dim) && (rc = embed_pack(w, packed, st))) return rc;
     return rc;
 }

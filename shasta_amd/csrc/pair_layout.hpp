@@ -77,7 +77,7 @@ SH_HD constexpr size_t ap_layer_offset(int layer, int D) {  // in fragments
 // Packed buffer sections (float offsets).  Dp = padded aff width (multiple of 4).
 struct PackedLayout {
     int F, nf, N, D, Dp, E12, ET;
-    size_t a4, wemb_prev, wemb_cur, bemb_cur, wbox_prev, wbox_cur, bbox_cur, aff0, affp, p16, embp, total;
+    size_t a4, wemb_prev, wemb_cur, bemb_cur, wbox_prev, wbox_cur, bbox_cur, aff0, affp, p16, p16w, embp, total;
     SH_HD PackedLayout(int max_obj, int num_feats, int f) {
         const PairDims d(f);
         F = f;
@@ -98,6 +98,7 @@ struct PackedLayout {
         aff0 = o;       o += (size_t)128 * Dp;         // aff.0.weight zero padded to (128, Dp)
         affp = o;       o += ap_layer_offset(6, D) * 256;  // the six aff layers as bf16 piece fragments (aff_pieces.hip)
         p16 = o;        o += (size_t)(2 * 4 * 64 * 4 + 4);  // second layers of the pair MLPs as fp16 piece fragments + 3 exponents (pair_f16.hip)
+        p16w = o;       o += (size_t)(2 * 16 * 64 * 4 + 4);  // the same as 32x32x16 fragments (pair_f16w.hip: up to 16 fragments x 2 pieces x 1 KB)
         // wemb_prev / wemb_cur as bf16 piece fragments [side][feature block][k step][piece][64 lanes] x 16 B (embed_rows.hip)
         embp = o;       o += (size_t)2 * ((E12 + 31) / 32) * (f / 16) * 3 * 256;
         total = o;

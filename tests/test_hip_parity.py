@@ -924,8 +924,8 @@ def test_f32_arithmetic_option_matches_oracle_and_pieces(name, B):
         ref = im["residual"].numpy()
         np.testing.assert_allclose(outs[mode][2], ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
     assert not np.array_equal(outs["pieces"][2], outs["f32"][2])  # different kernels ran
-    # without the pre-cut image the fp16 forms serve the weight stream above 64 frame-pairs and the pair MLPs at feature width 256 ...
-    assert np.array_equal(outs["pieces"][2], outs["f16x2-cut-in-kernel"][2]) == (B <= 64 and c["np"] * 64 != 256)
+    # without the pre-cut image the fp16 forms serve the weight stream above 64 frame-pairs and the pair MLPs at feature widths 256 / 320 ...
+    assert np.array_equal(outs["pieces"][2], outs["f16x2-cut-in-kernel"][2]) == (B <= 64 and c["np"] * 64 not in (256, 320))
     # ... with it (default) the fp16 weight stream serves every batch size from 17; above 64 both read the same pieces
     assert np.array_equal(outs["f16x2"][2], outs["f16x2-cut-in-kernel"][2]) == (B > 64)
 
@@ -955,10 +955,12 @@ def test_piece_kernels_are_fp32_accurate():
         assert max(a["max_abs_err"], p["max_abs_err"]) < 2e-5 * max(1.0, a["ref_scale"])
 
 
-def test_pair_kernels_are_fp32_accurate():
-    """The pair stage at F=256 runs its second layers on the f16 matrix path in the default arithmetic (pair_f16.hip) and entirely on
-    the f32 matrix path otherwise (pair_mfma4_kernel).  Both against a float64 evaluation of shasta.py:277-319 on the same tables
-    (tools/pair_check.py), default-init and sharpened pair weights: the fp16 form's error stays at the f32 kernel's level."""
+@pytest.mark.parametrize("points,feats", [(4, 7), (5, 3)])
+def test_pair_kernels_are_fp32_accurate(points, feats):
+    """The pair stage runs its second layers on the f16 matrix path in the default arithmetic - pair_f16.hip at F = 256 (16x16x32 tiles),
+    pair_f16w.hip at F = 320 (32x32x16 tiles, the shipped class configurations) - and entirely on the f32 matrix path otherwise
+    (pair_mfma4_kernel).  Both against a float64 evaluation of shasta.py:277-319 on the same tables (tools/pair_check.py),
+    default-init and sharpened pair weights: the fp16 form's error stays at the f32 kernel's level."""
     import json
     import os
     import subprocess
@@ -967,34 +969,37 @@ def test_pair_kernels_are_fp32_accurate():
     # --spread 3: feature rows from 1e-3 to 1e3 times the usual size meet in one detection tile: the per-track range scaling of the
     # fp16 form (largest |UP[t]| + the tile's largest |UC|) must neither overflow nor cost more than the f32 kernel's error at that scale
     for extra in ([], ["--gain", "2.0"], ["--spread", "3"]):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "pair_check.py"), "--max-obj", "150", "--batch", "2"] + extra,
-                           capture_output=True, text=True, cwd=root, timeout=900)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "pair_check.py"), "--max-obj", "150", "--batch", "2",
+                            "--points", str(points), "--feats", str(feats)] + extra, capture_output=True, text=True, cwd=root, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         rows = {d["arithmetic"]: d for d in (json.loads(l) for l in r.stdout.splitlines() if l.startswith("{"))}
         assert set(rows) == {"f16x2", "pieces", "f32", "f16grid"}  # (2 x 152 table rows: "f16grid" falls back to the per-pair cut here)
         f16, f32 = rows["f16x2"], rows["f32"]
+        assert f16["max_abs_err"] != f32["max_abs_err"], "the fp16-piece pair kernel did not run"
         assert f16["max_abs_err"] <= 2.0 * f32["max_abs_err"] + 1e-7 * f32["ref_scale"], (f16, f32)
         assert f16["rms_err"] <= 1.5 * f32["rms_err"] + 1e-8 * f32["ref_scale"], (f16, f32)
         assert f16["max_abs_err"] <= 1e-5 * f16["ref_scale"]
 
 
+@pytest.mark.parametrize("npnt,nf", [(4, 7), (5, 3)])
 @pytest.mark.parametrize("N,B", [(1, 1), (2, 3), (5, 2), (13, 4), (47, 2), (129, 1), (200, 3)])
-def test_fp16_pair_path_at_odd_table_sizes_matches_oracle(N, B):
-    """pair_f16_kernel (F = 256) deals a workgroup's tracks unevenly to the two waves of a SIMD (launch_pair_f16) and several workgroups
-    share a detection tile when the launch is small: table sizes from 3 rows (one track per early wave, none for most others) through
-    ragged last tiles and last waves, against the CPU oracle on the same seeded inputs; every row of matched1 must keep its arg-max."""
+def test_fp16_pair_path_at_odd_table_sizes_matches_oracle(N, B, npnt, nf):
+    """pair_f16_kernel (F = 256) deals a workgroup's tracks unevenly to the two waves of a SIMD (launch_pair_f16), pair_f16w_kernel
+    (F = 320) walks the tracks two per step with 32-detection tiles, and several workgroups share a detection tile when the launch is
+    small: table sizes from 3 rows (one step for one wave, none for the others) through ragged last tiles, odd track counts and
+    last waves, against the CPU oracle on the same seeded inputs; every row of matched1 must keep its arg-max."""
     import shasta_amd
     dev = _dev()
     torch.manual_seed(100 + N)
     m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
                                          bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075],
-                                                            out_stride=8), max_obj=N, num_feats=7, num_point=4)).eval()
+                                                            out_stride=8), max_obj=N, num_feats=nf, num_point=npnt)).eval()
     w = {k: v.detach().clone() for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(N)
     bev = torch.relu(torch.randn(B, 180, 180, 64, generator=g))
     pbev = torch.relu(torch.randn(B, 180, 180, 64, generator=g))
     det, prev = O.synth_boxes(g, B, N), O.synth_boxes(g, B, N)
-    r1, r2 = O.forward_from_bev(w, bev, pbev, det.clone(), prev.clone(), 7, 4)
+    r1, r2 = O.forward_from_bev(w, bev, pbev, det.clone(), prev.clone(), nf, npnt)
     m = m.to(dev)
     assert m.arithmetic == "f16x2"
     with torch.no_grad():
