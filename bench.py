@@ -355,7 +355,7 @@ def rooflines(cfg, arithmetic, r, with_traffic=True):
     pair_useful = 2.0 * wk.useful_pair_macs * wk.pairs * B
     pair_tflops = pair_useful / (pair_ms * 1e-3) / 1e12
     pair_f16 = arithmetic in ("f16x2", "f16grid") and wk.F in PAIR_F16_WIDTHS  # second layers as three fp16 piece products each
-    pair_kernel = "pair_f16_kernel" if pair_f16 else "pair_mfma4_kernel"
+    pair_kernel = ("pair_f16w_kernel" if wk.F == 320 else "pair_f16_kernel") if pair_f16 else "pair_mfma4_kernel"
     tr, src = _pmc_traffic(B, "pair", pair_kernel) if (with_traffic and headline and arithmetic == "f16x2") else (None, None)
     roof_pair = {"bound": "mfma", "achieved": pair_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": pair_tflops / MFMA_F32_PEAK_TFLOPS, "traffic": tr, "traffic_source": src,
@@ -366,11 +366,15 @@ def rooflines(cfg, arithmetic, r, with_traffic=True):
     T = wk.N + 2
     if pair_f16:
         roof_pair.update({
-            "kernel": "pair_f16_kernel: per-pair MLP tails (second layers on the f16 matrix path) + hand residual -> residual (B, %d, %d)" % (T, T),
+            "kernel": "%s: per-pair MLP tails (second layers on the f16 matrix path) + hand residual -> residual (B, %d, %d)" % (pair_kernel, T, T),
             "mfma_dtype": "f16 (layer 2: three piece products per fp32 product) + f32 (layers 3-4)",
             "executed_flops_per_launch": 2.0 * (3 * PAIR_F16_LAYER2_SLOTS[wk.F] + (wk.executed_pair_macs - wk.layer2_macs)) * wk.pairs * B,
             "note": "useful fp32 flops priced against the f32 MFMA peak, the yardstick of the f32 form (pair_mfma4_kernel, --arithmetic pieces); "
-                    "in this form the kernel is bound by VALU issue (cutting the activations into fp16 pieces), not by a matrix pipe"})
+                    "in this form the kernel is bound by VALU issue (cutting the activations into fp16 pieces), not by a matrix pipe"
+                    if wk.F != 320 else
+                    "useful fp32 flops priced against the f32 MFMA peak, the yardstick of the f32 form (pair_mfma4_kernel, --arithmetic pieces); "
+                    "32x32x16 tiles over the 144 columns: 60 f16 MFMAs + 102 f32 4x4x1 per 64 pairs keep the matrix pipe busy ~85 % of the time at the "
+                    "clock the power cap leaves, the cuts the vector pipe ~70 % (DESIGN.md K4)"})
     else:
         roof_pair.update({"kernel": "pair_mfma4_kernel<%d,8>: per-pair MLP tails + hand residual -> residual (B, %d, %d)" % (wk.F, T, T),
                           "mfma_dtype": "f32", "executed_flops_per_launch": 2.0 * wk.executed_pair_macs * wk.pairs * B})
@@ -378,8 +382,8 @@ def rooflines(cfg, arithmetic, r, with_traffic=True):
 
 
 PRECUT = True                            # Shasta.precut_weight_stream of this run (main() clears it for --no-precut)
-PAIR_F16_WIDTHS = (256,)                 # feature widths pair_f16_kernel is instantiated for
-PAIR_F16_LAYER2_SLOTS = {256: 2048}      # multiply-add slots of its layer-2 MFMAs per pair and piece product (16 rows x 128 k)
+PAIR_F16_WIDTHS = (256, 320)             # feature widths with an fp16-piece pair kernel (pair_f16_kernel / pair_f16w_kernel)
+PAIR_F16_LAYER2_SLOTS = {256: 2048, 320: 5120}  # multiply-add slots of the layer-2 MFMAs per pair and piece product (16 rows x 128 k; 10 fragments x 32 rows x 16 k)
 
 
 def brief(cfg, arithmetic, r):

@@ -355,7 +355,9 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
             // (exact, a power of two), so the clamp of one packed fma is the ReLU of two values; the conversion multiplies by 2^14.
             const float cs = __builtin_ldexpf(1.0f, e1 - 14);
             cs2 = pf2{cs, cs};
-            // this lane's UP values, scaled: 8 per k step (the same address in the 16 lanes of a k block: LDS broadcast)
+            // this lane's UP values, scaled: 8 per k step (the same address in the 16 lanes of a k block: LDS broadcast).  (Scaling the row
+            // ONCE in place in LDS - 2 packed multiplies per track instead of 16, as pair_f16w.hip does - measured slower here: 4.06 - 4.13 ->
+            // 4.18 - 4.21 ms at 512 frame-pairs: the write-read round trip through LDS sits on this kernel's critical path.)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const f32x4 a = *reinterpret_cast<const lf32x4*>(up + 32 * s + 8 * kb), c = *reinterpret_cast<const lf32x4*>(up + 32 * s + 8 * kb + 4);
