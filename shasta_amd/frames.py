@@ -15,10 +15,7 @@ detections, dead-track / false-positive ratios) draws from `rng` in the same ord
 import json
 import math
 import os
-import pickle
 import random as _random
-import subprocess
-import sys
 
 import numpy as np
 
@@ -179,57 +176,6 @@ def parse_frame(det_path, cls_info_path, token):
     return len(boxes), base, cls_info, by_class
 
 
-class ParseWorkers:
-    """Child processes that read and parse frame files (parse_frame) ahead of the chain: the JSON decoding is the largest host term of
-    configs 2-4 and cannot share the interpreter with the kernel launches (a thread takes the GIL from them).  Each child runs THIS FILE
-    as a script (`python -I frames.py --parse-worker ...`: numpy and json only - a child that imported the package would spend longer
-    importing torch than the parsing it takes over) and answers pickled token lists on its stdin with pickled lists of parse_frame
-    tuples on its stdout, in order.  request(i, tokens) / result(i) address child i % workers; close() ends them."""
-
-    def __init__(self, det_path, cls_info_path, workers=3):
-        cmd = [sys.executable, "-I", os.path.abspath(__file__), "--parse-worker", det_path, cls_info_path]
-        self.procs = [subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE) for _ in range(max(1, int(workers)))]
-
-    def request(self, i, tokens):
-        p = self.procs[i % len(self.procs)]
-        pickle.dump(list(tokens), p.stdin, protocol=pickle.HIGHEST_PROTOCOL)
-        p.stdin.flush()
-
-    def result(self, i):
-        p = self.procs[i % len(self.procs)]
-        try:
-            return pickle.load(p.stdout)
-        except EOFError:
-            raise RuntimeError("frame parse worker exited with code %s" % p.wait())
-
-    def close(self):
-        for p in self.procs:
-            try:
-                p.stdin.close()
-            except OSError:
-                pass
-        for p in self.procs:
-            p.stdout.close()
-            p.wait()
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        self.close()
-
-
-def _serve_parse_worker(det_path, cls_info_path):
-    inp, out = sys.stdin.buffer, sys.stdout.buffer
-    while True:
-        try:
-            tokens = pickle.load(inp)
-        except EOFError:
-            return
-        pickle.dump([parse_frame(det_path, cls_info_path, t) for t in tokens], out, protocol=pickle.HIGHEST_PROTOCOL)
-        out.flush()
-
-
 class SharedFrames:
     """`FramePairs.load` for SEVERAL detection classes over the same frames: every per-frame file is read and parsed once (the
     reference's per-class eval runs re-read both files of a frame twice per class, as current and as previous frame), the quaternion ->
@@ -250,7 +196,7 @@ class SharedFrames:
         return fr
 
     def adopt(self, token, parsed):
-        """Puts a parsed frame (parse_frame's tuple, e.g. from a ParseWorkers child) into the cache."""
+        """Puts a parsed frame (parse_frame's tuple) into the cache."""
         if len(self._parsed) >= self.cache:
             self._parsed.pop(next(iter(self._parsed)))
         fr = self._parsed[token] = tuple(parsed) + ({},)
@@ -362,8 +308,3 @@ def collate_pairs(samples, device=None):
             if k in batch:
                 batch[k] = batch[k].pin_memory().to(device, non_blocking=True) if device.type == "cuda" else batch[k].to(device)
     return batch
-
-
-if __name__ == "__main__":
-    if len(sys.argv) == 4 and sys.argv[1] == "--parse-worker":
-        _serve_parse_worker(sys.argv[2], sys.argv[3])

@@ -202,7 +202,7 @@ def _run_features(bev, models, names, run, device, bank_cache, timer=_NO_TIMER):
 
 
 def run_split(models, paths, scenes, bev, device, work_dir=None, split="val", max_age=4, batch_pairs=32, decode_on_device=True,
-              rank=0, world=1, group=None, forward_override=None, tracker_on_device=True, timer=None, prefetch=None):
+              rank=0, world=1, group=None, forward_override=None, tracker_on_device=True, timer=None):
     """Configs 2-4 end to end.  models: {class name: Shasta on `device`}; scenes: [(scene name, [tokens])] of the WHOLE split.
     Scenes are sharded over `world` ranks; rank 0 returns (per-class cp dicts, merged dict, tracking dict) and, with work_dir,
     writes <class>/cp_<split>.json, merged_cp_<split>.json and tracking_result.json like the reference CLIs; other ranks
@@ -226,7 +226,7 @@ def run_split(models, paths, scenes, bev, device, work_dir=None, split="val", ma
                              decode_on_device=decode_on_device, forward=forward_override[name], timer=timer)
             per_class[name] = replica.gather_decoded(dec, dst=0, group=group)
     else:
-        decs = _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, batch_pairs, decode_on_device, timer, prefetch)
+        decs = _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, batch_pairs, decode_on_device, timer)
         for name in names:
             per_class[name] = replica.gather_decoded(decs[name], dst=0, group=group)
     if rank != 0:
@@ -317,13 +317,13 @@ def _loader_run(run, share_prev=False):
     return out
 
 
-def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, batch_pairs, decode_on_device, timer, prefetch):
-    """prefetch: number of frame-parse worker processes (frames.ParseWorkers); 0 / False / None (default) - every file is parsed in line,
-    between the launches of one run and the host half of an earlier one.  Measured on the 20 x 40 split (MI355X box, 256 host cores):
-    in line 800 - 867 frames/s; 2 / 3 / 4 parse workers 650 - 840 / 700 - 717 / 617 - 682 (each child needs ~0.2 s to start and its
-    answers have to be unpickled here: at 800 frames that costs more than the 0.2 s of json decoding it takes over; a split of several
-    thousand frames amortises it); a loader THREAD 526 - 632 (parsing is pure Python: the thread takes the GIL from the launches);
-    multiprocessing pools 248 - 303 (every child imports the main module and torch)."""
+def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, batch_pairs, decode_on_device, timer):
+    """The loader runs in line, between the launches of one run and the host half of the previous one (the device is busy with the queued
+    run meanwhile).  Measured alternatives on the 20 x 40 split (MI355X box, 256 host cores; in line: 800 - 867 frames/s): a loader
+    THREAD 526 - 632 (parsing is pure Python: the thread takes the GIL from the launches); multiprocessing pools 248 - 303 (every child
+    imports the main module and torch); 2 - 4 child processes that import numpy and json only, parse the files and pipe the parsed frames
+    back 617 - 840 (unpickling the class dicts here costs what decoding their json costs; ~0.2 s of start-up); two runs in flight
+    instead of one: the event waits vanish, the total does not move."""
     max_obj = {n: CLASS_CONFIGS[n] for n in names}
     init = (paths["det_path"], paths["cls_info_path"], paths["frame_info_path"], max_obj, list(all_tokens))
     _loader_init(*init)
@@ -334,25 +334,7 @@ def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, ba
     if not runs:
         return decs
     share = bool(decode_on_device)  # the device-decision decode copies a previous-frame box before it writes to it
-    prefetch = 3 if prefetch is True else int(prefetch or 0)
-    pool = frames.ParseWorkers(paths["det_path"], paths["cls_info_path"], workers=prefetch) if prefetch else None
-
-    def run_tokens(run):
-        return ([run[0][1]] if run[0][1] else []) + [t for t, _ in run]
-
-    def batches_in_order():
-        ahead = 2 * prefetch
-        if pool:
-            for i in range(min(ahead, len(runs))):
-                pool.request(i, run_tokens(runs[i]))
-        for i, r in enumerate(runs):
-            if pool:
-                for t, fr in zip(run_tokens(r), pool.result(i)):
-                    _LOADER["frames"].adopt(t, fr)
-                if i + ahead < len(runs):
-                    pool.request(i + ahead, run_tokens(runs[i + ahead]))
-            yield _loader_run(r, share)
-    stream_of_batches = batches_in_order()
+    stream_of_batches = (_loader_run(r, share) for r in runs)
 
     def tensors(raw):
         for b in raw.values():
@@ -373,41 +355,37 @@ def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, ba
 
     bank_cache = {}
     waiting = []  # runs whose launches are queued and whose decisions have not been read yet
-    try:
-        for run in runs:
-            with timer.stage("loader + collate (wait)"):
-                batches = tensors(next(stream_of_batches))
-            feats = _run_features(bev, models, names, run, device, bank_cache, timer)
-            pending = []
-            with timer.stage("h2d + forward + decode kernel"):
-                for n in names:
-                    b = batches[n]
-                    ex = {k: v for k, v in b.items() if k != "_lags"}
-                    ex["det_boxes"] = b["det_boxes"].to(device, non_blocking=True)
-                    ex["prev_det_boxes"] = b["prev_det_boxes"].to(device, non_blocking=True)
-                    ex["bev_feature"], ex["prev_bev_feature"] = feats[n][1:], feats[n][:-1]
-                    with torch.no_grad():
-                        m1, m2, ex = models[n](ex, train_mode=False)
-                    if decode_on_device:
-                        buf = decode.decode_flags_launch(m1, m2, [len(p) for p in b["prev_cls_det_boxes"]], [len(c) for c in b["cls_det_boxes"]])
-                        host = torch.empty(buf.shape, dtype=buf.dtype, pin_memory=cuda)
-                        host.copy_(buf, non_blocking=True)
-                        pending.append((n, b, host, None, None))
-                    else:
-                        pending.append((n, b, None, m1, m2))
-                ev = None
-                if cuda:
-                    ev = torch.cuda.Event()
-                    ev.record()
-            # the host half of the PREVIOUS run is done while the device works on this one: one event wait per run, no stream-wide stall
-            with timer.stage("decode (host)"):
-                waiting.append((pending, ev))
-                if len(waiting) > 1:  # (two runs in flight were measured: the event waits vanish, the total does not move)
-                    finish(*waiting.pop(0))
+    for run in runs:
+        with timer.stage("loader + collate (wait)"):
+            batches = tensors(next(stream_of_batches))
+        feats = _run_features(bev, models, names, run, device, bank_cache, timer)
+        pending = []
+        with timer.stage("h2d + forward + decode kernel"):
+            for n in names:
+                b = batches[n]
+                ex = {k: v for k, v in b.items() if k != "_lags"}
+                ex["det_boxes"] = b["det_boxes"].to(device, non_blocking=True)
+                ex["prev_det_boxes"] = b["prev_det_boxes"].to(device, non_blocking=True)
+                ex["bev_feature"], ex["prev_bev_feature"] = feats[n][1:], feats[n][:-1]
+                with torch.no_grad():
+                    m1, m2, ex = models[n](ex, train_mode=False)
+                if decode_on_device:
+                    buf = decode.decode_flags_launch(m1, m2, [len(p) for p in b["prev_cls_det_boxes"]], [len(c) for c in b["cls_det_boxes"]])
+                    host = torch.empty(buf.shape, dtype=buf.dtype, pin_memory=cuda)
+                    host.copy_(buf, non_blocking=True)
+                    pending.append((n, b, host, None, None))
+                else:
+                    pending.append((n, b, None, m1, m2))
+            ev = None
+            if cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+        # the host half of the PREVIOUS run is done while the device works on this one: one event wait per run, no stream-wide stall
         with timer.stage("decode (host)"):
-            for w in waiting:
-                finish(*w)
-    finally:
-        if pool:
-            pool.close()
+            waiting.append((pending, ev))
+            if len(waiting) > 1:
+                finish(*waiting.pop(0))
+    with timer.stage("decode (host)"):
+        for w in waiting:
+            finish(*w)
     return decs

@@ -17,7 +17,6 @@ from shasta_amd import pipeline, scenes  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--top", type=int, default=40)
-    ap.add_argument("--prefetch", type=int, default=0)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     root = tempfile.mkdtemp(prefix="shasta_split_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -27,12 +26,12 @@ def main():
     for _ in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        pipeline.run_split(models, paths, sc, neck, dev, batch_pairs=40, prefetch=a.prefetch)
+        pipeline.run_split(models, paths, sc, neck, dev, batch_pairs=40)
         torch.cuda.synchronize()
         print("un-profiled: %.3f s" % (time.perf_counter() - t0), flush=True)
     pr = cProfile.Profile()
     pr.enable()
-    pipeline.run_split(models, paths, sc, neck, dev, batch_pairs=40, prefetch=a.prefetch)
+    pipeline.run_split(models, paths, sc, neck, dev, batch_pairs=40)
     torch.cuda.synchronize()
     pr.disable()
     st = pstats.Stats(pr)

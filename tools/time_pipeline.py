@@ -19,7 +19,6 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--maps", choices=["neck", "features"], default="neck", help="neck: (512,180,180) maps on the device + K0 for all heads; features: TokenBev (CPU stand-in)")
     ap.add_argument("--sync", type=int, default=1)
-    ap.add_argument("--prefetch", type=int, default=-1, help="frame-parse worker processes; 0 = in line, -1 = run_split's default")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     root = tempfile.mkdtemp(prefix="shasta_split_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -28,7 +27,7 @@ def main():
     print("split written in %.2f s: %d frames" % (time.perf_counter() - t0, a.scenes * a.frames), flush=True)
     models = {n: pipeline.build_class_model(n, dev, seed=1) for n in pipeline.CLASS_CONFIGS}
     bev = scenes.TokenNeck() if a.maps == "neck" else scenes.TokenBev()
-    kw = dict(prefetch=None if a.prefetch < 0 else a.prefetch)
+    kw = {}
     for rep in range(3):
         timer = pipeline.StageTimer(sync=bool(a.sync))
         torch.cuda.synchronize()
