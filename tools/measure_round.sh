@@ -26,6 +26,11 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_
 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_convlds_b8 -o p -- python3 $R/tools/conv_only.py --batch 8 --iters 4 > $O/pmc_convlds_b8.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_convfetch_b8 -o p -- python3 $R/tools/conv_only.py --batch 8 --iters 4 > $O/pmc_convfetch_b8.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_convwrite_b8 -o p -- python3 $R/tools/conv_only.py --batch 8 --iters 4 > $O/pmc_convwrite_b8.log 2>&1
+# pair stage at F = 320 (round 4, pair_f16w.hip): kernel stats at the car tables x 512 and at N = 500 x 256, matrix / vector pipe counters
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_pair320_car -o d -- python3 $R/tools/pair_time.py --max-obj 90 --batch 512 --iters 20 > $O/pair320_car.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_pair320_n500 -o d -- python3 $R/tools/pair_time.py --max-obj 500 --batch 256 --iters 10 > $O/pair320_n500.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_pair320mfma_b256 -o p -- python3 $R/tools/pair_time.py --max-obj 500 --batch 256 --iters 3 --modes f16x2 > $O/pmc_pair320mfma.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_pair320valu_b256 -o p -- python3 $R/tools/pair_time.py --max-obj 500 --batch 256 --iters 3 --modes f16x2 > $O/pmc_pair320valu.log 2>&1
 # the configs 2-4 chain (round 4)
 (cd $R && timeout 300 python3 tools/time_pipeline.py --scenes 20 --frames 40 --batch 40 --sync 1 > $O/pipeline_sync.log 2>&1; timeout 300 python3 tools/time_pipeline.py --scenes 20 --frames 40 --batch 40 --sync 0 > $O/pipeline.log 2>&1)
 for b in 1 128 512 1024; do
@@ -38,5 +43,5 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-for
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_valu_b512 -o p -- python3 $R/bench.py --batch 512 --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_valu_b512.log 2>&1
 (cd $R && python3 tools/stage_power.py 512 2 > $O/stage_power.log 2>&1)
 grep -h '^{' $O/bench_default.json $O/bench_b1.json $O/bench_b64.json $O/bench_b128.json $O/bench_b512.json $O/bench_pieces.json $O/bench_f32.json $O/bench_torchrun.json | cut -c1-230
-grep time $O/conv_check.jsonl | cut -c1-200; tail -1 $O/pipeline.log | cut -c1-400
+grep time $O/conv_check.jsonl | cut -c1-200; tail -1 $O/pipeline.log | cut -c1-400; grep -h "^{" $O/pair320_car.log $O/pair320_n500.log
 ls $O
