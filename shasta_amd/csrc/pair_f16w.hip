@@ -18,8 +18,17 @@
 //    sub-step A with those of sub-step B gives every lane ALL rows of ONE pair - lanes 0..31: (t, n), lanes 32..63: (t + 1, n) - in
 //    quads of four consecutive rows, which is what the lane-per-pair phase (layers 3 - 4 on v_mfma_f32_4x4x1, hand-designed residual,
 //    combine: as pair_mfma4_kernel) reads.  No transposition tile in LDS (106 KB at 8 waves with the pair_f16_kernel scheme).
-// Registers: 80 for the weight pieces + 72 for the UC values + 64 accumulators: one wave per SIMD (4 per workgroup, up to 512
-// registers each), which the independent sub-steps A / B and the k-step pipeline keep busy.
+// F = 256 through this kernel (8 fragments, 48 MFMAs of 32 cycles per 64 pairs instead of pair_f16_kernel's 48 of 16) was measured:
+// 4.71 - 4.84 ms against 4.10 ms at 512 frame-pairs of N = 500 - at that width the 32-row blocks are a third empty and the kernel turns
+// from vector-bound into matrix-bound; F = 256 stays on pair_f16_kernel.
+// Registers: 72 for the UC values + 64 accumulators + the pipeline's operands = 249: TWO waves per SIMD (two 4-wave workgroups per CU);
+// the weight pieces (80 registers) stay in LDS and are read per k step, 20 reads per 64 pairs.  (With them in registers - 256 + 74
+// registers, one wave per SIMD - the vector and matrix work of a wave did not overlap: 4.37 ms for the stage at N = 500 x 256 against
+// 3.51 ms.)  Where the time goes per 64 pairs and wave: 60 MFMAs of 32 cycles + 102 v_mfma_f32_4x4x1 of 8 = 2736 matrix cycles, ~780
+// vector instructions (the cut is 3 per value: v_pk_fma_f32 with clamp = ReLU, v_pk_mul_f32 2^14, v_cvt_pk_f16_f32, two v_fma_mix_f32,
+// v_cvt_pk_f16_f32 at 5.3 / 5.3 / 8.1 / 7 / 7 / 8.1 cycles per two values) = ~4200: with two waves per SIMD the matrix pipe is busy
+// ~85 % of the time at the ~1.7 GHz the power cap leaves under this load - removing vector work (the in-place UP scaling below:
+// -68 instructions) moved the time by 1.6 %.
 #include "common.hpp"
 #include "pair_layout.hpp"
 
@@ -167,18 +176,11 @@ int pair_f16w_pack(const shasta_weights* w, float* out, hipStream_t st) {
 }
 
 // ---- the kernel -------------------------------------------------------------------------------------------------------------
-constexpr int PWK_WPB = 4;       // waves per workgroup: one per SIMD
+constexpr int PWK_WPB = 4;       // waves per workgroup (two workgroups per CU: two waves per SIMD)
 constexpr int PWK_SLOT = 256;    // floats per UP row slot (a row = ET + 16 hand floats; one 1 KB LDS-DMA per row)
 
-#ifndef PWK_WLDS
-#define PWK_WLDS 1  // second-layer weight pieces: 1 = read from LDS per k step (2 waves per SIMD), 0 = 80 registers (1 wave per SIMD)
-#endif
 template <int F>
-__global__ __launch_bounds__(64 * PWK_WPB)
-#if PWK_WLDS
-__attribute__((amdgpu_waves_per_eu(2, 2)))
-#endif
-void pair_f16w_kernel(const float* __restrict__ packed, const uint32_t* __restrict__ p16,
+__global__ __launch_bounds__(64 * PWK_WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_f16w_kernel(const float* __restrict__ packed, const uint32_t* __restrict__ p16,
                                                                const float* __restrict__ UP, const float* __restrict__ UC,
                                                                const float* __restrict__ hand_prev, const float* __restrict__ hand_det,
                                                                const float* __restrict__ denom, float* __restrict__ residual, int T,
@@ -189,7 +191,7 @@ void pair_f16w_kernel(const float* __restrict__ packed, const uint32_t* __restri
     extern __shared__ __attribute__((aligned(16))) float s_dynw[];
     float* s_a4 = s_dynw;                          // [NA4] 4x4x1 operand table (layers 3-4 and the layer-2 biases)
     float* s_up = s_dynw + ((NA4 + 3) & ~3);       // [WPB][3 steps][2 rows][PWK_SLOT]
-    wu4* s_w = reinterpret_cast<wu4*>(s_up + PWK_WPB * 6 * PWK_SLOT);  // PWK_WLDS: [piece][fragment][lane] weight pieces
+    wu4* s_w = reinterpret_cast<wu4*>(s_up + PWK_WPB * 6 * PWK_SLOT);  // [piece][fragment][lane] second-layer weight pieces
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, d0 = blockIdx.x * 32, by = blockIdx.y;
@@ -224,17 +226,8 @@ void pair_f16w_kernel(const float* __restrict__ packed, const uint32_t* __restri
     for (int off = 16; off > 0; off >>= 1) mc = absmax_keep_nan(mc, __shfl_xor(mc, off, 64));  // (both halves hold the same 32 rows)
     const float dnm = denom[(size_t)b * D + dcl], rdn = 1.0f / dnm;
     // second-layer weight pieces: registers for the whole kernel
-#if PWK_WLDS
     for (int e = tid; e < 2 * NFRAG * 64; e += 64 * PWK_WPB) s_w[e] = reinterpret_cast<const wu4*>(p16)[e];
     const wu4* my_w = s_w + lane;
-#else
-    wu4 wh[NFRAG], wl[NFRAG];
-#pragma unroll
-    for (int f = 0; f < NFRAG; ++f) {
-        wh[f] = reinterpret_cast<const wu4*>(p16)[(0 * NFRAG + f) * 64 + lane];
-        wl[f] = reinterpret_cast<const wu4*>(p16)[(1 * NFRAG + f) * 64 + lane];
-    }
-#endif
     const int ew_fs = reinterpret_cast<const int*>(p16)[W::FRAG_DW + 0], ew_rc = reinterpret_cast<const int*>(p16)[W::FRAG_DW + 1],
               ew_fd = reinterpret_cast<const int*>(p16)[W::FRAG_DW + 2];
     __syncthreads();
@@ -319,7 +312,6 @@ void pair_f16w_kernel(const float* __restrict__ packed, const uint32_t* __restri
             k.a1 = *reinterpret_cast<const lf32x4*>(upA + 16 * ks + 8 * kb + 4);
             k.b0 = *reinterpret_cast<const lf32x4*>(upB + 16 * ks + 8 * kb);
             k.b1 = *reinterpret_cast<const lf32x4*>(upB + 16 * ks + 8 * kb + 4);
-#if PWK_WLDS
             if (W::has1(ks)) {
                 k.w1l = my_w[(NFRAG + W::frag1(ks)) * 64];
                 k.w1h = my_w[W::frag1(ks) * 64];
@@ -328,16 +320,6 @@ void pair_f16w_kernel(const float* __restrict__ packed, const uint32_t* __restri
                 k.w2l = my_w[(NFRAG + W::frag2(ks)) * 64];
                 k.w2h = my_w[W::frag2(ks) * 64];
             }
-#else
-            if (W::has1(ks)) {
-                k.w1l = wl[W::frag1(ks)];
-                k.w1h = wh[W::frag1(ks)];
-            }
-            if (W::has2(ks)) {
-                k.w2l = wl[W::frag2(ks)];
-                k.w2h = wh[W::frag2(ks)];
-            }
-#endif
         };
         KIn kin[2];
         fetch(0, kin[0]);
@@ -484,7 +466,7 @@ void pair_f16w_kernel(const float* __restrict__ packed, const uint32_t* __restri
 }
 
 size_t pair_f16w_lds_bytes(int F) {
-    return ((size_t)((a4_total(F) + 3) & ~3) + (size_t)PWK_WPB * 6 * PWK_SLOT) * sizeof(float) + (PWK_WLDS ? (size_t)PW<320>::FRAG_DW * 4 : 0);
+    return ((size_t)((a4_total(F) + 3) & ~3) + (size_t)PWK_WPB * 6 * PWK_SLOT) * sizeof(float) + (size_t)PW<320>::FRAG_DW * 4;
 }
 
 int launch_pair_f16w(const float* packed, const float* p16, const float* UP, const float* UC, const float* hand_prev,
