@@ -687,17 +687,20 @@ def extra_pipeline(bench, args, ex):
         neck = scenes.TokenNeck()
         wpaths, wsc = scenes.write_synthetic_split(os.path.join(root, "warm"), n_scenes=2, frames_per_scene=n_frames, seed=5)
         pipeline.run_split(models, wpaths, wsc, neck, dev, batch_pairs=n_frames)  # warm-up: weight packs, allocator
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pipeline.run_split(models, paths, sc, neck, dev, batch_pairs=n_frames)
-        torch.cuda.synchronize()
-        total = time.perf_counter() - t0
+        reps = []
+        for _ in range(3):  # the host side of the chain varies from run to run on a shared box (0.9 - 1.6 s measured): best of three, all listed
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipeline.run_split(models, paths, sc, neck, dev, batch_pairs=n_frames)
+            torch.cuda.synchronize()
+            reps.append(time.perf_counter() - t0)
+        total = min(reps)
         timer = pipeline.StageTimer(sync=True)
         pipeline.run_split(models, paths, sc, neck, dev, batch_pairs=n_frames, timer=timer)
         st = timer.seconds
         n = n_scenes * n_frames
         fwd_s = pipeline.forward_only_seconds(models, paths, sc, neck, dev, batch_pairs=n_frames)
-        e = {"frames": n, "classes": 7, "frames_per_run": n_frames, "seconds": total, "frames_per_s": n / total,
+        e = {"frames": n, "classes": 7, "frames_per_run": n_frames, "seconds": total, "seconds_all_runs": [round(v, 4) for v in reps], "frames_per_s": n / total,
              "class_frame_pairs_per_s": 7 * n / total,
              "stages_s": {k: round(v, 4) for k, v in st.items()},
              "forward_only_s": fwd_s, "forward_only_frames_per_s": n / fwd_s, "chain_over_forward_only": fwd_s / total,
