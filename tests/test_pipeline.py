@@ -213,3 +213,24 @@ def test_all_seven_classes_run_through_the_chain(tmp_path):
     n_in = sum(len(json.load(open(os.path.join(paths["cls_info_path"], t + ".json")))) for _, toks in sc for t in toks)
     n_out = sum(len(v) for v in merged["results"].values())
     assert 0 < n_out <= n_in + 50 and set(trk["results"]) == set(merged["results"])
+
+
+def test_the_chain_runs_with_the_cyclic_collector_off_and_restores_it():
+    """pipeline._no_cyclic_gc: the collector is off inside (the chain's heap of live dicts would be re-scanned at every generation-2 pass)
+    and back in its previous state afterwards, also after an exception."""
+    import gc
+    assert gc.isenabled()
+    with pipeline._no_cyclic_gc():
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    with pytest.raises(RuntimeError):
+        with pipeline._no_cyclic_gc():
+            raise RuntimeError("x")
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with pipeline._no_cyclic_gc():
+            pass
+        assert not gc.isenabled()
+    finally:
+        gc.enable()
