@@ -688,7 +688,7 @@ def extra_pipeline(bench, args, ex):
         wpaths, wsc = scenes.write_synthetic_split(os.path.join(root, "warm"), n_scenes=2, frames_per_scene=n_frames, seed=5)
         pipeline.run_split(models, wpaths, wsc, neck, dev, batch_pairs=n_frames)  # warm-up: weight packs, allocator
         reps = []
-        for _ in range(3):  # the host side of the chain varies from run to run on a shared box (0.9 - 1.6 s measured): best of three, all listed
+        for _ in range(3):  # best of three, all listed (the host side is Python: it varies with the box's CPU)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             pipeline.run_split(models, paths, sc, neck, dev, batch_pairs=n_frames)

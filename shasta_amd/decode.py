@@ -86,8 +86,12 @@ def decode_frame_from_flags(prev_class, prev_score, det_flags, det_score, cls_de
     """Same result as decode_frame, built from the device decisions of one frame (rows of decode_flags_device).  copy_fn: a propagated
     (false-negative) box of the previous frame is copied before it is moved and flagged, so prev_cls_det_boxes may hold shared dicts."""
     annos, fn_annos, dead_prev, keep_dets = [], [], [], []
-    for n in range(len(prev_cls_det_boxes)):
-        c = int(prev_class[n])
+    n_prev, n_cur = len(prev_cls_det_boxes), len(cls_det_boxes)
+    # (plain Python numbers: indexing a numpy array element by element costs more than the decisions themselves)
+    pc = prev_class[:n_prev].tolist() if hasattr(prev_class, "tolist") else prev_class
+    df = det_flags[:n_cur].tolist() if hasattr(det_flags, "tolist") else det_flags
+    for n in range(n_prev):
+        c = pc[n]
         if c == 1:
             dead_prev.append(n)
         elif c == 2:
@@ -99,14 +103,17 @@ def decode_frame_from_flags(prev_class, prev_score, det_flags, det_score, cls_de
             box["token"] = token
             box["ref_detection_score"] = 1 - float(prev_score[n])
             fn_annos.append(box)
-    for k in range(len(cls_det_boxes)):
-        f = int(det_flags[k])
-        if f & 1:
-            if f & 2:
-                cls_det_boxes[k]["newborn"] = True
-            cls_det_boxes[k]["ref_detection_score"] = 1 - float(det_score[k])
-            keep_dets.append(k)
-            annos.append(cls_det_boxes[k])
+    if n_cur:
+        ds = det_score[:n_cur].tolist() if hasattr(det_score, "tolist") else det_score
+        for k in range(n_cur):
+            f = df[k]
+            if f & 1:
+                box = cls_det_boxes[k]
+                if f & 2:
+                    box["newborn"] = True
+                box["ref_detection_score"] = 1 - ds[k]
+                keep_dets.append(k)
+                annos.append(box)
     annos.extend(fn_annos)
     return annos, dead_prev, keep_dets
 
