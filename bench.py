@@ -700,7 +700,14 @@ def extra_pipeline(bench, args, ex):
         st = timer.seconds
         n = n_scenes * n_frames
         fwd_s = pipeline.forward_only_seconds(models, paths, sc, neck, dev, batch_pairs=n_frames)
+        cpu = "?"
+        try:
+            with open("/proc/cpuinfo") as fh:
+                cpu = next((l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")), "?")
+        except OSError:
+            pass
         e = {"frames": n, "classes": 7, "frames_per_run": n_frames, "seconds": total, "seconds_all_runs": [round(v, 4) for v in reps], "frames_per_s": n / total,
+             "host_cpu": cpu,  # the chain is half host Python: 0.66 - 0.72 s on an EPYC 9575F box, 0.9 - 1.4 s on the slowest box seen
              "class_frame_pairs_per_s": 7 * n / total,
              "stages_s": {k: round(v, 4) for k, v in st.items()},
              "forward_only_s": fwd_s, "forward_only_frames_per_s": n / fwd_s, "chain_over_forward_only": fwd_s / total,

@@ -25,6 +25,11 @@ def main():
     t0 = time.perf_counter()
     paths, sc = scenes.write_synthetic_split(root, n_scenes=a.scenes, frames_per_scene=a.frames, seed=3)
     print("split written in %.2f s: %d frames" % (time.perf_counter() - t0, a.scenes * a.frames), flush=True)
+    try:
+        with open("/proc/cpuinfo") as fh:
+            print("host cpu:", next((l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")), "?"), flush=True)
+    except OSError:
+        pass
     models = {n: pipeline.build_class_model(n, dev, seed=1) for n in pipeline.CLASS_CONFIGS}
     bev = scenes.TokenNeck() if a.maps == "neck" else scenes.TokenBev()
     kw = {}
