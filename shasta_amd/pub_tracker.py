@@ -33,29 +33,39 @@ def center_greedy_device(problems, device=None, want_dist=True):
         return []
     Nmax = max(p[0].shape[0] for p in problems)
     Mmax = max(p[1].shape[0] for p in problems)
-    dxy, txy = np.zeros((S, Nmax, 2), np.float32), np.zeros((S, Mmax, 2), np.float32)
-    dc, tc = np.zeros((S, Nmax), np.int32), np.zeros((S, Mmax), np.int32)
-    md = np.zeros((S, Nmax), np.float32)
-    n, m = np.zeros(S, np.int32), np.zeros(S, np.int32)
+    # ONE host buffer -> one copy to the device, one result buffer -> one copy back (4-byte words; seven small copies in and three out
+    # cost more than the kernel at the sizes of a frame)
+    sizes = [S * Nmax * 2, S * Mmax * 2, S * Nmax, S * Nmax, S * Mmax, S, S]  # det_xy, trk_xy, max_diff | det_cat, trk_cat, n, m
+    offs = np.concatenate([[0], np.cumsum(sizes)]).tolist()
+    host = torch.zeros(offs[-1], dtype=torch.int32, pin_memory=device.type == "cuda")
+    hi, hf = host.numpy(), host.numpy().view(np.float32)
+    dxy, txy = hf[offs[0]:offs[1]].reshape(S, Nmax, 2), hf[offs[1]:offs[2]].reshape(S, Mmax, 2)
+    md = hf[offs[2]:offs[3]].reshape(S, Nmax)
+    dc, tc = hi[offs[3]:offs[4]].reshape(S, Nmax), hi[offs[4]:offs[5]].reshape(S, Mmax)
+    n, m = hi[offs[5]:offs[6]], hi[offs[6]:offs[7]]
     for s, (d, t, a, b, g) in enumerate(problems):
         n[s], m[s] = d.shape[0], t.shape[0]
         dxy[s, :n[s]], txy[s, :m[s]], dc[s, :n[s]], tc[s, :m[s]], md[s, :n[s]] = d, t, a, b, g
-    dev = [torch.from_numpy(x).to(device) for x in (dxy, txy, dc, tc, md, n, m)]
+    dbuf = host.to(device, non_blocking=True)
+    dev = [dbuf[offs[i]:offs[i + 1]] for i in range(7)]
+    dev = [dev[0].view(torch.float32), dev[1].view(torch.float32), dev[3], dev[4], dev[2].view(torch.float32), dev[5], dev[6]]
     dist = torch.empty(S, Nmax, Mmax, dtype=torch.float64, device=device) if want_dist else None
-    match = torch.empty(S, Nmax, dtype=torch.int32, device=device)
-    row_any = torch.zeros(S, Nmax, dtype=torch.int32, device=device)
-    col_any = torch.zeros(S, Mmax, dtype=torch.int32, device=device)
+    out = torch.zeros(S * (2 * Nmax + Mmax), dtype=torch.int32, device=device)  # match | row_any | col_any (the flags start at zero)
+    match, row_any, col_any = out[:S * Nmax], out[S * Nmax:2 * S * Nmax], out[2 * S * Nmax:]
     hip.check(lib.shasta_center_greedy_f32(*[hip.ptr(x) for x in dev], S, Nmax, Mmax, hip.ptr(dist), hip.ptr(match), hip.ptr(row_any),
                                            hip.ptr(col_any), hip.stream_ptr()), "shasta_center_greedy_f32")
-    match_h, row_h, col_h = match.cpu().numpy(), row_any.cpu().numpy() != 0, col_any.cpu().numpy() != 0
+    out_h = out.cpu().numpy()
+    match_h = out_h[:S * Nmax].reshape(S, Nmax)
+    row_h = out_h[S * Nmax:2 * S * Nmax].reshape(S, Nmax) != 0
+    col_h = out_h[2 * S * Nmax:].reshape(S, Mmax) != 0
     dist_h = dist.cpu().numpy() if want_dist else None
-    out = []
+    res = []
     for s in range(S):
         mi = match_h[s, :n[s]]
         rows = np.nonzero(mi >= 0)[0]
         pairs = np.stack([rows, mi[rows]], axis=1).astype(np.int32).reshape(-1, 2)
-        out.append((dist_h[s, :n[s], :m[s]].copy() if want_dist else None, pairs, row_h[s, :n[s]].copy(), col_h[s, :m[s]].copy()))
-    return out
+        res.append((dist_h[s, :n[s], :m[s]].copy() if want_dist else None, pairs, row_h[s, :n[s]].copy(), col_h[s, :m[s]].copy()))
+    return res
 
 
 class PubTracker(object):
@@ -221,18 +231,20 @@ class PubTrackerMerged(object):
         detections groups them by class and one array operation per class forms every detection's `ct` / `tracking` (the values of
         pub_tracker_merged.py:92-99, element for element; the per-detection arrays are rows of the class arrays)."""
         by_class = {}
-        for d in results:
-            by_class.setdefault(d["detection_name"], []).append(d)
+        for i, d in enumerate(results):
+            by_class.setdefault(d["detection_name"], []).append(i)
+        all_ct = np.array([d["translation"][:2] for d in results])                      # one array per frame, sliced per class below
+        all_trk = np.array([d["velocity"][:2] for d in results]) * -1 * time_lag
         tracks_by_class = {}
         for t in self.tracks:
             tracks_by_class.setdefault(t["detection_name"], []).append(t)
         per_class = []
         for label, name in enumerate(NUSCENES_TRACKING_NAMES):
-            dets = by_class.get(name)
-            if not dets:  # pub_tracker_merged.py:101-102: nothing of this class in the frame -> its tracks are dropped
+            idx = by_class.get(name)
+            if not idx:  # pub_tracker_merged.py:101-102: nothing of this class in the frame -> its tracks are dropped
                 continue
-            ct = np.array([d["translation"][:2] for d in dets])
-            trk = np.array([d["velocity"][:2] for d in dets]) * -1 * time_lag
+            dets = [results[i] for i in idx]
+            ct, trk = all_ct[idx], all_trk[idx]
             for i, d in enumerate(dets):
                 d["ct"], d["tracking"], d["label_preds"] = ct[i], trk[i], label
             tracks = tracks_by_class.get(name, [])
