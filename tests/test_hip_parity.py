@@ -668,19 +668,21 @@ def test_precut_weight_stream_is_bit_identical(N, B):
     assert all(torch.equal(a, b) for a, b in zip(plain2, pre2)) and not torch.equal(pre2[3], pre[3])
 
 
+@pytest.mark.parametrize("npnt,nf", [(4, 7), (5, 3)])
 @pytest.mark.parametrize("B", [3, 70])
-def test_non_finite_inputs_stay_non_finite(B):
+def test_non_finite_inputs_stay_non_finite(B, npnt, nf):
     """Round-2 advisor finding: the fp16 pair kernel fuses ReLU and range scaling into a clamped packed fma, which turns a NaN into 0 and
     saturates an infinity, and the row maxima it scales by were taken with fmaxf, which drops a NaN: a poisoned frame came out as
     FINITE numbers where the reference (and the f32 kernels) propagate NaN.  Now the row maxima keep non-finite values and such a
-    track / tile is written as NaN.  Frames next to the poisoned ones are untouched."""
+    track / tile is written as NaN.  Frames next to the poisoned ones are untouched.  F = 256 (pair_f16_kernel) and F = 320
+    (pair_f16w_kernel: two tracks per step, one scale each)."""
     import shasta_amd
     dev = _dev()
     torch.manual_seed(5)
     N = 40
     m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
                                          bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075],
-                                                            out_stride=30), max_obj=N, num_feats=7, num_point=4, in_channels=8)).eval().to(dev)
+                                                            out_stride=30), max_obj=N, num_feats=nf, num_point=npnt, in_channels=8)).eval().to(dev)
     g = torch.Generator().manual_seed(B)
     bev = torch.relu(torch.randn(B, 48, 48, 64, generator=g)).to(dev)
     pbev = torch.relu(torch.randn(B, 48, 48, 64, generator=g)).to(dev)
