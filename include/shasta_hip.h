@@ -389,6 +389,24 @@ int shasta_center_greedy_f32(const float* det_xy, const float* trk_xy, const int
                              const float* max_diff, const int32_t* n, const int32_t* m, int scenes, int Nmax, int Mmax,
                              double* dist, int32_t* match, int32_t* row_any, int32_t* col_any, shasta_stream_t stream);
 
+/* The merged tracker of whole scenes in ONE launch (replaces the per-frame loop of tools/nusc_shasta/pub_test.py:88-162 over
+ * tools/nusc_shasta/pub_tracker_merged.py:57-225 `PubTrackerMerged.step_centertrack`, one tracker per scene, greedy association,
+ * TRK_REF confidence refinement, `newborn` / `dead` suppression, coasting up to max_age).  Detections of all scenes lie in one set
+ * of arrays, frame f of scene s = rows frame_off[s][f] .. frame_off[s][f+1]-1 in file order ((scenes, Fmax+1) offsets, frames past
+ * n_frames[s] unused); det_cls = index into the class tables (-1: not a tracking class), det_flags bit 0 = 'newborn' in the
+ * detection dict, bit 1 = 'dead'; frame_lag (scenes, Fmax) = time_lag of step_centertrack.  Class tables (n_cls <= 8, HOST arrays):
+ * gate = NUSCENE_CLS_VELOCITY_ERROR, ref / alpha / beta = TRK_REF.  Outputs per detection: out_status 0 = not in the frame's result
+ * (suppressed or unknown class), 1 = took over a track, 2 = new track; out_id = tracking_id (per scene, from 1); out_ref = refined
+ * ref_detection_score = the tracking_score of the result row (rows with active == 0 - coasting tracks - are never emitted by
+ * pub_test.py).  Row order of a frame's result: class by class, matched detections then new ones, each in file order.  out_err
+ * (scenes,): 0, 1 = a frame holds more than 192 detections, 2 = more than 320 tracks alive (the caller falls back to the per-frame
+ * path).  Bit-identical to the host tracker of shasta_amd.pub_tracker (float64 arithmetic in the reference's operation order). */
+int shasta_track_merged_f64(const double* det_xy, const double* det_vel, const int32_t* det_cls, const double* det_score,
+                            const double* det_ref, const int32_t* det_flags, const int32_t* frame_off, const double* frame_lag,
+                            const int32_t* n_frames, int scenes, int Fmax, int n_cls, const float* cls_gate, const int32_t* cls_ref,
+                            const double* cls_alpha, const double* cls_beta, int max_age, int32_t* out_status, int32_t* out_id,
+                            double* out_ref, int32_t* out_err, shasta_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Training path, backward helpers (the nn.Linear layers run on shasta_gemm_strided_f32; the first layer of each pair MLP
  * is factorised over the table rows).  Replaces what torch autograd derives from det3d/models/tracker/shasta.py:241-325 in

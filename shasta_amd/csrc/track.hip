@@ -105,6 +105,186 @@ __global__ __launch_bounds__(64) void center_greedy_kernel(GreedyArgs a) {
     }
 }
 
+
+// ---- the merged tracker of a whole scene in one launch --------------------------------------------------------------------------
+// tools/nusc_shasta/pub_tracker_merged.py:57-225 as pub_test.py:88-162 drives it (one tracker per scene, reset at the scene's first
+// frame): every frame of the scene, in order - per-class association by the matrix / gate / greedy rule above, confidence refinement
+// (TRK_REF), the `newborn` / `dead` suppression rules, coasting of unmatched tracks up to max_age with ct += tracking * -1.  The host
+// keeps only the conversions: detection dicts -> arrays, results -> rows.  One wavefront per scene; the track list and the frame's
+// detections live in LDS; bookkeeping is serial on lane 0 (it IS serial: ids, ages, list order), distances and the argmin run over the
+// lanes.  Greedy over all detections of a frame in file order equals the per-class problems of step_batch_merged: a pair of different
+// classes is invalid (1e18), so a taken column only ever matters to detections of its own class, and "first minimum" over the whole
+// track list picks the same track as over the list restricted to the class (relative order is kept).
+constexpr int TM_TCAP = 320;   // tracks of a scene alive at one time (matched + new + coasting)
+constexpr int TM_DCAP = 192;   // detections of one frame
+constexpr int TM_NCLS = 8;
+
+struct TrackMergedArgs {
+    const double* det_xy;     // (D, 2) translation[:2]
+    const double* det_vel;    // (D, 2) velocity[:2]
+    const int* det_cls;       // (D,) tracking-class label 0 .. ncls-1, or -1 (ignored)
+    const double* det_score;  // (D,) detection_score
+    const double* det_ref;    // (D,) ref_detection_score of the decode
+    const int* det_flags;     // (D,) bit 0: 'newborn' in det, bit 1: 'dead' in det
+    const int* frame_off;     // (S, Fmax + 1) offsets into the detection arrays
+    const double* frame_lag;  // (S, Fmax) time_lag of step_centertrack
+    const int* n_frames;      // (S,)
+    int* out_status;          // (D,) 0: not in the frame's result, 1: matched to a track, 2: new track
+    int* out_id;              // (D,) tracking_id
+    double* out_ref;          // (D,) refined ref_detection_score
+    int* out_err;             // (S,) 0 ok, 1: a frame holds more than TM_DCAP detections, 2: more than TM_TCAP tracks
+    int Fmax, max_age, ncls;
+    float gate[TM_NCLS];
+    int ref_on[TM_NCLS];
+    double alpha[TM_NCLS], beta[TM_NCLS];
+};
+
+__global__ __launch_bounds__(64) void track_merged_kernel(TrackMergedArgs a) {
+    __shared__ double t_cx[2][TM_TCAP], t_cy[2][TM_TCAP], t_tx[2][TM_TCAP], t_ty[2][TM_TCAP], t_ref[2][TM_TCAP];
+    __shared__ int t_id[2][TM_TCAP], t_age[2][TM_TCAP], t_act[2][TM_TCAP], t_cls[2][TM_TCAP], t_flg[2][TM_TCAP];
+    __shared__ double d_cx[TM_DCAP], d_cy[TM_DCAP], d_tx[TM_DCAP], d_ty[TM_DCAP], d_sc[TM_DCAP], d_rf[TM_DCAP];
+    __shared__ float d_fx[TM_DCAP], d_fy[TM_DCAP];
+    __shared__ int d_cl[TM_DCAP], d_fl[TM_DCAP], d_match[TM_DCAP], d_near[TM_DCAP];
+    __shared__ int t_near[TM_TCAP];
+    __shared__ unsigned taken[TM_TCAP / 32];
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int* off = a.frame_off + (size_t)s * (a.Fmax + 1);
+    const int F = a.n_frames[s];
+    int cur = 0, nt = 0, idc = 0, err = 0;  // uniform: current track buffer, tracks in it, id counter
+    for (int f = 0; f < F && !err; ++f) {
+        const int g0 = off[f], n = off[f + 1] - g0;
+        const double lag = a.frame_lag[(size_t)s * a.Fmax + f];
+        if (n == 0) {  // pub_tracker_merged.py:85-87: an empty frame drops every track
+            nt = 0;
+            continue;
+        }
+        if (n > TM_DCAP) {
+            err = 1;
+            break;
+        }
+        for (int i = lane; i < n; i += 64) {
+            const double cx = a.det_xy[2 * (size_t)(g0 + i)], cy = a.det_xy[2 * (size_t)(g0 + i) + 1];
+            const double tx = (a.det_vel[2 * (size_t)(g0 + i)] * -1.0) * lag, ty = (a.det_vel[2 * (size_t)(g0 + i) + 1] * -1.0) * lag;
+            d_cx[i] = cx; d_cy[i] = cy; d_tx[i] = tx; d_ty[i] = ty;
+            d_fx[i] = (float)(cx + (double)(float)tx);  // (ct + tracking.astype(float32)).astype(float32)
+            d_fy[i] = (float)(cy + (double)(float)ty);
+            d_sc[i] = a.det_score[g0 + i]; d_rf[i] = a.det_ref[g0 + i];
+            d_cl[i] = a.det_cls[g0 + i]; d_fl[i] = a.det_flags[g0 + i];
+            d_match[i] = -1; d_near[i] = 0;
+        }
+        for (int j = lane; j < nt; j += 64) t_near[j] = 0;
+        for (int w = lane; w < TM_TCAP / 32; w += 64) taken[w] = 0u;
+        __syncthreads();
+        // which detections / tracks have a partner inside the gate, then the greedy assignment in file order
+        if (nt > 0) {
+            for (int i = 0; i < n; ++i) {
+                const int dc = d_cl[i];
+                if (dc < 0) continue;
+                const float md = a.gate[dc], dx = d_fx[i], dy = d_fy[i];
+                bool any = false;
+                for (int j = lane; j < nt; j += 64) {
+                    const double v = pair_dist64(dx, dy, (float)t_cx[cur][j], (float)t_cy[cur][j], md, dc, t_cls[cur][j]);
+                    if (v < 1e16) {
+                        any = true;
+                        t_near[j] = 1;
+                    }
+                }
+                if (__any(any) && lane == 0) d_near[i] = 1;
+            }
+            __syncthreads();
+            for (int i = 0; i < n; ++i) {
+                const int dc = d_cl[i];
+                if (dc < 0) continue;
+                const float md = a.gate[dc], dx = d_fx[i], dy = d_fy[i];
+                double best = 1.0e300;
+                int bj = 0x7fffffff;
+                for (int j = lane; j < nt; j += 64) {
+                    const bool tk = (taken[j >> 5] >> (j & 31)) & 1u;
+                    const double v = tk ? 1e18 : pair_dist64(dx, dy, (float)t_cx[cur][j], (float)t_cy[cur][j], md, dc, t_cls[cur][j]);
+                    if (v < best) {
+                        best = v;
+                        bj = j;
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double ov = __shfl_xor(best, o, 64);
+                    const int oj = __shfl_xor(bj, o, 64);
+                    if (ov < best || (ov == best && oj < bj)) {
+                        best = ov;
+                        bj = oj;
+                    }
+                }
+                if (best < 1e16 && lane == 0) {
+                    d_match[i] = bj;
+                    taken[bj >> 5] |= 1u << (bj & 31);
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        // the new track list, class by class (pub_tracker_merged.py:100-223); serial by nature
+        if (lane == 0) {
+            const int nxt = cur ^ 1;
+            int nr = 0;
+            int cnt_t[TM_NCLS];
+            for (int c = 0; c < a.ncls; ++c) cnt_t[c] = 0;
+            for (int j = 0; j < nt; ++j) cnt_t[t_cls[cur][j]] += 1;
+            for (int c = 0; c < a.ncls && !err; ++c) {
+                bool has = false;
+                for (int i = 0; i < n; ++i) has = has || d_cl[i] == c;
+                if (!has) continue;  // nothing of this class in the frame: its tracks are dropped
+                const double al = a.alpha[c], be = a.beta[c];
+                const bool rf = a.ref_on[c] != 0;
+                for (int i = 0; i < n && !err; ++i) {  // matched detections take over their track
+                    if (d_cl[i] != c || d_match[i] < 0) continue;
+                    if (nr >= TM_TCAP) { err = 2; break; }
+                    const int j = d_match[i];
+                    const double r = rf ? ((d_rf[i] > al ? 1.0 : 0.0) * be * d_sc[i] + (1.0 - be) * t_ref[cur][j]) : d_sc[i];
+                    t_cx[nxt][nr] = d_cx[i]; t_cy[nxt][nr] = d_cy[i]; t_tx[nxt][nr] = d_tx[i]; t_ty[nxt][nr] = d_ty[i];
+                    t_ref[nxt][nr] = r; t_id[nxt][nr] = t_id[cur][j]; t_age[nxt][nr] = 1; t_act[nxt][nr] = t_act[cur][j] + 1;
+                    t_cls[nxt][nr] = c; t_flg[nxt][nr] = d_fl[i];
+                    a.out_status[g0 + i] = 1; a.out_id[g0 + i] = t_id[cur][j]; a.out_ref[g0 + i] = r;
+                    ++nr;
+                }
+                for (int i = 0; i < n && !err; ++i) {  // unmatched detections start tracks unless suppressed
+                    if (d_cl[i] != c || d_match[i] >= 0) continue;
+                    if (cnt_t[c] > 0 && !(d_fl[i] & 1) && d_near[i]) continue;
+                    if (nr >= TM_TCAP) { err = 2; break; }
+                    const double r = rf ? be * d_sc[i] : d_sc[i];
+                    ++idc;
+                    t_cx[nxt][nr] = d_cx[i]; t_cy[nxt][nr] = d_cy[i]; t_tx[nxt][nr] = d_tx[i]; t_ty[nxt][nr] = d_ty[i];
+                    t_ref[nxt][nr] = r; t_id[nxt][nr] = idc; t_age[nxt][nr] = 1; t_act[nxt][nr] = 1;
+                    t_cls[nxt][nr] = c; t_flg[nxt][nr] = d_fl[i];
+                    a.out_status[g0 + i] = 2; a.out_id[g0 + i] = idc; a.out_ref[g0 + i] = r;
+                    ++nr;
+                }
+                for (int j = 0; j < nt && !err; ++j) {  // unmatched tracks coast
+                    if (t_cls[cur][j] != c) continue;
+                    if ((taken[j >> 5] >> (j & 31)) & 1u) continue;
+                    if ((t_flg[cur][j] & 2) && t_near[j]) continue;
+                    if (t_age[cur][j] < a.max_age) {
+                        if (nr >= TM_TCAP) { err = 2; break; }
+                        t_cx[nxt][nr] = t_cx[cur][j] + t_tx[cur][j] * -1.0; t_cy[nxt][nr] = t_cy[cur][j] + t_ty[cur][j] * -1.0;
+                        t_tx[nxt][nr] = t_tx[cur][j]; t_ty[nxt][nr] = t_ty[cur][j];
+                        t_ref[nxt][nr] = rf ? (1.0 - be) * t_ref[cur][j] : t_ref[cur][j];
+                        t_id[nxt][nr] = t_id[cur][j]; t_age[nxt][nr] = t_age[cur][j] + 1; t_act[nxt][nr] = 0;
+                        t_cls[nxt][nr] = c; t_flg[nxt][nr] = t_flg[cur][j];
+                        ++nr;
+                    }
+                }
+            }
+            nt = nr;
+        }
+        nt = __shfl(nt, 0, 64);
+        idc = __shfl(idc, 0, 64);
+        err = __shfl(err, 0, 64);
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (lane == 0) a.out_err[s] = err;
+}
+
 }  // namespace shasta
 
 using namespace shasta;
@@ -118,4 +298,28 @@ extern "C" int shasta_center_greedy_f32(const float* det_xy, const float* trk_xy
     GreedyArgs a{det_xy, trk_xy, det_cat, trk_cat, max_diff, n, m, dist, match, row_any, col_any, Nmax, Mmax};
     hipLaunchKernelGGL(center_greedy_kernel, dim3(scenes), dim3(64), 0, as_stream(stream), a);
     return check_launch("center_greedy");
+}
+
+extern "C" int shasta_track_merged_f64(const double* det_xy, const double* det_vel, const int32_t* det_cls, const double* det_score,
+                                       const double* det_ref, const int32_t* det_flags, const int32_t* frame_off, const double* frame_lag,
+                                       const int32_t* n_frames, int scenes, int Fmax, int n_cls, const float* cls_gate,
+                                       const int32_t* cls_ref, const double* cls_alpha, const double* cls_beta, int max_age,
+                                       int32_t* out_status, int32_t* out_id, double* out_ref, int32_t* out_err, shasta_stream_t stream) {
+    SHASTA_REQUIRE(det_xy && det_vel && det_cls && det_score && det_ref && det_flags && frame_off && frame_lag && n_frames, "track_merged: null input");
+    SHASTA_REQUIRE(cls_gate && cls_ref && cls_alpha && cls_beta && out_status && out_id && out_ref && out_err, "track_merged: null pointer");
+    SHASTA_REQUIRE(scenes >= 0 && Fmax >= 1 && n_cls >= 1 && n_cls <= TM_NCLS && max_age >= 0, "track_merged: bad size (at most 8 classes)");
+    if (scenes == 0) return SHASTA_OK;
+    TrackMergedArgs a;
+    a.det_xy = det_xy; a.det_vel = det_vel; a.det_cls = det_cls; a.det_score = det_score; a.det_ref = det_ref; a.det_flags = det_flags;
+    a.frame_off = frame_off; a.frame_lag = frame_lag; a.n_frames = n_frames;
+    a.out_status = out_status; a.out_id = out_id; a.out_ref = out_ref; a.out_err = out_err;
+    a.Fmax = Fmax; a.max_age = max_age; a.ncls = n_cls;
+    for (int c = 0; c < TM_NCLS; ++c) {  // (host arrays: class constants)
+        a.gate[c] = c < n_cls ? cls_gate[c] : 0.0f;
+        a.ref_on[c] = c < n_cls ? cls_ref[c] : 0;
+        a.alpha[c] = c < n_cls ? cls_alpha[c] : 0.0;
+        a.beta[c] = c < n_cls ? cls_beta[c] : 0.0;
+    }
+    hipLaunchKernelGGL(track_merged_kernel, dim3(scenes), dim3(64), 0, as_stream(stream), a);
+    return check_launch("track_merged");
 }

@@ -126,17 +126,57 @@ def merge_results(per_class):
     return out
 
 
+def _scenes_fit_device_tracker(results, max_dets=192):
+    """A cheap necessary condition for the whole-scene kernel (192 detections per frame); the kernel itself reports track overflow."""
+    return all(len(v) <= max_dets for v in results.values())
+
+
+def _track_scenes_on_device(predictions, scenes, max_age):
+    """run_tracking's fast path: the merged greedy tracker of every scene in one launch (pub_tracker.track_scenes_merged_device);
+    None when a scene exceeds the kernel's capacities."""
+    from .pub_tracker import track_scenes_merged_device
+    frames = []
+    for sc in scenes:
+        last, fr = None, []
+        for m in sc:
+            if m["first"]:
+                last = m["timestamp"]
+            fr.append((predictions[m["token"]], m["timestamp"] - last))
+            last = m["timestamp"]
+        frames.append(fr)
+    out = track_scenes_merged_device(frames, max_age=max_age)
+    if any(o is None for o in out):
+        return None
+    annos = {"results": {}, "meta": dict(META)}
+    for sc, rows in zip(scenes, out):
+        for m, items in zip(sc, rows):
+            token = m["token"]
+            annos["results"][token] = [
+                {"sample_token": token, "translation": d["translation"], "size": d["size"], "rotation": d["rotation"], "velocity": d["velocity"],
+                 "tracking_id": str(tid), "tracking_name": d["detection_name"], "tracking_score": ref} for d, tid, ref in items]
+    return annos
+
+
 def run_tracking(predictions, frames_meta, max_age=4, hungarian=False, merged=True, refine_confidence=False, alpha=0.5, beta=0.5,
-                 tracker_factory=None, batch_step=None):
+                 tracker_factory=None, batch_step=None, whole_scenes=False):
     """pub_test.py:88-162 (merged=True, PubTrackerMerged, tracking_score = ref_detection_score) or eval.py:226-300
     (merged=False, PubTracker).  The reference walks the frames of all scenes in file order with one tracker that is reset at
     every scene start; scenes are independent, so here every scene has its own tracker and all scenes advance together, one
-    kernel launch per frame index."""
+    kernel launch per frame index.  whole_scenes=True (merged greedy tracker only): every scene's whole run is ONE kernel launch and the
+    detection dicts are left untouched (the per-frame path annotates them in place, as the reference does); same rows."""
     scenes = []
     for fr in frames_meta:
         if fr["first"]:
             scenes.append([])
         scenes[-1].append(fr)
+    if whole_scenes:
+        if merged and not hungarian and tracker_factory is None and _scenes_fit_device_tracker(predictions):
+            annos = _track_scenes_on_device(predictions, scenes, max_age)
+            if annos is not None:
+                return annos
+        # beyond the kernel's capacities (or another tracker was asked for): the per-frame path below, on shallow copies - it writes
+        # top-level keys into the detection dicts and never into their lists
+        predictions = {tok: [dict(d) for d in annos] for tok, annos in predictions.items()}
     if tracker_factory is None:
         tracker_factory = (lambda: PubTrackerMerged(max_age=max_age, hungarian=hungarian)) if merged else \
             (lambda: PubTracker(max_age=max_age, hungarian=hungarian, refine_confidence=refine_confidence, alpha=alpha, beta=beta))
@@ -259,9 +299,8 @@ def _run_split(models, paths, scenes, bev, device, work_dir=None, split="val", m
             meta = json.load(f)["frames"]
     if tracker_on_device:
         with timer.stage("tracker"):
-            # the tracker writes top-level keys into the detection dicts (ct, tracking, tracking_id, age, ...) and never into their lists:
-            # a shallow copy per dict keeps `merged` as decoded (a deepcopy of the split was a third of the tracker's time)
-            tracking = run_tracking({tok: [dict(d) for d in annos] for tok, annos in merged["results"].items()}, meta, max_age=max_age)
+            # whole scenes in one launch; `merged` stays as decoded either way (run_tracking)
+            tracking = run_tracking(merged["results"], meta, max_age=max_age, whole_scenes=True)
     else:
         tracking = None
     if work_dir is not None:

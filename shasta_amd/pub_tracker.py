@@ -347,3 +347,95 @@ def step_batch_merged(trackers, results_list, time_lags):
         trk.tracks = ret
         outs.append(ret)
     return outs
+
+
+def track_scenes_merged_device(scene_frames, max_age=0, device=None):
+    """The merged tracker (PubTrackerMerged, greedy) for whole scenes in ONE launch (csrc/track.hip `track_merged_kernel`,
+    shasta_track_merged_f64): scene_frames = [[(detections of the frame: list of nuScenes-format dicts with `ref_detection_score`,
+    time_lag), ...] per scene].  Returns per scene, per frame, the result rows' sources in the order pub_test.py emits them:
+    a list of (detection dict, tracking_id, refined ref_detection_score) - class by class, matched detections then new ones - or None
+    when a scene exceeds the kernel's capacities (192 detections per frame, 320 tracks alive): the caller then takes the per-frame path.
+    The dicts are NOT modified (the host tracker annotates them in place)."""
+    import ctypes as C
+    lib = hip.load()
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    S = len(scene_frames)
+    if S == 0:
+        return []
+    label = {n: i for i, n in enumerate(NUSCENES_TRACKING_NAMES)}
+    Fmax = max(1, max(len(fr) for fr in scene_frames))
+    dets = [d for fr in scene_frames for (ds, _) in fr for d in ds]
+    D = len(dets)
+    off = np.zeros((S, Fmax + 1), np.int32)
+    lag = np.zeros((S, Fmax), np.float64)
+    nfr = np.zeros(S, np.int32)
+    g = 0
+    for s, fr in enumerate(scene_frames):
+        nfr[s] = len(fr)
+        for f, (ds, tl) in enumerate(fr):
+            off[s, f] = g
+            g += len(ds)
+            lag[s, f] = tl
+        off[s, len(fr):] = g
+    if D == 0:
+        return [[[] for _ in fr] for fr in scene_frames]
+    xy = np.array([d["translation"][:2] for d in dets], np.float64).reshape(D, 2)
+    vel = np.array([d["velocity"][:2] for d in dets], np.float64).reshape(D, 2)
+    cls = np.array([label.get(d["detection_name"], -1) for d in dets], np.int32)
+    score = np.array([d["detection_score"] for d in dets], np.float64)
+    ref = np.array([d["ref_detection_score"] for d in dets], np.float64)
+    flags = np.array([("newborn" in d) | (("dead" in d) << 1) for d in dets], np.int32)
+    # one 8-byte-word buffer in, one back
+    words = [2 * D, 2 * D, D, D, (D + 1) // 2, (D + 1) // 2, (off.size + 1) // 2, lag.size, (S + 1) // 2]
+    o = np.concatenate([[0], np.cumsum(words)]).tolist()
+    host = torch.zeros(o[-1], dtype=torch.float64, pin_memory=device.type == "cuda")
+    h = host.numpy()
+    h[o[0]:o[1]] = xy.ravel()
+    h[o[1]:o[2]] = vel.ravel()
+    h[o[2]:o[3]] = score
+    h[o[3]:o[4]] = ref
+    h[o[4]:o[5]].view(np.int32)[:D] = cls
+    h[o[5]:o[6]].view(np.int32)[:D] = flags
+    h[o[6]:o[7]].view(np.int32)[:off.size] = off.ravel()
+    h[o[7]:o[8]] = lag.ravel()
+    h[o[8]:o[9]].view(np.int32)[:S] = nfr
+    dbuf = host.to(device, non_blocking=True)
+    seg = [dbuf[o[i]:o[i + 1]] for i in range(9)]
+    out = torch.zeros(D + (D + 1) // 2 * 2 + (S + 1) // 2, dtype=torch.float64, device=device)  # ref | status | id | err
+    o_ref, o_st = out[:D], out[D:D + (D + 1) // 2].view(torch.int32)
+    o_id, o_err = out[D + (D + 1) // 2:D + 2 * ((D + 1) // 2)].view(torch.int32), out[D + 2 * ((D + 1) // 2):].view(torch.int32)
+    names = NUSCENES_TRACKING_NAMES
+    gate = (C.c_float * len(names))(*[float(NUSCENE_CLS_VELOCITY_ERROR[n]) for n in names])
+    refon = (C.c_int32 * len(names))(*[int(bool(TRK_REF[n]["ref"])) for n in names])
+    alpha = (C.c_double * len(names))(*[float(TRK_REF[n]["alpha"]) for n in names])
+    beta = (C.c_double * len(names))(*[float(TRK_REF[n]["beta"]) for n in names])
+    hip.check(lib.shasta_track_merged_f64(hip.ptr(seg[0]), hip.ptr(seg[1]), hip.ptr(seg[4].view(torch.int32)), hip.ptr(seg[2]), hip.ptr(seg[3]),
+                                          hip.ptr(seg[5].view(torch.int32)), hip.ptr(seg[6].view(torch.int32)), hip.ptr(seg[7]),
+                                          hip.ptr(seg[8].view(torch.int32)), S, Fmax, len(names), gate, refon, alpha, beta, int(max_age),
+                                          hip.ptr(o_st), hip.ptr(o_id), hip.ptr(o_ref), hip.ptr(o_err), hip.stream_ptr()),
+              "shasta_track_merged_f64")
+    oh = out.cpu().numpy()
+    r_ref = oh[:D].tolist()
+    r_st = oh[D:D + (D + 1) // 2].view(np.int32)[:D]
+    r_id = oh[D + (D + 1) // 2:D + 2 * ((D + 1) // 2)].view(np.int32)[:D].tolist()
+    r_err = oh[D + 2 * ((D + 1) // 2):].view(np.int32)[:S]
+    # result order inside a frame: class, then matched before new, then file order - one sort for the whole split
+    frame_of = np.zeros(D, np.int64)
+    bounds, fid = [], 0
+    for s in range(S):
+        for f in range(int(nfr[s])):
+            frame_of[off[s, f]:off[s, f + 1]] = fid
+            bounds.append((s, f))
+            fid += 1
+    kept = np.nonzero(r_st > 0)[0]
+    kept = kept[np.lexsort((kept, r_st[kept], cls[kept], frame_of[kept]))]
+    per_frame = np.bincount(frame_of[kept], minlength=fid) if fid else np.zeros(0, np.int64)
+    kept = kept.tolist()
+    res = [None if r_err[s] != 0 else [None] * int(nfr[s]) for s in range(S)]
+    p0 = 0
+    for k, (s, f) in enumerate(bounds):
+        cnt = int(per_frame[k])
+        if res[s] is not None:
+            res[s][f] = [(dets[i], r_id[i], r_ref[i]) for i in kept[p0:p0 + cnt]]
+        p0 += cnt
+    return res
