@@ -679,6 +679,9 @@ def extra_pipeline(bench, args, ex):
     from shasta_amd import pipeline, scenes
     root = tempfile.mkdtemp(prefix="shasta_split_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()  # the earlier extras leave GBs of cached blocks of other sizes: the chain's 2.7 GB map stacks start from a clean pool
         n_scenes, n_frames = 20, 40
         paths, sc = scenes.write_synthetic_split(root, n_scenes=n_scenes, frames_per_scene=n_frames, seed=3)
         models = {n: pipeline.build_class_model(n, dev, seed=1) for n in pipeline.CLASS_CONFIGS}
