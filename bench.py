@@ -715,8 +715,8 @@ def extra_pipeline(bench, args, ex):
              "stages_s": {k: round(v, 4) for k, v in st.items()},
              "forward_only_s": fwd_s, "forward_only_frames_per_s": n / fwd_s, "chain_over_forward_only": fwd_s / total,
              "note": "frames_per_s: whole chain; forward_only = device time (HIP events) of K0 for all heads + the seven class forwards + decode kernels over the same "
-                     "runs, nothing else; chain_over_forward_only = their ratio.  What separates the two is host Python: building the class "
-                     "dicts from the per-frame json files, the decode lists and the tracker's bookkeeping.  stages_s: a separate pass with the "
+                     "runs, nothing else; chain_over_forward_only = their ratio.  What separates the two is host Python on the "
+                     "reference's formats (per-frame json files -> class dicts -> decode lists -> result rows; the tracker itself is one kernel launch per split).  stages_s: a separate pass with the "
                      "device synchronised at every stage boundary (slower than the un-instrumented total)"}
         if not args.no_cpu_baseline:
             from oracle import pipeline_oracle as PO
