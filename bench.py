@@ -554,8 +554,8 @@ def extras(bench, args):
     bench.models.pop(tuple(sorted(cfg5.items())), None)  # 6.4 GB of weights + their companion image: released before the next extras
     torch = bench.torch
     torch.cuda.empty_cache()
-    for name, fn in (("shared_conv", extra_shared_conv), ("voxelize", extra_voxelize), ("train_step", extra_train_step),
-                     ("pipeline", extra_pipeline)):
+    for name, fn in (("pipeline", extra_pipeline), ("shared_conv", extra_shared_conv), ("voxelize", extra_voxelize),
+                     ("train_step", extra_train_step)):
         try:
             fn(bench, args, ex)
         except Exception as err:  # noqa: BLE001
