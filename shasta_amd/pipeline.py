@@ -380,7 +380,7 @@ def _loader_run(run, share_prev=False):
 
 def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, batch_pairs, decode_on_device, timer):
     """The loader runs in line, between the launches of one run and the host half of the previous one (the device is busy with the queued
-    run meanwhile).  Measured alternatives on the 20 x 40 split (MI355X box, 256 host cores; in line: 800 - 867 frames/s): a loader
+    run meanwhile).  Alternatives measured on the 20 x 40 split when this form ran at 800 - 867 frames/s (MI355X box, 256 host cores): a loader
     THREAD 526 - 632 (parsing is pure Python: the thread takes the GIL from the launches); multiprocessing pools 248 - 303 (every child
     imports the main module and torch); 2 - 4 child processes that import numpy and json only, parse the files and pipe the parsed frames
     back 617 - 840 (unpickling the class dicts here costs what decoding their json costs; ~0.2 s of start-up); two runs in flight
