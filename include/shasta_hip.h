@@ -399,7 +399,7 @@ int shasta_center_greedy_f32(const float* det_xy, const float* trk_xy, const int
  * (suppressed or unknown class), 1 = took over a track, 2 = new track; out_id = tracking_id (per scene, from 1); out_ref = refined
  * ref_detection_score = the tracking_score of the result row (rows with active == 0 - coasting tracks - are never emitted by
  * pub_test.py).  Row order of a frame's result: class by class, matched detections then new ones, each in file order.  out_err
- * (scenes,): 0, 1 = a frame holds more than 192 detections, 2 = more than 320 tracks alive (the caller falls back to the per-frame
+ * (scenes,): 0, 1 = a frame holds more than 512 detections, 2 = more than 768 tracks alive (the caller falls back to the per-frame
  * path).  Bit-identical to the host tracker of shasta_amd.pub_tracker (float64 arithmetic in the reference's operation order). */
 int shasta_track_merged_f64(const double* det_xy, const double* det_vel, const int32_t* det_cls, const double* det_score,
                             const double* det_ref, const int32_t* det_flags, const int32_t* frame_off, const double* frame_lag,

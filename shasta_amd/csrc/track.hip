@@ -115,9 +115,11 @@ __global__ __launch_bounds__(64) void center_greedy_kernel(GreedyArgs a) {
 // lanes.  Greedy over all detections of a frame in file order equals the per-class problems of step_batch_merged: a pair of different
 // classes is invalid (1e18), so a taken column only ever matters to detections of its own class, and "first minimum" over the whole
 // track list picks the same track as over the list restricted to the class (relative order is kept).
-constexpr int TM_TCAP = 320;   // tracks of a scene alive at one time (matched + new + coasting)
-constexpr int TM_DCAP = 192;   // detections of one frame
+constexpr int TM_TCAP = 768;   // tracks of a scene alive at one time (matched + new + coasting)
+constexpr int TM_DCAP = 512;   // detections of one frame
 constexpr int TM_NCLS = 8;
+// dynamic LDS (one workgroup = one wavefront per CU): 2 track buffers x 60 B x TM_TCAP + 64 B x TM_DCAP + flags = ~130 KB
+constexpr size_t TM_LDS_BYTES = (size_t)2 * TM_TCAP * (5 * 8 + 5 * 4) + (size_t)TM_DCAP * (6 * 8 + 2 * 4 + 4 * 4) + (size_t)TM_TCAP * 4 + TM_TCAP / 32 * 4;
 
 struct TrackMergedArgs {
     const double* det_xy;     // (D, 2) translation[:2]
@@ -140,13 +142,32 @@ struct TrackMergedArgs {
 };
 
 __global__ __launch_bounds__(64) void track_merged_kernel(TrackMergedArgs a) {
-    __shared__ double t_cx[2][TM_TCAP], t_cy[2][TM_TCAP], t_tx[2][TM_TCAP], t_ty[2][TM_TCAP], t_ref[2][TM_TCAP];
-    __shared__ int t_id[2][TM_TCAP], t_age[2][TM_TCAP], t_act[2][TM_TCAP], t_cls[2][TM_TCAP], t_flg[2][TM_TCAP];
-    __shared__ double d_cx[TM_DCAP], d_cy[TM_DCAP], d_tx[TM_DCAP], d_ty[TM_DCAP], d_sc[TM_DCAP], d_rf[TM_DCAP];
-    __shared__ float d_fx[TM_DCAP], d_fy[TM_DCAP];
-    __shared__ int d_cl[TM_DCAP], d_fl[TM_DCAP], d_match[TM_DCAP], d_near[TM_DCAP];
-    __shared__ int t_near[TM_TCAP];
-    __shared__ unsigned taken[TM_TCAP / 32];
+    extern __shared__ __attribute__((aligned(16))) double tm_lds[];
+    // carve-up: doubles first, then the 4-byte arrays
+    double (*t_cx)[TM_TCAP] = reinterpret_cast<double (*)[TM_TCAP]>(tm_lds);
+    double (*t_cy)[TM_TCAP] = t_cx + 2;
+    double (*t_tx)[TM_TCAP] = t_cy + 2;
+    double (*t_ty)[TM_TCAP] = t_tx + 2;
+    double (*t_ref)[TM_TCAP] = t_ty + 2;
+    double* d_cx = reinterpret_cast<double*>(t_ref + 2);
+    double* d_cy = d_cx + TM_DCAP;
+    double* d_tx = d_cy + TM_DCAP;
+    double* d_ty = d_tx + TM_DCAP;
+    double* d_sc = d_ty + TM_DCAP;
+    double* d_rf = d_sc + TM_DCAP;
+    int (*t_id)[TM_TCAP] = reinterpret_cast<int (*)[TM_TCAP]>(d_rf + TM_DCAP);
+    int (*t_age)[TM_TCAP] = t_id + 2;
+    int (*t_act)[TM_TCAP] = t_age + 2;
+    int (*t_cls)[TM_TCAP] = t_act + 2;
+    int (*t_flg)[TM_TCAP] = t_cls + 2;
+    float* d_fx = reinterpret_cast<float*>(t_flg + 2);
+    float* d_fy = d_fx + TM_DCAP;
+    int* d_cl = reinterpret_cast<int*>(d_fy + TM_DCAP);
+    int* d_fl = d_cl + TM_DCAP;
+    int* d_match = d_fl + TM_DCAP;
+    int* d_near = d_match + TM_DCAP;
+    int* t_near = d_near + TM_DCAP;
+    unsigned* taken = reinterpret_cast<unsigned*>(t_near + TM_TCAP);
     const int s = blockIdx.x, lane = threadIdx.x;
     const int* off = a.frame_off + (size_t)s * (a.Fmax + 1);
     const int F = a.n_frames[s];
@@ -320,6 +341,7 @@ extern "C" int shasta_track_merged_f64(const double* det_xy, const double* det_v
         a.alpha[c] = c < n_cls ? cls_alpha[c] : 0.0;
         a.beta[c] = c < n_cls ? cls_beta[c] : 0.0;
     }
-    hipLaunchKernelGGL(track_merged_kernel, dim3(scenes), dim3(64), 0, as_stream(stream), a);
+    (void)hipFuncSetAttribute((const void*)track_merged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TM_LDS_BYTES);
+    hipLaunchKernelGGL(track_merged_kernel, dim3(scenes), dim3(64), TM_LDS_BYTES, as_stream(stream), a);
     return check_launch("track_merged");
 }

@@ -126,8 +126,8 @@ def merge_results(per_class):
     return out
 
 
-def _scenes_fit_device_tracker(results, max_dets=192):
-    """A cheap necessary condition for the whole-scene kernel (192 detections per frame); the kernel itself reports track overflow."""
+def _scenes_fit_device_tracker(results, max_dets=512):
+    """A cheap necessary condition for the whole-scene kernel (512 detections per frame); the kernel itself reports track overflow."""
     return all(len(v) <= max_dets for v in results.values())
 
 

@@ -354,7 +354,7 @@ def track_scenes_merged_device(scene_frames, max_age=0, device=None):
     shasta_track_merged_f64): scene_frames = [[(detections of the frame: list of nuScenes-format dicts with `ref_detection_score`,
     time_lag), ...] per scene].  Returns per scene, per frame, the result rows' sources in the order pub_test.py emits them:
     a list of (detection dict, tracking_id, refined ref_detection_score) - class by class, matched detections then new ones - or None
-    when a scene exceeds the kernel's capacities (192 detections per frame, 320 tracks alive): the caller then takes the per-frame path.
+    when a scene exceeds the kernel's capacities (512 detections per frame, 768 tracks alive): the caller then takes the per-frame path.
     The dicts are NOT modified (the host tracker annotates them in place)."""
     import ctypes as C
     lib = hip.load()
