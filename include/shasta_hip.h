@@ -400,12 +400,15 @@ int shasta_center_greedy_f32(const float* det_xy, const float* trk_xy, const int
  * ref_detection_score = the tracking_score of the result row (rows with active == 0 - coasting tracks - are never emitted by
  * pub_test.py).  Row order of a frame's result: class by class, matched detections then new ones, each in file order.  out_err
  * (scenes,): 0, 1 = a frame holds more than 512 detections, 2 = more than 768 tracks alive (the caller falls back to the per-frame
- * path).  Bit-identical to the host tracker of shasta_amd.pub_tracker (float64 arithmetic in the reference's operation order). */
+ * path).  plain != 0: the single-list tracker of tools/nusc_shasta/pub_tracker.py:35-210 (eval.py:226-300) instead - all tracking
+ * classes form one group (result order: matched detections, then new ones), cls_ref[0] / cls_alpha[0] / cls_beta[0] are its
+ * refine_confidence / alpha / beta, a new track's score is its detection_score, coasting leaves scores alone.  Bit-identical to the
+ * host trackers of shasta_amd.pub_tracker (float64 arithmetic in the reference's operation order). */
 int shasta_track_merged_f64(const double* det_xy, const double* det_vel, const int32_t* det_cls, const double* det_score,
                             const double* det_ref, const int32_t* det_flags, const int32_t* frame_off, const double* frame_lag,
                             const int32_t* n_frames, int scenes, int Fmax, int n_cls, const float* cls_gate, const int32_t* cls_ref,
-                            const double* cls_alpha, const double* cls_beta, int max_age, int32_t* out_status, int32_t* out_id,
-                            double* out_ref, int32_t* out_err, shasta_stream_t stream);
+                            const double* cls_alpha, const double* cls_beta, int max_age, int plain, int32_t* out_status,
+                            int32_t* out_id, double* out_ref, int32_t* out_err, shasta_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training path, backward helpers (the nn.Linear layers run on shasta_gemm_strided_f32; the first layer of each pair MLP

@@ -136,6 +136,7 @@ struct TrackMergedArgs {
     double* out_ref;          // (D,) refined ref_detection_score
     int* out_err;             // (S,) 0 ok, 1: a frame holds more than TM_DCAP detections, 2: more than TM_TCAP tracks
     int Fmax, max_age, ncls;
+    int plain;                // 0: PubTrackerMerged (class by class, TRK_REF tables); 1: PubTracker (one list, refine / alpha[0] / beta[0])
     float gate[TM_NCLS];
     int ref_on[TM_NCLS];
     double alpha[TM_NCLS], beta[TM_NCLS];
@@ -244,56 +245,64 @@ __global__ __launch_bounds__(64) void track_merged_kernel(TrackMergedArgs a) {
             }
         }
         __syncthreads();
-        // the new track list, class by class (pub_tracker_merged.py:100-223); serial by nature
+        // the new track list: class by class (pub_tracker_merged.py:100-223) or, for the plain tracker (pub_tracker.py:110-208), all
+        // tracking classes as one group; serial by nature
         if (lane == 0) {
             const int nxt = cur ^ 1;
             int nr = 0;
             int cnt_t[TM_NCLS];
             for (int c = 0; c < a.ncls; ++c) cnt_t[c] = 0;
             for (int j = 0; j < nt; ++j) cnt_t[t_cls[cur][j]] += 1;
-            for (int c = 0; c < a.ncls && !err; ++c) {
+            const int ngroups = a.plain ? 1 : a.ncls;
+            for (int c = 0; c < ngroups && !err; ++c) {
+#define TM_DIN(i) (a.plain ? d_cl[i] >= 0 : d_cl[i] == c)
+#define TM_TIN(j) (a.plain ? true : t_cls[cur][j] == c)
                 bool has = false;
-                for (int i = 0; i < n; ++i) has = has || d_cl[i] == c;
-                if (!has) continue;  // nothing of this class in the frame: its tracks are dropped
+                for (int i = 0; i < n; ++i) has = has || TM_DIN(i);
+                if (!has) continue;  // merged: nothing of this class in the frame: its tracks are dropped
                 const double al = a.alpha[c], be = a.beta[c];
                 const bool rf = a.ref_on[c] != 0;
+                const int ntrk = a.plain ? nt : cnt_t[c];
                 for (int i = 0; i < n && !err; ++i) {  // matched detections take over their track
-                    if (d_cl[i] != c || d_match[i] < 0) continue;
+                    if (!TM_DIN(i) || d_match[i] < 0) continue;
                     if (nr >= TM_TCAP) { err = 2; break; }
                     const int j = d_match[i];
-                    const double r = rf ? ((d_rf[i] > al ? 1.0 : 0.0) * be * d_sc[i] + (1.0 - be) * t_ref[cur][j]) : d_sc[i];
+                    const double refined = (d_rf[i] > al ? 1.0 : 0.0) * be * d_sc[i] + (1.0 - be) * t_ref[cur][j];
+                    const double r = rf ? refined : (a.plain ? d_rf[i] : d_sc[i]);
                     t_cx[nxt][nr] = d_cx[i]; t_cy[nxt][nr] = d_cy[i]; t_tx[nxt][nr] = d_tx[i]; t_ty[nxt][nr] = d_ty[i];
                     t_ref[nxt][nr] = r; t_id[nxt][nr] = t_id[cur][j]; t_age[nxt][nr] = 1; t_act[nxt][nr] = t_act[cur][j] + 1;
-                    t_cls[nxt][nr] = c; t_flg[nxt][nr] = d_fl[i];
+                    t_cls[nxt][nr] = d_cl[i]; t_flg[nxt][nr] = d_fl[i];
                     a.out_status[g0 + i] = 1; a.out_id[g0 + i] = t_id[cur][j]; a.out_ref[g0 + i] = r;
                     ++nr;
                 }
                 for (int i = 0; i < n && !err; ++i) {  // unmatched detections start tracks unless suppressed
-                    if (d_cl[i] != c || d_match[i] >= 0) continue;
-                    if (cnt_t[c] > 0 && !(d_fl[i] & 1) && d_near[i]) continue;
+                    if (!TM_DIN(i) || d_match[i] >= 0) continue;
+                    if (ntrk > 0 && !(d_fl[i] & 1) && d_near[i]) continue;
                     if (nr >= TM_TCAP) { err = 2; break; }
-                    const double r = rf ? be * d_sc[i] : d_sc[i];
+                    const double r = (rf && !a.plain) ? be * d_sc[i] : d_sc[i];
                     ++idc;
                     t_cx[nxt][nr] = d_cx[i]; t_cy[nxt][nr] = d_cy[i]; t_tx[nxt][nr] = d_tx[i]; t_ty[nxt][nr] = d_ty[i];
                     t_ref[nxt][nr] = r; t_id[nxt][nr] = idc; t_age[nxt][nr] = 1; t_act[nxt][nr] = 1;
-                    t_cls[nxt][nr] = c; t_flg[nxt][nr] = d_fl[i];
+                    t_cls[nxt][nr] = d_cl[i]; t_flg[nxt][nr] = d_fl[i];
                     a.out_status[g0 + i] = 2; a.out_id[g0 + i] = idc; a.out_ref[g0 + i] = r;
                     ++nr;
                 }
                 for (int j = 0; j < nt && !err; ++j) {  // unmatched tracks coast
-                    if (t_cls[cur][j] != c) continue;
+                    if (!TM_TIN(j)) continue;
                     if ((taken[j >> 5] >> (j & 31)) & 1u) continue;
                     if ((t_flg[cur][j] & 2) && t_near[j]) continue;
                     if (t_age[cur][j] < a.max_age) {
                         if (nr >= TM_TCAP) { err = 2; break; }
                         t_cx[nxt][nr] = t_cx[cur][j] + t_tx[cur][j] * -1.0; t_cy[nxt][nr] = t_cy[cur][j] + t_ty[cur][j] * -1.0;
                         t_tx[nxt][nr] = t_tx[cur][j]; t_ty[nxt][nr] = t_ty[cur][j];
-                        t_ref[nxt][nr] = rf ? (1.0 - be) * t_ref[cur][j] : t_ref[cur][j];
+                        t_ref[nxt][nr] = (rf && !a.plain) ? (1.0 - be) * t_ref[cur][j] : t_ref[cur][j];
                         t_id[nxt][nr] = t_id[cur][j]; t_age[nxt][nr] = t_age[cur][j] + 1; t_act[nxt][nr] = 0;
-                        t_cls[nxt][nr] = c; t_flg[nxt][nr] = t_flg[cur][j];
+                        t_cls[nxt][nr] = t_cls[cur][j]; t_flg[nxt][nr] = t_flg[cur][j];
                         ++nr;
                     }
                 }
+#undef TM_DIN
+#undef TM_TIN
             }
             nt = nr;
         }
@@ -324,7 +333,7 @@ extern "C" int shasta_center_greedy_f32(const float* det_xy, const float* trk_xy
 extern "C" int shasta_track_merged_f64(const double* det_xy, const double* det_vel, const int32_t* det_cls, const double* det_score,
                                        const double* det_ref, const int32_t* det_flags, const int32_t* frame_off, const double* frame_lag,
                                        const int32_t* n_frames, int scenes, int Fmax, int n_cls, const float* cls_gate,
-                                       const int32_t* cls_ref, const double* cls_alpha, const double* cls_beta, int max_age,
+                                       const int32_t* cls_ref, const double* cls_alpha, const double* cls_beta, int max_age, int plain,
                                        int32_t* out_status, int32_t* out_id, double* out_ref, int32_t* out_err, shasta_stream_t stream) {
     SHASTA_REQUIRE(det_xy && det_vel && det_cls && det_score && det_ref && det_flags && frame_off && frame_lag && n_frames, "track_merged: null input");
     SHASTA_REQUIRE(cls_gate && cls_ref && cls_alpha && cls_beta && out_status && out_id && out_ref && out_err, "track_merged: null pointer");
@@ -334,7 +343,7 @@ extern "C" int shasta_track_merged_f64(const double* det_xy, const double* det_v
     a.det_xy = det_xy; a.det_vel = det_vel; a.det_cls = det_cls; a.det_score = det_score; a.det_ref = det_ref; a.det_flags = det_flags;
     a.frame_off = frame_off; a.frame_lag = frame_lag; a.n_frames = n_frames;
     a.out_status = out_status; a.out_id = out_id; a.out_ref = out_ref; a.out_err = out_err;
-    a.Fmax = Fmax; a.max_age = max_age; a.ncls = n_cls;
+    a.Fmax = Fmax; a.max_age = max_age; a.ncls = n_cls; a.plain = plain ? 1 : 0;
     for (int c = 0; c < TM_NCLS; ++c) {  // (host arrays: class constants)
         a.gate[c] = c < n_cls ? cls_gate[c] : 0.0f;
         a.ref_on[c] = c < n_cls ? cls_ref[c] : 0;

@@ -100,7 +100,7 @@ SYMBOLS = {
     "shasta_nms_normal_f32": (_I, [_P, _I, _F, _P, _Z, _P, _P, _P]),
     "shasta_boxes_bev_f32": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "shasta_center_greedy_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
-    "shasta_track_merged_f64": (_I, [_P] * 9 + [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "shasta_track_merged_f64": (_I, [_P] * 9 + [_I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "shasta_decode_flags_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "shasta_gemm_strided_f32": (_I, [_P, C.c_long, C.c_long, _P, C.c_long, C.c_long, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "shasta_gemm_nt_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),

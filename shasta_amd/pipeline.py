@@ -131,9 +131,10 @@ def _scenes_fit_device_tracker(results, max_dets=512):
     return all(len(v) <= max_dets for v in results.values())
 
 
-def _track_scenes_on_device(predictions, scenes, max_age):
-    """run_tracking's fast path: the merged greedy tracker of every scene in one launch (pub_tracker.track_scenes_merged_device);
-    None when a scene exceeds the kernel's capacities."""
+def _track_scenes_on_device(predictions, scenes, max_age, merged=True, refine_confidence=False, alpha=0.5, beta=0.5):
+    """run_tracking's fast path: the greedy tracker (merged or plain) of every scene in one launch
+    (pub_tracker.track_scenes_merged_device); None when a scene exceeds the kernel's capacities or - plain tracker - a frame has
+    detections but none of a tracking class (the per-frame path then raises like the reference)."""
     from .pub_tracker import track_scenes_merged_device
     frames = []
     for sc in scenes:
@@ -141,19 +142,28 @@ def _track_scenes_on_device(predictions, scenes, max_age):
         for m in sc:
             if m["first"]:
                 last = m["timestamp"]
-            fr.append((predictions[m["token"]], m["timestamp"] - last))
+            dets = predictions[m["token"]]
+            if not merged and dets and not any(d["detection_name"] in NUSCENES_TRACKING_NAMES for d in dets):
+                return None
+            fr.append((dets, m["timestamp"] - last))
             last = m["timestamp"]
         frames.append(fr)
-    out = track_scenes_merged_device(frames, max_age=max_age)
+    out = track_scenes_merged_device(frames, max_age=max_age, plain=not merged, refine_confidence=refine_confidence, alpha=alpha, beta=beta)
     if any(o is None for o in out):
         return None
     annos = {"results": {}, "meta": dict(META)}
     for sc, rows in zip(scenes, out):
         for m, items in zip(sc, rows):
             token = m["token"]
-            annos["results"][token] = [
-                {"sample_token": token, "translation": d["translation"], "size": d["size"], "rotation": d["rotation"], "velocity": d["velocity"],
-                 "tracking_id": str(tid), "tracking_name": d["detection_name"], "tracking_score": ref} for d, tid, ref in items]
+            if merged:
+                annos["results"][token] = [
+                    {"sample_token": token, "translation": d["translation"], "size": d["size"], "rotation": d["rotation"], "velocity": d["velocity"],
+                     "tracking_id": str(tid), "tracking_name": d["detection_name"], "tracking_score": ref} for d, tid, ref in items]
+            else:
+                annos["results"][token] = [
+                    {"sample_token": token, "translation": d["translation"], "size": d["size"], "rotation": d["rotation"], "velocity": d["velocity"],
+                     "tracking_id": str(tid), "tracking_name": d["detection_name"],
+                     "tracking_score": ref if refine_confidence else d["detection_score"], "attribute_name": d["attribute_name"]} for d, tid, ref in items]
     return annos
 
 
@@ -162,7 +172,7 @@ def run_tracking(predictions, frames_meta, max_age=4, hungarian=False, merged=Tr
     """pub_test.py:88-162 (merged=True, PubTrackerMerged, tracking_score = ref_detection_score) or eval.py:226-300
     (merged=False, PubTracker).  The reference walks the frames of all scenes in file order with one tracker that is reset at
     every scene start; scenes are independent, so here every scene has its own tracker and all scenes advance together, one
-    kernel launch per frame index.  whole_scenes=True (merged greedy tracker only): every scene's whole run is ONE kernel launch and the
+    kernel launch per frame index.  whole_scenes=True (greedy assignment, either tracker): every scene's whole run is ONE kernel launch and the
     detection dicts are left untouched (the per-frame path annotates them in place, as the reference does); same rows."""
     scenes = []
     for fr in frames_meta:
@@ -170,8 +180,8 @@ def run_tracking(predictions, frames_meta, max_age=4, hungarian=False, merged=Tr
             scenes.append([])
         scenes[-1].append(fr)
     if whole_scenes:
-        if merged and not hungarian and tracker_factory is None and _scenes_fit_device_tracker(predictions):
-            annos = _track_scenes_on_device(predictions, scenes, max_age)
+        if not hungarian and tracker_factory is None and _scenes_fit_device_tracker(predictions):
+            annos = _track_scenes_on_device(predictions, scenes, max_age, merged, refine_confidence, alpha, beta)
             if annos is not None:
                 return annos
         # beyond the kernel's capacities (or another tracker was asked for): the per-frame path below, on shallow copies - it writes

@@ -349,8 +349,9 @@ def step_batch_merged(trackers, results_list, time_lags):
     return outs
 
 
-def track_scenes_merged_device(scene_frames, max_age=0, device=None):
-    """The merged tracker (PubTrackerMerged, greedy) for whole scenes in ONE launch (csrc/track.hip `track_merged_kernel`,
+def track_scenes_merged_device(scene_frames, max_age=0, device=None, plain=False, refine_confidence=False, alpha=0.5, beta=0.5):
+    """The merged tracker (PubTrackerMerged, greedy; plain=True: PubTracker with its refine_confidence / alpha / beta - one list over all
+    tracking classes, result order matched detections then new ones) for whole scenes in ONE launch (csrc/track.hip `track_merged_kernel`,
     shasta_track_merged_f64): scene_frames = [[(detections of the frame: list of nuScenes-format dicts with `ref_detection_score`,
     time_lag), ...] per scene].  Returns per scene, per frame, the result rows' sources in the order pub_test.py emits them:
     a list of (detection dict, tracking_id, refined ref_detection_score) - class by class, matched detections then new ones - or None
@@ -383,7 +384,7 @@ def track_scenes_merged_device(scene_frames, max_age=0, device=None):
     vel = np.array([d["velocity"][:2] for d in dets], np.float64).reshape(D, 2)
     cls = np.array([label.get(d["detection_name"], -1) for d in dets], np.int32)
     score = np.array([d["detection_score"] for d in dets], np.float64)
-    ref = np.array([d["ref_detection_score"] for d in dets], np.float64)
+    ref = np.array([d.get("ref_detection_score", 0.0) for d in dets], np.float64) if plain else np.array([d["ref_detection_score"] for d in dets], np.float64)
     flags = np.array([("newborn" in d) | (("dead" in d) << 1) for d in dets], np.int32)
     # one 8-byte-word buffer in, one back
     words = [2 * D, 2 * D, D, D, (D + 1) // 2, (D + 1) // 2, (off.size + 1) // 2, lag.size, (S + 1) // 2]
@@ -406,12 +407,17 @@ def track_scenes_merged_device(scene_frames, max_age=0, device=None):
     o_id, o_err = out[D + (D + 1) // 2:D + 2 * ((D + 1) // 2)].view(torch.int32), out[D + 2 * ((D + 1) // 2):].view(torch.int32)
     names = NUSCENES_TRACKING_NAMES
     gate = (C.c_float * len(names))(*[float(NUSCENE_CLS_VELOCITY_ERROR[n]) for n in names])
-    refon = (C.c_int32 * len(names))(*[int(bool(TRK_REF[n]["ref"])) for n in names])
-    alpha = (C.c_double * len(names))(*[float(TRK_REF[n]["alpha"]) for n in names])
-    beta = (C.c_double * len(names))(*[float(TRK_REF[n]["beta"]) for n in names])
+    if plain:
+        refon = (C.c_int32 * len(names))(*([int(bool(refine_confidence))] * len(names)))
+        alpha = (C.c_double * len(names))(*([float(alpha)] * len(names)))
+        beta = (C.c_double * len(names))(*([float(beta)] * len(names)))
+    else:
+        refon = (C.c_int32 * len(names))(*[int(bool(TRK_REF[n]["ref"])) for n in names])
+        alpha = (C.c_double * len(names))(*[float(TRK_REF[n]["alpha"]) for n in names])
+        beta = (C.c_double * len(names))(*[float(TRK_REF[n]["beta"]) for n in names])
     hip.check(lib.shasta_track_merged_f64(hip.ptr(seg[0]), hip.ptr(seg[1]), hip.ptr(seg[4].view(torch.int32)), hip.ptr(seg[2]), hip.ptr(seg[3]),
                                           hip.ptr(seg[5].view(torch.int32)), hip.ptr(seg[6].view(torch.int32)), hip.ptr(seg[7]),
-                                          hip.ptr(seg[8].view(torch.int32)), S, Fmax, len(names), gate, refon, alpha, beta, int(max_age),
+                                          hip.ptr(seg[8].view(torch.int32)), S, Fmax, len(names), gate, refon, alpha, beta, int(max_age), int(bool(plain)),
                                           hip.ptr(o_st), hip.ptr(o_id), hip.ptr(o_ref), hip.ptr(o_err), hip.stream_ptr()),
               "shasta_track_merged_f64")
     oh = out.cpu().numpy()
@@ -428,7 +434,8 @@ def track_scenes_merged_device(scene_frames, max_age=0, device=None):
             bounds.append((s, f))
             fid += 1
     kept = np.nonzero(r_st > 0)[0]
-    kept = kept[np.lexsort((kept, r_st[kept], cls[kept], frame_of[kept]))]
+    group = np.zeros(D, np.int32) if plain else cls  # the plain tracker's result is one list: matched, then new
+    kept = kept[np.lexsort((kept, r_st[kept], group[kept], frame_of[kept]))]
     per_frame = np.bincount(frame_of[kept], minlength=fid) if fid else np.zeros(0, np.int64)
     kept = kept.tolist()
     res = [None if r_err[s] != 0 else [None] * int(nfr[s]) for s in range(S)]
