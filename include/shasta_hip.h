@@ -173,6 +173,10 @@ typedef struct shasta_linear {
                                       a third fewer vector instructions in the pair kernel, errors of the residual 2x (max) / 5x (rms)
                                       those of the fp32 kernels (about 1e-6 of its range): NOT fp32-equivalent, opt-in */
 
+#define SHASTA_OPT_TWO_PASS_AFF 128 /* from 8192 table rows: keep the two-kernel form of the aff stage (six layers + row softmax, then a
+                                       column-softmax pass over the stored logits) instead of the single pass whose workgroups exchange
+                                       per-column partials; same layer arithmetic, softmax sums in another order */
+
 typedef struct shasta_weights {
     int max_obj;   /* N */
     int num_feats; /* nf: 1..7 */

@@ -263,12 +263,18 @@ __global__ __launch_bounds__(64 * AFF_WAVES) void aff_fused_kernel(AffArgs a) {
     }
 }
 
-size_t aff_workspace_bytes(int B, int N) {
+size_t aff_frame_workspace_bytes(int B, int N);
+static size_t aff_matched_bytes(int B, int N) {
     const int T = N + 2, Dp = (T + 3) / 4 * 4;
-    return align_up((size_t)B * T * Dp * sizeof(float), 256);  // matched (B, T, Dp) between the row MLP and the column softmax
+    return align_up((size_t)B * T * Dp * sizeof(float), 256);
 }
+// matched (B, T, Dp) between the row MLP and the column softmax (two-kernel forms), then the column partials and arrival counters of
+// the one-pass form
+size_t aff_workspace_bytes(int B, int N) { return aff_matched_bytes(B, N) + aff_frame_workspace_bytes(B, N); }
 
 bool aff_pieces_serves(int D);
+int launch_aff_frame(const shasta_weights* w, const float* packed_pieces, const float* residual, int ld, float* matched, int ldm, float* m1,
+                     float* m2, int B, void* ws, hipStream_t st);
 int launch_aff_pieces(const shasta_weights* w, const float* packed_pieces, const float* residual, int ld, float* matched, int ldm,
                       float* m1, int M, hipStream_t st);
 
@@ -298,6 +304,12 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
     // kernel.  Small batches stay on the f32 kernel (16-row workgroups: more parallelism, less latency).
     const bool pieces = M >= 8192 && !(w->options & SHASTA_OPT_F32_AFF) && aff_pieces_serves(D) && ld % 4 == 0 &&
                         (uintptr_t)residual % 16 == 0 && (uintptr_t)ws % 16 == 0;
+    // ... and, unless SHASTA_OPT_TWO_PASS_AFF asks for the two-kernel form, with both softmaxes in the same pass (aff_frame_kernel):
+    // `matched` is then written only when the caller wants it
+    if (pieces && !(w->options & SHASTA_OPT_TWO_PASS_AFF)) {
+        if ((rc = launch_aff_frame(w, packed + P.affp, residual, ld, matched_out ? matched : nullptr, Dp, m1, m2, B, base + aff_matched_bytes(B, N), st)))
+            return rc;
+    } else {
     if (pieces) {
         if ((rc = launch_aff_pieces(w, packed + P.affp, residual, ld, matched, Dp, m1, M, st))) return rc;
     } else if (lds > 160 * 1024) {  // max_obj <= 2046 (check_weights) keeps 16 rows within 140 KB
@@ -337,6 +349,7 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
     else if (T <= 1024) hipLaunchKernelGGL(softmax_cols_kernel<64>, dim3(cdiv(N, 64), B), dim3(1024), 0, st, matched, m2, N, T, Dp);
     else hipLaunchKernelGGL(softmax_cols_kernel<128>, dim3(cdiv(N, 64), B), dim3(1024), 0, st, matched, m2, N, T, Dp);
     if ((rc = check_launch("softmax_cols"))) return rc;
+    }
     if (matched_out) {
         hipError_t e = hipMemcpy2DAsync(matched_out, (size_t)D * sizeof(float), matched, (size_t)Dp * sizeof(float),
                                         (size_t)D * sizeof(float), (size_t)M, hipMemcpyDeviceToDevice, st);
