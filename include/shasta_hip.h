@@ -177,6 +177,10 @@ typedef struct shasta_linear {
                                        column-softmax pass over the stored logits) instead of the single pass whose workgroups exchange
                                        per-column partials; same layer arithmetic, softmax sums in another order */
 
+#define SHASTA_OPT_F16X2_AFF 256 /* from 8192 table rows: the six aff layers from two range-scaled fp16 pieces per operand (three products
+                                    per fp32 product; one scale per weight row, per activation row and layer, in layer 1 per row and
+                                    32-column chunk) instead of three bf16 pieces (six) */
+
 typedef struct shasta_weights {
     int max_obj;   /* N */
     int num_feats; /* nf: 1..7 */

@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libshasta_hip.so")
-SOURCES = ["abi.hip", "bev_gather.hip", "gemm_f32.hip", "gemm_pieces.hip", "anchor.hip", "anchor_mfma.hip", "anchor_split.hip", "pair.hip", "pair_f16.hip", "pair_f16w.hip", "embed_rows.hip", "aff.hip", "aff_pieces.hip", "forward.hip",
+SOURCES = ["abi.hip", "bev_gather.hip", "gemm_f32.hip", "gemm_pieces.hip", "anchor.hip", "anchor_mfma.hip", "anchor_split.hip", "pair.hip", "pair_f16.hip", "pair_f16w.hip", "embed_rows.hip", "aff.hip", "aff_pieces.hip", "aff_f16.hip", "forward.hip",
            "voxelize.hip", "shared_conv.hip", "shared_conv_f16.hip", "iou3d.hip", "decode.hip", "train.hip", "track.hip", "nms.hip"]
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fmaf(); products that the
 # reference rounds separately stay separately rounded (parity with the PyTorch fp32 forward).
@@ -22,7 +22,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 # 4 waves per SIMD become possible, and a layer's accumulators feed the next layer without v_accvgpr_read)
 # gemm_pieces.hip: same switch - with AGPR accumulators the allocator moved all 64 of them through VGPRs in every K slice
 EXTRA_FLAGS = {"pair.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "gemm_pieces.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-               "aff_pieces.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "pair_f16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "aff_pieces.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "aff_f16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "pair_f16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "embed_rows.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 

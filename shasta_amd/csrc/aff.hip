@@ -273,6 +273,8 @@ static size_t aff_matched_bytes(int B, int N) {
 size_t aff_workspace_bytes(int B, int N) { return aff_matched_bytes(B, N) + aff_frame_workspace_bytes(B, N); }
 
 bool aff_pieces_serves(int D);
+int launch_aff_frame16(const shasta_weights* w, const float* packed16, const float* residual, int ld, float* matched, int ldm, float* m1,
+                       float* m2, int B, void* ws, hipStream_t st);
 int launch_aff_frame(const shasta_weights* w, const float* packed_pieces, const float* residual, int ld, float* matched, int ldm, float* m1,
                      float* m2, int B, void* ws, hipStream_t st);
 int launch_aff_pieces(const shasta_weights* w, const float* packed_pieces, const float* residual, int ld, float* matched, int ldm,
@@ -307,8 +309,12 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
     // ... and, unless SHASTA_OPT_TWO_PASS_AFF asks for the two-kernel form, with both softmaxes in the same pass (aff_frame_kernel):
     // `matched` is then written only when the caller wants it
     if (pieces && !(w->options & SHASTA_OPT_TWO_PASS_AFF)) {
-        if ((rc = launch_aff_frame(w, packed + P.affp, residual, ld, matched_out ? matched : nullptr, Dp, m1, m2, B, base + aff_matched_bytes(B, N), st)))
-            return rc;
+        // SHASTA_OPT_F16X2_AFF: the layers on fp16 pieces (aff_f16.hip: three products per fp32 product instead of six)
+        if (w->options & SHASTA_OPT_F16X2_AFF)
+            rc = launch_aff_frame16(w, packed + P.aff16, residual, ld, matched_out ? matched : nullptr, Dp, m1, m2, B, base + aff_matched_bytes(B, N), st);
+        else
+            rc = launch_aff_frame(w, packed + P.affp, residual, ld, matched_out ? matched : nullptr, Dp, m1, m2, B, base + aff_matched_bytes(B, N), st);
+        if (rc) return rc;
     } else {
     if (pieces) {
         if ((rc = launch_aff_pieces(w, packed + P.affp, residual, ld, matched, Dp, m1, M, st))) return rc;

@@ -25,8 +25,7 @@
 //  Where a workgroup's time goes (tools/probes/aff_probe.hip, 128 rows, shader cycles): layer 1 56 k (MFMA 25 k, LDS reads 16 k
 //  and the cuts 15 k do not overlap: one barrier per chunk keeps the two waves of a SIMD in step), layers 2-5 31 k (latency of
 //  their weight loads and four barriers), layer 6 30 k (MFMA-bound), softmax statistics 30 k, output 61 k (20 k without the stores).
-#include "common.hpp"
-#include "pair_layout.hpp"
+#include "aff_frame.hpp"
 
 // the LDS-DMA asm below names m0 in its clobber list on purpose (it writes it)
 #pragma clang diagnostic ignored "-Winline-asm"
@@ -34,35 +33,9 @@
 namespace shasta {
 
 typedef __bf16 qbf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t qu32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t qu32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int AP_AROW = 272;  // bytes per row of image A (128 bf16 + 16 B pad: 68 dwords, conflict-free b128 reads)
-constexpr int AP_BROW = 144;  // bytes per row of image B (64 bf16 + 16 B pad: 36 dwords, conflict-free)
-constexpr int AP_SCOLS = 256, AP_SROW = AP_SCOLS + 4;  // output staging: ROWS x 256 features per pass
 #ifndef AP_PACE
 #define AP_PACE 4  // s_sleep units between the MFMA groups of layer 1 (see there)
 #endif
-
-// Shape of a workgroup: ROWS residual rows (RB = ROWS / 32 row blocks) on WAVES = 2 RB wavefronts.
-//  <128, 8>: one workgroup per CU (160 KB of LDS); every weight fragment feeds 4 x 6 MFMAs.
-//  < 64, 4>: two workgroups per CU (80 KB each); fragments feed 2 x 6 MFMAs (twice the L2 -> CU weight traffic per row), but the
-//            phases of the two co-resident workgroups overlap: one streams its output rows while the other is in its MFMAs.
-template <int ROWS, int WAVES>
-struct ApShape {
-    static_assert(WAVES * 16 == ROWS, "WAVES = 2 * row blocks");
-    static constexpr int RB = ROWS / 32;
-    static constexpr int NFW = 16 / WAVES;                              // feature blocks of layer 6 per wave (tables up to 512 columns)
-    static constexpr int AIMG = ROWS * AP_AROW, BIMG = ROWS * AP_BROW;  // one piece of image A / B
-    static constexpr int ABYTES = 3 * AIMG, BBYTES = 3 * BIMG;          // 128 rows: 104448 + 55296 = 159744 B; 64 rows: 79872 B
-    static constexpr int STAT = ROWS * AP_SROW * 4;                     // byte offset of the softmax scratch behind the staging
-    static constexpr int L1X = ROWS * 128, L1SLOT = L1X + 24 * 1024;    // layer-1 ring slot: x chunk + 24 weight fragments
-    static constexpr int NS = (ABYTES + BBYTES) / L1SLOT >= 3 ? 3 : 2;  // ring slots
-    static constexpr int WPW = 24 / WAVES, PER = 2 + WPW;               // LDS-DMA instructions per chunk and wave: weights, total
-    static_assert(NS * L1SLOT <= ABYTES + BBYTES, "the layer-1 ring lies over the two images");
-    static_assert(STAT + (2 * WAVES + 2) * ROWS * 4 <= ABYTES + BBYTES, "staging + softmax scratch must fit the two images");
-    static_assert(PER * (NS - 1) <= 63, "vmcnt is 6 bits");
-};
 
 __device__ __forceinline__ void ap_cut3(float a, float& h, float& m, float& l) {
     h = __uint_as_float(__float_as_uint(a) & 0xffff0000u);
@@ -112,23 +85,6 @@ int aff_pieces_pack(const shasta_weights* w, float* out, hipStream_t st) {
     hipLaunchKernelGGL(aff_pieces_pack_kernel, dim3(128), dim3(256), 0, st, a);
     return check_launch("aff_pieces_pack");
 }
-
-#ifdef SHASTA_AFF_STAMP  // diagnostic build only (tools/probes/aff_probe.hip): s_memtime at the phase boundaries of a workgroup
-__device__ unsigned long long g_aff_stamp[4096][8];
-#define AP_STAMP(i) \
-    if (threadIdx.x == 0 && blockIdx.x < 4096) g_aff_stamp[blockIdx.x][i] = __builtin_amdgcn_s_memtime()
-#else
-#define AP_STAMP(i)
-#endif
-
-struct AffPiecesArgs {
-    const uint32_t* wp;  // piece fragments of the six layers
-    const float* bias[6];
-    const float* residual;
-    float* matched;  // (M, ldm) pre-softmax, for the column softmax
-    float* m1;       // (B, N, D)
-    int M, T, N, D, Dp, ld, ldm;
-};
 
 #define AP_MFMA(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(qbf16x8, (a)), __builtin_bit_cast(qbf16x8, (b)), (c), 0, 0, 0)
@@ -509,73 +465,11 @@ __global__ __launch_bounds__(64 * WAVES) void aff_pieces_kernel(AffPiecesArgs a)
     AP_STAMP(5);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// aff_frame_kernel: the six layers AND BOTH softmaxes (shasta.py:323-325) in one pass over the residual - `matched` is never written
-// (unless the caller asks for it).  The rows of a frame are dealt to G = ceil(T / ROWS) workgroups with consecutive block ids, each
-// keeps its ROWS x D logits in the accumulator registers of layer 6, and
-//   * matched1 = softmax over the columns of a row: complete inside the workgroup, as in aff_pieces_kernel;
-//   * matched2 = softmax over the T rows of a column: every workgroup reduces its rows to (max, sum of exp(x - max)) per column,
-//     publishes the 2 x D floats, counts itself on the frame's arrival counter and waits for its G - 1 siblings; all of them then
-//     combine the G partials in the same fixed order and write their rows of matched2 straight from the registers.
-// Waiting is safe: workgroups are dispatched in block-id order (per XCD), so the siblings of a resident workgroup are resident,
-// finished or next in line, never behind a workgroup that waits (the lowest unfinished frame always has all its workgroups on the
-// chip).  A wait that nevertheless outlasts ~2 s poisons this workgroup's rows of matched2 with NaN instead of hanging the device.
-// Partials cross the XCDs' L2s as agent-scope (sc1) stores / loads - no cache-wide write-back or invalidate.
-// exp(x - m) = v_exp_f32(fma(x, log2 e, c)), c = fl(-m log2 e): the rounding of c is common to a whole row (column), i.e. it cancels
-// between the sum and the terms; the G column partials are rescaled by exp2(c_frame - c_group) with the very same constants.
-struct AffFrameArgs {
-    AffPiecesArgs p;   // p.matched == nullptr: do not write the logits
-    float* m2;         // (B, T, N)
-    float* part;       // [B][G][2][512]: per row group the column maxima, then the column sums
-    unsigned* arrive;  // [B], zero on entry
-    int G;
-};
-
-constexpr float AP_LOG2E = 1.44269504088896340736f;
-
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ float ap_dpp(float old, float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
-}
-// maximum / sum over the 32 lanes of a half wave, valid in lanes 16-31 (48-63): quad swaps, half-row mirror, row mirror, then
-// lane 15 of rows 0 and 2 broadcast into rows 1 and 3 (row_bcast:15)
-__device__ __forceinline__ float ap_half_max(float v) {
-    v = fmaxf(v, ap_dpp<0xB1, 0xf>(v, v));
-    v = fmaxf(v, ap_dpp<0x4E, 0xf>(v, v));
-    v = fmaxf(v, ap_dpp<0x141, 0xf>(v, v));
-    v = fmaxf(v, ap_dpp<0x140, 0xf>(v, v));
-    return fmaxf(v, ap_dpp<0x142, 0xa>(v, v));
-}
-__device__ __forceinline__ float ap_half_sum(float v) {
-    v += ap_dpp<0xB1, 0xf>(0.0f, v);
-    v += ap_dpp<0x4E, 0xf>(0.0f, v);
-    v += ap_dpp<0x141, 0xf>(0.0f, v);
-    v += ap_dpp<0x140, 0xf>(0.0f, v);
-    return v + ap_dpp<0x142, 0xa>(0.0f, v);
-}
-// the additive constant of exp2 for a maximum m: -m log2(e); an empty (-inf) maximum gives 0 so that its terms are exp2(-inf) = 0
-__device__ __forceinline__ float ap_expc(float m) { return m == -INFINITY ? 0.0f : -m * AP_LOG2E; }
-__device__ __forceinline__ float ap_exp(float x, float c) { return __builtin_amdgcn_exp2f(__builtin_fmaf(x, AP_LOG2E, c)); }
-
-// four consecutive columns of an output row: streaming (nt) stores; `o` has the same alignment in every lane of the wave (rows are
-// written by whole waves).  A 16-byte store needs no more than the 4-byte alignment of its dwords in hardware (unaligned access mode of
-// the HSA runtime), which the odd rows of matched1 (D = 2 mod 4: 8 bytes off) rely on: two 8-byte stores per lane instead cost a third
-// of the write-out of a workgroup (33.7 k -> 23 k cycles on an otherwise idle chip).
-__device__ __forceinline__ void ap_store4(float* o, const f32x4& e, int nvalid) {
-    if (nvalid >= 4) {
-        asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(o), "v"(e) : "memory");
-    } else {
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-            if (q < nvalid) __builtin_nontemporal_store(e[q], o + q);
-    }
-}
-
+// aff_frame_kernel: the bf16-piece layers (ap_mlp) + the one-pass tail of aff_frame.hpp
 template <int ROWS, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void aff_frame_kernel(AffFrameArgs fa) {
     using S = ApShape<ROWS, WAVES>;
-    constexpr int RB = S::RB, NFW = S::NFW, NT = 64 * WAVES;
-    static_assert(S::STAT + (2 * WAVES + 3) * ROWS * 4 + 4 * 512 * 4 <= S::ABYTES + S::BBYTES, "staging + softmax scratch must fit the two images");
+    constexpr int RB = S::RB, NFW = S::NFW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AffPiecesArgs& a = fa.p;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -583,247 +477,14 @@ __global__ __launch_bounds__(64 * WAVES) void aff_frame_kernel(AffFrameArgs fa) 
     const int G = fa.G;
     const int b = blockIdx.x / G, q = blockIdx.x - b * G;
     const int nrows = min(ROWS, a.T - q * ROWS), g0 = b * a.T + q * ROWS;
-    const int D = a.D, N = a.N, nfb = ap_fblocks(5, D);
     f32x16 acc[NFW][RB];
 #ifdef AP_STAGGER
     if (blockIdx.x < 256)
         for (int k = 0; k < (int)((blockIdx.x >> 3) & 3) * AP_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
 #endif
     ap_mlp<ROWS, WAVES>(a, smem, g0, g0 + nrows - 1, tid, lane, wid, acc);
-
-    float* xs = reinterpret_cast<float*>(smem);              // [ROWS][AP_SROW] staging
-    float* pmax = reinterpret_cast<float*>(smem + S::STAT);  // [WAVES][ROWS]
-    float* psum = pmax + WAVES * ROWS;                       // [WAVES][ROWS]
-    float* rnm = psum + WAVES * ROWS;                        // [ROWS] -max log2(e) of the row
-    float* rinv = rnm + ROWS;                                // [ROWS] 1 / sum
-    float* cmaxl = rinv + 2 * ROWS;                          // [512] column maxima of this row group (16-byte aligned)
-    float* csuml = cmaxl + 512;                              // [512] column sums
-    float* ccst = csuml + 512;                               // [512] frame-wide: -max log2(e)
-    float* cinv = ccst + 512;                                // [512] frame-wide: 1 / sum
-    const int n = lane & 31, hh = lane >> 5;
-    bool rv[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) rv[rb] = rb * 32 + n < nrows;
-    // bias; maxima of the rows (over the valid columns) and of the columns (over the valid rows) held by this lane
-    float mx[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) mx[rb] = -INFINITY;
-    __syncthreads();  // every wave is done reading image A: the scratch may overwrite it
-#pragma unroll
-    for (int i = 0; i < NFW; ++i) {
-        const int fb = wid + WAVES * i;
-        if (fb >= nfb) continue;  // wave-uniform
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float cm[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int f = fb * 32 + 8 * g + 4 * hh + j;
-                const float bv = f < D ? a.bias[5][f] : 0.0f;
-                float c = -INFINITY;
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    const float v = acc[i][rb][4 * g + j] + bv;
-                    acc[i][rb][4 * g + j] = v;
-                    if (f < D) mx[rb] = fmaxf(mx[rb], v);
-                    c = fmaxf(c, rv[rb] ? v : -INFINITY);
-                }
-                cm[j] = ap_half_max(c);
-            }
-            if (n == 16) *reinterpret_cast<f32x4*>(cmaxl + fb * 32 + 8 * g + 4 * hh) = f32x4{cm[0], cm[1], cm[2], cm[3]};
-        }
-    }
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const float o = fmaxf(mx[rb], __shfl_xor(mx[rb], 32, 64));
-        if (hh == 0) pmax[wid * ROWS + rb * 32 + n] = o;
-    }
-    __syncthreads();
-    float nm[RB], se[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        float m = pmax[rb * 32 + n];
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) m = fmaxf(m, pmax[w * ROWS + rb * 32 + n]);
-        nm[rb] = ap_expc(m);
-        se[rb] = 0.0f;
-    }
-    // sums: of a row over the valid columns, of a column over the valid rows of this group (relative to the group's own maximum)
-#pragma unroll
-    for (int i = 0; i < NFW; ++i) {
-        const int fb = wid + WAVES * i;
-        if (fb >= nfb) continue;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 cmx = *reinterpret_cast<const f32x4*>(cmaxl + fb * 32 + 8 * g + 4 * hh);  // written by this wave
-            float cs[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int f = fb * 32 + 8 * g + 4 * hh + j;
-                const float cc = ap_expc(cmx[j]);
-                float s = 0.0f;
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    const float v = acc[i][rb][4 * g + j];
-                    if (f < D) se[rb] += ap_exp(v, nm[rb]);
-                    const float ec = ap_exp(v, cc);
-                    s += rv[rb] ? ec : 0.0f;
-                }
-                cs[j] = ap_half_sum(s);
-            }
-            if (n == 16) *reinterpret_cast<f32x4*>(csuml + fb * 32 + 8 * g + 4 * hh) = f32x4{cs[0], cs[1], cs[2], cs[3]};
-        }
-    }
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const float o = se[rb] + __shfl_xor(se[rb], 32, 64);
-        if (hh == 0) psum[wid * ROWS + rb * 32 + n] = o;
-    }
-    __syncthreads();
-    if (tid < ROWS) {
-        float s = psum[tid];
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) s += psum[w * ROWS + tid];  // fixed order
-        float m = pmax[tid];
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) m = fmaxf(m, pmax[w * ROWS + tid]);
-        rnm[tid] = ap_expc(m);
-        rinv[tid] = 1.0f / s;
-    }
-    // publish this group's column partials (agent scope: the siblings sit behind other L2s)
-    float* mypart = fa.part + ((size_t)b * G + q) * 1024;
-    if (G > 1) {
-        for (int c = tid; c < N; c += NT) {
-            __hip_atomic_store(mypart + c, cmaxl[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(mypart + 512 + c, csuml[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    AP_STAMP(4);
-    bool poisoned = false;
-    // Write-out in two passes of HR = ROWS / 2 rows through the staging [HR][512 + 4]: a wave then owns WHOLE rows - its stores of one
-    // row are 2 KB contiguous and the eight waves write eight consecutive rows, i.e. the workgroup walks linearly through its (dense)
-    // blocks of matched1 and matched2 (staging by column halves - 1 KB pieces 2 KB apart - left the DRAM side of the stores at
-    // ~1.2 TB/s).  matched1 = exp(x - row max) / row sum for the rows t < N, matched2 = exp(x - column max) / column sum for the
-    // columns d < N, the logits only on request.
-    constexpr int HR = ROWS / 2, XROW = 2 * AP_SCOLS + 4;
-    static_assert(HR * XROW * 4 <= S::STAT, "row-half staging must fit below the softmax scratch");
-    f32x4 kc[2], ki[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if (i == 1) __syncthreads();  // the read-out of pass 0 is finished
-#pragma unroll
-        for (int k = 0; k < NFW; ++k) {
-            const int fb = wid + WAVES * k;
-            if (fb < nfb) {
-#pragma unroll
-                for (int rb = i * RB / 2; rb < (i + 1) * RB / 2; ++rb)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<f32x4*>(xs + ((rb - i * RB / 2) * 32 + n) * XROW + fb * 32 + 8 * g + 4 * hh) =
-                            f32x4{acc[k][rb][4 * g], acc[k][rb][4 * g + 1], acc[k][rb][4 * g + 2], acc[k][rb][4 * g + 3]};
-            }
-        }
-        if (i == 0) {
-            // arrival: all partial stores of this workgroup have completed (vmcnt) before thread 0 counts it in; then the frame-wide
-            // column statistics, identically in every sibling
-            if (G > 1) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) {
-                    // polled with the same read-modify-write path that counts the arrivals
-                    unsigned seen = __hip_atomic_fetch_add(fa.arrive + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u, spins = 0;
-                    while (seen < (unsigned)G) {
-                        __builtin_amdgcn_s_sleep(16);
-                        seen = __hip_atomic_fetch_add(fa.arrive + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (++spins > (1u << 21)) {
-                            poisoned = true;
-                            break;
-                        }
-                    }
-                    cinv[511] = poisoned ? 1.0f : 0.0f;  // column 511 is never a column of matched2
-                }
-                __syncthreads();
-                poisoned = cinv[511] != 0.0f;
-                for (int c = tid; c < N; c += NT) {
-                    float mg[512 / ROWS], sg[512 / ROWS];
-                    const float* fp = fa.part + (size_t)b * G * 1024 + c;
-#pragma unroll
-                    for (int g = 0; g < 512 / ROWS; ++g)
-                        if (g < G) {
-                            mg[g] = __hip_atomic_load(fp + g * 1024, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            sg[g] = __hip_atomic_load(fp + g * 1024 + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    float m = mg[0];
-#pragma unroll
-                    for (int g = 1; g < 512 / ROWS; ++g)
-                        if (g < G) m = fmaxf(m, mg[g]);
-                    const float cf = ap_expc(m);
-                    float s = 0.0f;
-#pragma unroll
-                    for (int g = 0; g < 512 / ROWS; ++g)
-                        if (g < G) s += mg[g] == -INFINITY ? 0.0f : sg[g] * __builtin_amdgcn_exp2f(cf - ap_expc(mg[g]));
-                    ccst[c] = cf;
-                    cinv[c] = poisoned ? __builtin_nanf("") : 1.0f / s;
-                }
-            } else {
-                __syncthreads();
-                for (int c = tid; c < N; c += NT) {
-                    ccst[c] = ap_expc(cmaxl[c]);
-                    cinv[c] = 1.0f / csuml[c];
-                }
-            }
-        }
-        __syncthreads();
-        if (i == 0) {
-            AP_STAMP(5);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int col = h * AP_SCOLS + 4 * lane;
-                kc[h] = f32x4{0, 0, 0, 0}, ki[h] = f32x4{0, 0, 0, 0};
-                if (col < N) {  // N <= 510: the float4s of ccst / cinv reach at most column 511
-                    kc[h] = *reinterpret_cast<const f32x4*>(ccst + col);
-                    ki[h] = *reinterpret_cast<const f32x4*>(cinv + col);
-                }
-            }
-        }
-#pragma unroll 2
-        for (int rr = 0; rr < HR / WAVES; ++rr) {
-            const int rl = wid + rr * WAVES, r = i * HR + rl;
-            if (r >= nrows) break;  // wave-uniform
-            const float cr = rnm[r], inv = rinv[r];
-            const int t = q * ROWS + r;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int col = h * AP_SCOLS + 4 * lane;
-                if (col >= a.ldm) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(xs + rl * XROW + col);
-                if (a.matched) {
-                    f32x4 z = v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (col + e >= D) z[e] = 0.0f;  // the padding columns of `matched`
-                    *reinterpret_cast<f32x4*>(a.matched + (size_t)(g0 + r) * a.ldm + col) = z;
-                }
-#ifndef AP_NOM1
-                if (t < N && col < D) {
-                    f32x4 e;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) e[k] = ap_exp(v[k], cr) * inv;
-                    ap_store4(a.m1 + ((size_t)b * N + t) * D + col, e, D - col);
-                }
-#endif
-#ifndef AP_NOM2
-                if (col < N) {
-                    f32x4 e;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) e[k] = ap_exp(v[k], kc[h][k]) * ki[h][k];
-                    ap_store4(fa.m2 + ((size_t)b * a.T + t) * N + col, e, N - col);
-                }
-#endif
-            }
-        }
-    }
-    AP_STAMP(6);
+    const float rs[RB] = {};
+    ap_frame_tail<ROWS, WAVES, false>(fa, smem, acc, b, q, nrows, g0, tid, lane, wid, nullptr, rs);
 }
 
 // LDS bytes of the workgroup shapes (independent of the table width, which must not exceed 512 columns)

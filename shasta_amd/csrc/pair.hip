@@ -609,6 +609,7 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
 }
 
 int aff_pieces_pack(const shasta_weights* w, float* out, hipStream_t st);
+int aff_f16_pack(const shasta_weights* w, float* out, hipStream_t st);
 int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {
     PackArgs a;
     for (int i = 0; i < 4; ++i) a.fs[i] = w->fuse_shape[i];
@@ -624,6 +625,7 @@ int pack_weights(const shasta_weights* w, float* packed, hipStream_t st) {
     if (rc) return rc;
     const PackedLayout P(w->max_obj, w->num_feats, w->feat_dim);
     if ((rc = aff_pieces_pack(w, packed + P.affp, st))) return rc;
+    if ((rc = aff_f16_pack(w, packed + P.aff16, st))) return rc;
     if (w->feat_dim == 256 && (rc = pair_f16_pack(w, packed + P.p16, st))) return rc;
     if (pair_f16w_serves(w->feat_dim) && (rc = pair_f16w_pack(w, packed + P.p16w, st))) return rc;
     if (embed_rows_serves(w->feat_dim) && (rc = embed_pack(w, packed, st))) return rc;

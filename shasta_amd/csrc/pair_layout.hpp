@@ -74,10 +74,25 @@ SH_HD constexpr size_t ap_layer_offset(int layer, int D) {  // in fragments
     return o;
 }
 
+// the same layers as fp16 piece fragments (aff_f16.hip): two pieces per (feature block, k step), every output row scaled by a
+// power of two; behind the fragments one float per output feature and layer (padded to whole feature blocks): the factor 2^-e that
+// undoes the scale.  Offsets in floats from the start of the section.
+SH_HD constexpr size_t ap16_frag_offset(int layer, int D) {  // in fragments of 256 floats
+    size_t o = 0;
+    for (int l = 0; l < layer; ++l) o += (size_t)ap_fblocks(l, D) * ap_ksteps(l, D) * 2;
+    return o;
+}
+SH_HD constexpr size_t ap16_scale_offset(int layer, int D) {
+    size_t o = (ap16_frag_offset(6, D) + 2) * 256;  // two spare fragments: the phantom k step behind an odd layer-1 width reads them
+    for (int l = 0; l < layer; ++l) o += (size_t)ap_fblocks(l, D) * 32;
+    return o;
+}
+SH_HD constexpr size_t ap16_total(int D) { return ap16_scale_offset(6, D); }
+
 // Packed buffer sections (float offsets).  Dp = padded aff width (multiple of 4).
 struct PackedLayout {
     int F, nf, N, D, Dp, E12, ET;
-    size_t a4, wemb_prev, wemb_cur, bemb_cur, wbox_prev, wbox_cur, bbox_cur, aff0, affp, p16, p16w, embp, total;
+    size_t a4, wemb_prev, wemb_cur, bemb_cur, wbox_prev, wbox_cur, bbox_cur, aff0, affp, p16, p16w, embp, aff16, total;
     SH_HD PackedLayout(int max_obj, int num_feats, int f) {
         const PairDims d(f);
         F = f;
@@ -101,6 +116,7 @@ struct PackedLayout {
         p16w = o;       o += (size_t)(2 * 16 * 64 * 4 + 4);  // the same as 32x32x16 fragments (pair_f16w.hip: up to 16 fragments x 2 pieces x 1 KB)
         // wemb_prev / wemb_cur as bf16 piece fragments [side][feature block][k step][piece][64 lanes] x 16 B (embed_rows.hip)
         embp = o;       o += (size_t)2 * ((E12 + 31) / 32) * (f / 16) * 3 * 256;
+        aff16 = o;      o += ap16_total(D);  // the six aff layers as fp16 piece fragments + their descale factors (aff_f16.hip)
         total = o;
     }
 };

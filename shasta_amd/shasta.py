@@ -254,8 +254,8 @@ class Shasta(BaseTrack):
         if self.arithmetic not in ("pieces", "f32", "f16x2", "f16grid"):
             raise ValueError("Shasta.arithmetic must be 'pieces', 'f32', 'f16x2' or 'f16grid'")
         o = {"pieces": 0, "f32": hip.OPT_F32_WEIGHT_STREAM | hip.OPT_F32_EMBED_GEMM | hip.OPT_F32_AFF,
-             "f16x2": hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_F16X2_PAIR,
-             "f16grid": hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_F16X2_PAIR | hip.OPT_F16GRID_PAIR}[self.arithmetic]
+             "f16x2": hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_F16X2_PAIR | hip.OPT_F16X2_AFF,
+             "f16grid": hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_F16X2_PAIR | hip.OPT_F16GRID_PAIR | hip.OPT_F16X2_AFF}[self.arithmetic]
         if self.arithmetic in ("f16x2", "f16grid") and self.precut_weight_stream:
             o |= hip.OPT_PRECUT_WEIGHT_STREAM
         return o
