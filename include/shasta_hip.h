@@ -181,6 +181,10 @@ typedef struct shasta_linear {
                                     per fp32 product; one scale per weight row, per activation row and layer, in layer 1 per row and
                                     32-column chunk) instead of three bf16 pieces (six) */
 
+#define SHASTA_OPT_ONE_PASS_AFF 512 /* the one-pass form of the aff stage (layers + both softmaxes, bf16 or - with SHASTA_OPT_F16X2_AFF -
+                                       fp16 pieces) for EVERY row count, not only from 8192 table rows (where it is the default);
+                                       small batches are otherwise served by 16-row workgroups on the f32 matrix path */
+
 typedef struct shasta_weights {
     int max_obj;   /* N */
     int num_feats; /* nf: 1..7 */

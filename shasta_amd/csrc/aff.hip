@@ -304,7 +304,7 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
     // From 8192 residual rows up the six layers run as exact bf16 piece products (aff_pieces.hip: 2.7 x fewer matrix cycles per
     // fp32 product) for tables up to 512 columns whose rows are 16-byte aligned; SHASTA_OPT_F32_AFF keeps the f32
     // kernel.  Small batches stay on the f32 kernel (16-row workgroups: more parallelism, less latency).
-    const bool pieces = M >= 8192 && !(w->options & SHASTA_OPT_F32_AFF) && aff_pieces_serves(D) && ld % 4 == 0 &&
+    const bool pieces = (M >= 8192 || (w->options & SHASTA_OPT_ONE_PASS_AFF)) && !(w->options & SHASTA_OPT_F32_AFF) && aff_pieces_serves(D) && ld % 4 == 0 &&
                         (uintptr_t)residual % 16 == 0 && (uintptr_t)ws % 16 == 0;
     // ... and, unless SHASTA_OPT_TWO_PASS_AFF asks for the two-kernel form, with both softmaxes in the same pass (aff_frame_kernel):
     // `matched` is then written only when the caller wants it

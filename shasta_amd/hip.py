@@ -28,6 +28,7 @@ OPT_PRECUT_WEIGHT_STREAM = 32
 OPT_F16GRID_PAIR = 64
 OPT_TWO_PASS_AFF = 128
 OPT_F16X2_AFF = 256
+OPT_ONE_PASS_AFF = 512
 F16X2_MAX_ROW_RATIO = 16384.0  # SHASTA_F16X2_MAX_ROW_RATIO
 PRECUT_MIN_BATCH = 17  # csrc/anchor.hip: from this many frame-pairs per call the pre-cut fp16 weight stream serves the call
 

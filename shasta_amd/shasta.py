@@ -203,8 +203,8 @@ class Shasta(BaseTrack):
     # ---- HIP plumbing --------------------------------------------------------------------------------------
     def _small_params(self):
         mods = [self.fuse_shape[0], self.fuse_shape[2], self.fuse_shape[4], self.fuse_shape[6], self.fuse_det[0],
-                self.fuse_det[2], self.fuse_det[4], self.res_coeff[0], self.res_coeff[2], self.res_coeff[4],
-                self.aff[0]]
+                self.fuse_det[2], self.fuse_det[4], self.res_coeff[0], self.res_coeff[2], self.res_coeff[4]]
+        mods += [self.aff[k] for k in (0, 2, 4, 6, 8, 10)]  # all six: the piece kernels read every aff layer from the packed copy
         return [p for m in mods for p in (m.weight, m.bias)]
 
     def _apply(self, fn, *a, **k):  # .to() / .cuda() / .float(): parameter storage moves -> drop pointer caches

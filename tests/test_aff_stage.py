@@ -1,0 +1,164 @@
+"""GPU tests of the aff stage on its own (shasta_aff_softmax_f32): the six aff layers and the two softmaxes of
+det3d/models/tracker/shasta.py:94-109,323-325 on a given residual.  Three forms must agree with a float64 evaluation on the host:
+  * two kernels on the f32 matrix path (aff_fused_kernel + softmax_cols, SHASTA_OPT_F32_AFF),
+  * one pass on bf16 pieces (aff_frame_kernel),
+  * one pass on fp16 pieces (aff_frame16_kernel, the default arithmetic) - whose workgroups exchange per-column partials of the column
+    softmax and wait for each other: frames of one workgroup (no wait), of several, ragged last row groups, odd widths, batch 1 and 3
+    (SHASTA_OPT_ONE_PASS_AFF forces the one-pass form below its 8192-row threshold) and replay from a captured graph."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from shasta_amd import hip
+from tests.helpers import build_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    return torch.device("cuda", 0)
+
+
+def _model(N, gain, dev, seed=3):
+    c = dict(max_obj=N, np=1, nf=3, seed=seed, cin=16, stride=8)  # F = 64: small aug_shape matrices, the aff stage does not see F
+    m = build_model(c).to(dev)
+    if gain != 1.0:
+        with torch.no_grad():
+            for k in (0, 2, 4, 6, 8, 10):
+                m.aff[k].weight.mul_(gain)
+    return m
+
+
+def _float64(m, res, N):
+    """shasta.py:94-106 applied as :323, then :324-325, in float64 on the host."""
+    D = N + 2
+    h = res[:, :, :D].double().cpu()
+    for i, k in enumerate((0, 2, 4, 6, 8, 10)):
+        h = h @ m.aff[k].weight.detach().double().cpu().T + m.aff[k].bias.detach().double().cpu()
+        if i < 5:
+            h = torch.relu(h)
+    return h, torch.softmax(h[:, :N, :], dim=2), torch.softmax(h[:, :, :N], dim=1)
+
+
+class _Aff:
+    """shasta_aff_softmax_f32 on a model's weights with chosen option bits."""
+
+    def __init__(self, m, B, dev):
+        self.m, self.B, self.N = m, B, m.max_obj
+        self.lib = hip.load()
+        self.w = m._weights()
+        m._ensure_packed(self.w, dev)
+        N, T = self.N, self.N + 2
+        self.Dp = (T + 3) // 4 * 4
+        self.nws = self.lib.shasta_forward_workspace_bytes(B, N, m.num_feats, m.aug_shape_output)
+        self.ws = torch.empty(self.nws // 4 + 64, dtype=torch.float32, device=dev)
+        self.m1 = torch.empty(B, N, T, device=dev)
+        self.m2 = torch.empty(B, T, N, device=dev)
+        self.logits = torch.empty(B, T, T, device=dev)
+
+    def __call__(self, res, options, want_logits=True):
+        w = hip.Weights.from_buffer_copy(self.w)
+        w.options = options
+        self.m1.fill_(float("nan"))
+        self.m2.fill_(float("nan"))
+        hip.check(self.lib.shasta_aff_softmax_f32(C.byref(w), hip.ptr(self.m._packed), self.B, hip.ptr(res), self.Dp, hip.ptr(self.m1),
+                                                  hip.ptr(self.m2), hip.ptr(self.logits) if want_logits else None, hip.ptr(self.ws),
+                                                  self.nws, hip.stream_ptr()), "shasta_aff_softmax_f32")
+        return self.logits.clone() if want_logits else None, self.m1.clone(), self.m2.clone()
+
+
+def _residual(B, N, dev, seed, scale=1.0):
+    T = N + 2
+    Dp = (T + 3) // 4 * 4
+    g = torch.Generator().manual_seed(seed)
+    res = (torch.randn(B, T, Dp, generator=g) * scale).to(dev)
+    res[:, :, T:] = float("nan")  # whatever a caller leaves in the padding columns must not reach the result
+    return res
+
+
+FORMS = {"f32 two-pass": hip.OPT_F32_AFF,
+         "bf16 pieces two-pass": hip.OPT_ONE_PASS_AFF | hip.OPT_TWO_PASS_AFF,
+         "bf16 pieces one-pass": hip.OPT_ONE_PASS_AFF,
+         "fp16 pieces one-pass": hip.OPT_ONE_PASS_AFF | hip.OPT_F16X2_AFF}
+
+
+@pytest.mark.parametrize("gain", [1.0, 3.0])
+@pytest.mark.parametrize("B,N", [(1, 500), (3, 500), (5, 37), (7, 201), (40, 90), (17, 500), (2, 509), (3, 126), (2, 127), (1, 1), (2, 4)])
+def test_aff_forms_against_float64(B, N, gain):
+    dev = _dev()
+    m = _model(N, gain, dev)
+    aff = _Aff(m, B, dev)
+    res = _residual(B, N, dev, seed=B * 1000 + N, scale=1.0 if gain == 1.0 else 4.0)
+    ref, r1, r2 = _float64(m, res, N)
+    scale = float(ref.abs().max())
+    err, out = {}, {}
+    for name, opt in FORMS.items():
+        lg, m1, m2 = aff(res, opt)
+        out[name] = (lg, m1, m2)
+        assert torch.isfinite(m1).all() and torch.isfinite(m2).all(), name
+        err[name] = float((lg.double().cpu() - ref).abs().max())
+        # softmaxes against the float64 softmax of the form's OWN logits: the exchange / reduction machinery, free of layer rounding
+        own = lg.double().cpu()
+        assert float((m1.double().cpu() - torch.softmax(own[:, :N, :], dim=2)).abs().max()) < 5e-7, name
+        assert float((m2.double().cpu() - torch.softmax(own[:, :, :N], dim=1)).abs().max()) < 5e-7, name
+        # ... and against the float64 evaluation of everything (BASELINE: 1e-4) wherever the logits are O(1) .. O(10)
+        if scale < 30:
+            assert float((m1.double().cpu() - r1).abs().max()) < 1e-5, name
+            assert float((m2.double().cpu() - r2).abs().max()) < 1e-5, name
+    # the two forms of the bf16-piece layers share their logits bit for bit; the piece forms stay at the f32 kernel's error level
+    assert torch.equal(out["bf16 pieces two-pass"][0], out["bf16 pieces one-pass"][0])
+    assert not torch.equal(out["fp16 pieces one-pass"][0], out["bf16 pieces one-pass"][0]), "the fp16-piece kernel did not run"
+    for name in ("bf16 pieces one-pass", "fp16 pieces one-pass"):
+        assert err[name] <= 2.0 * err["f32 two-pass"] + 2e-7 * scale, (err, scale)
+    # without the logits output the one-pass kernels never write `matched`: same results
+    for name in ("bf16 pieces one-pass", "fp16 pieces one-pass"):
+        _, m1, m2 = aff(res, FORMS[name], want_logits=False)
+        assert torch.equal(m1, out[name][1]) and torch.equal(m2, out[name][2]), name
+
+
+def test_one_pass_aff_is_batch_independent_and_deterministic():
+    """A frame's result depends neither on its position in the batch nor on the run: the partials of the column softmax are combined in a
+    fixed order, identically in every sibling workgroup."""
+    dev = _dev()
+    N = 500
+    m = _model(N, 1.0, dev)
+    res = _residual(24, N, dev, seed=11)
+    big = _Aff(m, 24, dev)
+    _, a1, a2 = big(res, FORMS["fp16 pieces one-pass"], want_logits=False)
+    _, b1, b2 = big(res, FORMS["fp16 pieces one-pass"], want_logits=False)
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    one = _Aff(m, 1, dev)
+    for i in (0, 7, 23):
+        _, s1, s2 = one(res[i:i + 1].contiguous(), FORMS["fp16 pieces one-pass"], want_logits=False)
+        assert torch.equal(s1[0], a1[i]) and torch.equal(s2[0], a2[i]), i
+
+
+def test_one_pass_aff_in_a_captured_graph():
+    """The arrival counters are reset by a memset node in front of the kernel: a captured call replays correctly on new data."""
+    dev = _dev()
+    N, B = 500, 20  # 10 040 rows: the default path (no forcing), eight 64-row workgroups per frame
+    m = _model(N, 1.0, dev)
+    aff = _Aff(m, B, dev)
+    opt = hip.OPT_F16X2_AFF
+    res = _residual(B, N, dev, seed=1)
+    other = _residual(B, N, dev, seed=2)
+    _, e1, e2 = aff(other, opt, want_logits=False)
+    w = hip.Weights.from_buffer_copy(aff.w)
+    w.options = opt
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        aff(res, opt, want_logits=False)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        hip.check(aff.lib.shasta_aff_softmax_f32(C.byref(w), hip.ptr(m._packed), B, hip.ptr(res), aff.Dp, hip.ptr(aff.m1), hip.ptr(aff.m2), None,
+                                                 hip.ptr(aff.ws), aff.nws, hip.stream_ptr()), "shasta_aff_softmax_f32")
+    res.copy_(other)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(aff.m1, e1) and torch.equal(aff.m2, e2)
