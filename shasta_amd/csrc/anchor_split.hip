@@ -613,6 +613,165 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
     }
 }
 
+// ---- 512 items per weight pass (pre-cut fp16 form) ---------------------------------------------------------------------------------
+// The kernel above at 256 items per pass runs with the matrix pipe 76 % busy on a chip that sits on its power cap (~1.54 GHz), reads
+// every weight tile once per 256 items (four passes at 1024 frame-pairs: 9 GB of HBM-side traffic for 5.2 GB of operands) and has every
+// one of its four waves read the whole 32 KB activation tile out of LDS (144 KB of ds_read per 48 x 4 MFMAs).  This form:
+//  * 512 items per pass: the weights cross the fabric half as often;
+//  * a workgroup of EIGHT waves = 2 row-group pairs x 4 item groups: a wave owns 64 weight rows x 128 items (8 accumulators as
+//    before), reads 4 weight + 8 activation fragments per 24 MFMAs - 96 KB of ds_read per k step and workgroup for twice the items,
+//    a third less per product - and two waves share a SIMD, so one's waits (barrier, LDS, DMA) are the other's issue slots;
+//  * a ring slot holds ONE k step (16 wide): 8 KB of weight fragments (4 row groups x 2 pieces) + 32 KB of activation fragments
+//    (16 item blocks x 2 pieces) = 40 KB, four slots = the whole LDS.  The pre-cut image and the activation image are unchanged (their
+//    4 KB / 64 KB blocks are k-step-major resp. hold whole fragments: a slot takes 1 KB fragments wherever they lie).
+// Per accumulator the products arrive in the order of the 256-item kernel (k steps ascending; w_l x_h, w_h x_l, w_h x_h).
+template <int NS>
+__global__ __launch_bounds__(512) void anchor_l1_wide_kernel(AnchorSplitArgs a) {
+    constexpr int XT = 16;                         // 32-item blocks per pass
+    constexpr int SLOT = (8 + 2 * XT) * 256;       // dwords per ring slot
+    constexpr int ND = 5, NR = 12, NM = 24;        // per k step and wave: LDS-DMA instructions, ds_read_b128, MFMAs
+    static_assert(ND * (NS - 1) <= 63, "vmcnt is 6 bits");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rg2 = wid & 1, ig = wid >> 1;        // row-group pair, item group
+
+    const int ncombo = 2 * a.KS;                   // (K chunk, frame) pairs: consecutive blocks -> consecutive XCDs (as above)
+    const int combo = blockIdx.x % ncombo, rest = blockIdx.x / ncombo;
+    const int quad = rest / a.NBLK, bblk = rest % a.NBLK;
+    const int ks = combo >> 1, src = combo & 1;
+    const int G2 = 2 * a.groups_per_mlp;           // 32-row groups over the two MLPs that read this frame
+    const int tpc = a.Kc >> 5;
+    const int kt_beg = ks * tpc, NT = 2 * (min(a.KT, kt_beg + tpc) - kt_beg);  // k steps of this chunk
+
+    auto group_base = [&](int gq, int& mlp, int& r0) {  // group gq of the quad (a spare one repeats the last)
+        const int gg = min(quad * 4 + gq, G2 - 1);
+        mlp = 2 * src + gg / a.groups_per_mlp;
+        r0 = (gg % a.groups_per_mlp) * 32;
+    };
+    // this wave's share of a slot: weight fragment wid = (group wid >> 1, piece wid & 1), activation fragments 4 wid .. 4 wid + 3
+    int mlpw, r0w;
+    group_base(wid >> 1, mlpw, r0w);
+    const char* wub = reinterpret_cast<const char*>(a.wimg) + (((size_t)mlpw * a.groups_per_mlp + (r0w >> 5)) * a.KT + kt_beg) * 4096 + (wid & 1) * 1024;
+    const char* xub = reinterpret_cast<const char*>(a.xs) + ((((size_t)src * a.NBLK + bblk) * a.KT + kt_beg) * (4 * XT)) * 1024;
+    const uint32_t loff = (uint32_t)(lane * 16);
+    const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) float*)lds);
+    auto dma = [&](int t, int slot, int idx) {  // k step t of the chunk = (k tile t >> 1, step t & 1)
+        if (idx == 0) {
+            const char* base = wub + (size_t)(t >> 1) * 4096 + (size_t)(t & 1) * 2048;
+            const uint32_t dst = lds0 + (uint32_t)((slot * SLOT + wid * 256) * 4);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(loff), "s"(base), "s"(dst) : "memory", "m0");
+        } else {
+            const int f = 4 * wid + idx - 1, u = f >> 1, pc = f & 1;  // fragment (item block u, piece) of the slot
+            const char* base = xub + (size_t)(t >> 1) * (4 * XT * 1024) + (size_t)(((u * 2 + (t & 1)) * 2 + pc) * 1024);
+            const uint32_t dst = lds0 + (uint32_t)((slot * SLOT + 2048 + f * 256) * 4);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(loff), "s"(base), "s"(dst) : "memory", "m0");
+        }
+    };
+    struct Frag {
+        u32x4 A[2][2];  // [row group of the pair][piece]
+        u32x4 X[4][2];  // [item block of the group][piece]
+    };
+    auto read_one = [&](int slot, Frag& f, int idx) {
+        const float* sl = lds + slot * SLOT + lane * 4;
+        if (idx < 4) f.A[idx >> 1][idx & 1] = *reinterpret_cast<const u32x4*>(sl + ((2 * rg2 + (idx >> 1)) * 2 + (idx & 1)) * 256);
+        else f.X[(idx - 4) >> 1][idx & 1] = *reinterpret_cast<const u32x4*>(sl + 2048 + ((4 * ig + ((idx - 4) >> 1)) * 2 + (idx & 1)) * 256);
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[j][u] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int PW2[3] = {1, 0, 0}, PX2[3] = {0, 1, 0};  // piece products, small to large
+    auto mma_one = [&](const Frag& f, int i) {             // product-major: eight independent accumulators between two products of one
+        const int pr = i >> 3, j = (i >> 2) & 1, u = i & 3;
+        acc[j][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.A[j][PW2[pr]]), __builtin_bit_cast(f16x8, f.X[u][PX2[pr]]),
+                                                           acc[j][u], 0, 0, 0);
+    };
+    {
+        int sl = 0;
+#pragma unroll 1
+        for (int t = 0; t < NS && t < NT; ++t, ++sl)
+#pragma unroll
+            for (int j = 0; j < ND; ++j) dma(t, sl, j);
+    }
+    Frag fa, fb;
+    if (NT >= NS) wait_vm_split<ND*(NS - 1)>();
+    else wait_vm_split<0>();
+    __builtin_amdgcn_s_barrier();
+    if (NT > 0) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) read_one(0, fa, i);
+    }
+    // One k step: `cur` holds step t in registers; slot sc (step t's) is refilled with step t + NS after the barrier; step t + 1 is read
+    // out of slot sn into `nxt`.  Everything that is not an MFMA sits between two MFMAs.
+    auto step = [&](const Frag& cur, Frag& nxt, int t, int sc, auto steady) {
+        constexpr bool STEADY = decltype(steady)::value;
+        const int sn = sc + 1 == NS ? 0 : sc + 1;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            mma_one(cur, i);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of step t's slot have retired
+                if constexpr (STEADY) wait_vm_split<ND*(NS - 2)>();
+                else wait_vm_split<0>();
+                __builtin_amdgcn_s_barrier();
+                if constexpr (!STEADY) {
+                    if (t + NS < NT) {
+#pragma unroll
+                        for (int j = 0; j < ND; ++j) dma(t + NS, sc, j);
+                    }
+                }
+            }
+            if (i >= 1 && i - 1 < ND) {
+                if constexpr (STEADY) dma(t + NS, sc, i - 1);
+            }
+            if (i >= 1 && i - 1 < NR) read_one(sn, nxt, i - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    int t = 0, sc = 0;
+    auto next = [&](int s) { return s + 1 == NS ? 0 : s + 1; };
+#pragma unroll 1
+    for (; t + NS + 1 < NT; t += 2) {
+        step(fa, fb, t, sc, std::true_type{});
+        sc = next(sc);
+        step(fb, fa, t + 1, sc, std::true_type{});
+        sc = next(sc);
+    }
+#pragma unroll 1
+    for (; t + 1 < NT; t += 2) {
+        step(fa, fb, t, sc, std::false_type{});
+        sc = next(sc);
+        step(fb, fa, t + 1, sc, std::false_type{});
+        sc = next(sc);
+    }
+    if (t < NT) step(fa, fb, t, sc, std::false_type{});
+    // D[i = weight row][j = item]
+    const int frow = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (quad * 4 + 2 * rg2 + j >= G2) continue;  // a spare group
+        int mlp, r0;
+        group_base(2 * rg2 + j, mlp, r0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = (bblk * XT + 4 * ig + u) * 32 + frow;
+            if (b >= a.B) continue;
+            float* o = a.part + ((size_t)ks * a.B + b) * (4 * a.H) + mlp * a.H;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (row < a.H) o[row] = acc[j][u][r];
+            }
+        }
+    }
+}
+
+// the wide form serves the pre-cut fp16 stream whenever 512-item passes pad the batch no more than 256-item passes do
+static inline bool split_wide(int B, int np, bool precut) { return np == 2 && precut && !kPrecutShape16 && B > 256 && cdiv(B, 512) * 512 <= cdiv(B, 256) * 256; }
+
 // np = pieces per operand: 3 = bf16 (six products), 2 = fp16 (three products, SHASTA_OPT_F16X2_WEIGHT_STREAM)
 // np == 2 without the pre-cut image is used above 64 rows only; with it, 32 / 64 items per pass serve the smaller batches too
 static inline int split_xt(int B, int np) { return np == 2 ? (B > 128 ? 8 : B > 64 ? 4 : B > 32 ? 2 : 1) : (B <= 64 ? 2 : 4); }
@@ -632,7 +791,8 @@ bool anchor_split_serves(int B, int K, int x_batch_stride) { return B > 32 && K 
 // cut the activations of both frames into the bf16 fragment image `xs`
 void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, int B, int x_batch_stride, int np, const unsigned* xmax,
                     bool precut, hipStream_t st) {
-    const int XT = split_xt(B, np), NBLK = split_nblk(B, np), KT = K / 32;
+    const bool wide = split_wide(B, np, precut);
+    const int XT = wide ? 16 : split_xt(B, np), NBLK = wide ? cdiv(B, 512) : split_nblk(B, np), KT = K / 32;
     SplitXArgs sx;
     sx.x[0] = feat;
     sx.x[1] = prev_feat;
@@ -650,7 +810,8 @@ void launch_split_x(const float* feat, const float* prev_feat, void* xs, int K, 
 
 void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part, int H, int K, int B, int* ks_out, int np,
                             const unsigned* wmax, const void* wimg, hipStream_t st) {
-    const int XT = split_xt(B, np), NBLK = split_nblk(B, np), KT = K / 32;
+    const bool wide = split_wide(B, np, wimg != nullptr);
+    const int XT = wide ? 16 : split_xt(B, np), NBLK = wide ? cdiv(B, 512) : split_nblk(B, np), KT = K / 32;
     AnchorSplitArgs a;
     for (int i = 0; i < 4; ++i) a.W[i] = W[i];
     a.xs = static_cast<const uint32_t*>(xs);
@@ -697,7 +858,17 @@ void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         hipLaunchKernelGGL(kern, dim3(2 * a.KS * quads * NBLK), dim3(256), ldsb, st, a);
     };
-    if (np == 2 && wimg) {
+    if (wide) {
+        const size_t ldsb = (size_t)4 * (8 + 2 * 16) * 1024;  // four slots of 40 KB: all of the CU's LDS
+        if (hipFuncSetAttribute((const void*)anchor_l1_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) == hipSuccess) {
+            hipLaunchKernelGGL(anchor_l1_wide_kernel<4>, dim3(2 * a.KS * quads * NBLK), dim3(512), ldsb, st, a);
+        } else {  // a device that grants less: three slots
+            (void)hipGetLastError();
+            const size_t lds3 = (size_t)3 * (8 + 2 * 16) * 1024;
+            (void)hipFuncSetAttribute((const void*)anchor_l1_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            hipLaunchKernelGGL(anchor_l1_wide_kernel<3>, dim3(2 * a.KS * quads * NBLK), dim3(512), lds3, st, a);
+        }
+    } else if (np == 2 && wimg) {
         if (XT == 1) launch(anchor_l1_split_kernel<1, 6, 2, true>, 6, 1);
         else if (XT == 2) launch(anchor_l1_split_kernel<2, 5, 2, true>, 5, 2);
         else if (XT == 4) launch(anchor_l1_split_kernel<4, 4, 2, true>, 4, 4);
