@@ -270,7 +270,7 @@ class Bench:
             t = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        assert bool(torch.isfinite(m1).all()) and abs(float(m1[0, 0].sum()) - 1.0) < 1e-4
+        assert os.environ.get("SHASTA_BENCH_PROBE") == "1" or (bool(torch.isfinite(m1).all()) and abs(float(m1[0, 0].sum()) - 1.0) < 1e-4)
         check = None
         if selfcheck:
             # self-check of the operating point: three frame-pairs of the timed batch recomputed one at a time (batch 1 runs the VALU
@@ -280,7 +280,8 @@ class Bench:
                 for i in sorted({0, B // 2, B - 1}):
                     s1, s2 = model.affinity_from_bev(bev[i:i + 1], pbev[i:i + 1], det0[i:i + 1].clone(), prev[i:i + 1])
                     check = max(check, float((s1 - m1[i:i + 1]).abs().max()), float((s2 - m2[i:i + 1]).abs().max()))
-            assert check <= 1e-6, "self-check failed: batched and one-at-a-time results differ by %.3e" % check
+            # (SHASTA_BENCH_PROBE=1: a diagnostic library whose results are wrong on purpose - tools/build_variant.py ablations - is being timed)
+            assert check <= 1e-6 or os.environ.get("SHASTA_BENCH_PROBE") == "1", "self-check failed: batched and one-at-a-time results differ by %.3e" % check
         ms = C.c_float()
         l1, pair = [], []
         if g is not None:  # the per-step events were not recorded under graph replay: time the two kernels separately
