@@ -540,6 +540,22 @@ def extras(bench, args):
     for b, k in ((1, 200), (8, 200), (B, 30)):
         if b <= B:
             car["b%d" % b] = point(CAR, b, k, args.arithmetic)
+    try:  # rows 4-16 of one frame pair replayed from a captured hipGraph: launch gaps out of the way
+        model = bench.model(CAR)
+        model.arithmetic = args.arithmetic
+        det0, prev = bench.boxes(CAR)
+        det0, prev, bev1, pbev1 = det0[:1], prev[:1], bench.bev[:1], bench.pbev[:1]
+        work = det0.clone()
+
+        def one():
+            work.copy_(det0)
+            return model.affinity_from_bev(bev1, pbev1, work, prev)
+        with bench.torch.no_grad():
+            ms = graph_ms(bench.torch, one, 500)
+        car["b1_graph"] = {"ms_per_step": ms, "frame_pairs_per_s": 1e3 / ms, "arithmetic": args.arithmetic,
+                           "note": "batch 1 replayed from a captured hipGraph (events around 500 replays); b1 is the eager loop"}
+    except Exception as err:  # noqa: BLE001
+        car["b1_graph"] = {"error": "%s: %s" % (type(err).__name__, str(err)[:300])}
     if B >= 64:
         car["b%d_pieces" % B] = point(CAR, B, 30, "pieces")
     car["config"] = "max_obj 90, num_point 5 (F = 320), num_feats 3: configs/nusc/car.py:22-39 of the reference; 180 x 180 x 64 BEV maps"
@@ -735,6 +751,30 @@ def extra_pipeline(bench, args, ex):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def graph_ms(torch, fn, iters, warm=5):
+    """fn() captured into a hipGraph (after `warm` eager calls on a side stream), replayed `iters` times between two events on the current
+    stream: mean device time of one replay in ms - what a batch-1 loop costs once the host's launch work is out of the way."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    for _ in range(3):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
 def extra_shared_conv(bench, args, ex):
     """K0 (SURVEY.md 8(f)-1, det3d/models/tracker/shasta.py:42-47,223-228): the 3x3 512 -> 64 convolution + BN + ReLU -> NHWC that a real
     nuScenes forward starts with, both maps of a frame pair per launch.  Arithmetic "f16x2" (csrc/shared_conv_f16.hip, incl. its
@@ -781,6 +821,17 @@ def extra_shared_conv(bench, args, ex):
                 ms = timed_ms(torch, fwd, 50, warm=5)
                 ex["car_90_320_3"]["from_neck_b1"] = {"ms_per_step": ms, "frame_pairs_per_s": 1e3 / ms, "arithmetic": args.arithmetic,
                                                        "note": "Shasta.forward from the neck outputs: shared_conv (both maps) + rows 4-16, one frame pair"}
+                try:  # the same step replayed from a captured hipGraph (tools/nusc_shasta/eval.py:96-101 is a batch-1 loop)
+                    work = det0.clone()
+
+                    def fwd_static():
+                        work.copy_(det0)
+                        return car(dict(det_boxes=work, prev_det_boxes=prev, bev_map=x, prev_bev_map=xp), train_mode=False)
+                    ms = graph_ms(torch, fwd_static, 200)
+                    ex["car_90_320_3"]["from_neck_b1_graph"] = {"ms_per_step": ms, "frame_pairs_per_s": 1e3 / ms, "arithmetic": args.arithmetic,
+                                                                 "note": "the same step replayed from a captured hipGraph, events around 200 replays"}
+                except Exception as err:  # noqa: BLE001
+                    ex["car_90_320_3"]["from_neck_b1_graph"] = {"error": "%s: %s" % (type(err).__name__, str(err)[:300])}
             del x, xp
     car.arithmetic = args.arithmetic
     ex["shared_conv"] = sc

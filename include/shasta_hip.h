@@ -37,6 +37,7 @@ typedef void* shasta_stream_t; /* a hipStream_t; NULL = the null stream */
 #define SHASTA_E_WORKSPACE (-2) /* workspace too small */
 #define SHASTA_E_LAUNCH (-3)    /* hipGetLastError() != hipSuccess after a launch */
 #define SHASTA_E_ALIGN (-4)     /* pointer or leading dimension not aligned as documented */
+#define SHASTA_E_UNSUPPORTED (-5) /* the device refuses a resource the kernel needs (LDS per workgroup): take the documented other path */
 
 /* Library/ABI version (bumped on any signature change) and a human readable build string. */
 int shasta_abi_version(void);

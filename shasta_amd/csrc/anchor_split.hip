@@ -625,6 +625,11 @@ __global__ __launch_bounds__(256) void anchor_l1_split_kernel(AnchorSplitArgs a)
 //    (16 item blocks x 2 pieces) = 40 KB, four slots = the whole LDS.  The pre-cut image and the activation image are unchanged (their
 //    4 KB / 64 KB blocks are k-step-major resp. hold whole fragments: a slot takes 1 KB fragments wherever they lie).
 // Per accumulator the products arrive in the order of the 256-item kernel (k steps ascending; w_l x_h, w_h x_l, w_h x_h).
+// Counters (profiles/r05_pmc_*): the matrix pipe is 85 % busy in CYCLES (76 % in the 256-item form); what still moves the kernel is the
+// CLOCK the chip holds at its power cap: ablation builds (WIDE_EXP_*) run at 1.82 GHz without the ds_reads, 1.62 GHz without the
+// LDS-DMA, 1.45 GHz with everything (under the profiler).  A four-wave form with 128 x 128 register tiles whose activation fragments
+// go from L2 straight into registers (32 KB of ds_read per k step instead of 96) was built and measured: correct, but one wave per SIMD
+// leaves the pipe 76 % busy and the launch 3 % longer (LABNOTES section 12; git history: anchor_l1_direct_kernel).
 template <int NS>
 __global__ __launch_bounds__(512) void anchor_l1_wide_kernel(AnchorSplitArgs a) {
     constexpr int XT = 16;                         // 32-item blocks per pass
@@ -778,163 +783,6 @@ __global__ __launch_bounds__(512) void anchor_l1_wide_kernel(AnchorSplitArgs a) 
     }
 }
 
-// ---- 512 items per weight pass, activations straight into registers ------------------------------------------------------------------
-// Counters of the form above (profiles/r05_*): the matrix pipe is 85 % busy in CYCLES, what moves the kernel is the CLOCK the chip
-// can hold at its power cap - 1.45 GHz with everything, 1.82 GHz with the ds_reads removed, 1.62 GHz with the LDS-DMA removed
-// (ablation builds WIDE_EXP_*).  So the operands have to move less: here a wave owns 128 weight rows x 128 items (16 accumulators,
-// four waves = one per SIMD), which makes the activation fragments PRIVATE to a wave - they go from L2 straight into registers
-// (global_load_dwordx4 of whole 1 KB fragments, three k steps ahead), never through LDS - and only the 8 KB of weight fragments of a
-// k step, which all four waves need, pass the LDS (LDS-DMA ring of eight slots: seven k steps of HBM latency covered).  Per k step
-// and workgroup: 32 KB of ds_read instead of 96 KB, 8 KB instead of 40 KB written into LDS, the same 40 KB requested from L2.
-template <int NSW>
-__global__ __launch_bounds__(256) void anchor_l1_direct_kernel(AnchorSplitArgs a) {
-    constexpr int XT = 16;     // 32-item blocks per pass
-    constexpr int PD = 3;      // k steps between the request of an activation fragment and its use
-    constexpr int PER = 2 + 8; // vector-memory instructions per k step and wave: 2 LDS-DMA (weights), 8 loads (activations)
-    static_assert(NSW >= PD + 2, "the weight ring must cover the activation prefetch");
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [NSW][4 row groups][2 pieces][64 lanes][4 dwords]
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // = item group: items 128 wid .. 128 wid + 127 of the pass
-
-    const int ncombo = 2 * a.KS;
-    const int combo = blockIdx.x % ncombo, rest = blockIdx.x / ncombo;
-    const int quad = rest / a.NBLK, bblk = rest % a.NBLK;
-    const int ks = combo >> 1, src = combo & 1;
-    const int G2 = 2 * a.groups_per_mlp;
-    const int tpc = a.Kc >> 5;
-    const int kt_beg = ks * tpc, NT = 2 * (min(a.KT, kt_beg + tpc) - kt_beg);  // k steps of this chunk
-
-    auto group_base = [&](int gq, int& mlp, int& r0) {  // group gq of the quad (a spare one repeats the last)
-        const int gg = min(quad * 4 + gq, G2 - 1);
-        mlp = 2 * src + gg / a.groups_per_mlp;
-        r0 = (gg % a.groups_per_mlp) * 32;
-    };
-    // this wave's share of a weight slot: fragments 2 wid, 2 wid + 1 = (row group wid, both pieces)
-    int mlpw, r0w;
-    group_base(wid, mlpw, r0w);
-    const char* wub = reinterpret_cast<const char*>(a.wimg) + (((size_t)mlpw * a.groups_per_mlp + (r0w >> 5)) * a.KT + kt_beg) * 4096;
-    // this wave's activation fragments: item blocks 4 wid .. 4 wid + 3
-    const u32x4* xub = reinterpret_cast<const u32x4*>(a.xs) + ((((size_t)src * a.NBLK + bblk) * a.KT + kt_beg) * (4 * XT) + 16 * wid) * 64 + lane;
-    const uint32_t loff = (uint32_t)(lane * 16);
-    const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) float*)lds);
-    auto dma_w = [&](int t, int slot, int pc) {
-        const char* base = wub + (size_t)(t >> 1) * 4096 + (size_t)(t & 1) * 2048 + (size_t)pc * 1024;
-        const uint32_t dst = lds0 + (uint32_t)((slot * 2048 + (2 * wid + pc) * 256) * 4);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(loff), "s"(base), "s"(dst) : "memory", "m0");
-    };
-    struct XF {
-        u32x4 X[4][2];  // [item block][piece]
-    };
-    struct AF {
-        u32x4 A[4][2];  // [row group][piece]
-    };
-    auto load_x = [&](int t, XF& f, int idx) {  // fragment (item block idx >> 1, piece idx & 1) of k step t
-        f.X[idx >> 1][idx & 1] = xub[((size_t)(t >> 1) * (4 * XT) + (size_t)(((idx >> 1) * 2 + (t & 1)) * 2 + (idx & 1))) * 64];
-    };
-    auto read_a = [&](int slot, AF& f, int idx) {
-        f.A[idx >> 1][idx & 1] = *reinterpret_cast<const u32x4*>(lds + slot * 2048 + idx * 256 + lane * 4);
-    };
-    f32x16 acc[4][4];  // [row group][item block]
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[j][u] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    constexpr int PW2[3] = {1, 0, 0}, PX2[3] = {0, 1, 0};  // piece products, small to large
-    auto mma_one = [&](const AF& fa, const XF& fx, int i) {  // product-major: sixteen independent accumulators between two products of one
-        const int pr = i >> 4, j = (i >> 2) & 3, u = i & 3;
-        acc[j][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa.A[j][PW2[pr]]), __builtin_bit_cast(f16x8, fx.X[u][PX2[pr]]),
-                                                           acc[j][u], 0, 0, 0);
-    };
-    // prologue: weights of k steps 0 .. NSW - 2, activations of k steps 0 .. PD - 1; weight fragments of k step 0 into registers
-    XF x0, x1, x2, x3;
-    AF a0, a1;
-#pragma unroll 1
-    for (int t = 0; t < NSW - 1 && t < NT; ++t) {
-        dma_w(t, t, 0);
-        dma_w(t, t, 1);
-    }
-    if (NT > 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) load_x(0, x0, i);
-    }
-    if (NT > 1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) load_x(1, x1, i);
-    }
-    if (NT > 2) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) load_x(2, x2, i);
-    }
-    wait_vm_split<0>();
-    __builtin_amdgcn_s_barrier();
-    if (NT > 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) read_a(0, a0, i);
-    }
-    // One k step t: MFMAs on (ac, xc); between them: the activation fragments of step t + PD into xn, the weight fragments of step
-    // t + 1 out of their slot into an, the weights of step t + NSW - 1 into the slot step t - 1 has left.
-    auto step = [&](const AF& ac, AF& an, const XF& xc, XF& xn, int t, auto steady) {
-        constexpr bool STEADY = decltype(steady)::value;
-        const int sn = (t + 1) % NSW, sf = (t + NSW - 1) % NSW;
-#pragma unroll
-        for (int i = 0; i < 48; ++i) {
-            mma_one(ac, xc, i);
-            __builtin_amdgcn_sched_barrier(0);
-            if (i == 0) {
-                // everything up to the requests of step t - 3 has landed: this wave's weights of step t + 1 (requested NSW - 2 steps
-                // ago; the barrier: every wave's); the compiler's own waits guard the activation registers
-                if constexpr (STEADY) wait_vm_split<2 * PER>();
-                else wait_vm_split<0>();
-                __builtin_amdgcn_s_barrier();
-            }
-            if (i >= 1 && i < 3) {
-                if (STEADY || t + NSW - 1 < NT) dma_w(t + NSW - 1, sf, i - 1);
-            }
-            if (i >= 3 && i < 11) {
-                if (STEADY || t + PD < NT) load_x(t + PD, xn, i - 3);
-            }
-            if (i >= 12 && i < 20) {
-                if (STEADY || t + 1 < NT) read_a(sn, an, i - 12);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    int t = 0;
-#pragma unroll 1
-    for (; t + 4 + NSW <= NT; t += 4) {
-        step(a0, a1, x0, x3, t, std::true_type{});
-        step(a1, a0, x1, x0, t + 1, std::true_type{});
-        step(a0, a1, x2, x1, t + 2, std::true_type{});
-        step(a1, a0, x3, x2, t + 3, std::true_type{});
-    }
-#pragma unroll 1
-    for (; t < NT; t += 4) {
-        step(a0, a1, x0, x3, t, std::false_type{});
-        if (t + 1 < NT) step(a1, a0, x1, x0, t + 1, std::false_type{});
-        if (t + 2 < NT) step(a0, a1, x2, x1, t + 2, std::false_type{});
-        if (t + 3 < NT) step(a1, a0, x3, x2, t + 3, std::false_type{});
-    }
-    // D[i = weight row][j = item]
-    const int frow = lane & 31, fh = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (quad * 4 + j >= G2) continue;  // a spare group
-        int mlp, r0;
-        group_base(j, mlp, r0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int b = (bblk * XT + 4 * wid + u) * 32 + frow;
-            if (b >= a.B) continue;
-            float* o = a.part + ((size_t)ks * a.B + b) * (4 * a.H) + mlp * a.H;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (row < a.H) o[row] = acc[j][u][r];
-            }
-        }
-    }
-}
-
 // the wide form serves the pre-cut fp16 stream whenever 512-item passes pad the batch no more than 256-item passes do
 static inline bool split_wide(int B, int np, bool precut) { return np == 2 && precut && !kPrecutShape16 && B > 256 && cdiv(B, 512) * 512 <= cdiv(B, 256) * 256; }
 
@@ -1024,12 +872,6 @@ void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         hipLaunchKernelGGL(kern, dim3(2 * a.KS * quads * NBLK), dim3(256), ldsb, st, a);
     };
-#ifndef WIDE_VIA_LDS
-    if (wide) {
-        constexpr int NSW = 8;
-        hipLaunchKernelGGL(anchor_l1_direct_kernel<NSW>, dim3(2 * a.KS * quads * NBLK), dim3(256), (size_t)NSW * 8192, st, a);
-    } else
-#endif
     if (wide) {
         const size_t ldsb = (size_t)4 * (8 + 2 * 16) * 1024;  // four slots of 40 KB: all of the CU's LDS
 #ifdef WIDE_EXP_NS3

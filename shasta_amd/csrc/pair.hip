@@ -565,7 +565,7 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
         if (ev0) (void)hipEventRecord(ev0, st);
         rc = launch_pair_f16w(packed, packed + P.p16w, UP, UC, hand_prev, hand_det, denom, residual, B, T, D, ld, F, st);
         if (ev1) (void)hipEventRecord(ev1, st);
-        return rc;
+        if (rc != SHASTA_E_UNSUPPORTED) return rc;  // a device that does not grant its LDS: the f32 kernel below serves the call
     }
     // lane = pair, 4x4x1 MFMA.  The 8 waves of a workgroup share one 64-detection UC tile and take different track ranges
     // (two workgroups per CU by LDS, 113 VGPRs in the VGPR MFMA form: 4 waves per SIMD).

@@ -484,7 +484,11 @@ int launch_pair_f16w(const float* packed, const float* p16, const float* UP, con
     const int twg = cdiv(cdiv(T, ny), unit) * unit;
     const size_t lds = pair_f16w_lds_bytes(F);
     dim3 grd(cdiv(D, 32), cdiv(T, twg), B);
-    (void)hipFuncSetAttribute((const void*)pair_f16w_kernel<320>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipFuncSetAttribute((const void*)pair_f16w_kernel<320>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error_msg("pair_f16w: the device does not grant the kernel's LDS per workgroup");
+        return SHASTA_E_UNSUPPORTED;
+    }
     hipLaunchKernelGGL((pair_f16w_kernel<320>), grd, dim3(64 * PWK_WPB), lds, st, packed, reinterpret_cast<const uint32_t*>(p16), UP, UC,
                        hand_prev, hand_det, denom, residual, T, D, ld, twg);
     return check_launch("pair_f16w");

@@ -350,7 +350,11 @@ extern "C" int shasta_track_merged_f64(const double* det_xy, const double* det_v
         a.alpha[c] = c < n_cls ? cls_alpha[c] : 0.0;
         a.beta[c] = c < n_cls ? cls_beta[c] : 0.0;
     }
-    (void)hipFuncSetAttribute((const void*)track_merged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TM_LDS_BYTES);
+    if (hipFuncSetAttribute((const void*)track_merged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TM_LDS_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error_msg("track_merged: the device does not grant the kernel's LDS (one workgroup holds a scene's tracks): use the per-frame tracker");
+        return SHASTA_E_UNSUPPORTED;
+    }
     hipLaunchKernelGGL(track_merged_kernel, dim3(scenes), dim3(64), TM_LDS_BYTES, as_stream(stream), a);
     return check_launch("track_merged");
 }

@@ -19,6 +19,7 @@ class ShastaHipError(RuntimeError):
     pass
 
 
+E_UNSUPPORTED = -5  # include/shasta_hip.h SHASTA_E_UNSUPPORTED
 OPT_F32_WEIGHT_STREAM = 1  # include/shasta_hip.h SHASTA_OPT_*
 OPT_F32_EMBED_GEMM = 2
 OPT_F32_AFF = 4

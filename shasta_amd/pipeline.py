@@ -231,12 +231,18 @@ def _scene_runs(scenes, mine, known, frame_info, batch_pairs):
     for name, toks in scenes:
         if name not in mine:
             continue
-        for i in range(0, len(toks), batch_pairs):
-            run = []
-            for t in toks[i:i + batch_pairs]:
-                prev = frame_info[t]["prev"]
-                run.append((t, prev if prev in known else ""))
-            assert all(run[j][1] == run[j - 1][0] for j in range(1, len(run))), "frames of a scene must be listed in time order"
+        run = []
+        for t in toks:
+            prev = frame_info[t]["prev"]
+            prev = prev if prev in known else ""
+            # a frame whose previous frame is not the list's preceding element (a token list that skips frames, a frame whose `prev`
+            # is missing from the split: eval.py then falls back to the frame itself) starts a run of its own: its previous maps are
+            # looked up by token (row 0 of the run's stack), exactly as the class-major chain does frame by frame
+            if run and (len(run) == batch_pairs or prev != run[-1][0]):
+                yield run
+                run = []
+            run.append((t, prev))
+        if run:
             yield run
 
 
@@ -267,8 +273,12 @@ def _run_features(bev, models, names, run, device, bank_cache, timer=_NO_TIMER):
     return {n: f for n in names}
 
 
-def run_split(models, paths, scenes, bev, device, **kw):
-    """Configs 2-4 end to end (see _run_split for the arguments) with the cyclic garbage collector off for the duration (_no_cyclic_gc)."""
+def run_split(models, paths, scenes, bev, device, manage_gc=True, **kw):
+    """Configs 2-4 end to end (see _run_split for the arguments).  manage_gc=True (default): the cyclic garbage collector of the PROCESS is
+    switched off for the duration (_no_cyclic_gc: the loader is 2x faster without its generation-2 passes) and restored afterwards - not
+    thread-safe; a caller that runs other Python threads, or manages the collector itself, passes manage_gc=False."""
+    if not manage_gc:
+        return _run_split(models, paths, scenes, bev, device, **kw)
     with _no_cyclic_gc():
         return _run_split(models, paths, scenes, bev, device, **kw)
 

@@ -415,11 +415,13 @@ def track_scenes_merged_device(scene_frames, max_age=0, device=None, plain=False
         refon = (C.c_int32 * len(names))(*[int(bool(TRK_REF[n]["ref"])) for n in names])
         alpha = (C.c_double * len(names))(*[float(TRK_REF[n]["alpha"]) for n in names])
         beta = (C.c_double * len(names))(*[float(TRK_REF[n]["beta"]) for n in names])
-    hip.check(lib.shasta_track_merged_f64(hip.ptr(seg[0]), hip.ptr(seg[1]), hip.ptr(seg[4].view(torch.int32)), hip.ptr(seg[2]), hip.ptr(seg[3]),
+    rc = lib.shasta_track_merged_f64(hip.ptr(seg[0]), hip.ptr(seg[1]), hip.ptr(seg[4].view(torch.int32)), hip.ptr(seg[2]), hip.ptr(seg[3]),
                                           hip.ptr(seg[5].view(torch.int32)), hip.ptr(seg[6].view(torch.int32)), hip.ptr(seg[7]),
                                           hip.ptr(seg[8].view(torch.int32)), S, Fmax, len(names), gate, refon, alpha, beta, int(max_age), int(bool(plain)),
-                                          hip.ptr(o_st), hip.ptr(o_id), hip.ptr(o_ref), hip.ptr(o_err), hip.stream_ptr()),
-              "shasta_track_merged_f64")
+                                          hip.ptr(o_st), hip.ptr(o_id), hip.ptr(o_ref), hip.ptr(o_err), hip.stream_ptr())
+    if rc == hip.E_UNSUPPORTED:  # a device that does not grant the kernel its LDS: every scene takes the per-frame path
+        return [None] * S
+    hip.check(rc, "shasta_track_merged_f64")
     oh = out.cpu().numpy()
     r_ref = oh[:D].tolist()
     r_st = oh[D:D + (D + 1) // 2].view(np.int32)[:D]

@@ -7,6 +7,7 @@ one read of the map.  Arithmetic: fp32 in, fp32 out, fp32 accumulation, products
 arithmetic of `Shasta.arithmetic`); eval-mode BatchNorm only.  No CPU path.
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -30,12 +31,21 @@ class SharedConvBank:
         cin = {m.shared_conv[0].in_channels for m in models}
         if len(cin) != 1 or any(m.shared_conv[0].out_channels != 64 for m in models):
             raise ValueError("SharedConvBank: every head must be Conv2d(Cin -> 64) with the same Cin")
-        self.models = models
+        # weak references: a model that keeps its own one-head bank (Shasta._conv_bank) must not form a cycle with it - the bank holds
+        # device buffers that `del model` should free at once, without a pass of the cyclic collector
+        self._models = [weakref.ref(m) for m in models]
         self.in_channels = cin.pop()
         self.cin_padded = (self.in_channels + 15) // 16 * 16
         self._packed = None
         self._key = None
         self._ws = None
+
+    @property
+    def models(self):
+        ms = [r() for r in self._models]
+        if any(m is None for m in ms):
+            raise hip.ShastaHipError("SharedConvBank: a model of this bank no longer exists")
+        return ms
 
     def supported(self, H, W):
         return bool(hip.load().shasta_shared_conv_f16x2_supported(self.cin_padded, H, W))

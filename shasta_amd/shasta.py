@@ -311,10 +311,8 @@ class Shasta(BaseTrack):
         THIS weight set falls back to the exact bf16-piece form.  `self.f16x2_guard` says what was measured and decided."""
         wkey = tuple((self.aug_shape[i][0].weight.data_ptr(), self.aug_shape[i][0].weight._version) for i in range(4))
         fp16_bits = hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_PRECUT_WEIGHT_STREAM
-        if self._guard_key is not None and self._guard_key != wkey:  # other weights: decide again
+        if self._guard_key is not None and self._guard_key != wkey:  # other weights: decide again (w is a fresh copy with all its bits)
             self._guard_key = None
-            if not training:
-                w.options = self._options()
         if self._guard_key == wkey and self._guard_key is not None:
             w.options &= ~fp16_bits
         small = bool(w.options & hip.OPT_PRECUT_WEIGHT_STREAM) and not training and B >= hip.PRECUT_MIN_BATCH
@@ -467,11 +465,12 @@ class Shasta(BaseTrack):
         dev = det_boxes.device
         if B == 0:  # nothing to launch
             return torch.empty(0, N, N + 2, device=dev), torch.empty(0, N + 2, N, device=dev)
-        w = self._weights()
+        # a per-call copy of the cached struct: what this call decides (range guard, companion buffer, the training path's bits)
+        # never sticks to the cache
+        w = hip.Weights.from_buffer_copy(self._weights())
         if _train_keep is not None and (w.options & hip.OPT_PRECUT_WEIGHT_STREAM):
-            # training steps change the weights every step: they keep the kernels that read the fp32 tensors (a private copy of the
-            # struct without the bit, so that no 4 GB piece image is rebuilt per step only to be streamed once)
-            w = hip.Weights.from_buffer_copy(w)
+            # training steps change the weights every step: they keep the kernels that read the fp32 tensors (no 4 GB piece image is
+            # rebuilt per step only to be streamed once)
             w.options &= ~hip.OPT_PRECUT_WEIGHT_STREAM
         self._ensure_packed(w, dev)
         self._ensure_aux(w, B, dev, training=_train_keep is not None)

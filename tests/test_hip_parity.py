@@ -66,6 +66,16 @@ def test_forward_matches_reference_golden(name):
           (e1, e2, ", ".join("%s %.2f" % kv for kv in worst.items())))
     for k, t in (("newborn", m.newborn), ("fp", m.fp), ("dead_trk", m.dead_trk), ("fn", m.fn)):  # the module attributes
         np.testing.assert_allclose(t.cpu().numpy(), z[k], rtol=1e-5, atol=1e-5 * float(np.abs(z[k]).max()))
+    # K0 on the device against the REFERENCE's own shared_conv output on the same neck maps (bev_probe / prev_bev_probe: a 4 x 4 grid of
+    # pixels of out["bev_feature"] and of shared_conv(prev_bev), tests/golden/make_golden.py:98-99), in both arithmetics, full-size maps
+    step = max(1, c["hw"] // 4)
+    for arith in ("f16x2", "f32"):
+        m.arithmetic = arith
+        with torch.no_grad():
+            for src, key in ((bev, "bev_probe"), (pbev, "prev_bev_probe")):
+                got = m.shared_conv_nhwc(src.to(dev))[:, ::step, ::step, :].cpu().numpy()
+                assert got.shape == z[key].shape
+                np.testing.assert_allclose(got, z[key], rtol=1e-5, atol=1e-5 * float(np.abs(z[key]).max()), err_msg="%s %s %s" % (name, arith, key))
 
 
 def _tables(m):
@@ -1087,6 +1097,38 @@ def test_fp16_weight_stream_with_outliers_inside_a_row(kind):
     err = {mode: float(((hid[mode] - ref).abs() / mag).max()) for mode in hid}
     assert err["f16x2"] <= 2.0 * err["f32"] + 2e-8, (kind, err, m.f16x2_guard)
     assert err["f32"] < 1e-5, err
+
+
+def test_range_guard_is_decided_again_after_a_training_step():
+    """A tripped range guard belongs to ONE weight set: after the weights changed under a training step (which never evaluates the guard)
+    the next inference call measures the rows again and returns to the fp16 stream when they allow it; nothing sticks to the cached
+    weight struct."""
+    import shasta_amd
+    from shasta_amd import hip
+    dev = _dev()
+    torch.manual_seed(5)
+    N, B = 40, 70
+    m = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075],
+                                                            out_stride=8), max_obj=N, num_feats=7, num_point=4, in_channels=8)).eval().to(dev)
+    bits = hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_PRECUT_WEIGHT_STREAM
+
+    def call(training=False):
+        w = hip.Weights.from_buffer_copy(m._weights())
+        if training:
+            w.options &= ~hip.OPT_PRECUT_WEIGHT_STREAM
+        m._ensure_aux(w, B, dev, training=training)
+        return w.options
+    assert call() & bits == bits and not m.f16x2_guard["tripped"]
+    with torch.no_grad():
+        m.aug_shape[2][0].weight[:, 777] = m.aug_shape[2][0].weight.abs().mean() * 2.0 ** 20
+    assert call() & bits == 0 and m.f16x2_guard["tripped"]
+    assert call() & bits == 0                      # same weights: decided once
+    assert m._weights().options & bits == bits     # the cached struct keeps the model's arithmetic
+    with torch.no_grad():
+        m.aug_shape[2][0].weight[:, 777] = 0.01    # "optimizer step": other weights, in place
+    assert call(training=True) & hip.OPT_F16X2_WEIGHT_STREAM
+    assert call() & bits == bits and not m.f16x2_guard["tripped"]
 
 
 def test_fp16_form_is_range_safe():

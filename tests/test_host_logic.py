@@ -178,3 +178,19 @@ def test_two_rank_gloo_gather_equals_single_process(tmp_path):
     for k in single["results"]:
         assert merged["results"][k] == single["results"][k]
     assert any(a.get("dead") for a in merged["results"]["scene3_t0"])
+
+
+def test_scene_runs_split_where_a_frame_does_not_follow_its_predecessor():
+    """pipeline._scene_runs: runs are consecutive frames of one scene; a token list that skips a frame, or a frame whose `prev` is not part
+    of the split (eval.py falls back to the frame itself), starts a new run instead of raising - with or without `python -O`."""
+    from shasta_amd import pipeline
+    info = {"a": {"prev": ""}, "b": {"prev": "a"}, "c": {"prev": "b"}, "d": {"prev": "c"}, "e": {"prev": "d"}, "f": {"prev": "zz"}, "g": {"prev": "f"}}
+    scenes = [("s0", ["a", "b", "d", "e", "f", "g"]), ("s1", ["c"])]
+    known = {"a", "b", "c", "d", "e", "f", "g"}
+    runs = list(pipeline._scene_runs(scenes, {"s0", "s1"}, known, info, 8))
+    assert runs == [[("a", ""), ("b", "a")], [("d", "c"), ("e", "d")], [("f", ""), ("g", "f")], [("c", "b")]]
+    for run in runs:  # the invariant the stacked maps rely on
+        assert all(run[j][1] == run[j - 1][0] for j in range(1, len(run)))
+    # the run length is still capped, and scenes of other ranks are skipped
+    assert [len(r) for r in pipeline._scene_runs([("s", list("abc"))], {"s"}, known, info, 2)] == [2, 1]
+    assert list(pipeline._scene_runs(scenes, {"s1"}, known, info, 8)) == [[("c", "b")]]

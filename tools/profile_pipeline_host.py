@@ -1,6 +1,8 @@
 """GPU-box helper: cProfile of the configs 2-4 chain (host side) on the 20 x 40 synthetic split.
     python tools/profile_pipeline_host.py [--top 40]"""
 import argparse
+import atexit
+import shutil
 import cProfile
 import os
 import pstats
@@ -20,6 +22,7 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     root = tempfile.mkdtemp(prefix="shasta_split_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    atexit.register(shutil.rmtree, root, ignore_errors=True)  # the split lives in RAM (tmpfs): never leave it behind
     paths, sc = scenes.write_synthetic_split(root, n_scenes=20, frames_per_scene=40, seed=3)
     models = {n: pipeline.build_class_model(n, dev, seed=1) for n in pipeline.CLASS_CONFIGS}
     neck = scenes.TokenNeck()

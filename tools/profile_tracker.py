@@ -1,3 +1,5 @@
+import atexit
+import shutil
 """GPU-box helper: where the merged tracker's time goes on the 20 x 40 synthetic split (after one chain run has produced `merged`).
     python tools/profile_tracker.py"""
 import cProfile
@@ -17,6 +19,7 @@ from shasta_amd import pipeline, pub_tracker, scenes  # noqa: E402
 def main():
     dev = torch.device("cuda", 0)
     root = tempfile.mkdtemp(prefix="shasta_split_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    atexit.register(shutil.rmtree, root, ignore_errors=True)  # the split lives in RAM (tmpfs): never leave it behind
     paths, sc = scenes.write_synthetic_split(root, n_scenes=20, frames_per_scene=40, seed=3)
     models = {n: pipeline.build_class_model(n, dev, seed=1) for n in pipeline.CLASS_CONFIGS}
     _, merged, _ = pipeline.run_split(models, paths, sc, scenes.TokenNeck(), dev, batch_pairs=40)

@@ -21,12 +21,24 @@ def short(name):
 
 
 def kernel_stats(src, dst):
-    rows = list(csv.DictReader(open(src)))
+    """rocprofv3's --stats table, one row per (kernel, launch shape): a bench run launches its kernels at the timed batch AND - in the
+    self-check of bench.py - at batch 1; a mean over both is no launch time.  With the kernel trace next to the stats file the rows are
+    rebuilt from it with the grid as part of the key (column Grid); without it the stats table is copied as is (Grid empty)."""
+    trace = os.path.join(os.path.dirname(src), os.path.basename(src).replace("kernel_stats", "kernel_trace"))
     with open(dst, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
-        for r in rows:
-            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+        w.writerow(["Name", "Grid", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        if os.path.exists(trace):
+            acc = collections.defaultdict(list)
+            for r in csv.DictReader(open(trace)):
+                grid = "x".join(str(int(r["Grid_Size_" + a]) // max(1, int(r["Workgroup_Size_" + a]))) for a in "XYZ")
+                acc[(short(r["Kernel_Name"]), grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            total = float(sum(sum(v) for v in acc.values())) or 1.0
+            for (name, grid), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+                w.writerow([name, grid, len(v), sum(v), "%.1f" % (sum(v) / len(v)), "%.4g" % (100.0 * sum(v) / total), min(v), max(v)])
+        else:
+            for r in csv.DictReader(open(src)):
+                w.writerow([short(r["Name"]), "", r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 
 
 def pmc(dirs, dst):

@@ -1,6 +1,8 @@
 """GPU-box helper: configs 2-4 chain on a synthetic split, wall time per stage.
-    python tools/time_pipeline.py [--scenes 20] [--frames 40] [--batch 32] [--frame-major 0|1]"""
+    python tools/time_pipeline.py [--scenes 20] [--frames 40] [--batch 32] [0|1]"""
 import argparse
+import atexit
+import shutil
 import json
 import os
 import sys
@@ -22,6 +24,7 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     root = tempfile.mkdtemp(prefix="shasta_split_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    atexit.register(shutil.rmtree, root, ignore_errors=True)  # the split lives in RAM (tmpfs): never leave it behind
     t0 = time.perf_counter()
     paths, sc = scenes.write_synthetic_split(root, n_scenes=a.scenes, frames_per_scene=a.frames, seed=3)
     print("split written in %.2f s: %d frames" % (time.perf_counter() - t0, a.scenes * a.frames), flush=True)
