@@ -632,8 +632,12 @@ def extra_train_step(bench, args, ex):
     torch, dev = bench.torch, bench.dev
     from shasta_amd import training
     ts = {"note": "ms per step = forward (rows 4-16) + loss + backward + Adam; frame-pairs/s = B / step; fwd / bwd / adam from events on the stream"}
+    ts["note"] += ("; *_dense: the four first-layer gradients of aug_shape written out and read back by Adam (36 B per parameter), the others: "
+                   "Adam straight from their factors (FusedAdam(lowrank_first_layers=model), 24 B per parameter)")
     for (cfg, B, steps) in ((CAR, 16, 10), (CAR, 64, 6), (HEADLINE, 8, 3)):
-        for prec in ("fp32", "bf16"):
+        for prec in ("fp32", "bf16", "fp32_dense"):
+            if prec == "fp32_dense" and cfg is not HEADLINE:
+                continue
             key = "n%d_b%d_%s" % (cfg["max_obj"], B, prec)
             try:
                 torch.manual_seed(0)
@@ -641,9 +645,9 @@ def extra_train_step(bench, args, ex):
                     model = bench.shasta.build_simp_track(dict(
                         type="Shasta", reader=None, backbone=None, neck=None,
                         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8), **cfg)).train()
-                model.train_precision = prec
+                model.train_precision = prec.split("_")[0]
                 params = training.affinity_params(model)
-                opt = training.FusedAdam(params, lr=1e-4)
+                opt = training.FusedAdam(params, lr=1e-4, lowrank_first_layers=None if prec.endswith("_dense") else model)
                 N = cfg["max_obj"]
                 det0, prev = bench.boxes(cfg)
                 det0, prev, bev, pbev = det0[:B], prev[:B], bench.bev[:B], bench.pbev[:B]
@@ -905,15 +909,21 @@ def dry_run(args, rank, world):
     if world > 1:
         dist.init_process_group(backend="gloo")
         dist.barrier()
-    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    # the timed region of measure() in miniature: every rank "works" 1 ms per step between the barriers, the slowest rank's time is
+    # the job's (SHASTA_BENCH_DRY_SLOW_RANK = r: that rank takes half a second longer - the MAX must show it, whichever rank it is)
+    t0 = time.perf_counter()
+    time.sleep(1e-3 * args.steps + (0.5 if os.environ.get("SHASTA_BENCH_DRY_SLOW_RANK") == str(rank) else 0.0))
+    own = time.perf_counter() - t0
+    t = torch.tensor([float(rank + 1), own], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
-    assert int(t.item()) == world and args.gpus == world
+    assert int(t[0].item()) == world and args.gpus == world
     if rank == 0:
         print(json.dumps({"metric": "affinity frame-pairs/sec at N=M=500, F=256", "value": None, "unit": "frame-pairs/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "dry_run": True,
-                          "max_over_ranks": t.item()}), flush=True)
+                          "max_over_ranks": t[0].item(), "ms_per_step": t[1].item() / max(1, args.steps) * 1e3,
+                          "elapsed_max_over_ranks_s": t[1].item(), "elapsed_rank0_s": own}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

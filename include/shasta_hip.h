@@ -474,6 +474,13 @@ int shasta_scale_f32(float* x, long n, float alpha, shasta_stream_t stream);
 int shasta_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                          float beta2, float eps, float weight_decay, int step, shasta_stream_t stream);
 
+/* The same update for an (H, K) matrix whose gradient is the rank-R product g[h][k] = sum_r G[r][h] X[r][k] (G: (R, H) at ldg, X: (R, K) at
+ * ldx; the first aug_shape layers of tools/nusc_shasta/train.py:198-218: G = gradient of the hidden activations - already divided by
+ * the world size when the factors were gathered over the ranks -, X = the layer's inputs, R = frame-pairs of the step over all ranks,
+ * 1..64).  The gradient is formed in registers inside the pass and never touches memory.  K and ldx multiples of 4. */
+int shasta_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_sq, int H, int K, const float* G, int ldg, const float* X, int ldx,
+                            int R, float lr, float beta1, float beta2, float eps, float weight_decay, int step, shasta_stream_t stream);
+
 #pragma GCC visibility pop
 
 #ifdef __cplusplus

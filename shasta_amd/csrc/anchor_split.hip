@@ -854,8 +854,11 @@ void launch_anchor_l1_split(const float* const W[4], const void* xs, float* part
     const int cmin = KT >= 64 ? 4 : 1;
     int ks = cmin;
     double best = -1.0;
+    // (the split is chosen for the 256-item form's grid whichever form runs: an accumulator's chunk of K - and with it every sum, bit for
+    // bit - is then the same with and without the pre-cut image, 256 or 512 items per pass)
+    const int nblk_split = split_nblk(B, np);
     for (int c = cmin; c <= 64 && c * 16 <= KT; ++c) {
-        const int wgs = 2 * cdiv(KT, cdiv(KT, c)) * quads * NBLK;
+        const int wgs = 2 * cdiv(KT, cdiv(KT, c)) * quads * nblk_split;
         const int rounds = cdiv(wgs, ncu);
         const double eff = (double)wgs / ((double)rounds * ncu);
         if (eff > best + 1e-9) {

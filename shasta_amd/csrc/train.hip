@@ -339,6 +339,49 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     if (i < n) adam_one(p[i], g[i], m[i], v[i], a);
 }
 
+// Adam for a matrix whose gradient is a rank-R product, g[h][k] = sum_r G[r][h] X[r][k] (the first aug_shape layers: G = gradient of the
+// hidden activations, X = the layer's inputs, R = frame-pairs of the step over all ranks): the gradient is formed in registers inside the
+// Adam pass - it is never written to memory and never read back.  24 bytes per parameter (p, m, v in and out) instead of the 36 of
+// "write the gradient, read it in the Adam kernel".  A thread owns COLS consecutive columns and keeps its R x COLS slice of X in
+// registers; G[r][h] is uniform over the workgroup (scalar loads).
+template <int RMAX, int COLS>
+__global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                           const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx, int R,
+                                                           int H, int K, int rows_per_block, AdamArgs a) {
+    typedef float fv __attribute__((ext_vector_type(COLS)));
+    const long k0 = ((long)blockIdx.x * 256 + threadIdx.x) * COLS;
+    if (k0 >= K) return;
+    fv xv[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        xv[r] = fv(0.0f);
+        if (r < R) xv[r] = *reinterpret_cast<const fv*>(X + (size_t)r * ldx + k0);
+    }
+    const int h0 = blockIdx.y * rows_per_block, h1 = min(H, h0 + rows_per_block);
+    for (int h = h0; h < h1; ++h) {
+        const size_t at = (size_t)h * K + k0;
+        fv pp = *reinterpret_cast<const fv*>(p + at), mm = *reinterpret_cast<const fv*>(m + at), vv = *reinterpret_cast<const fv*>(v + at);
+        fv g = fv(0.0f);
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const float gr = r < R ? G[(size_t)r * ldg + h] : 0.0f;  // wave-uniform: scalar load
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) g[c] = fmaf(gr, xv[r][c], g[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) {
+            float pk = pp[c], mk = mm[c], vk = vv[c];
+            adam_one(pk, g[c], mk, vk, a);
+            pp[c] = pk;
+            mm[c] = mk;
+            vv[c] = vk;
+        }
+        *reinterpret_cast<fv*>(p + at) = pp;
+        *reinterpret_cast<fv*>(m + at) = mm;
+        *reinterpret_cast<fv*>(v + at) = vv;
+    }
+}
+
 __global__ void scale_kernel(float* __restrict__ x, long n, float alpha) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] *= alpha;
@@ -591,6 +634,35 @@ extern "C" int shasta_adam_step_f32(float* param, const float* grad, float* exp_
     const long blocks = std::min<long>((n / 4 + 255) / 256 + 1, 256L * 16);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, a);
     return check_launch("adam_step");
+}
+
+extern "C" int shasta_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_sq, int H, int K, const float* G, int ldg, const float* X,
+                                       int ldx, int R, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                       shasta_stream_t stream) {
+    SHASTA_REQUIRE(param && exp_avg && exp_avg_sq && G && X && H >= 0 && K >= 0 && step >= 1, "adam_lowrank: bad argument");
+    SHASTA_REQUIRE(R >= 1 && R <= 64, "adam_lowrank: 1 <= R <= 64 (frame-pairs of a step over all ranks)");
+    SHASTA_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && ldg >= H && ldx >= K, "adam_lowrank: K and ldx multiples of 4, ldg >= H, ldx >= K");
+    SHASTA_REQUIRE((((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)X) & 15) == 0, "adam_lowrank: 16-byte alignment");
+    if (H == 0 || K == 0) return SHASTA_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamArgs a;
+    a.lr_over_bc1 = (float)((double)lr / bc1);
+    a.beta1 = beta1;
+    a.beta2 = beta2;
+    a.eps = eps;
+    a.weight_decay = weight_decay;
+    a.rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    auto launch = [&](auto kern, int cols) {
+        const int kblocks = cdiv(K / cols, 256);
+        const int rpb = std::max(1, std::min(64, cdiv(H, std::max(1, 4096 / kblocks))));  // >= ~4096 workgroups, <= 64 rows each
+        hipLaunchKernelGGL(kern, dim3(kblocks, cdiv(H, rpb)), dim3(256), 0, as_stream(stream), param, exp_avg, exp_avg_sq, G, ldg, X, ldx, R, H, K,
+                           rpb, a);
+    };
+    if (R <= 8) launch(adam_lowrank_kernel<8, 4>, 4);
+    else if (R <= 16) launch(adam_lowrank_kernel<16, 4>, 4);
+    else if (R <= 32) launch(adam_lowrank_kernel<32, 2>, 2);
+    else launch(adam_lowrank_kernel<64, 2>, 2);
+    return check_launch("adam_lowrank");
 }
 
 extern "C" int shasta_scale_f32(float* x, long n, float alpha, shasta_stream_t stream) {

@@ -250,6 +250,9 @@ class _AffinityTrainFn(torch.autograd.Function):
         if world > 1:
             _check_equal_local_batch(B, world, group, dev)
         exchange = world > 1 or getattr(model, "_force_factor_exchange", False)  # the latter: single-rank test of the path
+        # model.lowrank_adam (set by FusedAdam(..., lowrank_first_layers=model)): the four 1 GB first-layer gradients are not formed at
+        # all - their factors go to the optimizer, which builds the gradient in registers inside its pass (shasta_adam_lowrank_f32)
+        lowrank = bool(getattr(model, "lowrank_adam", False)) and world * B <= 64 and (N * F) % 4 == 0
         shape_grads, box_grads, ghids = [None] * 4, [None] * 4, [None] * 4
         for i in range(4):
             # aug_shape[i]: input = rows < N of feat (i<2) / prev_feat (i>=2); output row N + (i&1) of prev_feat (i<2) / feat (i>=2)
@@ -258,7 +261,7 @@ class _AffinityTrainFn(torch.autograd.Function):
             g_out = gtab[:, N + (i & 1), :].contiguous()
             Hs_ = N * F // 64
             hid = S["shape_hidden"][:, i * Hs_:(i + 1) * Hs_].contiguous() if Hs_ > 0 else None
-            grads, ghid, w1 = anchor_bwd(model.aug_shape[i], x, T * F, N * F, g_out, 0, F, hid=hid, defer_w1=exchange)
+            grads, ghid, w1 = anchor_bwd(model.aug_shape[i], x, T * F, N * F, g_out, 0, F, hid=hid, defer_w1=exchange or lowrank)
             shape_grads[i] = grads
             ghids[i] = ghid
             if ghid is not None:  # dx = ghid W1 accumulated into the rows < N of the INPUT table's gradient
@@ -284,11 +287,17 @@ class _AffinityTrainFn(torch.autograd.Function):
             hip.check(lib.shasta_scale_f32(hip.ptr(gh_all), gh_all.numel(), 1.0 / world, st()), "shasta_scale_f32")
             for i in range(4):
                 w1p = model.aug_shape[i][0].weight
+                if lowrank:  # (the parameter's .grad stays None; allreduce_gradients skips it)
+                    w1p._shasta_grad_factors = (gh_all[:, i * Hs_:], 4 * Hs_, xs[0 if i < 2 else 1], K, world * B)
+                    continue
                 gW1 = torch.empty_like(w1p)
                 _outer(lib, gh_all[:, i * Hs_:], 4 * Hs_, xs[0 if i < 2 else 1], K, world * B, Hs_, K, gW1)
                 g = shape_grads[i]
                 shape_grads[i] = (gW1, g[1], g[2], g[3])
                 w1p._shasta_grad_is_global = True  # allreduce_gradients must not reduce it again
+        elif lowrank and ghids[0] is not None:
+            for i in range(4):  # one rank: the local factors as they are (the input rows lie T * F apart in the feature table)
+                model.aug_shape[i][0].weight._shasta_grad_factors = (ghids[i], ghids[i].shape[1], S["feat"] if i < 2 else S["prev_feat"], T * F, B)
 
         # ---- gather (shasta.py:231-238) -> gradient of the two NHWC maps ----
         def gather_bwd(gtab, boxes):
@@ -390,8 +399,14 @@ class FusedAdam(torch.optim.Optimizer):
     unfused optimizer's seven.  Same param_groups keys (so OneCycleLR, which cycles `lr` and `betas`, train.py:172, drives
     it unchanged) and the same state names (`step`, `exp_avg`, `exp_avg_sq`)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lowrank_first_layers=None):
+        """lowrank_first_layers = the Shasta model: its four aug_shape first-layer matrices (4 x 1 GB at N = 500) are updated straight from
+        the FACTORS of their gradient (shasta_adam_lowrank_f32: 24 bytes per parameter instead of 36) - the backward then leaves their
+        .grad None and hands the factors over on the parameter; same update, the gradient's sum over the step's frame-pairs in another
+        order."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if lowrank_first_layers is not None:
+            lowrank_first_layers.lowrank_adam = True
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -403,7 +418,8 @@ class FusedAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
-                if p.grad is None:
+                factors = p.__dict__.pop("_shasta_grad_factors", None)
+                if p.grad is None and factors is None:
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                     raise hip.ShastaHipError("FusedAdam needs contiguous fp32 device parameters (no CPU path)")
@@ -413,6 +429,14 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] = int(st["step"]) + 1
+                if p.grad is None:  # a matrix whose gradient is G^T X: formed inside the pass
+                    G, ldg, X, ldx, R = factors
+                    hip.check(lib.shasta_adam_lowrank_f32(hip.ptr(p), hip.ptr(st["exp_avg"]), hip.ptr(st["exp_avg_sq"]), p.shape[0], p.shape[1],
+                                                          hip.ptr_view(G), ldg, hip.ptr_view(X), ldx, R, float(group["lr"]), float(b1), float(b2),
+                                                          float(group["eps"]), float(group["weight_decay"]), st["step"], hip.stream_ptr()),
+                              "shasta_adam_lowrank_f32")
+                    torch.autograd.graph.increment_version(p)
+                    continue
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 hip.check(lib.shasta_adam_step_f32(hip.ptr(p), hip.ptr(g), hip.ptr(st["exp_avg"]), hip.ptr(st["exp_avg_sq"]), p.numel(),
                                                    float(group["lr"]), float(b1), float(b2), float(group["eps"]),

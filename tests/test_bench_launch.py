@@ -63,3 +63,15 @@ def test_a_dead_rank_ends_the_launch_instead_of_hanging_it():
     assert r.returncode == 7, (r.returncode, r.stderr[-1000:])
     assert "rank 1 exited with code 7" in r.stderr and not _json_lines(r.stdout)
     assert time.monotonic() - t0 < 120
+
+
+def test_the_slowest_of_eight_ranks_sets_the_time():
+    """bench.py's timed region is the MAX over ranks: with rank 5 of 8 deliberately half a second slower (test hook of --dry-run) the
+    line reports that rank's time, not rank 0's own."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=dict(_env(), SHASTA_BENCH_DRY_SLOW_RANK="5"), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8
+    assert lines[0]["elapsed_max_over_ranks_s"] >= 0.5 > lines[0]["elapsed_rank0_s"]
+    assert abs(lines[0]["ms_per_step"] - lines[0]["elapsed_max_over_ranks_s"] / 4 * 1e3) < 1e-6

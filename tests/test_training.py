@@ -387,3 +387,75 @@ def test_lowrank_outer_and_smallm_nn(R, H, K):
         assert float((Y[:, :K].double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
         assert torch.equal(Y[:, K:], y0[:, K:])  # padding columns untouched
         Y.copy_(y0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [1, 3, 8, 16, 17, 40, 64])
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_fused_adam_from_gradient_factors_matches_torch_adam(R, wd):
+    """shasta_adam_lowrank_f32: Adam for a matrix whose gradient is G^T X, formed inside the pass (24 instead of 36 bytes per parameter) -
+    against torch.optim.Adam fed the materialised product, strided factors, OneCycleLR cycling lr and betas."""
+    from shasta_amd.training import FusedAdam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(R)
+    H, K = 37, 1032
+    pa = torch.nn.Parameter(torch.randn(H, K, device=dev))
+    pb = torch.nn.Parameter(pa.detach().clone())
+    oa = FusedAdam([pa], lr=3e-3, weight_decay=wd)
+    ob = torch.optim.Adam([pb], lr=3e-3, weight_decay=wd)
+    sa = torch.optim.lr_scheduler.OneCycleLR(oa, max_lr=1e-2, total_steps=8)
+    sb = torch.optim.lr_scheduler.OneCycleLR(ob, max_lr=1e-2, total_steps=8)
+    for it in range(6):
+        G = torch.randn(R, 4 * H + 3, device=dev) * (0.1 + it)  # the layer's slice of a wider factor: ldg > H
+        X = torch.randn(R, K + 8, device=dev)                   # ldx > K
+        pa._shasta_grad_factors = (G[:, H:], 4 * H + 3, X, K + 8, R)
+        pa.grad = None
+        pb.grad = (G[:, H:2 * H].double().t() @ X[:, :K].double()).float()
+        oa.step()
+        ob.step()
+        sa.step()
+        sb.step()
+        assert not hasattr(pa, "_shasta_grad_factors")  # consumed by the step
+    assert float((pa - pb).abs().max()) <= 5e-6 * max(1.0, float(pb.abs().max()))
+    assert int(oa.state[pa]["step"]) == 6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", [False, True])
+def test_train_steps_with_adam_from_the_factors_equal_the_dense_steps(exchange):
+    """FusedAdam(..., lowrank_first_layers=model): the backward hands the factors of the four aug_shape first-layer gradients to the
+    optimizer instead of forming 4 x (N F / 64, N F) gradients; three steps give the parameters of the dense path (local factors, and
+    the gathered factors of the data-parallel exchange on a one-rank RCCL group), weight decay and all."""
+    import copy
+    import torch.distributed as dist
+    from shasta_amd import training
+    from tests.test_training_ddp import _free_port
+    c, model, w, a, b, det, prev, gt = _case(12, 7, 4, 3, seed=21)
+    dev = torch.device("cuda:0")
+    dense = model.to(dev).train()
+    lowrank = copy.deepcopy(dense)
+    ad, bd, gtd = a.to(dev), b.to(dev), gt.to(dev)
+    detd, prevd = det.to(dev).contiguous(), prev.to(dev).contiguous()
+    opts = [training.FusedAdam(dense.parameters(), lr=1e-3, weight_decay=0.01),
+            training.FusedAdam(lowrank.parameters(), lr=1e-3, weight_decay=0.01, lowrank_first_layers=lowrank)]
+    assert lowrank.lowrank_adam and not getattr(dense, "lowrank_adam", False)
+    if exchange:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    try:
+        for m, opt in zip((dense, lowrank), opts):
+            m._force_factor_exchange = exchange
+            for _ in range(3):
+                opt.zero_grad()
+                m1, m2 = training.affinity_train(m, ad, bd, detd.clone(), prevd)
+                training.affinity_loss(m1, m2, gtd).backward()
+                if m is lowrank:
+                    assert all(m.aug_shape[i][0].weight.grad is None for i in range(4))
+                training.allreduce_gradients(list(m.parameters()))
+                opt.step()
+    finally:
+        if exchange:
+            dist.destroy_process_group()
+    for (k, p), (_, q) in zip(dense.named_parameters(), lowrank.named_parameters()):
+        assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(p.abs().max())), k
+    moved = float((dense.aug_shape[0][0].weight - w["aug_shape.0.0.weight"].to(dev)).abs().max())
+    assert moved > 1e-4  # the steps did something
