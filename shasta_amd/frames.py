@@ -230,15 +230,20 @@ class SharedFrames:
             hit = fr[4][name] = (keep, fr[1][keep])
         return hit
 
-    def load_run(self, name, run, share_prev=False):
+    def load_run(self, name, run, share_prev=False, out=None):
         """Every frame pair of a run of consecutive frames ([(token, prev token or "")], pipeline._scene_runs) for one class, as the stacked
         batch `collate_pairs([load(name, t) for t in run])` gives (same fp32 rows, same class dicts), without building each frame twice
         (as current frame and as the next one's previous frame): the rows of a (frame, class) are assembled once and written straight into
         the (n, max_obj, 11) fp32 stacks.  share_prev: the previous frame's class dicts are the cached ones, NOT fresh copies - for a
         consumer that copies before it writes (decode.decode_frame_from_flags(copy_fn=True)); the current frame's dicts are always fresh.
-        Returns None when a frame holds more than max_obj detections of the class (random sub-sampling: use `load`)."""
+        out: (det, prev) arrays to fill instead of fresh ones.  Returns None when a frame holds more than max_obj detections of the class (random sub-sampling: use `load`)."""
         N, n = self.max_objects[name], len(run)
-        det, prev = np.zeros((n, N, 11), np.float32), np.zeros((n, N, 11), np.float32)
+        if out is None:
+            det, prev = np.zeros((n, N, 11), np.float32), np.zeros((n, N, 11), np.float32)
+        else:  # the caller's (n, N, 11) fp32 arrays (pinned staging memory of the chain): filled in place
+            det, prev = out
+            det[...] = 0.0
+            prev[...] = 0.0
         out = dict(det_boxes=det, prev_det_boxes=prev, num_det_boxes=[], num_prev_det_boxes=[], cls_det_boxes=[], prev_cls_det_boxes=[],
                    metadata=[], prev_metadata=[])
         for i, (token, prev_token) in enumerate(run):

@@ -309,7 +309,9 @@ class Shasta(BaseTrack):
         Range guard (inference): the same pass records every row's max|w| / mean|w|; when the largest of them exceeds
         hip.F16X2_MAX_ROW_RATIO (a row that one fp16 scale cannot represent to fp32 accuracy, include/shasta_hip.h) the weight stream of
         THIS weight set falls back to the exact bf16-piece form.  `self.f16x2_guard` says what was measured and decided."""
-        wkey = tuple((self.aug_shape[i][0].weight.data_ptr(), self.aug_shape[i][0].weight._version) for i in range(4))
+        plist = getattr(self, "_plist", None)  # (_weights() keeps the parameter objects: nn.Module attribute look-ups cost 10 us each)
+        first = [plist[4 * i] for i in range(4)] if plist else [self.aug_shape[i][0].weight for i in range(4)]
+        wkey = tuple((p.data_ptr(), p._version) for p in first)
         fp16_bits = hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_PRECUT_WEIGHT_STREAM
         if self._guard_key is not None and self._guard_key != wkey:  # other weights: decide again (w is a fresh copy with all its bits)
             self._guard_key = None
