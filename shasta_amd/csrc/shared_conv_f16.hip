@@ -448,6 +448,283 @@ __global__ __launch_bounds__(512 / PB, PB == 1 ? 2 : 1) void shared_conv_f16_ker
     }
 }
 
+// ---- 512-pixel tiles (maps in bulk) -----------------------------------------------------------------------------------------------
+// Per chunk the kernel above reads 432 KB of operand fragments out of LDS (3 375 cycles of its 128 B / clk) for 3 456 cycles of matrix
+// work per SIMD: the two limits coincide and do not overlap perfectly - a chunk takes ~6 300 cycles.  Three quarters of those reads are
+// the weight fragments, which every wave fetches for its single 32-pixel block.  Here a wave owns TWO pixel blocks (64 pixels x 64
+// channels, four accumulators) and the workgroup of eight waves 512 consecutive pixels: a weight fragment feeds two MFMAs, 8 instead
+// of 12 ds_read_b128 per 12 MFMAs, and the weights cross from L2 into LDS once per 512 pixels.  Two waves per SIMD as before.  LDS: the
+// input tile grows to 2 x 57 KB (912 padded slots), so the weights of a chunk are no longer double-buffered whole: their 36 fragments
+// sit in ONE 36 KB region in two halves - taps 0-4 and taps 5-8 - each refilled by LDS-DMA as soon as every wave has passed it (a
+// barrier in the middle of the chunk, one at its end): half B of chunk c is requested at the top of chunk c and has the time of taps
+// 0-4 to land, half A of chunk c + 1 is requested behind the middle barrier and has taps 5-8.
+// Waits (every vector-memory operation of the loop is ours, see above): the waves that cut early (w < 4, the SIMD partners of the late
+// ones) issue their 32 loads of chunk c + 2 between the two DMA batches of a trip - middle: everything but those loads, end:
+// everything; the late waves issue them behind both - middle: everything, end: everything but the loads.
+constexpr int W2_TILE = 512;
+constexpr int W2_NSLOT = 912;                  // padded pixel slots incl. the 8 trash slots (W = 187: 900 + 8)
+constexpr int W2_PLANE = W2_NSLOT * 16;
+constexpr int W2_INBUF = 4 * W2_PLANE;         // [piece 2][octet 2] planes
+constexpr int W2_LDS = C16_WBUF + 2 * W2_INBUF;  // 153 600 bytes
+constexpr int W2_NIT = 4;                      // staged (64-pixel block, octet) items per lane and chunk: up to 32 blocks over 8 waves
+constexpr int W2_HALF = 20;                    // fragments of taps 0-4
+
+__global__ __launch_bounds__(512, 2) void shared_conv_f16w_kernel(Conv16Args a) {
+    constexpr int NW = 8, PB = 2, NIT = W2_NIT;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xl = blockIdx.x & 7, bslot = blockIdx.x >> 3;
+    const int head = bslot % a.heads, tl = bslot / a.heads;
+    const int t = xl * a.tiles_per_xcd + tl;
+    if (t >= a.ntiles) return;
+    const int z = t / a.tiles_per_map, tile = t - z * a.tiles_per_map;
+    const bool second = z >= a.B;
+    const int b = second ? z - a.B : z;
+    const int W = a.W, WT = W + 2, npix = a.H * W, Cin = a.Cin;
+    const float* xin = (second ? a.x[1] : a.x[0]) + (size_t)b * Cin * npix;
+    float* out = (second ? a.out[1][head] : a.out[0][head]) + (size_t)b * npix * 64;
+    const char* wsrc = a.packed + (size_t)head * a.head_stride;
+    const int eimg = range_exponent_bits(a.xmax[z]);
+    const int p0 = tile * W2_TILE;
+    const int y0 = p0 / W, x0 = p0 - y0 * W;
+    const int first = (y0 - 1) * WT + x0;  // padded index (y * WT + x + 1) of pixel (y0 - 1, x0 - 1) = slot 0
+    char* const in_lds = lds + C16_WBUF;
+    {   // zero both input buffers once: padding slots and rows outside the image are never written afterwards
+        const w32x4 zz = {0u, 0u, 0u, 0u};
+        for (int i = tid; i < 2 * W2_INBUF / 16; i += 64 * NW) reinterpret_cast<w32x4*>(in_lds)[i] = zz;
+    }
+    // staging roles of this lane (as above): block 8 i + w of the 64-pixel blocks (first all of octet 0, then those of octet 1) is item i of wave w
+    const int p_last = min(p0 + W2_TILE, npix) - 1;
+    const int qs = p0 - W - 1, qe = p_last + W + 1;
+    const int nblk = (qe - qs + 64) >> 6;  // (the host guarantees 2 nblk <= 32)
+    int st_addr[NIT];
+    unsigned ld_off[NIT];
+    bool item_live[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int blk = it * NW + wv;
+        const int oct = blk >= nblk ? 1 : 0;
+        const int q = qs + 64 * (blk - oct * nblk) + lane;
+        item_live[it] = blk < 2 * nblk;
+        const bool ok = item_live[it] && q >= 0 && q < npix && q <= qe;
+        const int yy = ok ? q / W : 0, xx = q - yy * W;
+        const int sl = yy * WT + xx + 1 - first;
+        st_addr[it] = (min(oct, 1) * W2_PLANE) + ((ok && sl >= 0 && sl < W2_NSLOT - 8) ? sl : W2_NSLOT - 8 + (lane & 7)) * 16;
+        ld_off[it] = 4u * (unsigned)(oct * 8 * npix + (ok ? q : 0));
+    }
+    const float scale = __builtin_ldexpf(1.0f, eimg);
+    const c16f2 scale2 = {scale, scale};
+    float r[NIT][8];
+    auto load_chunk = [&](int ch) __attribute__((always_inline)) {
+        const char* xc = reinterpret_cast<const char*>(xin + (size_t)ch * 16 * npix);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const char* xj = uniform_ptr(xc + (size_t)j * npix * 4);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) asm volatile("global_load_dword %0, %1, %2" : "=v"(r[it][j]) : "v"(ld_off[it]), "s"(xj) : "memory");
+        }
+    };
+    auto wait_tile = [&](auto left) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[0][3]), "+v"(r[0][4]), "+v"(r[0][5]), "+v"(r[0][6]), "+v"(r[0][7])
+                     : "n"(decltype(left)::value));
+#pragma unroll
+        for (int it = 1; it < NIT; ++it)
+            asm volatile("" : "+v"(r[it][0]), "+v"(r[it][1]), "+v"(r[it][2]), "+v"(r[it][3]), "+v"(r[it][4]), "+v"(r[it][5]), "+v"(r[it][6]), "+v"(r[it][7]));
+    };
+    const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds);
+    const uint32_t dma_off = (uint32_t)(lane * 16);
+    // fragments first .. first + count - 1 of chunk ch (its 36 fragments lie in the packed buffer as in LDS): wave w copies first + w, + 8, ...
+    auto dma_frags = [&](int ch, auto firstc, auto countc) __attribute__((always_inline)) {
+        constexpr int F0 = decltype(firstc)::value, CNT = decltype(countc)::value;
+        const char* src = wsrc + (size_t)ch * C16_WBUF + (F0 + wv) * 1024;
+        const uint32_t dst0 = lds0 + (uint32_t)((F0 + wv) * 1024);
+        const uint32_t off = dma_off;
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) {
+            const char* base = uniform_ptr(src + j * (NW * 1024));
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)(j * (NW * 1024)));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory", "m0");
+        }
+    };
+    auto cut_store = [&](auto bufc) __attribute__((always_inline)) {
+        constexpr int IB = C16_WBUF + decltype(bufc)::value * W2_INBUF;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (!item_live[it]) continue;  // wave-uniform
+            w32x4 hi, lo;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const c16f2 sv = c16f2{r[it][2 * jj], r[it][2 * jj + 1]} * scale2;
+                const uint32_t hp = pack2h((_Float16)sv[0], (_Float16)sv[1]);
+                hi[jj] = hp;
+                lo[jj] = pack2h((_Float16)c16_res_lo(sv[0], hp), (_Float16)c16_res_hi(sv[1], hp));
+            }
+            *reinterpret_cast<w32x4*>(lds + IB + st_addr[it]) = hi;
+            *reinterpret_cast<w32x4*>(lds + IB + 2 * W2_PLANE + st_addr[it]) = lo;
+        }
+    };
+    // operand addresses of this lane: pixel block pb of this wave = pixels 64 w + 32 pb + (lane & 31)
+    const int li = lane & 31, h = lane >> 5;
+    int a_row[PB][3];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        const int p = min(p0 + 32 * (PB * wv + pb) + li, npix - 1);
+        const int py = p / W, px = p - py * W;
+        const int sc = py * WT + px + 1 - first;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) a_row[pb][dy] = h * W2_PLANE + (sc + (dy - 1) * WT - 1) * 16;
+    }
+    const int b_lane = lane * 16;
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc[PB][2];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) acc[pb][0] = acc[pb][1] = zero16;
+    struct Frag {
+        h16x8 ah[PB], al[PB], b0h, b0l, b1h, b1l;
+    };
+    auto read_tap = [&](auto bufc, int tap, Frag& f) __attribute__((always_inline)) {
+        const char* ib = in_lds + decltype(bufc)::value * W2_INBUF;
+        const char* wb = lds + b_lane;
+        const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            f.ah[pb] = *reinterpret_cast<const h16x8*>(ib + a_row[pb][dy] + dx * 16);
+            f.al[pb] = *reinterpret_cast<const h16x8*>(ib + a_row[pb][dy] + dx * 16 + 2 * W2_PLANE);
+        }
+        f.b0h = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 0) * 1024);
+        f.b0l = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 1) * 1024);
+        f.b1h = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 2) * 1024);
+        f.b1l = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 3) * 1024);
+    };
+    auto mma_tap = [&](const Frag& f) __attribute__((always_inline)) {  // piece products, small to large
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            acc[pb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[pb], f.b0h, acc[pb][0], 0, 0, 0);
+            acc[pb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[pb], f.b1h, acc[pb][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            acc[pb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[pb], f.b0l, acc[pb][0], 0, 0, 0);
+            acc[pb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[pb], f.b1l, acc[pb][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            acc[pb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[pb], f.b0h, acc[pb][0], 0, 0, 0);
+            acc[pb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[pb], f.b1h, acc[pb][1], 0, 0, 0);
+        }
+    };
+    const int nchunk = Cin / 16;
+    constexpr int NLD = 8 * NIT;
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using I0 = std::integral_constant<int, 0>;
+    const bool early = wv < 4;  // three fragments of half A and the early cut; the SIMD partner w + 4: two and the late cut
+    // prologue: all 36 fragments of chunk 0, tile 0 cut into buffer 0, the raw tile of chunk 1 in registers; everything has landed (see
+    // the note at this point of the kernel above)
+    if (early) dma_frags(0, I0{}, std::integral_constant<int, 3>{});
+    else dma_frags(0, I0{}, std::integral_constant<int, 2>{});
+    dma_frags(0, std::integral_constant<int, W2_HALF>{}, std::integral_constant<int, 2>{});
+    load_chunk(0);
+    __syncthreads();  // the zero fill is complete
+    wait_tile(I0{});
+    cut_store(B0{});
+    load_chunk(min(1, nchunk - 1));
+    wait_tile(I0{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // One chunk (EARLY / buffer parity compile-time).  On entry: LDS holds tile ch, ALL 36 weight fragments of chunk ch when ch == 0,
+    // otherwise half A of chunk ch (half B still chunk ch - 1's, consumed by everybody: requested now); r[] = the raw tile of ch + 1.
+    auto chunk = [&](int ch, auto bufc, auto earlyc) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(bufc)::value;
+        constexpr bool EARLY = decltype(earlyc)::value;
+        constexpr int CUT = EARLY ? 2 : 7;  // taps multiplied before this wave cuts the next tile
+        using NXT = std::integral_constant<int, CUR ^ 1>;
+        const int nxt = min(ch + 1, nchunk - 1), nx2 = min(ch + 2, nchunk - 1);
+        if (ch > 0) dma_frags(ch, std::integral_constant<int, W2_HALF>{}, std::integral_constant<int, 2>{});  // half B of this chunk
+        auto stage = [&]() __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+            wait_tile(std::integral_constant<int, EARLY ? 2 : 2>{});  // everything but the two fragments this wave requested last
+            cut_store(NXT{});
+            load_chunk(nx2);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        Frag fa, fb;
+        read_tap(bufc, 0, fa);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            Frag& cur = (tap & 1) ? fb : fa;
+            Frag& nx = (tap & 1) ? fa : fb;
+            if (tap + 1 < 9 && tap != 4) read_tap(bufc, tap + 1, nx);  // (tap 5's weights: behind the middle barrier)
+            mma_tap(cur);
+            if (tap + 1 == CUT) stage();
+            if (tap == 4) {
+                // middle: half B of this chunk has landed (this wave's share; the barrier: everybody's) and everybody is past half A,
+                // which takes chunk ch + 1's fragments
+                if (EARLY) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (EARLY) dma_frags(nxt, I0{}, std::integral_constant<int, 3>{});
+                else dma_frags(nxt, I0{}, std::integral_constant<int, 2>{});
+                read_tap(bufc, 5, nx);
+            }
+        }
+        if (EARLY) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto all_chunks = [&](auto earlyc) __attribute__((always_inline)) {
+        int ch = 0;
+#pragma unroll 1
+        for (; ch + 1 < nchunk; ch += 2) {
+            chunk(ch, B0{}, earlyc);
+            chunk(ch + 1, B1{}, earlyc);
+        }
+        if (ch < nchunk) chunk(ch, B0{}, earlyc);
+    };
+    if (early) all_chunks(std::true_type{});
+    else all_chunks(std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged-again last chunk and the last refill of half A: nothing in flight at the end
+
+    // epilogue: D[pixel][channel]: lane = channel (32 nb + li), pixel = (r & 3) + 8 (r >> 2) + 4 h of the block's 32
+    const float* par = reinterpret_cast<const float*>(wsrc + (size_t)nchunk * C16_WBUF);
+    const float back = __builtin_ldexpf(1.0f, -eimg);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        const int pblk = p0 + 32 * (PB * wv + pb);
+        if (pblk >= npix) continue;  // wave-uniform
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int chn = 32 * nb + li;
+            const float alpha = par[chn], beta2 = par[64 + chn], bias = par[128 + chn], un = par[192 + chn] * back;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int pp = pblk + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+                if (pp < npix) {
+                    const float sv = acc[pb][nb][rr] * un;
+                    const float v = (sv + bias) * alpha + beta2;
+                    out[(size_t)pp * 64 + chn] = relu_nan(v);
+                }
+            }
+        }
+    }
+}
+
+static int conv16w_slots(int H, int W) {
+    const int np = min(W2_TILE, H * W);
+    const int wraps = (W - 1 + np - 1) / W;
+    return np + 2 * (W + 2) + 2 + 2 * wraps;
+}
+// the 512-pixel form serves a launch when the map fits its staging and there is enough work to fill the chip with its (half as many) tiles
+static bool conv16w_serves(int H, int W, int nmaps, int heads) {
+    if (conv16w_slots(H, W) > W2_NSLOT - 8) return false;
+    if (2 * ((min(W2_TILE, H * W) + 2 * W + 2 + 63) / 64) > 8 * W2_NIT) return false;
+    return (long)cdiv(H * W, W2_TILE) * nmaps * heads >= 512;
+}
+
 // slots one staged tile needs at this map width (see the kernel: np + 2 WT + 2 + 2 x row wraps)
 static int conv16_slots(int H, int W) {
     const int np = min(C16_TILE, H * W);
@@ -532,6 +809,18 @@ extern "C" int shasta_shared_conv_multi_f32(const float* x, const float* x_prev,
     a.H = H;
     a.W = W;
     a.heads = heads;
+#ifndef C16_NO_WIDE
+    if (conv16w_serves(H, W, nmaps, heads)) {
+        a.tiles_per_map = cdiv(H * W, W2_TILE);
+        a.ntiles = a.tiles_per_map * nmaps;
+        a.tiles_per_xcd = cdiv(a.ntiles, 8);
+        if (hipFuncSetAttribute((const void*)shared_conv_f16w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS) == hipSuccess) {
+            hipLaunchKernelGGL(shared_conv_f16w_kernel, dim3(8 * a.tiles_per_xcd * heads), dim3(512), W2_LDS, st, a);
+            return check_launch("shared_conv_f16w");
+        }
+        (void)hipGetLastError();  // a device that grants less LDS: the 256-pixel form below
+    }
+#endif
     a.tiles_per_map = cdiv(H * W, C16_TILE);
     a.ntiles = a.tiles_per_map * nmaps;
     a.tiles_per_xcd = cdiv(a.ntiles, 8);

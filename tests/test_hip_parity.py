@@ -321,11 +321,13 @@ def _conv_models(n, cin, seed0=20):
     return ms
 
 
-@pytest.mark.parametrize("heads,B,cin,H,W", [(7, 1, 64, 40, 180), (3, 2, 24, 9, 37), (8, 1, 16, 5, 7), (2, 1, 512, 180, 180)])
+@pytest.mark.parametrize("heads,B,cin,H,W", [(7, 1, 64, 40, 180), (3, 2, 24, 9, 37), (8, 1, 16, 5, 7), (2, 1, 512, 180, 180),
+                                             (7, 3, 32, 90, 180), (4, 2, 512, 180, 180), (8, 5, 16, 61, 183), (6, 24, 16, 23, 30)])
 def test_shared_conv_bank_equals_the_single_heads_and_the_oracle(heads, B, cin, H, W):
     """shasta_shared_conv_multi_f32: the class heads of tools/nusc_shasta/eval.py:86-101 in one launch.  Every head's output is
-    bit-identical to that model's own shared_conv_nhwc (same kernel, heads = 1) and within the K0 tolerance of the oracle; the
-    packed images follow a change of a head's tensors."""
+    bit-identical to that model's own shared_conv_nhwc (heads = 1) and within the K0 tolerance of the oracle; the packed images follow a
+    change of a head's tensors.  The last four cases are large enough (>= 512 tiles x maps x heads) for the 512-pixel-tile kernel
+    (shared_conv_f16w_kernel) while the single-head calls take the 256-pixel one: the two forms give the same bits."""
     from shasta_amd.shared_conv import SharedConvBank
     dev = _dev()
     ms = _conv_models(heads, cin)
