@@ -141,6 +141,11 @@ int shasta_shared_conv_pack_f16x2(const float* weight, const float* bias, const 
                                   float bn_eps, int in_channels, void* packed, size_t packed_bytes,
                                   shasta_stream_t stream);
 size_t shasta_shared_conv_multi_workspace_bytes(int B);
+/* The workspace that lets a call of this shape (B frame pairs - two_maps != 0 - or B single maps, `heads` class heads) take its fastest
+ * form: from three heads over enough maps on, the input is cut ONCE into an fp16 piece image (68 MB per 512 x 180 x 180 map, behind the
+ * image maxima) that every head's workgroups fetch by LDS-DMA.  A call given less (at least shasta_shared_conv_multi_workspace_bytes(B))
+ * cuts the input tile per workgroup; same results bit for bit. */
+size_t shasta_shared_conv_multi_workspace_bytes_for(int B, int in_channels, int H, int W, int heads, int two_maps);
 int shasta_shared_conv_multi_f32(const float* x, const float* x_prev, int B, int in_channels, int H, int W,
                                  const void* packed, size_t head_stride_bytes, int heads, float* const* h_out,
                                  float* const* h_out_prev, void* workspace, size_t workspace_bytes,

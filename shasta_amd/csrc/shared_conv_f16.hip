@@ -599,6 +599,10 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16w_kernel(Conv16Args a) 
         f.b1l = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 3) * 1024);
     };
     auto mma_tap = [&](const Frag& f) __attribute__((always_inline)) {  // piece products, small to large
+#ifdef W2_ABL_NO_MFMA
+        asm volatile("" ::"v"(f.ah[0]), "v"(f.al[0]), "v"(f.ah[1]), "v"(f.al[1]), "v"(f.b0h), "v"(f.b0l), "v"(f.b1h), "v"(f.b1l));
+        return;
+#endif
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
             acc[pb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[pb], f.b0h, acc[pb][0], 0, 0, 0);
@@ -645,9 +649,13 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16w_kernel(Conv16Args a) 
         if (ch > 0) dma_frags(ch, std::integral_constant<int, W2_HALF>{}, std::integral_constant<int, 2>{});  // half B of this chunk
         auto stage = [&]() __attribute__((always_inline)) {
             __builtin_amdgcn_sched_barrier(0);
-            wait_tile(std::integral_constant<int, EARLY ? 2 : 2>{});  // everything but the two fragments this wave requested last
+            wait_tile(std::integral_constant<int, 2>{});  // everything but the two fragments this wave requested last
+#ifndef W2_ABL_NO_CUT   // ablation builds (tools/build_variant.py; results are wrong)
             cut_store(NXT{});
+#endif
+#ifndef W2_ABL_NO_LOAD
             load_chunk(nx2);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         Frag fa, fb;
@@ -713,6 +721,239 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16w_kernel(Conv16Args a) 
     }
 }
 
+// ---- the input cut once for all heads (maps in bulk, several class heads) ----------------------------------------------------------
+// Ablation builds of the kernel above (W2_ABL_*, 8 frame pairs, one head): 0.89 ms with everything, 0.67 ms without its staging (loads,
+// cut, LDS stores: the vector work that competes with the SIMD partner's matrix instructions), and the seven class heads of
+// tools/nusc_shasta/eval.py:86-101 each cut the SAME input tile again.  Here a bandwidth-bound pre-pass (conv16_precut_kernel) cuts every
+// map once into the fp16 piece image of ALL its tiles - [chunk][piece][octet][padded pixel slot][8 fp16], slots numbered as in the image
+// with one zero column either side and one zero row above and below, i.e. exactly the numbering of the staged tiles - and a tile of any
+// workgroup is a CONTIGUOUS window of that image: the matrix kernel (shared_conv_f16p_kernel) fetches it by LDS-DMA and holds nothing
+// but DMA, ds_read and MFMA in its loop (no staging registers: 218 -> ~150 VGPRs).  Costs one write and one read of the map's worth of
+// bytes extra (0.4 ms at 8 frame pairs): taken from three heads per launch on; 68 MB of workspace per map.
+constexpr int P3_NSLOT = 896;                  // slots of a staged tile: 14 LDS-DMA instructions of 1 KB per plane (W <= 185)
+constexpr int P3_PLANE = P3_NSLOT * 16;
+constexpr int P3_INBUF = 4 * P3_PLANE;         // [piece 2][octet 2] planes
+constexpr int P3_LDS = C16_WBUF + 2 * P3_INBUF;  // 151 552 bytes
+// slots of one plane of a map's piece image: the padded image and a zero tail as long as a tile window
+static inline long conv16p_plane_slots(int H, int W) { return ((long)(H + 2) * (W + 2) + P3_NSLOT + 63) / 64 * 64; }
+
+// grid (ceil(plane slots / 256), 2 chunks-octets ..., maps): thread = (padded slot, octet) of one chunk
+__global__ __launch_bounds__(256) void conv16_precut_kernel(const float* __restrict__ xa, const float* __restrict__ xb, int B, int Cin, int H, int W,
+                                                            const unsigned* __restrict__ xmax, w32x4* __restrict__ img, long plane_slots) {
+    const int z = blockIdx.z, co = blockIdx.y, ch = co >> 1, oct = co & 1;
+    const long s = (long)blockIdx.x * 256 + threadIdx.x;
+    if (s >= plane_slots) return;
+    const int WT = W + 2, npix = H * W;
+    const long row = s / WT;
+    const int xp = (int)(s - row * WT);
+    const bool real = row >= 1 && row <= H && xp >= 1 && xp <= W;
+    w32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+    if (real) {
+        const float* x = (z >= B ? xb + (size_t)(z - B) * Cin * npix : xa + (size_t)z * Cin * npix) + (size_t)(16 * ch + 8 * oct) * npix + (row - 1) * W + (xp - 1);
+        const float scale = __builtin_ldexpf(1.0f, range_exponent_bits(xmax[z]));
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const float v0 = x[(size_t)(2 * jj) * npix] * scale, v1 = x[(size_t)(2 * jj + 1) * npix] * scale;
+            const uint32_t hp = pack2h((_Float16)v0, (_Float16)v1);
+            hi[jj] = hp;
+            lo[jj] = pack2h((_Float16)c16_res_lo(v0, hp), (_Float16)c16_res_hi(v1, hp));
+        }
+    }
+    w32x4* o = img + (((size_t)z * (Cin / 16) + ch) * 4 + oct) * plane_slots + s;
+    o[0] = hi;
+    o[2 * plane_slots] = lo;
+}
+
+struct Conv16pArgs {
+    Conv16Args c;
+    const char* img;   // [map][chunk][piece 2][octet 2][plane slots][16 B]
+    long plane_slots;
+};
+
+__global__ __launch_bounds__(512, 2) void shared_conv_f16p_kernel(Conv16pArgs pa) {
+    constexpr int NW = 8, PB = 2;
+    const Conv16Args& a = pa.c;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xl = blockIdx.x & 7, bslot = blockIdx.x >> 3;
+    const int head = bslot % a.heads, tl = bslot / a.heads;
+    const int t = xl * a.tiles_per_xcd + tl;
+    if (t >= a.ntiles) return;
+    const int z = t / a.tiles_per_map, tile = t - z * a.tiles_per_map;
+    const bool second = z >= a.B;
+    const int b = second ? z - a.B : z;
+    const int W = a.W, WT = W + 2, npix = a.H * W, Cin = a.Cin;
+    float* out = (second ? a.out[1][head] : a.out[0][head]) + (size_t)b * npix * 64;
+    const char* wsrc = a.packed + (size_t)head * a.head_stride;
+    const int eimg = range_exponent_bits(a.xmax[z]);
+    const int p0 = tile * W2_TILE;
+    const int y0 = p0 / W, x0 = p0 - y0 * W;
+    const long gidx0 = (long)y0 * WT + x0;  // image slot of tile slot 0 = pixel (y0 - 1, x0 - 1): (row y0 - 1 + 1) * WT + (x0 - 1 + 1)
+    char* const in_lds = lds + C16_WBUF;
+    const int nchunk = Cin / 16;
+    const char* tsrc = pa.img + ((size_t)z * nchunk * 4 * pa.plane_slots + (size_t)gidx0) * 16;  // plane (chunk 0, piece 0, octet 0), slot gidx0
+    const size_t plane_bytes = (size_t)pa.plane_slots * 16;
+
+    const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds);
+    const uint32_t dma_off = (uint32_t)(lane * 16);
+    auto dma_frags = [&](int ch, auto firstc, auto countc) __attribute__((always_inline)) {
+        constexpr int F0 = decltype(firstc)::value, CNT = decltype(countc)::value;
+        const char* src = wsrc + (size_t)ch * C16_WBUF + (F0 + wv) * 1024;
+        const uint32_t dst0 = lds0 + (uint32_t)((F0 + wv) * 1024);
+        const uint32_t off = dma_off;
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) {
+            const char* base = uniform_ptr(src + j * (NW * 1024));
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)(j * (NW * 1024)));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory", "m0");
+        }
+    };
+    // the tile of chunk ch into input buffer `buf`: 4 planes x 14 KB = 56 instructions of 1 KB, seven per wave (instruction 8 j + w)
+    auto dma_tile = [&](int ch, int buf) __attribute__((always_inline)) {
+        const uint32_t off = dma_off;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int i = 8 * j + wv, pl = i / 14, k = i - pl * 14;  // plane (piece * 2 + octet), KB within it
+            const char* base = uniform_ptr(tsrc + ((size_t)ch * 4 + pl) * plane_bytes + (size_t)k * 1024);
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(C16_WBUF + buf * P3_INBUF + pl * P3_PLANE + k * 1024));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory", "m0");
+        }
+    };
+    const int li = lane & 31, h = lane >> 5;
+    int a_row[PB][3];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        const int p = min(p0 + 32 * (PB * wv + pb) + li, npix - 1);
+        const int py = p / W, px = p - py * W;
+        const int sc = (int)((long)(py + 1) * WT + px + 1 - gidx0);  // tile slot of the pixel itself
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) a_row[pb][dy] = h * P3_PLANE + (sc + (dy - 1) * WT - 1) * 16;
+    }
+    const int b_lane = lane * 16;
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc[PB][2];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) acc[pb][0] = acc[pb][1] = zero16;
+    struct Frag {
+        h16x8 ah[PB], al[PB], b0h, b0l, b1h, b1l;
+    };
+    auto read_tap = [&](auto bufc, int tap, Frag& f) __attribute__((always_inline)) {
+        const char* ib = in_lds + decltype(bufc)::value * P3_INBUF;
+        const char* wb = lds + b_lane;
+        const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            f.ah[pb] = *reinterpret_cast<const h16x8*>(ib + a_row[pb][dy] + dx * 16);
+            f.al[pb] = *reinterpret_cast<const h16x8*>(ib + a_row[pb][dy] + dx * 16 + 2 * P3_PLANE);
+        }
+        f.b0h = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 0) * 1024);
+        f.b0l = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 1) * 1024);
+        f.b1h = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 2) * 1024);
+        f.b1l = *reinterpret_cast<const h16x8*>(wb + (tap * 4 + 3) * 1024);
+    };
+    auto mma_tap = [&](const Frag& f) __attribute__((always_inline)) {  // piece products, small to large
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            acc[pb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[pb], f.b0h, acc[pb][0], 0, 0, 0);
+            acc[pb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[pb], f.b1h, acc[pb][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            acc[pb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[pb], f.b0l, acc[pb][0], 0, 0, 0);
+            acc[pb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[pb], f.b1l, acc[pb][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            acc[pb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[pb], f.b0h, acc[pb][0], 0, 0, 0);
+            acc[pb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[pb], f.b1h, acc[pb][1], 0, 0, 0);
+        }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using I0 = std::integral_constant<int, 0>;
+    const bool three = wv < 4;  // three fragments of half A (the others two)
+    // prologue: all 36 fragments and the tile of chunk 0
+    if (three) dma_frags(0, I0{}, std::integral_constant<int, 3>{});
+    else dma_frags(0, I0{}, std::integral_constant<int, 2>{});
+    dma_frags(0, std::integral_constant<int, W2_HALF>{}, std::integral_constant<int, 2>{});
+    dma_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // One chunk.  Top: half B of this chunk (2) and the next chunk's tile (7) are requested; middle: half B has landed (the 7 tile
+    // requests are younger), barrier, half A of the next chunk is requested; end: everything has landed, barrier.
+    auto chunk = [&](int ch, auto bufc, auto threec) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(bufc)::value;
+        const int nxt = min(ch + 1, nchunk - 1);
+        if (ch > 0) dma_frags(ch, std::integral_constant<int, W2_HALF>{}, std::integral_constant<int, 2>{});
+        dma_tile(nxt, CUR ^ 1);
+        Frag fa, fb;
+        read_tap(bufc, 0, fa);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            Frag& cur = (tap & 1) ? fb : fa;
+            Frag& nx = (tap & 1) ? fa : fb;
+            if (tap + 1 < 9 && tap != 4) read_tap(bufc, tap + 1, nx);
+            mma_tap(cur);
+            if (tap == 4) {
+                asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                dma_frags(nxt, I0{}, threec);
+                read_tap(bufc, 5, nx);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto all_chunks = [&](auto threec) __attribute__((always_inline)) {
+        int ch = 0;
+#pragma unroll 1
+        for (; ch + 1 < nchunk; ch += 2) {
+            chunk(ch, B0{}, threec);
+            chunk(ch + 1, B1{}, threec);
+        }
+        if (ch < nchunk) chunk(ch, B0{}, threec);
+    };
+    if (three) all_chunks(std::integral_constant<int, 3>{});
+    else all_chunks(std::integral_constant<int, 2>{});
+
+    // epilogue: D[pixel][channel]: lane = channel (32 nb + li), pixel = (r & 3) + 8 (r >> 2) + 4 h of the block's 32
+    const float* par = reinterpret_cast<const float*>(wsrc + (size_t)nchunk * C16_WBUF);
+    const float back = __builtin_ldexpf(1.0f, -eimg);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        const int pblk = p0 + 32 * (PB * wv + pb);
+        if (pblk >= npix) continue;  // wave-uniform
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int chn = 32 * nb + li;
+            const float alpha = par[chn], beta2 = par[64 + chn], bias = par[128 + chn], un = par[192 + chn] * back;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int pp = pblk + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+                if (pp < npix) {
+                    const float sv = acc[pb][nb][rr] * un;
+                    const float v = (sv + bias) * alpha + beta2;
+                    out[(size_t)pp * 64 + chn] = relu_nan(v);
+                }
+            }
+        }
+    }
+}
+
+// the pre-cut form serves a launch of at least three heads whose maps fit its tile window
+static bool conv16p_serves(int H, int W, int nmaps, int heads) {
+    const int np = min(W2_TILE, H * W);
+    const int wraps = (W - 1 + np - 1) / W;
+    if (np + 2 * (W + 2) + 2 + 2 * wraps > P3_NSLOT) return false;
+    return heads >= 3 && (long)cdiv(H * W, W2_TILE) * nmaps * heads >= 512;
+}
+static size_t conv16p_image_bytes(int in_channels, int H, int W, int nmaps) {
+    return (size_t)nmaps * (in_channels / 16) * 4 * (size_t)conv16p_plane_slots(H, W) * 16;
+}
+
 static int conv16w_slots(int H, int W) {
     const int np = min(W2_TILE, H * W);
     const int wraps = (W - 1 + np - 1) / W;
@@ -765,6 +1006,14 @@ extern "C" int shasta_shared_conv_pack_f16x2(const float* weight, const float* b
 
 extern "C" size_t shasta_shared_conv_multi_workspace_bytes(int B) { return B <= 0 ? 0 : align_up((size_t)2 * B * sizeof(unsigned), 256); }
 
+extern "C" size_t shasta_shared_conv_multi_workspace_bytes_for(int B, int in_channels, int H, int W, int heads, int two_maps) {
+    if (B <= 0 || in_channels <= 0 || in_channels % 16 || H <= 0 || W <= 0) return 0;
+    const int nmaps = two_maps ? 2 * B : B;
+    size_t n = shasta_shared_conv_multi_workspace_bytes(B);
+    if (conv16p_serves(H, W, nmaps, heads)) n += conv16p_image_bytes(in_channels, H, W, nmaps);
+    return n;
+}
+
 extern "C" int shasta_shared_conv_multi_f32(const float* x, const float* x_prev, int B, int in_channels, int H, int W, const void* packed,
                                             size_t head_stride_bytes, int heads, float* const* h_out, float* const* h_out_prev,
                                             void* workspace, size_t workspace_bytes, shasta_stream_t stream) {
@@ -809,6 +1058,27 @@ extern "C" int shasta_shared_conv_multi_f32(const float* x, const float* x_prev,
     a.H = H;
     a.W = W;
     a.heads = heads;
+#ifndef C16_NO_PRECUT
+    // several heads over many maps and a workspace that holds the piece image: the input is cut once for all of them
+    if (conv16p_serves(H, W, nmaps, heads) &&
+        workspace_bytes >= shasta_shared_conv_multi_workspace_bytes(B) + conv16p_image_bytes(in_channels, H, W, nmaps) &&
+        hipFuncSetAttribute((const void*)shared_conv_f16p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P3_LDS) == hipSuccess) {
+        Conv16pArgs pa;
+        pa.plane_slots = conv16p_plane_slots(H, W);
+        char* img = static_cast<char*>(workspace) + shasta_shared_conv_multi_workspace_bytes(B);
+        pa.img = img;
+        hipLaunchKernelGGL(conv16_precut_kernel, dim3((unsigned)cdiv((int)pa.plane_slots, 256), 2 * (in_channels / 16), nmaps), dim3(256), 0, st, x, x_prev, B,
+                           in_channels, H, W, xmax, reinterpret_cast<w32x4*>(img), pa.plane_slots);
+        if ((rc = check_launch("shared_conv_multi (piece image)")) != SHASTA_OK) return rc;
+        a.tiles_per_map = cdiv(H * W, W2_TILE);
+        a.ntiles = a.tiles_per_map * nmaps;
+        a.tiles_per_xcd = cdiv(a.ntiles, 8);
+        pa.c = a;
+        hipLaunchKernelGGL(shared_conv_f16p_kernel, dim3(8 * a.tiles_per_xcd * heads), dim3(512), P3_LDS, st, pa);
+        return check_launch("shared_conv_f16p");
+    }
+    (void)hipGetLastError();
+#endif
 #ifndef C16_NO_WIDE
     if (conv16w_serves(H, W, nmaps, heads)) {
         a.tiles_per_map = cdiv(H * W, W2_TILE);

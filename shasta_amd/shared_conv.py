@@ -87,14 +87,16 @@ class SharedConvBank:
         if xp is not None and xp.shape != x.shape:
             raise ValueError("bev_map and prev_bev_map must have the same shape")
         B, _, H, W = x.shape
+        nh = len(self._models)
         if not lib.shasta_shared_conv_f16x2_supported(self.cin_padded, H, W):
             raise hip.ShastaHipError("shared_conv (fp16 form): map %dx%d not served by this kernel" % (H, W))
-        nh = len(self.models)
         outs = [torch.empty(B, H, W, 64, device=dev) for _ in range(nh)]
         outs_p = None if xp is None else [torch.empty(B, H, W, 64, device=dev) for _ in range(nh)]
-        wsb = lib.shasta_shared_conv_multi_workspace_bytes(max(B, 1))
+        # (from three heads on: room for the piece image of the maps, cut once for all heads - 68 MB per 512 x 180 x 180 map)
+        wsb = lib.shasta_shared_conv_multi_workspace_bytes_for(max(B, 1), self.cin_padded, H, W, nh, int(xp is not None))
         if self._ws is None or self._ws.numel() * 4 < wsb or self._ws.device != dev:
-            self._ws = torch.empty(wsb // 4, dtype=torch.int32, device=dev)
+            self._ws = None
+            self._ws = torch.empty((wsb + 3) // 4, dtype=torch.int32, device=dev)
         arr = (C.c_void_p * nh)(*[t.data_ptr() for t in outs])
         arr_p = None if outs_p is None else (C.c_void_p * nh)(*[t.data_ptr() for t in outs_p])
         hip.check(lib.shasta_shared_conv_multi_f32(hip.ptr(x), hip.ptr(xp), B, self.cin_padded, H, W, C.c_void_p(self._packed.data_ptr()),
