@@ -324,12 +324,15 @@ def rooflines(cfg, arithmetic, r, with_traffic=True):
     l1_tflops = l1_flops / (l1_ms * 1e-3) / 1e12
     # the two-piece fp16 weight stream serves B > 64, and with the pre-cut weight image (default) every batch of at least 17
     f32_forced, f16x2 = arithmetic == "f32", arithmetic in ("f16x2", "f16grid") and (B > 64 or (PRECUT and B >= 17))
+    wide = False
     if B == 1 or (B <= 32 and not f16x2):
         passes, nprod = 1, 1
     elif f32_forced:
         passes, nprod = -(-B // 64), 1
-    elif f16x2:  # 32 / 64 / 128 items per weight pass up to 128 frame-pairs, 256 above; three fp16 piece products per fp32 product
-        passes, nprod = (1 if B <= 128 else -(-B // 256)), 3
+    elif f16x2:  # 32 / 64 / 128 items per weight pass up to 128 frame-pairs, 256 above - 512 with the pre-cut weight image when that
+        # pads the batch no more (anchor_l1_wide_kernel, anchor_split.hip: split_wide); three fp16 piece products per fp32 product
+        wide = PRECUT and B > 256 and -(-B // 512) * 512 <= -(-B // 256) * 256
+        passes, nprod = (1 if B <= 128 else -(-B // 512) if wide else -(-B // 256)), 3
     else:        # 64 / 128 items per pass; six bf16 piece products
         passes, nprod = (1 if B <= 64 else -(-B // 128)), 6
     hbm_bound = B == 1 or (B <= 32 and not f16x2) or (not f32_forced and (B <= 128 if f16x2 else B <= 64))  # <= 1024 matrix cycles per 4 KB weight tile
@@ -344,6 +347,7 @@ def rooflines(cfg, arithmetic, r, with_traffic=True):
                    "note": "executed %s MFMA flops = %d piece products per fp32 product, against the dense bf16 / f16 peak"
                            % ("f16" if f16x2 else "bf16", nprod)}
     l1_kernel = ("anchor_l1_kernel<1,8> (VALU GEMV)" if B == 1 else
+                 "anchor_l1_wide_kernel (fp16 pieces, pre-cut weight image, 512 items per pass)" if (f16x2 and B > 128 and wide) else
                  ("anchor_l1_split_kernel (fp16 pieces%s)" % (", pre-cut weight image" if PRECUT else "")) if f16x2 else
                  "anchor_l1_mfma_kernel (f32 MFMA)" if (B <= 32 or f32_forced) else "anchor_l1_split_kernel (bf16 pieces)")
     tr, src = _pmc_traffic(B, "l1", l1_kernel) if (with_traffic and headline and arithmetic == "f16x2") else (None, None)

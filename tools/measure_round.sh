@@ -42,6 +42,11 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $O/pmc_hit_b512 -o p -- python3 $R/bench.py --batch 512 --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_hit_b512.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_valu_b512 -o p -- python3 $R/bench.py --batch 512 --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_valu_b512.log 2>&1
 (cd $R && python3 tools/stage_power.py 512 2 > $O/stage_power.log 2>&1)
+# round 5: the one-pass aff kernels (phase stamps of a workgroup, both arithmetics), K0 forms (conv_check prints 1 head / 7 heads)
+if [ -x $R/tools/probes/_bin/affq128 ]; then
+  (AFF_F16=1 $R/tools/probes/_bin/affq128 1024 500 2; $R/tools/probes/_bin/affq128 1024 500 2) > $O/aff_frame_probe.log 2>&1
+fi
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_convmfma7_b8 -o p -- python3 $R/tools/conv_only.py --batch 8 --iters 4 --heads 7 > $O/pmc_convmfma7_b8.log 2>&1
 grep -h '^{' $O/bench_default.json $O/bench_b1.json $O/bench_b64.json $O/bench_b128.json $O/bench_b512.json $O/bench_pieces.json $O/bench_f32.json $O/bench_torchrun.json | cut -c1-230
 grep time $O/conv_check.jsonl | cut -c1-200; tail -1 $O/pipeline.log | cut -c1-400; grep -h "^{" $O/pair320_car.log $O/pair320_n500.log
 ls $O
