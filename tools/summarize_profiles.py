@@ -50,14 +50,15 @@ def pmc(dirs, dst):
             for r in csv.DictReader(open(path)):
                 if "shasta" not in r["Kernel_Name"]:
                     continue
-                k = (short(r["Kernel_Name"]), r["Counter_Name"])
+                # one row per (kernel, launch shape, counter): the self-check of bench.py launches the same kernels at batch 1
+                k = (short(r["Kernel_Name"]), str(r.get("Grid_Size", "")), r["Counter_Name"])
                 acc[k].append(float(r["Counter_Value"]))
                 dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-            for (k, c), v in sorted(acc.items()):
-                out.append([label, k, c, len(v), sum(v) / len(v), sum(dur[(k, c)]) / len(v)])
+            for (k, g, c), v in sorted(acc.items()):
+                out.append([label, k, g, c, len(v), sum(v) / len(v), sum(dur[(k, g, c)]) / len(v)])
     with open(dst, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["run", "kernel", "counter", "launches", "mean_value_per_launch", "mean_duration_ns"])
+        w.writerow(["run", "kernel", "grid_size", "counter", "launches", "mean_value_per_launch", "mean_duration_ns"])
         w.writerows(out)
 
 
