@@ -175,6 +175,17 @@ class AffinityDecoder:
                 self.dead_tracker[token]["keep_idx"] = keep
             self.results[token] = annos
 
+    def finalize_tokens(self, tokens):
+        """The `dead` post-pass of finalize() for some frames only (all decodes that can mark them - their own and the following
+        frame's - must be in); idempotent, finalize() may run over them again."""
+        for token in tokens:
+            annos, info = self.results.get(token), self.dead_tracker.get(token)
+            if annos is None or info is None:
+                continue
+            for i in info["dead_idx"]:
+                if i in info["keep_idx"]:
+                    annos[info["keep_idx"].index(i)]["dead"] = True
+
     def finalize(self):
         for token, annos in self.results.items():
             info = self.dead_tracker[token]

@@ -132,6 +132,36 @@ def _scenes_fit_device_tracker(results, max_dets=512):
     return all(len(v) <= max_dets for v in results.values())
 
 
+def _scene_frames(predictions, sc, merged):
+    """[(detections of the frame, time since the previous frame)] of one scene (a list of its frames' meta entries), or None when - plain
+    tracker - a frame has detections but none of a tracking class (the per-frame path then raises like the reference)."""
+    last, fr = None, []
+    for m in sc:
+        if m["first"]:
+            last = m["timestamp"]
+        dets = predictions[m["token"]]
+        if not merged and dets and not any(d["detection_name"] in NUSCENES_TRACKING_NAMES for d in dets):
+            return None
+        fr.append((dets, m["timestamp"] - last))
+        last = m["timestamp"]
+    return fr
+
+
+def _tracking_rows(results, sc, rows, merged, refine_confidence):
+    """The result rows of one scene (pub_test.py:125-140 / eval.py:263-280) from the whole-scene kernel's (dict, id, score) triples."""
+    for m, items in zip(sc, rows):
+        token = m["token"]
+        if merged:
+            results[token] = [
+                {"sample_token": token, "translation": d["translation"], "size": d["size"], "rotation": d["rotation"], "velocity": d["velocity"],
+                 "tracking_id": str(tid), "tracking_name": d["detection_name"], "tracking_score": ref} for d, tid, ref in items]
+        else:
+            results[token] = [
+                {"sample_token": token, "translation": d["translation"], "size": d["size"], "rotation": d["rotation"], "velocity": d["velocity"],
+                 "tracking_id": str(tid), "tracking_name": d["detection_name"],
+                 "tracking_score": ref if refine_confidence else d["detection_score"], "attribute_name": d["attribute_name"]} for d, tid, ref in items]
+
+
 def _track_scenes_on_device(predictions, scenes, max_age, merged=True, refine_confidence=False, alpha=0.5, beta=0.5):
     """run_tracking's fast path: the greedy tracker (merged or plain) of every scene in one launch
     (pub_tracker.track_scenes_merged_device); None when a scene exceeds the kernel's capacities or - plain tracker - a frame has
@@ -139,33 +169,71 @@ def _track_scenes_on_device(predictions, scenes, max_age, merged=True, refine_co
     from .pub_tracker import track_scenes_merged_device
     frames = []
     for sc in scenes:
-        last, fr = None, []
-        for m in sc:
-            if m["first"]:
-                last = m["timestamp"]
-            dets = predictions[m["token"]]
-            if not merged and dets and not any(d["detection_name"] in NUSCENES_TRACKING_NAMES for d in dets):
-                return None
-            fr.append((dets, m["timestamp"] - last))
-            last = m["timestamp"]
+        fr = _scene_frames(predictions, sc, merged)
+        if fr is None:
+            return None
         frames.append(fr)
     out = track_scenes_merged_device(frames, max_age=max_age, plain=not merged, refine_confidence=refine_confidence, alpha=alpha, beta=beta)
     if any(o is None for o in out):
         return None
     annos = {"results": {}, "meta": dict(META)}
     for sc, rows in zip(scenes, out):
-        for m, items in zip(sc, rows):
-            token = m["token"]
-            if merged:
-                annos["results"][token] = [
-                    {"sample_token": token, "translation": d["translation"], "size": d["size"], "rotation": d["rotation"], "velocity": d["velocity"],
-                     "tracking_id": str(tid), "tracking_name": d["detection_name"], "tracking_score": ref} for d, tid, ref in items]
-            else:
-                annos["results"][token] = [
-                    {"sample_token": token, "translation": d["translation"], "size": d["size"], "rotation": d["rotation"], "velocity": d["velocity"],
-                     "tracking_id": str(tid), "tracking_name": d["detection_name"],
-                     "tracking_score": ref if refine_confidence else d["detection_score"], "attribute_name": d["attribute_name"]} for d, tid, ref in items]
+        _tracking_rows(annos["results"], sc, rows, merged, refine_confidence)
     return annos
+
+
+class _SceneTrackers:
+    """The chain's tracker, scene by scene while the device still works on later scenes: as soon as every frame of a scene has been decoded
+    for all classes (its `dead` marks included - they come from the NEXT frame's decode, eval.py:175-181), the scene's class lists are
+    merged and its whole merged-tracker run is queued on a side stream (pub_tracker.track_scenes_launch); collect() waits for the copies
+    back and builds the rows in the order of the frames file.  None from collect(): a scene did not fit the kernel - the caller runs
+    run_tracking over the finished split instead."""
+
+    def __init__(self, meta, decs, names, max_age, device):
+        self.scenes = []
+        for fr in meta:
+            if fr["first"]:
+                self.scenes.append([])
+            self.scenes[-1].append(fr)
+        self.scene_of = {m["token"]: k for k, sc in enumerate(self.scenes) for m in sc}
+        self.left = [len(sc) for sc in self.scenes]
+        self.decs, self.names, self.max_age, self.device = decs, names, max_age, device
+        self.stream = torch.cuda.Stream(device=device)
+        self.handles = [None] * len(self.scenes)
+        self.merged = {}
+
+    def frames_done(self, tokens):
+        from .pub_tracker import track_scenes_launch
+        for t in tokens:
+            k = self.scene_of.get(t)
+            if k is None:
+                continue
+            self.left[k] -= 1
+            if self.left[k] != 0:
+                continue
+            sc = self.scenes[k]
+            toks = [m["token"] for m in sc]
+            for n in self.names:
+                self.decs[n].finalize_tokens(toks)
+            for tok in toks:  # merge_results.py:37-59 for these tokens
+                row = []
+                for n in self.names:
+                    row.extend(self.decs[n].results.get(tok, ()))
+                self.merged[tok] = row
+            if all(len(self.merged[tok]) <= 512 for tok in toks):
+                self.handles[k] = track_scenes_launch([_scene_frames(self.merged, sc, True)], max_age=self.max_age, device=self.device, stream=self.stream)
+
+    def collect(self):
+        from .pub_tracker import track_scenes_collect
+        if any(h is None for h in self.handles):
+            return None
+        annos = {"results": {}, "meta": dict(META)}
+        for sc, h in zip(self.scenes, self.handles):
+            rows = track_scenes_collect(h)[0]
+            if rows is None:
+                return None
+            _tracking_rows(annos["results"], sc, rows, True, False)
+        return annos
 
 
 def run_tracking(predictions, frames_meta, max_age=4, hungarian=False, merged=True, refine_confidence=False, alpha=0.5, beta=0.5,
@@ -309,19 +377,31 @@ def _run_split(models, paths, scenes, bev, device, work_dir=None, split="val", m
                              decode_on_device=decode_on_device, forward=forward_override[name], timer=timer)
             per_class[name] = replica.gather_decoded(dec, dst=0, group=group)
     else:
-        decs = _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, batch_pairs, decode_on_device, timer)
+        with open(paths["frames_meta_path"]) as f:
+            meta = json.load(f)["frames"]
+        # one rank on a GPU: every scene's tracker run is queued as soon as the scene is decoded, behind the next scenes' launches
+        early = []
+        hook = None
+        if world == 1 and tracker_on_device and device.type == "cuda":
+            def hook(decs_):
+                early.append(_SceneTrackers(meta, decs_, names, max_age, device))
+                return early[0].frames_done
+        decs = _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, batch_pairs, decode_on_device, timer, on_decs=hook)
         for name in names:
             per_class[name] = replica.gather_decoded(decs[name], dst=0, group=group)
     if rank != 0:
         return None
     with timer.stage("merge"):
         merged = merge_results(per_class)
-        with open(paths["frames_meta_path"]) as f:
-            meta = json.load(f)["frames"]
+        if forward_override is not None:
+            with open(paths["frames_meta_path"]) as f:
+                meta = json.load(f)["frames"]
     if tracker_on_device:
         with timer.stage("tracker"):
-            # whole scenes in one launch; `merged` stays as decoded either way (run_tracking)
-            tracking = run_tracking(merged["results"], meta, max_age=max_age, whole_scenes=True)
+            tracking = early[0].collect() if (forward_override is None and early) else None
+            if tracking is None:
+                # whole scenes in one launch (or, beyond the kernel's capacities, frame by frame); `merged` stays as decoded either way
+                tracking = run_tracking(merged["results"], meta, max_age=max_age, whole_scenes=True)
     else:
         tracking = None
     if work_dir is not None:
@@ -409,7 +489,7 @@ def _loader_run(run, share_prev=False, staging=None):
     return out
 
 
-def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, batch_pairs, decode_on_device, timer):
+def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, batch_pairs, decode_on_device, timer, on_decs=None):
     """The loader runs in line, between the launches of one run and the host half of the previous one (the device is busy with the queued
     run meanwhile).  Alternatives measured on the 20 x 40 split when this form ran at 800 - 867 frames/s (MI355X box, 256 host cores): a loader
     THREAD 526 - 632 (parsing is pure Python: the thread takes the GIL from the launches); multiprocessing pools 248 - 303 (every child
@@ -421,6 +501,7 @@ def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, ba
     _loader_init(*init)
     known = _LOADER["known"]
     decs = {n: decode.AffinityDecoder() for n in names}
+    frames_done = on_decs(decs) if on_decs is not None else None  # (the chain's scene-by-scene tracker: told which frames are decoded)
     cuda = device.type == "cuda"
     runs = list(_scene_runs(scenes, mine, known, _LOADER["frames"].frame_info, batch_pairs))
     if not runs:
@@ -464,6 +545,8 @@ def _frame_major(models, names, paths, scenes, mine, all_tokens, bev, device, ba
                 decs[n].add_batch(None, None, b, flags=decode.decode_flags_unpack(host), lags=b["_lags"], copy_fn=share)
             else:
                 decs[n].add_batch(m1, m2, b, on_device=False, lags=b["_lags"])
+        if frames_done is not None and pending:
+            frames_done([md["token"] for md in pending[0][1]["metadata"]])
 
     bank_cache = {}
     waiting = []  # runs whose launches are queued and whose decisions have not been read yet

@@ -9,6 +9,8 @@ scenes with ONE launch: the greedy loop is sequential inside a scene, so the dev
 host, fed with the device-computed matrix, like the reference."""
 import copy
 
+import contextlib
+
 import numpy as np
 import torch
 
@@ -350,19 +352,28 @@ def step_batch_merged(trackers, results_list, time_lags):
 
 
 def track_scenes_merged_device(scene_frames, max_age=0, device=None, plain=False, refine_confidence=False, alpha=0.5, beta=0.5):
+    """track_scenes_collect(track_scenes_launch(...)): see there."""
+    return track_scenes_collect(track_scenes_launch(scene_frames, max_age=max_age, device=device, plain=plain, refine_confidence=refine_confidence,
+                                                    alpha=alpha, beta=beta))
+
+
+def track_scenes_launch(scene_frames, max_age=0, device=None, plain=False, refine_confidence=False, alpha=0.5, beta=0.5, stream=None):
     """The merged tracker (PubTrackerMerged, greedy; plain=True: PubTracker with its refine_confidence / alpha / beta - one list over all
     tracking classes, result order matched detections then new ones) for whole scenes in ONE launch (csrc/track.hip `track_merged_kernel`,
     shasta_track_merged_f64): scene_frames = [[(detections of the frame: list of nuScenes-format dicts with `ref_detection_score`,
     time_lag), ...] per scene].  Returns per scene, per frame, the result rows' sources in the order pub_test.py emits them:
     a list of (detection dict, tracking_id, refined ref_detection_score) - class by class, matched detections then new ones - or None
     when a scene exceeds the kernel's capacities (512 detections per frame, 768 tracks alive): the caller then takes the per-frame path.
-    The dicts are NOT modified (the host tracker annotates them in place)."""
+    The dicts are NOT modified (the host tracker annotates them in place).
+    This half packs the inputs, queues one copy in, the kernel and one copy out on `stream` (default: the current one) and returns a handle
+    at once; track_scenes_collect(handle) waits for the copy out and builds the rows - the chain launches a scene's tracker on a side
+    stream while the device works on the next scenes' maps."""
     import ctypes as C
     lib = hip.load()
     device = device or torch.device("cuda", torch.cuda.current_device())
     S = len(scene_frames)
     if S == 0:
-        return []
+        return dict(done=[])
     label = {n: i for i, n in enumerate(NUSCENES_TRACKING_NAMES)}
     Fmax = max(1, max(len(fr) for fr in scene_frames))
     dets = [d for fr in scene_frames for (ds, _) in fr for d in ds]
@@ -379,7 +390,7 @@ def track_scenes_merged_device(scene_frames, max_age=0, device=None, plain=False
             lag[s, f] = tl
         off[s, len(fr):] = g
     if D == 0:
-        return [[[] for _ in fr] for fr in scene_frames]
+        return dict(done=[[[] for _ in fr] for fr in scene_frames])
     xy = np.array([d["translation"][:2] for d in dets], np.float64).reshape(D, 2)
     vel = np.array([d["velocity"][:2] for d in dets], np.float64).reshape(D, 2)
     cls = np.array([label.get(d["detection_name"], -1) for d in dets], np.int32)
@@ -400,29 +411,48 @@ def track_scenes_merged_device(scene_frames, max_age=0, device=None, plain=False
     h[o[6]:o[7]].view(np.int32)[:off.size] = off.ravel()
     h[o[7]:o[8]] = lag.ravel()
     h[o[8]:o[9]].view(np.int32)[:S] = nfr
-    dbuf = host.to(device, non_blocking=True)
-    seg = [dbuf[o[i]:o[i + 1]] for i in range(9)]
-    out = torch.zeros(D + (D + 1) // 2 * 2 + (S + 1) // 2, dtype=torch.float64, device=device)  # ref | status | id | err
-    o_ref, o_st = out[:D], out[D:D + (D + 1) // 2].view(torch.int32)
-    o_id, o_err = out[D + (D + 1) // 2:D + 2 * ((D + 1) // 2)].view(torch.int32), out[D + 2 * ((D + 1) // 2):].view(torch.int32)
-    names = NUSCENES_TRACKING_NAMES
-    gate = (C.c_float * len(names))(*[float(NUSCENE_CLS_VELOCITY_ERROR[n]) for n in names])
-    if plain:
-        refon = (C.c_int32 * len(names))(*([int(bool(refine_confidence))] * len(names)))
-        alpha = (C.c_double * len(names))(*([float(alpha)] * len(names)))
-        beta = (C.c_double * len(names))(*([float(beta)] * len(names)))
-    else:
-        refon = (C.c_int32 * len(names))(*[int(bool(TRK_REF[n]["ref"])) for n in names])
-        alpha = (C.c_double * len(names))(*[float(TRK_REF[n]["alpha"]) for n in names])
-        beta = (C.c_double * len(names))(*[float(TRK_REF[n]["beta"]) for n in names])
-    rc = lib.shasta_track_merged_f64(hip.ptr(seg[0]), hip.ptr(seg[1]), hip.ptr(seg[4].view(torch.int32)), hip.ptr(seg[2]), hip.ptr(seg[3]),
-                                          hip.ptr(seg[5].view(torch.int32)), hip.ptr(seg[6].view(torch.int32)), hip.ptr(seg[7]),
-                                          hip.ptr(seg[8].view(torch.int32)), S, Fmax, len(names), gate, refon, alpha, beta, int(max_age), int(bool(plain)),
-                                          hip.ptr(o_st), hip.ptr(o_id), hip.ptr(o_ref), hip.ptr(o_err), hip.stream_ptr())
-    if rc == hip.E_UNSUPPORTED:  # a device that does not grant the kernel its LDS: every scene takes the per-frame path
-        return [None] * S
-    hip.check(rc, "shasta_track_merged_f64")
-    oh = out.cpu().numpy()
+    ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+    with ctx:
+        dbuf = host.to(device, non_blocking=True)
+        seg = [dbuf[o[i]:o[i + 1]] for i in range(9)]
+        out = torch.zeros(D + (D + 1) // 2 * 2 + (S + 1) // 2, dtype=torch.float64, device=device)  # ref | status | id | err
+        o_ref, o_st = out[:D], out[D:D + (D + 1) // 2].view(torch.int32)
+        o_id, o_err = out[D + (D + 1) // 2:D + 2 * ((D + 1) // 2)].view(torch.int32), out[D + 2 * ((D + 1) // 2):].view(torch.int32)
+        names = NUSCENES_TRACKING_NAMES
+        gate = (C.c_float * len(names))(*[float(NUSCENE_CLS_VELOCITY_ERROR[n]) for n in names])
+        if plain:
+            refon = (C.c_int32 * len(names))(*([int(bool(refine_confidence))] * len(names)))
+            alpha = (C.c_double * len(names))(*([float(alpha)] * len(names)))
+            beta = (C.c_double * len(names))(*([float(beta)] * len(names)))
+        else:
+            refon = (C.c_int32 * len(names))(*[int(bool(TRK_REF[n]["ref"])) for n in names])
+            alpha = (C.c_double * len(names))(*[float(TRK_REF[n]["alpha"]) for n in names])
+            beta = (C.c_double * len(names))(*[float(TRK_REF[n]["beta"]) for n in names])
+        rc = lib.shasta_track_merged_f64(hip.ptr(seg[0]), hip.ptr(seg[1]), hip.ptr(seg[4].view(torch.int32)), hip.ptr(seg[2]), hip.ptr(seg[3]),
+                                         hip.ptr(seg[5].view(torch.int32)), hip.ptr(seg[6].view(torch.int32)), hip.ptr(seg[7]),
+                                         hip.ptr(seg[8].view(torch.int32)), S, Fmax, len(names), gate, refon, alpha, beta, int(max_age), int(bool(plain)),
+                                         hip.ptr(o_st), hip.ptr(o_id), hip.ptr(o_ref), hip.ptr(o_err), hip.stream_ptr())
+        if rc == hip.E_UNSUPPORTED:  # a device that does not grant the kernel its LDS: every scene takes the per-frame path
+            return dict(done=[None] * S)
+        hip.check(rc, "shasta_track_merged_f64")
+        back = torch.empty(out.shape, dtype=out.dtype, pin_memory=device.type == "cuda")
+        back.copy_(out, non_blocking=True)
+        ev = None
+        if device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+    return dict(back=back, ev=ev, keep=(host, dbuf, out), D=D, S=S, dets=dets, off=off, nfr=nfr, cls=cls, plain=plain)
+
+
+def track_scenes_collect(handle):
+    """Second half of track_scenes_merged_device: per scene, per frame, [(detection dict, tracking id, refined score)] or None (see
+    track_scenes_launch)."""
+    if "done" in handle:
+        return handle["done"]
+    if handle["ev"] is not None:
+        handle["ev"].synchronize()
+    D, S, dets, off, nfr, cls, plain = (handle[k] for k in ("D", "S", "dets", "off", "nfr", "cls", "plain"))
+    oh = handle["back"].numpy()
     r_ref = oh[:D].tolist()
     r_st = oh[D:D + (D + 1) // 2].view(np.int32)[:D]
     r_id = oh[D + (D + 1) // 2:D + 2 * ((D + 1) // 2)].view(np.int32)[:D].tolist()
