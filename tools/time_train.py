@@ -36,7 +36,7 @@ cfg = dict(type="Shasta", reader=None, backbone=None, neck=None,
 model = shasta_amd.build_simp_track(cfg).to(dev).train()
 model.train_precision = a.precision
 params = training.affinity_params(model)
-opt = torch.optim.Adam(params, lr=1e-4) if a.torch_adam else training.FusedAdam(params, lr=1e-4)
+opt = torch.optim.Adam(params, lr=1e-4) if a.torch_adam else training.FusedAdam(params, lr=1e-4, lowrank_first_layers=model)
 N, B = a.max_obj, a.batch
 g = torch.Generator(device="cpu").manual_seed(1 + rank)
 bev = torch.relu(torch.randn(B, a.hw, a.hw, 64, generator=g)).to(dev)
