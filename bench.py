@@ -472,9 +472,10 @@ def main():
                    "arithmetic": args.arithmetic + ": " + {"f16x2": "fp32 operands in HBM, fp32 accumulation throughout; the first aug_shape layer (from 17 frame-pairs per step "
                                            "with the pre-cut weight image, above 64 without) and the second layers of the pair MLPs form every fp32 product from three products of "
                                            "two range-scaled fp16 pieces per operand (round to nearest; measured max error vs float64: weight "
-                                           "stream 5.5e-6 against 7.0e-6 for the f32 MFMA kernel, pair stage 1.8e-6 against 2.3e-6); from 8192 "
-                                           "table rows the row-embedding GEMMs and the aff layers use six products of three exact bf16 "
-                                           "pieces (--arithmetic pieces / f32 select the other forms; extra.arithmetic_f32 is the strict-fp32 figure)",
+                                           "stream 5.5e-6 against 7.0e-6 for the f32 MFMA kernel, pair stage 1.8e-6 against 2.3e-6), and so do the six "
+                                           "aff layers from 8192 table rows (one pass with both softmaxes; logits within 2x the f32 kernel's error); the "
+                                           "row-embedding GEMMs use six products of three exact bf16 pieces from 8192 table rows "
+                                           "(--arithmetic pieces / f32 select the other forms; extra.arithmetic_f32 is the strict-fp32 figure)",
                                   "pieces": "fp32 operands, fp32 accumulation throughout; above 32 frame-pairs per step the first aug_shape "
                                             "layer, and from 8192 table rows the row-embedding GEMMs and the aff layers, form every fp32 product "
                                             "from six exact bf16 piece products on the bf16 MFMA path",
