@@ -111,8 +111,9 @@ __device__ __forceinline__ void ap_store4(float* o, const f32x4& e, int nvalid) 
 
 // The tail of a one-pass aff kernel.  On entry acc[i][rb] holds the layer-6 sums of features (wid + WAVES i) 32 + 8 (r >> 2) +
 // 4 (lane >> 5) + (r & 3) for row 32 rb + (lane & 31) of the row group (b, q) - plain (SCALED = false: logit = acc + bias) or in the
-// block-scaled form of the fp16 kernels (SCALED: logit = acc dsc[feature] rs[rb] + bias, dsc and rs exact powers of two) - and the
-// workgroup no longer needs anything of its LDS but [ABYTES + BBYTES) from smem on.
+// block-scaled form of the fp16 kernels (SCALED: logit = acc dsc[feature] rs[rb] + bias, dsc and rs exact powers of two).  The tail
+// lays its staging and scratch over the first ApShape::ABYTES + BBYTES bytes of the workgroup's LDS: nothing the caller still needs may
+// live there (the other waves may still READ the layer-5 image behind `smem` - the tail's first barrier waits for them).
 template <int ROWS, int WAVES, bool SCALED>
 __device__ __forceinline__ void ap_frame_tail(const AffFrameArgs& fa, char* smem, f32x16 (&acc)[ApShape<ROWS, WAVES>::NFW][ApShape<ROWS, WAVES>::RB],
                                               int b, int q, int nrows, int g0, int tid, int lane, int wid, const float* __restrict__ dsc,
@@ -357,7 +358,7 @@ __device__ __forceinline__ void ap_frame_tail(const AffFrameArgs& fa, char* smem
                         if (col + e >= D) z[e] = 0.0f;  // the padding columns of `matched`
                     *reinterpret_cast<f32x4*>(a.matched + (size_t)(g0 + r) * a.ldm + col) = z;
                 }
-#ifndef AP_NOM1
+#ifndef AP_ABL_NO_M1  // ablation builds of tools/probes/aff_frame_probe.hip (results are wrong)
                 if (t < N && col < D) {
                     f32x4 e;
 #pragma unroll
@@ -365,7 +366,7 @@ __device__ __forceinline__ void ap_frame_tail(const AffFrameArgs& fa, char* smem
                     ap_store4(a.m1 + ((size_t)b * N + t) * D + col, e, D - col);
                 }
 #endif
-#ifndef AP_NOM2
+#ifndef AP_ABL_NO_M2
                 if (col < N) {
                     f32x4 e;
 #pragma unroll

@@ -478,10 +478,6 @@ __global__ __launch_bounds__(64 * WAVES) void aff_frame_kernel(AffFrameArgs fa) 
     const int b = blockIdx.x / G, q = blockIdx.x - b * G;
     const int nrows = min(ROWS, a.T - q * ROWS), g0 = b * a.T + q * ROWS;
     f32x16 acc[NFW][RB];
-#ifdef AP_STAGGER
-    if (blockIdx.x < 256)
-        for (int k = 0; k < (int)((blockIdx.x >> 3) & 3) * AP_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-#endif
     ap_mlp<ROWS, WAVES>(a, smem, g0, g0 + nrows - 1, tid, lane, wid, acc);
     const float rs[RB] = {};
     ap_frame_tail<ROWS, WAVES, false>(fa, smem, acc, b, q, nrows, g0, tid, lane, wid, nullptr, rs);
