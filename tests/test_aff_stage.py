@@ -162,3 +162,33 @@ def test_one_pass_aff_in_a_captured_graph():
         graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(aff.m1, e1) and torch.equal(aff.m2, e2)
+
+
+def test_one_pass_aff_on_two_streams_at_once():
+    """Two launches of the one-pass kernel in flight on two streams (two class models of the chain would do that): workgroups of both
+    interleave on the CUs, every frame's siblings still meet - results equal to the launches run alone, nothing poisoned, nothing hangs."""
+    dev = _dev()
+    N, B = 500, 48
+    m = _model(N, 1.0, dev)
+    opt = hip.OPT_F16X2_AFF
+    affs = [_Aff(m, B, dev) for _ in range(2)]
+    res = [_residual(B, N, dev, seed=21 + i) for i in range(2)]
+    want = [affs[i](res[i], opt, want_logits=False) for i in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    for _ in range(10):
+        for i in range(2):
+            streams[i].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(streams[i]):
+                w = hip.Weights.from_buffer_copy(affs[i].w)
+                w.options = opt
+                affs[i].m1.fill_(float("nan"))
+                affs[i].m2.fill_(float("nan"))
+                hip.check(affs[i].lib.shasta_aff_softmax_f32(C.byref(w), hip.ptr(m._packed), B, hip.ptr(res[i]), affs[i].Dp, hip.ptr(affs[i].m1),
+                                                             hip.ptr(affs[i].m2), None, hip.ptr(affs[i].ws), affs[i].nws, hip.stream_ptr()),
+                          "shasta_aff_softmax_f32")
+        for s in streams:
+            torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for i in range(2):
+            assert torch.equal(affs[i].m1, want[i][1]) and torch.equal(affs[i].m2, want[i][2]), i
