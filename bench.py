@@ -818,6 +818,13 @@ def extra_shared_conv(bench, args, ex):
             e["miopen"] = {"ms": ms, "ms_per_frame_pair": ms / B, "tflops": B * flop_pair / ms / 1e9}
             ms = timed_ms(torch, lambda: bank(x, xp), 20 if B == 1 else 5)
             e["f16x2_7_heads"] = {"ms": ms, "ms_per_frame_pair_per_head": ms / B / 7, "tflops": 7 * B * flop_pair / ms / 1e9}
+            # the producer of the maps names their largest magnitude (relu of normals from 24-bit uniforms: < 5.8): no maxima pass
+            one = SharedConvBank([car])
+            ms = timed_ms(torch, lambda: one(x, xp, bound=8.0), 30 if B == 1 else 10)
+            e["f16x2_bounded"] = {"ms": ms, "ms_per_frame_pair": ms / B, "tflops": B * flop_pair / ms / 1e9,
+                                  "note": "shasta_shared_conv_multi_bounded_f32: the caller supplies max |x|, the maps are not read a second time"}
+            ms = timed_ms(torch, lambda: bank(x, xp, bound=8.0), 20 if B == 1 else 5)
+            e["f16x2_7_heads_bounded"] = {"ms": ms, "ms_per_frame_pair_per_head": ms / B / 7, "tflops": 7 * B * flop_pair / ms / 1e9}
             e["f16x2_over_miopen"] = e["miopen"]["ms"] / e["f16x2"]["ms"]
             sc["b%d" % B] = e
             if B == 1:

@@ -140,6 +140,14 @@ int shasta_shared_conv_pack_f16x2(const float* weight, const float* bias, const 
                                   const float* bn_bias, const float* bn_mean, const float* bn_var,
                                   float bn_eps, int in_channels, void* packed, size_t packed_bytes,
                                   shasta_stream_t stream);
+/* The same with the largest magnitude of the maps supplied by the caller (x_absmax_bound > 0: the producer of the neck output knows a
+ * bound of it) instead of found by a pass over them: every image is cut under the bound's scale.  The bound need not be tight - an fp16
+ * piece pair keeps 22 significant bits of every element within 2^-17 of it; an element beyond 4 x the bound overflows fp16 and comes
+ * out as NaN / Inf, never as a wrong finite number. */
+int shasta_shared_conv_multi_bounded_f32(const float* x, const float* x_prev, int B, int in_channels, int H, int W,
+                                         const void* packed, size_t head_stride_bytes, int heads, float* const* h_out,
+                                         float* const* h_out_prev, void* workspace, size_t workspace_bytes,
+                                         float x_absmax_bound, shasta_stream_t stream);
 size_t shasta_shared_conv_multi_workspace_bytes(int B);
 /* The workspace that lets a call of this shape (B frame pairs - two_maps != 0 - or B single maps, `heads` class heads) take its fastest
  * form: from three heads over enough maps on, the input is cut ONCE into an fp16 piece image (68 MB per 512 x 180 x 180 map, behind the

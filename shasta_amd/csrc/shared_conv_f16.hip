@@ -25,6 +25,8 @@
 // with the heads of a tile next to each other on one XCD, so the map is read from HBM once and 6 of 7 tile reads hit that L2.
 #include "common.hpp"
 
+#include <string.h>
+
 #pragma clang diagnostic ignored "-Winline-asm"
 #include <type_traits>
 
@@ -1014,9 +1016,27 @@ extern "C" size_t shasta_shared_conv_multi_workspace_bytes_for(int B, int in_cha
     return n;
 }
 
+static int conv_multi(const float* x, const float* x_prev, int B, int in_channels, int H, int W, const void* packed, size_t head_stride_bytes,
+                      int heads, float* const* h_out, float* const* h_out_prev, void* workspace, size_t workspace_bytes, float x_bound,
+                      shasta_stream_t stream);
+
 extern "C" int shasta_shared_conv_multi_f32(const float* x, const float* x_prev, int B, int in_channels, int H, int W, const void* packed,
                                             size_t head_stride_bytes, int heads, float* const* h_out, float* const* h_out_prev,
                                             void* workspace, size_t workspace_bytes, shasta_stream_t stream) {
+    return conv_multi(x, x_prev, B, in_channels, H, W, packed, head_stride_bytes, heads, h_out, h_out_prev, workspace, workspace_bytes, 0.0f, stream);
+}
+
+extern "C" int shasta_shared_conv_multi_bounded_f32(const float* x, const float* x_prev, int B, int in_channels, int H, int W, const void* packed,
+                                                    size_t head_stride_bytes, int heads, float* const* h_out, float* const* h_out_prev,
+                                                    void* workspace, size_t workspace_bytes, float x_absmax_bound, shasta_stream_t stream) {
+    SHASTA_REQUIRE(x_absmax_bound > 0.0f && x_absmax_bound < INFINITY, "shared_conv_multi_bounded: the bound must be positive and finite");
+    return conv_multi(x, x_prev, B, in_channels, H, W, packed, head_stride_bytes, heads, h_out, h_out_prev, workspace, workspace_bytes,
+                      x_absmax_bound, stream);
+}
+
+static int conv_multi(const float* x, const float* x_prev, int B, int in_channels, int H, int W, const void* packed, size_t head_stride_bytes,
+                      int heads, float* const* h_out, float* const* h_out_prev, void* workspace, size_t workspace_bytes, float x_bound,
+                      shasta_stream_t stream) {
     SHASTA_REQUIRE(x && packed && h_out, "shared_conv_multi: null pointer");
     SHASTA_REQUIRE((x_prev == nullptr) == (h_out_prev == nullptr), "shared_conv_multi: x_prev and h_out_prev go together");
     SHASTA_REQUIRE(heads >= 1 && heads <= C16_MAXH, "shared_conv_multi: 1 to 8 heads per call");
@@ -1035,12 +1055,21 @@ extern "C" int shasta_shared_conv_multi_f32(const float* x, const float* x_prev,
     const int nmaps = x_prev ? 2 * B : B;
     const long per_image = (long)in_channels * H * W;
     unsigned* xmax = static_cast<unsigned*>(workspace);
-    if (hipMemsetAsync(xmax, 0, (size_t)nmaps * sizeof(unsigned), st) != hipSuccess) return SHASTA_E_LAUNCH;
-    int slices = 1;
-    while (slices < 1024 && slices * nmaps < 2048 && per_image / (slices * 2) >= 16384) slices *= 2;
-    hipLaunchKernelGGL(conv16_absmax_kernel, dim3(slices, nmaps), dim3(256), 0, st, x, x_prev, per_image, B, xmax);
-    int rc = check_launch("shared_conv_multi (image maxima)");
-    if (rc != SHASTA_OK) return rc;
+    int rc = SHASTA_OK;
+    if (x_bound > 0.0f) {
+        // the caller vouches for max |x| <= x_bound (the producer of the maps knows it): every image is cut under the bound's scale and
+        // the maps are not read a second time.  The bound need not be tight (a piece pair keeps 22 bits of every element within 2^-17
+        // of it); an element beyond 4 x the bound overflows fp16 and comes out as a NaN / Inf, never as a wrong finite number
+        unsigned bits;
+        memcpy(&bits, &x_bound, sizeof(bits));
+        if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(xmax), (int)bits, (size_t)nmaps, st) != hipSuccess) return SHASTA_E_LAUNCH;
+    } else {
+        if (hipMemsetAsync(xmax, 0, (size_t)nmaps * sizeof(unsigned), st) != hipSuccess) return SHASTA_E_LAUNCH;
+        int slices = 1;
+        while (slices < 1024 && slices * nmaps < 2048 && per_image / (slices * 2) >= 16384) slices *= 2;
+        hipLaunchKernelGGL(conv16_absmax_kernel, dim3(slices, nmaps), dim3(256), 0, st, x, x_prev, per_image, B, xmax);
+        if ((rc = check_launch("shared_conv_multi (image maxima)")) != SHASTA_OK) return rc;
+    }
 
     Conv16Args a;
     a.x[0] = x;

@@ -67,6 +67,7 @@ SYMBOLS = {
     "shasta_shared_conv_multi_workspace_bytes": (_Z, [_I]),
     "shasta_shared_conv_multi_workspace_bytes_for": (_Z, [_I, _I, _I, _I, _I, _I]),
     "shasta_shared_conv_multi_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _Z, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, _Z, _P]),
+    "shasta_shared_conv_multi_bounded_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _Z, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, _Z, _F, _P]),
     "shasta_packed_bytes": (_Z, [_I, _I, _I]),
     "shasta_pack_weights_f32": (_I, [_WP, _P, _Z, _P]),
     "shasta_aug_shape_aux_bytes": (_Z, [_I, _I, _I]),

@@ -331,7 +331,7 @@ def _run_features(bev, models, names, run, device, bank_cache, timer=_NO_TIMER):
             x = bev.neck_batch(toks, device)
         with timer.stage("maps: shared_conv, all class heads (K0)"):
             with torch.no_grad():
-                outs = bank_cache["bank"](x)
+                outs = bank_cache["bank"](x, bound=getattr(bev, "neck_bound", None))  # the producer's bound of its maps, if it has one
         return dict(zip(names, outs))
     with timer.stage("maps: features (stand-in for backbone + neck + shared_conv)"):
         if hasattr(bev, "device_batch"):
@@ -438,7 +438,7 @@ def forward_only_seconds(models, paths, scenes, bev, device, batch_pairs=32):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         with torch.no_grad():
-            feats = dict(zip(names, bank_cache["bank"](x)))
+            feats = dict(zip(names, bank_cache["bank"](x, bound=getattr(bev, "neck_bound", None))))
             for n in names:
                 b = batches[n]
                 ex = dict(b, det_boxes=dev_in[n][0], prev_det_boxes=dev_in[n][1], bev_feature=feats[n][1:], prev_bev_feature=feats[n][:-1])

@@ -121,6 +121,10 @@ class TokenNeck:
     of the frame token, generated ON the device (a seeded device generator per token), so that a timed chain holds no host-side
     stand-in work.  `neck_batch(tokens, device)` -> (n, Cin, H, W) fp32."""
 
+    # relu of standard normals drawn from 24-bit uniforms: never above sqrt(2 ln 2^24) = 5.8.  A real neck knows the range of its own
+    # ReLU(BatchNorm(.)) output the same way; shared_conv then skips its pass over the maps (SharedConvBank(..., bound=))
+    neck_bound = 8.0
+
     def __init__(self, hw=180, channels=512, seed=0):
         self.hw, self.channels, self.seed = hw, channels, seed
         self._gen = {}

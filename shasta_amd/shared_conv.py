@@ -72,8 +72,10 @@ class SharedConvBank:
                                                         hip.stream_ptr()), "shasta_shared_conv_pack_f16x2")
         self._key = key
 
-    def __call__(self, bev_map, prev_bev_map=None):
-        """(B, Cin, H, W) fp32 device map(s) -> list over heads of (B, H, W, 64) NHWC tensors; with prev_bev_map a pair of lists."""
+    def __call__(self, bev_map, prev_bev_map=None, bound=None):
+        """(B, Cin, H, W) fp32 device map(s) -> list over heads of (B, H, W, 64) NHWC tensors; with prev_bev_map a pair of lists.
+        bound: max |x| of the maps as the producer knows it (need not be tight, must hold within a factor 4: beyond that the result is
+        NaN / Inf) - the pass that finds the maxima is then skipped (shasta_shared_conv_multi_bounded_f32)."""
         maps = [t for t in (bev_map, prev_bev_map) if t is not None]
         if not all(t.is_cuda for t in maps):
             raise hip.ShastaHipError("SharedConvBank needs device tensors; there is no CPU path")
@@ -99,9 +101,14 @@ class SharedConvBank:
             self._ws = torch.empty((wsb + 3) // 4, dtype=torch.int32, device=dev)
         arr = (C.c_void_p * nh)(*[t.data_ptr() for t in outs])
         arr_p = None if outs_p is None else (C.c_void_p * nh)(*[t.data_ptr() for t in outs_p])
-        hip.check(lib.shasta_shared_conv_multi_f32(hip.ptr(x), hip.ptr(xp), B, self.cin_padded, H, W, C.c_void_p(self._packed.data_ptr()),
-                                                   self._stride, nh, arr, arr_p, hip.ptr(self._ws), self._ws.numel() * 4, hip.stream_ptr()),
-                  "shasta_shared_conv_multi_f32")
+        if bound is not None:
+            hip.check(lib.shasta_shared_conv_multi_bounded_f32(hip.ptr(x), hip.ptr(xp), B, self.cin_padded, H, W, C.c_void_p(self._packed.data_ptr()),
+                                                               self._stride, nh, arr, arr_p, hip.ptr(self._ws), self._ws.numel() * 4, float(bound),
+                                                               hip.stream_ptr()), "shasta_shared_conv_multi_bounded_f32")
+        else:
+            hip.check(lib.shasta_shared_conv_multi_f32(hip.ptr(x), hip.ptr(xp), B, self.cin_padded, H, W, C.c_void_p(self._packed.data_ptr()),
+                                                       self._stride, nh, arr, arr_p, hip.ptr(self._ws), self._ws.numel() * 4, hip.stream_ptr()),
+                      "shasta_shared_conv_multi_f32")
         return outs if outs_p is None else (outs, outs_p)
 
     def _prep(self, t):

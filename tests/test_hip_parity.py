@@ -355,6 +355,44 @@ def test_shared_conv_bank_equals_the_single_heads_and_the_oracle(heads, B, cin, 
         np.testing.assert_allclose(again[1].cpu().numpy(), ref1.numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(ref1.abs().max())))
 
 
+@pytest.mark.parametrize("heads,B,cin,H,W", [(1, 2, 32, 40, 90), (3, 8, 16, 64, 64), (7, 3, 32, 90, 180)])
+def test_shared_conv_with_a_caller_supplied_bound(heads, B, cin, H, W):
+    """shasta_shared_conv_multi_bounded_f32: the producer of the maps names their largest magnitude and the pass that finds it is skipped.
+    A bound in the true maximum's binade gives the same bits; a loose one (6 x) too, up to elements whose low piece goes subnormal (a
+    power-of-two scale commutes with fp16's rounding; a piece pair keeps 22 bits of every element within 2^-17 of the bound); an input far
+    beyond the bound comes out non-finite, never as a wrong finite number.  All three forms of the kernel (256-pixel tiles, 512-pixel tiles, the input cut once for all heads)."""
+    from shasta_amd.shared_conv import SharedConvBank
+    dev = _dev()
+    ms = _conv_models(heads, cin, seed0=40)
+    w0 = {k: v.detach().clone() for k, v in ms[0].state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    x, xp = torch.relu(torch.randn(B, cin, H, W, generator=g)), torch.relu(torch.randn(B, cin, H, W, generator=g))
+    top = float(max(x.max(), xp.max()))
+    for t in (x, xp):  # every image reaches the same maximum: the pass then finds the scale the bound gives
+        t[:, 0, 0, 0] = top
+    bank = SharedConvBank([m.to(dev) for m in ms])
+    xd, xpd = x.to(dev), xp.to(dev)
+    with torch.no_grad():
+        plain, plain_p = bank(xd, xpd)
+        same, same_p = bank(xd, xpd, bound=top)
+        loose, loose_p = bank(xd, xpd, bound=6.0 * top)
+    for a, b in zip(plain + plain_p, same + same_p):
+        assert torch.equal(a, b)
+    ref, refp = O.shared_conv_nhwc(w0, x), O.shared_conv_nhwc(w0, xp)
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    np.testing.assert_allclose(loose[0].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=tol)
+    np.testing.assert_allclose(loose_p[0].cpu().numpy(), refp.numpy(), rtol=1e-4, atol=tol)
+    # (a power-of-two scale commutes with fp16's rounding: the loose bound gives the SAME bits wherever no low piece went subnormal)
+    assert float((loose[0] - plain[0]).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))
+    bad = xd.clone()
+    bad[0, 1, H // 2, W // 2] = 300.0 * top
+    with torch.no_grad():
+        out = bank(bad, xpd, bound=top)[0][0]
+    assert not torch.isfinite(out[0, H // 2, W // 2]).all() and torch.isfinite(out[1:]).all()
+    with pytest.raises(Exception):
+        bank(xd, xpd, bound=0.0)
+
+
 @pytest.mark.parametrize("kind", ["tiny", "huge", "spike", "mixed_images", "wide_weights"])
 def test_shared_conv_fp16_form_is_range_safe(kind):
     """The fp16 form scales every image by one power of two (its largest magnitude) and every output channel's weights by another:
