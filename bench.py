@@ -837,6 +837,10 @@ def extra_shared_conv(bench, args, ex):
                 ms = timed_ms(torch, fwd, 50, warm=5)
                 ex["car_90_320_3"]["from_neck_b1"] = {"ms_per_step": ms, "frame_pairs_per_s": 1e3 / ms, "arithmetic": args.arithmetic,
                                                        "note": "Shasta.forward from the neck outputs: shared_conv (both maps) + rows 4-16, one frame pair"}
+                ms = timed_ms(torch, lambda: car(dict(det_boxes=det0.clone(), prev_det_boxes=prev, bev_map=x, prev_bev_map=xp, bev_map_bound=8.0),
+                                                 train_mode=False), 50, warm=5)
+                ex["car_90_320_3"]["from_neck_b1_bounded"] = {"ms_per_step": ms, "frame_pairs_per_s": 1e3 / ms, "arithmetic": args.arithmetic,
+                                                               "note": "example['bev_map_bound'] = the producer's max |x| of the maps: shared_conv skips its maxima pass"}
                 try:  # the same step replayed from a captured hipGraph (tools/nusc_shasta/eval.py:96-101 is a batch-1 loop)
                     work = det0.clone()
 

@@ -372,13 +372,14 @@ class Shasta(BaseTrack):
         return dict(feat=cur["feat"][:B], prev_feat=cur["prev_feat"][:B], det_tab=cur["det_tab"][:B],
                     prev_tab=cur["prev_tab"][:B], ws=cur["ws"], ws_bytes=cur["ws_bytes"])
 
-    def shared_conv_nhwc(self, bev_map, prev_bev_map=None):
+    def shared_conv_nhwc(self, bev_map, prev_bev_map=None, bound=None):
         """shasta.py:223-228: relu(bn(conv3x3(map))) -> NHWC for the current (and, in the same launch, the previous) neck
         output, by the hand-written implicit-GEMM kernels: csrc/shared_conv_f16.hip (arithmetic "f16x2" / "f16grid": fp32 products
         from two fp16 pieces per operand; maps up to 187 columns wide) or csrc/shared_conv.hip (strict f32 MFMA: "f32", "pieces",
         wider maps).  Eval-mode BatchNorm (running
         statistics) only: in train() mode the module's own nn.Sequential is used so that batch statistics behave like
-        the reference.  Returns one tensor, or a pair when prev_bev_map is given."""
+        the reference.  Returns one tensor, or a pair when prev_bev_map is given.  bound: max |x| of the maps as their producer knows
+        it (fp16 form only; SharedConvBank.__call__): the pass over the maps that finds it is skipped."""
         conv, bn = self.shared_conv[0], self.shared_conv[1]
         maps = [t for t in (bev_map, prev_bev_map) if t is not None]
         if not all(t.is_cuda for t in maps):
@@ -395,7 +396,7 @@ class Shasta(BaseTrack):
                 from .shared_conv import SharedConvBank
                 self._conv_bank = SharedConvBank([self])
             if self._conv_bank.supported(bev_map.shape[2], bev_map.shape[3]):
-                res = self._conv_bank(bev_map, prev_bev_map)
+                res = self._conv_bank(bev_map, prev_bev_map, bound=bound)
                 return res[0] if prev_bev_map is None else (res[0][0], res[1][0])
         if conv.in_channels % 8 != 0:  # the kernel's K chunks are 8 channels wide: zero-pad the channel axis (exact)
             return self._shared_conv_padded(bev_map, prev_bev_map)
@@ -536,7 +537,7 @@ class Shasta(BaseTrack):
             prev_bev = example["prev_bev_feature"].float().contiguous()
         else:
             bev_map, _, prev_bev_map, _ = self.extract_feat(example)
-            bev, prev_bev = self.shared_conv_nhwc(bev_map, prev_bev_map)
+            bev, prev_bev = self.shared_conv_nhwc(bev_map, prev_bev_map, bound=example.get("bev_map_bound"))
         example["bev_feature"] = bev
         inplace = det.dtype == torch.float32 and det.is_contiguous() and det.shape[2] >= 10
         det_k = det if inplace else det.float().contiguous()
