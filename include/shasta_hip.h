@@ -446,6 +446,22 @@ int shasta_pair_hidden_f32(const float* UP, int ldp, const float* UC, int ldc, i
                            shasta_stream_t stream);
 /* its transpose: gUP[(b,t)] = sum_d gZ[(b,t,d)], gUC[(b,d)] = sum_t gZ[(b,t,d)]  (dense (B*T, E) outputs, fixed order) */
 int shasta_pair_reduce_f32(const float* gZ, int B, int T, int D, int E, float* gUP, float* gUC, shasta_stream_t stream);
+/* One pair MLP behind its factorised first layer, per pair on chip (pair_bwd.hip; det3d/models/tracker/shasta.py:59-92, 286-316):
+ * kind 0 = fuse_shape, 1 = fuse_det, 2 = res_coeff; UP (B*T, E1), UC (B*D, E1) dense = the first layer's two table products (bias in
+ * UC), E1 = F/8 | 32 | 32 + F/8.  wt = six device pointers {W2, b2, W3, b3, W4, b4} - the later layers' weights and biases as
+ * nn.Linear holds them ((out, in) row-major), W4 / b4 NULL for the three-layer MLPs.  forward: out (B*T*D, n_out) with n_out = 1 | 1 | 3.  backward: gout
+ * (B*T*D, n_out) -> gUP (B*T, E1), gUC (B*D, E1) (gradients of the first layer's pre-activation summed over the detections / the
+ * tracks) and gW = the later layers' gradients as one flat image [gW2 (out, in) | gb2 | gW3 | gb3 | gW4 | gb4] of
+ * shasta_pair_mlp_grad_floats() floats; fixed summation order.  feat_dim 64, 256, 320 (shasta_pair_mlp_supported); others:
+ * SHASTA_E_UNSUPPORTED (callers keep the dense formulation: shasta_pair_hidden_f32 + shasta_gemm_strided_f32). */
+int shasta_pair_mlp_supported(int feat_dim);
+int shasta_pair_mlp_grad_floats(int kind, int feat_dim);
+size_t shasta_pair_mlp_workspace_bytes(int kind, int feat_dim, int B, int T, int D);
+int shasta_pair_mlp_forward_f32(int kind, int feat_dim, const float* UP, const float* UC, const float* const* wt, int B, int T, int D,
+                                float* out, shasta_stream_t stream);
+int shasta_pair_mlp_backward_f32(int kind, int feat_dim, const float* UP, const float* UC, const float* const* wt, const float* gout,
+                                 int B, int T, int D, float* gUP, float* gUC, float* gW, float* ws, size_t ws_bytes,
+                                 shasta_stream_t stream);
 /* hand-designed residual (shasta.py:277-283) materialised: dist (B,T,ld), denom (>= 2*B*D floats: column norms, scratch) */
 int shasta_hand_dist_f32(const float* prev_tab, const float* det_tab, int B, int T, int D, int nf, float* dist, int ld,
                          float* denom, shasta_stream_t stream);

@@ -9,7 +9,7 @@ import os
 
 import torch
 
-ABI_VERSION = 10  # must equal shasta_abi_version() of the loaded library
+ABI_VERSION = 11  # must equal shasta_abi_version() of the loaded library
 # SHASTA_HIP_LIB: load another build of the same ABI (A/B timing of kernel variants on one box)
 _LIB_PATH = os.environ.get("SHASTA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libshasta_hip.so")
 _lib = None
@@ -93,6 +93,11 @@ SYMBOLS = {
     "shasta_softmax_bwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _I, _P]),
     "shasta_pair_hidden_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
     "shasta_pair_reduce_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "shasta_pair_mlp_supported": (_I, [_I]),
+    "shasta_pair_mlp_grad_floats": (_I, [_I, _I]),
+    "shasta_pair_mlp_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "shasta_pair_mlp_forward_f32": (_I, [_I, _I, _P, _P, C.POINTER(_P), _I, _I, _I, _P, _P]),
+    "shasta_pair_mlp_backward_f32": (_I, [_I, _I, _P, _P, C.POINTER(_P), _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "shasta_colsum_f32": (_I, [_P, _I, _I, _I, _P, _P, C.c_size_t, _P]),
     "shasta_lowrank_outer_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "shasta_smallm_nn_workspace_bytes": (_Z, [_I, _I, _I]),

@@ -150,8 +150,9 @@ class _AffinityTrainFn(torch.autograd.Function):
         mods = {"fs": lin(model.fuse_shape, (0, 2, 4, 6)), "rc": lin(model.res_coeff, (0, 2, 4)), "fd": lin(model.fuse_det, (0, 2, 4))}
         R = B * T
 
-        def first_layer(name):
-            """H (P, E) = relu(UP[t] + UC[d]); returns H and the column offsets of the parts inside W0."""
+        def first_layer_tables(name):
+            """The first layer's two table products: UP (B*T, E) over the previous side's rows, UC (B*D, E) over the current side's
+            (bias in UC); and the column offsets of the parts inside W0."""
             w0, b0 = mods[name][0]
             E, kin = w0.shape
             UP, UC = torch.empty(R, E, device=dev), torch.empty(R, E, device=dev)
@@ -161,16 +162,27 @@ class _AffinityTrainFn(torch.autograd.Function):
                     _gemm(lib, tab, (ld, 1), w0[:, col:], (kin, 1), R, E, wd, U, bias=b0 if (side == 1 and k == 0) else None, accum=k > 0, bf16=bf)
                     offs.append(col)
                     col += wd
+            return UP, UC, offs
+
+        def first_layer(name):
+            """H (P, E) = relu(UP[t] + UC[d]); returns H and the column offsets of the parts inside W0."""
+            UP, UC, offs = first_layer_tables(name)
+            E = UP.shape[1]
             H = torch.empty(P, E, device=dev)
             hip.check(lib.shasta_pair_hidden_f32(hip.ptr(UP), E, hip.ptr(UC), E, B, T, D, E, hip.ptr(H), st()), "shasta_pair_hidden_f32")
             return H, offs
 
         def first_layer_bwd(name, gZ, offs):
             """gZ (P, E) gradient of the first layer's pre-activation -> (gW0, gb0); table gradients accumulated."""
-            w0, b0 = mods[name][0]
-            E, kin = w0.shape
+            E = mods[name][0][0].shape[0]
             gUP, gUC = torch.empty(R, E, device=dev), torch.empty(R, E, device=dev)
             hip.check(lib.shasta_pair_reduce_f32(hip.ptr(gZ), B, T, D, E, hip.ptr(gUP), hip.ptr(gUC), st()), "shasta_pair_reduce_f32")
+            return first_layer_bwd_rows(name, gUP, gUC, offs)
+
+        def first_layer_bwd_rows(name, gUP, gUC, offs):
+            """gUP (B*T, E), gUC (B*D, E): the pre-activation's gradient summed over the detections / the tracks -> (gW0, gb0)."""
+            w0, b0 = mods[name][0]
+            E, kin = w0.shape
             gW0, gb0 = torch.empty_like(w0), torch.empty_like(b0)
             _colsum(lib, gUC, E, R, E, gb0, ws)
             k = 0
@@ -182,9 +194,23 @@ class _AffinityTrainFn(torch.autograd.Function):
                     _gemm(lib, gU, (E, 1), w0[:, col:], (1, kin), R, wd, E, gtab, ldc=ld, accum=True, bf16=bf)      # dX += gU W0 block
             return gW0, gb0
 
-        tails, Hs, offs_ = {}, {}, {}
+        # The later layers of a pair MLP.  Default (fp32, F = 64 | 256 | 320): recomputed and back-propagated per pair on chip
+        # (csrc/pair_bwd.hip) - per pair only the MLP's output is written and its gradient read.  Otherwise (bf16 operands, other
+        # widths, Shasta.dense_pair_backward): the dense formulation - hidden activations of every pair materialised, strided GEMMs.
+        on_chip = (not bf) and bool(lib.shasta_pair_mlp_supported(F)) and not getattr(model, "dense_pair_backward", False)
+        kinds = {"fs": 0, "fd": 1, "rc": 2}
+        tails, Hs, offs_, tabs, wts = {}, {}, {}, {}, {}
         outs = {}
         for name in ("fs", "rc", "fd"):
+            if on_chip:
+                UP_, UC_, offs_[name] = first_layer_tables(name)
+                tabs[name] = (UP_, UC_)
+                later = [t for wb in mods[name][1:] for t in wb] + [None] * (8 - 2 * len(mods[name]))
+                wts[name] = ((C.c_void_p * 6)(*[None if t is None else t.data_ptr() for t in later]), later)  # (the tensors kept alive)
+                outs[name] = torch.empty(P, mods[name][-1][0].shape[0], device=dev)
+                hip.check(lib.shasta_pair_mlp_forward_f32(kinds[name], F, hip.ptr(UP_), hip.ptr(UC_), wts[name][0], B, T, D,
+                                                          hip.ptr(outs[name]), st()), "shasta_pair_mlp_forward_f32")
+                continue
             Hs[name], offs_[name] = first_layer(name)
             tails[name] = _Mlp(lib, mods[name][1:], ws, bf16=bf)
             outs[name] = tails[name].forward(Hs[name], Hs[name].shape[1], P)
@@ -199,6 +225,23 @@ class _AffinityTrainFn(torch.autograd.Function):
                                              hip.ptr(gcoeff), hip.ptr(gfused), hip.ptr(gshape), hip.ptr(gdist), st()), "shasta_combine_bwd_f32")
         pair_grads = {}
         for name, gout in (("fs", gshape), ("rc", gcoeff), ("fd", gfused)):
+            if on_chip:
+                UP_, UC_ = tabs[name]
+                E = UP_.shape[1]
+                nb = lib.shasta_pair_mlp_workspace_bytes(kinds[name], F, B, T, D)
+                pws = torch.empty((nb + 3) // 4, device=dev)
+                gUP, gUC = torch.empty(R, E, device=dev), torch.empty(R, E, device=dev)
+                img = torch.empty(lib.shasta_pair_mlp_grad_floats(kinds[name], F), device=dev)
+                hip.check(lib.shasta_pair_mlp_backward_f32(kinds[name], F, hip.ptr(UP_), hip.ptr(UC_), wts[name][0], hip.ptr(gout), B, T, D,
+                                                           hip.ptr(gUP), hip.ptr(gUC), hip.ptr(img), hip.ptr(pws), nb, st()),
+                          "shasta_pair_mlp_backward_f32")
+                tail_grads, o = [], 0
+                for w_, b_ in mods[name][1:]:  # the image: [gW2 | gb2 | gW3 | gb3 | gW4 | gb4]
+                    tail_grads.append((img[o:o + w_.numel()].view_as(w_), img[o + w_.numel():o + w_.numel() + b_.numel()]))
+                    o += w_.numel() + b_.numel()
+                pair_grads[name] = [first_layer_bwd_rows(name, gUP, gUC, offs_[name])] + tail_grads
+                del pws
+                continue
             tail_grads, gZ = tails[name].backward(gout, mask_input=True)
             pair_grads[name] = [first_layer_bwd(name, gZ, offs_[name])] + tail_grads
             del gZ

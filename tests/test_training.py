@@ -268,6 +268,96 @@ def test_pair_hidden_and_reduce(B, T, E):
     assert float((gUC.view(B, T, E).double() - g4.sum(1)).abs().max()) < 1e-4
 
 
+_PAIR_MLP_WIDTHS = {  # (kind, F) -> layer widths behind the factorised first layer (det3d/models/tracker/shasta.py:59-92)
+    (0, 64): (8, 4, 2, 1), (1, 64): (32, 8, 1), (2, 64): (40, 10, 3), (0, 256): (32, 16, 8, 1), (1, 256): (32, 8, 1), (2, 256): (64, 16, 3),
+    (0, 320): (40, 20, 10, 1), (1, 320): (32, 8, 1), (2, 320): (72, 18, 3)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,F,B,T,D", [(0, 64, 2, 5, 7), (2, 64, 1, 22, 22), (1, 64, 3, 66, 65), (0, 256, 2, 92, 92), (2, 256, 1, 130, 70),
+                                          (1, 256, 2, 9, 200), (0, 320, 1, 33, 129), (2, 320, 2, 92, 92), (2, 256, 3, 1, 1)])
+def test_pair_mlp_on_chip_matches_autograd(kind, F, B, T, D):
+    """csrc/pair_bwd.hip: a pair MLP behind its factorised first layer, forward and backward per pair on chip, against torch autograd of
+    the dense formulation in float64: the output, the gradients of both first-layer tables (sums over the detections / the tracks) and
+    of every later weight and bias; twice the same bits (fixed summation order)."""
+    import ctypes as C
+    from shasta_amd import hip
+    lib = hip.load()
+    dev = torch.device("cuda:0")
+    assert lib.shasta_pair_mlp_supported(F) == 1 and lib.shasta_pair_mlp_supported(128) == 0
+    widths = _PAIR_MLP_WIDTHS[(kind, F)]
+    g = torch.Generator().manual_seed(100 * kind + F + T)
+    UP = torch.randn(B * T, widths[0], generator=g)
+    UC = torch.randn(B * D, widths[0], generator=g)
+    layers = [(torch.randn(widths[i + 1], widths[i], generator=g) / widths[i] ** 0.5, torch.randn(widths[i + 1], generator=g) * 0.3) for i in range(len(widths) - 1)]
+    gout = torch.randn(B * T * D, widths[-1], generator=g)
+    # float64 autograd of the dense formulation
+    UPd, UCd = UP.double().requires_grad_(True), UC.double().requires_grad_(True)
+    ld = [(w.double().requires_grad_(True), b.double().requires_grad_(True)) for w, b in layers]
+    h = torch.relu(UPd.view(B, T, 1, -1) + UCd.view(B, 1, D, -1))
+    for i, (w, b) in enumerate(ld):
+        h = h @ w.t() + b
+        if i + 1 < len(ld):
+            h = torch.relu(h)
+    want = h.reshape(B * T * D, -1)
+    want.backward(gout.double())
+    dl = [(w.to(dev).contiguous(), b.to(dev).contiguous()) for w, b in layers]
+    flat = [t for wb in dl for t in wb] + [None] * (6 - 2 * len(dl))
+    wt = (C.c_void_p * 6)(*[None if t is None else t.data_ptr() for t in flat])
+    UPg, UCg, goutg = UP.to(dev), UC.to(dev), gout.to(dev)
+    out = torch.empty(B * T * D, widths[-1], device=dev)
+    hip.check(lib.shasta_pair_mlp_forward_f32(kind, F, hip.ptr(UPg), hip.ptr(UCg), wt, B, T, D, hip.ptr(out), hip.stream_ptr()), "pair_mlp_forward")
+    assert float((out.double().cpu() - want.detach()).abs().max()) <= 2e-5 * max(1.0, float(want.detach().abs().max()))
+    nb = lib.shasta_pair_mlp_workspace_bytes(kind, F, B, T, D)
+    nimg = lib.shasta_pair_mlp_grad_floats(kind, F)
+    assert nb > 0 and nimg == sum(w.numel() + b.numel() for w, b in layers)
+    res = []
+    for _ in range(2):
+        ws = torch.full(((nb + 3) // 4,), float("nan"), device=dev)
+        gUP, gUC = torch.full_like(UPg, float("nan")), torch.full_like(UCg, float("nan"))
+        img = torch.full((nimg,), float("nan"), device=dev)
+        hip.check(lib.shasta_pair_mlp_backward_f32(kind, F, hip.ptr(UPg), hip.ptr(UCg), wt, hip.ptr(goutg), B, T, D, hip.ptr(gUP), hip.ptr(gUC),
+                                                   hip.ptr(img), hip.ptr(ws), nb, hip.stream_ptr()), "pair_mlp_backward")
+        res.append((gUP.cpu(), gUC.cpu(), img.cpu()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b), "the gradients are sums in a fixed order"
+    gUP, gUC, img = res[0]
+    _close("gUP", gUP, UPd.grad, rtol=1e-5)
+    _close("gUC", gUC, UCd.grad, rtol=1e-5)
+    o = 0
+    for i, (w, b) in enumerate(ld):
+        _close("gW%d" % (i + 2), img[o:o + w.numel()].view_as(w), w.grad, rtol=1e-5)
+        _close("gb%d" % (i + 2), img[o + w.numel():o + w.numel() + b.numel()], b.grad, rtol=1e-5)
+        o += w.numel() + b.numel()
+    # too small a workspace, an unsupported width: errors, not writes
+    assert lib.shasta_pair_mlp_backward_f32(kind, F, hip.ptr(UPg), hip.ptr(UCg), wt, hip.ptr(goutg), B, T, D, hip.ptr(gUP.to(dev)), hip.ptr(gUC.to(dev)),
+                                            hip.ptr(img.to(dev)), hip.ptr(ws), nb - 4, hip.stream_ptr()) != 0
+    assert lib.shasta_pair_mlp_forward_f32(kind if kind != 1 else 0, 128, hip.ptr(UPg), hip.ptr(UCg), wt, B, T, D, hip.ptr(out), hip.stream_ptr()) == hip.E_UNSUPPORTED
+
+
+@pytest.mark.gpu
+def test_on_chip_and_dense_pair_backward_agree():
+    """Shasta.dense_pair_backward = True keeps the round-4 formulation (hidden activations of every pair in HBM, strided GEMMs); the
+    default recomputes per pair on chip.  Same gradients up to fp32 summation order."""
+    from shasta_amd import training
+    c, model, w, a, b, det, prev, gt = _case(20, 3, 4, 3, seed=9, n_real=15)
+    dev = torch.device("cuda:0")
+    model = model.to(dev).train()
+    grads = {}
+    for dense in (False, True):
+        model.dense_pair_backward = dense
+        model.zero_grad(set_to_none=True)
+        ad, bd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        m1, m2 = training.affinity_train(model, ad, bd, det.to(dev).contiguous(), prev.to(dev).contiguous())
+        training.affinity_loss(m1, m2, gt.to(dev)).backward()
+        grads[dense] = ({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, ad.grad.clone(), bd.grad.clone())
+    assert set(grads[False][0]) == set(grads[True][0]) and len(grads[False][0]) == 2 * (8 + 4 + 8 + 3 + 3 + 6)
+    for k in grads[False][0]:
+        _close(k, grads[False][0][k], grads[True][0][k], rtol=2e-5)
+    _close("d bev", grads[False][1], grads[True][1], rtol=2e-5)
+    _close("d prev_bev", grads[False][2], grads[True][2], rtol=2e-5)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("nf", [3, 7])
 def test_hand_dist_forward_and_anchor_gradient(nf):
@@ -376,7 +466,7 @@ def test_lowrank_outer_and_smallm_nn(R, H, K):
     dW = torch.empty(H, K, device=dev)
     hip.check(lib.shasta_lowrank_outer_f32(hip.ptr(G), H + 5, hip.ptr(X), K + 64, R, H, K, hip.ptr(dW), hip.stream_ptr()), "outer")
     want = G[:, :H].double().t() @ X[:, :K].double()
-    assert float((dW.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert float((dW.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.detach().abs().max()))
     Y = torch.randn(R, K + 8, device=dev)
     y0 = Y.clone()
     nb = lib.shasta_smallm_nn_workspace_bytes(R, H, K)
@@ -384,7 +474,7 @@ def test_lowrank_outer_and_smallm_nn(R, H, K):
     for acc in (1, 0):
         hip.check(lib.shasta_smallm_nn_f32(hip.ptr(G), H + 5, hip.ptr(W), R, H, K, hip.ptr(Y), K + 8, acc, hip.ptr(ws), nb, hip.stream_ptr()), "nn")
         want = G[:, :H].double() @ W.double() + (y0[:, :K].double() if acc else 0)
-        assert float((Y[:, :K].double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+        assert float((Y[:, :K].double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.detach().abs().max()))
         assert torch.equal(Y[:, K:], y0[:, K:])  # padding columns untouched
         Y.copy_(y0)
 
