@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void gemm_strided_bf16_kernel(GemmS g) {
 // C[row][col] = sum_z part[z*stride + i], i = row*N + col: 16 elements x 16 z-groups per block, each group sums its
 // slices in order and the groups are combined in order (fixed association -> deterministic)
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, long stride, int nz, float* __restrict__ C,
-                                                          long n, int N, int ldc) {
+                                                          long n, int N, int ldc, const float* __restrict__ bias, int act) {
     __shared__ float red[16][17];
     const int e = threadIdx.x & 15, q = threadIdx.x >> 4;
     const long i = (long)blockIdx.x * 16 + e;
@@ -532,6 +532,9 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restric
         float t = red[0][e];
 #pragma unroll
         for (int k = 1; k < 16; ++k) t += red[k][e];
+        if (bias) t += bias[i % N];
+        if ((act & 3) == 1) t = relu_nan(t);
+        else if ((act & 3) == 2) t = fabsf(t);
         C[(i / N) * ldc + (i % N)] = t;
     }
 }
@@ -549,7 +552,8 @@ int launch_gemm_strided(const float* A, long sa_m, long sa_k, const float* W, lo
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     int nz = 1;
     // long reductions with few output tiles (weight gradients): split the reduction over grid.z
-    if (splitk_ws && K >= 1024 && tiles < 128 && !mask && (act & 7) == 0 && !bias) {
+    // (bias and activation then belong to the sum of the slices: gemm_reduce_kernel applies them)
+    if (splitk_ws && K >= 1024 && tiles < 128 && !mask && (act & 4) == 0) {
         nz = min(min(512, cdiv(1024, tiles)), cdiv(K, 256));
         while (nz > 1 && (size_t)nz * M * N * sizeof(float) > splitk_ws_bytes) --nz;
     }
@@ -563,6 +567,8 @@ int launch_gemm_strided(const float* A, long sa_m, long sa_k, const float* W, lo
     g.kslice = cdiv(cdiv(K, nz), BK) * BK;
     nz = cdiv(K, g.kslice);
     g.C = splitk_ws;
+    g.bias = nullptr;
+    g.act = act & 8;
     g.ldc = N;
     g.slice_stride = (long)M * N;
     if (act & 8) hipLaunchKernelGGL(gemm_strided_bf16_kernel, dim3(cdiv(N, BN), cdiv(M, BM), nz), dim3(256), 0, st, g);
@@ -570,7 +576,7 @@ int launch_gemm_strided(const float* A, long sa_m, long sa_k, const float* W, lo
     int rc = check_launch("gemm_strided(split-K)");
     if (rc) return rc;
     const long n = (long)M * N;
-    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, splitk_ws, g.slice_stride, nz, C, n, N, ldc);
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, splitk_ws, g.slice_stride, nz, C, n, N, ldc, bias, act);
     return check_launch("gemm_reduce");
 }
 

@@ -312,6 +312,27 @@ __global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict
     out[i] = s;
 }
 
+// the same for many slices of a short vector (the weight image: one slice per wave of the backward kernel): 16 elements x 16 slice
+// groups per block; a group sums its slices g, g + 16, ... in order, the groups are combined in order
+__global__ __launch_bounds__(256) void sum_many_slices_kernel(const float* __restrict__ part, int nslices, int n, float* __restrict__ out) {
+    __shared__ float red[16][17];
+    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + e;
+    float s = 0.0f;
+    if (i < n) {
+#pragma unroll 8
+        for (int k = g; k < nslices; k += 16) s += part[(size_t)k * n + i];
+    }
+    red[g][e] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float t = red[0][e];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][e];
+        out[i] = t;
+    }
+}
+
 namespace {
 
 struct PbPlan {
@@ -370,7 +391,7 @@ int pb_backward(const float* UP, const float* UC, const float* const* w, const f
     const long n1 = (long)B * T * M::E1, n2 = (long)B * D * M::E1;
     hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, gup, p.nd, n1, gUP);
     hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, guc, p.nslice, n2, gUC);
-    hipLaunchKernelGGL(sum_slices_kernel, dim3(cdiv(M::NE, 256)), dim3(256), 0, st, wp, B * p.nd * p.nslice, (long)M::NE, gW);
+    hipLaunchKernelGGL(sum_many_slices_kernel, dim3(cdiv(M::NE, 16)), dim3(256), 0, st, wp, B * p.nd * p.nslice, (int)M::NE, gW);
     return check_launch("pair_mlp_backward sums");
 }
 

@@ -261,10 +261,10 @@ class _AffinityTrainFn(torch.autograd.Function):
             if hid is None:
                 hid = torch.empty(B, max(H, 1), device=dev)
                 if H > 0:
-                    _gemm(lib, x, (sx_m, 1), w1, (K, 1), B, H, K, hid, ldc=max(H, 1), bias=b1, act=1)
+                    _gemm(lib, x, (sx_m, 1), w1, (K, 1), B, H, K, hid, ldc=max(H, 1), bias=b1, act=1, ws=ws)  # (few rows, long K: split)
             pre = torch.empty(B, nout, device=dev)
             if H > 0:
-                _gemm(lib, hid, (max(H, 1), 1), w2, (H, 1), B, nout, H, pre, bias=b2)
+                _gemm(lib, hid, (max(H, 1), 1), w2, (H, 1), B, nout, H, pre, bias=b2, ws=ws)
             else:
                 pre.copy_(b2.expand(B, nout))
             gpre = torch.empty(B, nout, device=dev)
