@@ -503,6 +503,12 @@ int shasta_scale_f32(float* x, long n, float alpha, shasta_stream_t stream);
 int shasta_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                          float beta2, float eps, float weight_decay, int step, shasta_stream_t stream);
 
+/* The same update for `count` tensors (host arrays of device pointers and element counts) that share lr / betas / eps / weight_decay /
+ * step: one launch per 48 tensors (the small weight and bias tensors of a model); no alignment requirement. */
+int shasta_adam_multi_f32(int count, float* const* param, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
+                          const long* n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                          shasta_stream_t stream);
+
 /* The same update for an (H, K) matrix whose gradient is the rank-R product g[h][k] = sum_r G[r][h] X[r][k] (G: (R, H) at ldg, X: (R, K) at
  * ldx; the first aug_shape layers of tools/nusc_shasta/train.py:198-218: G = gradient of the hidden activations - already divided by
  * the world size when the factors were gathered over the ranks -, X = the layer's inputs, R = frame-pairs of the step over all ranks,

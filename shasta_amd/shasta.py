@@ -258,7 +258,7 @@ class Shasta(BaseTrack):
              "f16grid": hip.OPT_F16X2_WEIGHT_STREAM | hip.OPT_F16X2_PAIR | hip.OPT_F16GRID_PAIR | hip.OPT_F16X2_AFF}[self.arithmetic]
         if self.arithmetic in ("f16x2", "f16grid") and self.precut_weight_stream:
             o |= hip.OPT_PRECUT_WEIGHT_STREAM
-        return o
+        return o | int(getattr(self, "extra_options", 0))  # (hip.OPT_ONE_PASS_AFF / OPT_TWO_PASS_AFF: the forms of the aff stage)
 
     def _build_weights(self):
         def lin(m):

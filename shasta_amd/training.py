@@ -238,7 +238,7 @@ class _AffinityTrainFn(torch.autograd.Function):
                 tail_grads, o = [], 0
                 for w_, b_ in mods[name][1:]:  # the image: [gW2 | gb2 | gW3 | gb3 | gW4 | gb4]
                     tail_grads.append((img[o:o + w_.numel()].view_as(w_), img[o + w_.numel():o + w_.numel() + b_.numel()]))
-                    o += w_.numel() + b_.numel()
+                    o += w_.numel() + b_.numel()  # (views at any 4-byte offset: FusedAdam updates small tensors without alignment demands)
                 pair_grads[name] = [first_layer_bwd_rows(name, gUP, gUC, offs_[name])] + tail_grads
                 del pws
                 continue
@@ -442,6 +442,8 @@ class FusedAdam(torch.optim.Optimizer):
     unfused optimizer's seven.  Same param_groups keys (so OneCycleLR, which cycles `lr` and `betas`, train.py:172, drives
     it unchanged) and the same state names (`step`, `exp_avg`, `exp_avg_sq`)."""
 
+    MULTI_MAX_NUMEL = 1 << 18  # tensors up to this size are updated together, 48 per launch
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lowrank_first_layers=None):
         """lowrank_first_layers = the Shasta model: its four aug_shape first-layer matrices (4 x 1 GB at N = 500) are updated straight from
         the FACTORS of their gradient (shasta_adam_lowrank_f32: 24 bytes per parameter instead of 36) - the backward then leaves their
@@ -460,6 +462,7 @@ class FusedAdam(torch.optim.Optimizer):
         lib = hip.load()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            small = {}  # step count -> the small tensors that share it: one launch for all of them (shasta_adam_multi_f32)
             for p in group["params"]:
                 factors = p.__dict__.pop("_shasta_grad_factors", None)
                 if p.grad is None and factors is None:
@@ -481,12 +484,27 @@ class FusedAdam(torch.optim.Optimizer):
                     torch.autograd.graph.increment_version(p)
                     continue
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if g.dtype != torch.float32 or not g.is_cuda:
+                    raise hip.ShastaHipError("FusedAdam needs fp32 device gradients")
+                if p.numel() <= self.MULTI_MAX_NUMEL:
+                    small.setdefault(st["step"], []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+                    continue
+                if g.data_ptr() % 16:
+                    g = g.clone()
                 hip.check(lib.shasta_adam_step_f32(hip.ptr(p), hip.ptr(g), hip.ptr(st["exp_avg"]), hip.ptr(st["exp_avg_sq"]), p.numel(),
                                                    float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                    float(group["weight_decay"]), st["step"], hip.stream_ptr()), "shasta_adam_step_f32")
                 # the kernel wrote through the raw pointer: tell torch (Shasta._ensure_packed and the conv-weight cache key
                 # their packed copies on (data_ptr, _version); autograd's saved-tensor checks rely on it too)
                 torch.autograd.graph.increment_version(p)
+            for step_no, items in small.items():
+                k = len(items)
+                arr = lambda j: (C.c_void_p * k)(*[it[j].data_ptr() for it in items])  # noqa: E731
+                hip.check(lib.shasta_adam_multi_f32(k, arr(0), arr(1), arr(2), arr(3), (C.c_long * k)(*[it[0].numel() for it in items]),
+                                                    float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                                    step_no, hip.stream_ptr()), "shasta_adam_multi_f32")
+                for it in items:
+                    torch.autograd.graph.increment_version(it[0])
         return loss
 
 

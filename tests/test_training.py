@@ -398,7 +398,8 @@ def test_fused_adam_matches_torch_adam(wd):
     from shasta_amd.training import FusedAdam
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    shapes = [(7,), (33, 5), (1000, 129), (1,)]
+    # small tensors go 48 to a launch (shasta_adam_multi_f32: here two launches), (600, 500) is above FusedAdam.MULTI_MAX_NUMEL
+    shapes = [(7,), (33, 5), (1000, 129), (1,), (600, 500)] + [(3, 5), (11,)] * 26
     pa = [torch.nn.Parameter(torch.randn(*s, device=dev)) for s in shapes]
     pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
     oa = FusedAdam(pa, lr=3e-3, weight_decay=wd)
@@ -408,7 +409,9 @@ def test_fused_adam_matches_torch_adam(wd):
     for it in range(10):
         for x, y in zip(pa, pb):
             g = torch.randn_like(x) * (0.1 + it)
-            x.grad, y.grad = g.clone(), g.clone()
+            odd = torch.empty(g.numel() + 1, device=dev)  # a gradient that is a view at a 4-byte offset (csrc/pair_bwd.hip's image)
+            odd[1:].copy_(g.flatten())
+            x.grad, y.grad = odd[1:].view_as(g), g.clone()
         oa.step()
         ob.step()
         sa.step()

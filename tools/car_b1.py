@@ -17,3 +17,9 @@ r = bn.measure(bench.CAR, B, steps, 10, "f16x2")
 print("car B=%d: %.4f ms per step (%.0f fp/s), weight stream %.4f ms, pair %.4f ms" % (B, r["ms_per_step"], r["value"], r["l1_ms"], r["pair_ms"]))
 r = bn.measure(bench.CAR, B, steps, 10, "f16x2", graph=True)
 print("car B=%d, hipGraph replay: %.4f ms per step (%.0f fp/s)" % (B, r["ms_per_step"], r["value"]))
+if os.environ.get("CAR_B1_ONE_PASS"):
+    from shasta_amd import hip  # noqa: E402
+    bn.model(bench.CAR).extra_options = hip.OPT_ONE_PASS_AFF
+    bn.model(bench.CAR).invalidate_weights_cache()
+    r = bn.measure(bench.CAR, B, steps, 10, "f16x2", graph=True)
+    print("car B=%d, one-pass aff, hipGraph replay: %.4f ms per step (%.0f fp/s)" % (B, r["ms_per_step"], r["value"]))
