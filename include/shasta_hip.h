@@ -473,6 +473,13 @@ int shasta_hand_dist_bwd_f32(const float* gdist, int ldg, const float* prev_tab,
 int shasta_combine_bwd_f32(const float* gres, const float* coeff, int ldc, const float* fused, int ldf, const float* shape,
                            int lds, const float* dist, int B, int T, int D, int ld, float* gcoeff, float* gfused,
                            float* gshape, float* gdist, shasta_stream_t stream);
+/* The training loss of tools/nusc_shasta/train.py:200-211 on m1 (B, N, N+2), m2 (B, N+2, N), gt (B, N+2, N+2), all dense:
+ * sums[0..3] = sum(gt1 . -log(m1 + 1e-10)), sum(gt1), sum(gt2 . -log(m2 + 1e-10)), sum(gt2); sums[4] = the loss; ws: 4 B (N+2) floats.
+ * _bwd: g1 = dloss/dm1, g2 = dloss/dm2 scaled by the device scalar gloss[0].  Fixed summation order. */
+int shasta_affinity_loss_f32(const float* m1, const float* m2, const float* gt, int B, int N, float* ws, float* sums,
+                             shasta_stream_t stream);
+int shasta_affinity_loss_bwd_f32(const float* m1, const float* m2, const float* gt, const float* sums, const float* gloss, int B, int N,
+                                 float* g1, float* g2, shasta_stream_t stream);
 /* gradient of the two softmaxes (shasta.py:324-325) w.r.t. matched (B, N+2, ld) */
 int shasta_softmax_bwd_f32(const float* m1, const float* g1, const float* m2, const float* g2, int B, int N, float* gmatched,
                            int ld, shasta_stream_t stream);

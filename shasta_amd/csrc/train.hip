@@ -199,6 +199,76 @@ __global__ void combine_bwd_kernel(const float* __restrict__ gres, const float* 
     gdist[bt * ld + d] = g * be;
 }
 
+// ---- the training loss (tools/nusc_shasta/train.py:200-211) and its gradient ------------------------------------------------
+//   loss = (sum(gt1 . -log(m1 + 1e-10)) / sum(gt1) + sum(gt2 . -log(m2 + 1e-10)) / sum(gt2)) / 2,  gt1 = gt[:, :N, :], gt2 = gt[:, :, :N]
+// one block per row (b, t) of gt: the four sums of the row in a fixed order; loss_finish_kernel adds the rows in order.
+__global__ __launch_bounds__(256) void loss_rows_kernel(const float* __restrict__ m1, const float* __restrict__ m2, const float* __restrict__ gt,
+                                                        int N, float* __restrict__ part) {
+    __shared__ float red[4][256];
+    const int T = N + 2, t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* g = gt + ((size_t)b * T + t) * T;
+    float s1 = 0.0f, c1 = 0.0f, s2 = 0.0f, c2 = 0.0f;
+    for (int d = tid; d < T; d += 256) {
+        const float w = g[d];
+        if (t < N) {
+            s1 = fmaf(w, -logf(m1[((size_t)b * N + t) * T + d] + 1e-10f), s1);
+            c1 += w;
+        }
+        if (d < N) {
+            s2 = fmaf(w, -logf(m2[((size_t)b * T + t) * N + d] + 1e-10f), s2);
+            c2 += w;
+        }
+    }
+    red[0][tid] = s1; red[1][tid] = c1; red[2][tid] = s2; red[3][tid] = c2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[k][tid] += red[k][tid + off];
+        __syncthreads();
+    }
+    if (tid < 4) part[((size_t)b * T + t) * 4 + tid] = red[tid][0];
+}
+
+// sums[0..3] = (s1, c1, s2, c2) over all rows, sums[4] = the loss
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ part, int rows, float* __restrict__ sums) {
+    __shared__ float red[4][64];
+    const int k = threadIdx.x & 3, q = threadIdx.x >> 2;
+    float s = 0.0f;
+    for (int r = q; r < rows; r += 64) s += part[(size_t)r * 4 + k];
+    red[k][q] = s;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float t = 0.0f;
+        for (int j = 0; j < 64; ++j) t += red[threadIdx.x][j];
+        sums[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) sums[4] = (sums[0] / sums[1] + sums[2] / sums[3]) * 0.5f;
+}
+
+// g1 = dloss/dm1 = -gt1 / (m1 + 1e-10) * gloss / (2 sum(gt1)), g2 likewise; gloss read from device memory
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ m1, const float* __restrict__ m2, const float* __restrict__ gt,
+                                                       const float* __restrict__ sums, const float* __restrict__ gloss, int N, long n1,
+                                                       float* __restrict__ g1, float* __restrict__ g2) {
+    const int T = N + 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n1) return;
+    const float gl = gloss[0] * 0.5f;
+    {  // element i of m1 (B, N, T)
+        const int d = i % T;
+        const long bt = i / T;
+        const long b = bt / N;
+        const int t = bt - b * N;
+        g1[i] = -gt[((size_t)b * T + t) * T + d] / (m1[i] + 1e-10f) * (gl / sums[1]);
+    }
+    {  // element i of m2 (B, T, N): the same count
+        const int d = i % N;
+        const long bt = i / N;
+        g2[i] = -gt[(size_t)bt * T + d] / (m2[i] + 1e-10f) * (gl / sums[3]);
+    }
+}
+
 // ---- softmax backward (shasta.py:324-325): gmatched = rows-part + cols-part ------------------------------------------
 // rows t < N: gz = m1 * (g1 - sum_d g1*m1) over the D entries ; cols d < N: gz = m2 * (g2 - sum_t g2*m2) over the T entries
 __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ m1, const float* __restrict__ g1, int B,
@@ -576,6 +646,25 @@ extern "C" int shasta_combine_bwd_f32(const float* gres, const float* coeff, int
     hipLaunchKernelGGL(combine_bwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, as_stream(stream), gres, coeff, ldc, fused,
                        ldf, shape, lds_, dist, D, ld, P, gcoeff, gfused, gshape, gdist);
     return check_launch("combine_bwd");
+}
+
+extern "C" int shasta_affinity_loss_f32(const float* m1, const float* m2, const float* gt, int B, int N, float* ws, float* sums,
+                                        shasta_stream_t stream) {
+    SHASTA_REQUIRE(m1 && m2 && gt && ws && sums && B > 0 && N > 0, "affinity_loss: bad argument");
+    hipLaunchKernelGGL(loss_rows_kernel, dim3(N + 2, B), dim3(256), 0, as_stream(stream), m1, m2, gt, N, ws);
+    int rc = check_launch("affinity_loss rows");
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), ws, B * (N + 2), sums);
+    return check_launch("affinity_loss");
+}
+
+extern "C" int shasta_affinity_loss_bwd_f32(const float* m1, const float* m2, const float* gt, const float* sums, const float* gloss, int B,
+                                            int N, float* g1, float* g2, shasta_stream_t stream) {
+    SHASTA_REQUIRE(m1 && m2 && gt && sums && gloss && g1 && g2 && B > 0 && N > 0, "affinity_loss_bwd: bad argument");
+    const long n1 = (long)B * N * (N + 2);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, as_stream(stream), m1, m2, gt, sums, gloss, N, n1, g1,
+                       g2);
+    return check_launch("affinity_loss_bwd");
 }
 
 extern "C" int shasta_softmax_bwd_f32(const float* m1, const float* g1, const float* m2, const float* g2, int B, int N, float* gmatched,

@@ -428,8 +428,40 @@ def affinity_train(model, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes):
     return _AffinityTrainFn.apply(model, bev_nhwc, prev_bev_nhwc, det_boxes, prev_det_boxes, *affinity_params(model))
 
 
+class _AffinityLossFn(torch.autograd.Function):
+    """The loss below in two launches and its gradient in one (csrc/train.hip) instead of ~25 elementwise / reduction launches."""
+
+    @staticmethod
+    def forward(ctx, m1, m2, gt):
+        lib = hip.load()
+        B, N = m1.shape[0], m1.shape[1]
+        m1, m2, gt = m1.contiguous(), m2.contiguous(), gt.contiguous()
+        ws = torch.empty(4 * B * (N + 2), device=m1.device)
+        sums = torch.empty(8, device=m1.device)
+        hip.check(lib.shasta_affinity_loss_f32(hip.ptr(m1), hip.ptr(m2), hip.ptr(gt), B, N, hip.ptr(ws), hip.ptr(sums), hip.stream_ptr()),
+                  "shasta_affinity_loss_f32")
+        ctx.save_for_backward(m1, m2, gt, sums)
+        return sums[4].clone()
+
+    @staticmethod
+    def backward(ctx, gloss):
+        m1, m2, gt, sums = ctx.saved_tensors
+        lib = hip.load()
+        B, N = m1.shape[0], m1.shape[1]
+        g1, g2 = torch.empty_like(m1), torch.empty_like(m2)
+        gl = gloss.detach().float().reshape(1).contiguous()
+        hip.check(lib.shasta_affinity_loss_bwd_f32(hip.ptr(m1), hip.ptr(m2), hip.ptr(gt), hip.ptr(sums), hip.ptr(gl), B, N, hip.ptr(g1), hip.ptr(g2),
+                                                   hip.stream_ptr()), "shasta_affinity_loss_bwd_f32")
+        return g1, g2, None
+
+
 def affinity_loss(m1, m2, gt):
-    """tools/nusc_shasta/train.py:200-211."""
+    """tools/nusc_shasta/train.py:200-211.  Device fp32 tensors of the shapes affinity_train returns: the fused kernels; anything else
+    (the reference loop's own tensors, CPU tensors of the host-side tests): the same formula in torch operations."""
+    N = m1.shape[1]
+    if (m1.is_cuda and m1.dtype == m2.dtype == gt.dtype == torch.float32 and m1.dim() == 3 and tuple(m1.shape) == (m1.shape[0], N, N + 2)
+            and tuple(m2.shape) == (m1.shape[0], N + 2, N) and tuple(gt.shape) == (m1.shape[0], N + 2, N + 2) and not gt.requires_grad):
+        return _AffinityLossFn.apply(m1, m2, gt)
     gt1, gt2 = gt[:, :-2, :], gt[:, :, :-2]
     lf = (gt1 * (-torch.log(m1 + 1e-10))).sum() / gt1.sum()
     lb = (gt2 * (-torch.log(m2 + 1e-10))).sum() / gt2.sum()

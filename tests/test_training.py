@@ -268,6 +268,33 @@ def test_pair_hidden_and_reduce(B, T, E):
     assert float((gUC.view(B, T, E).double() - g4.sum(1)).abs().max()) < 1e-4
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(1, 1), (3, 20), (2, 500), (5, 90)])
+def test_fused_loss_matches_the_torch_formula(B, N):
+    """training.affinity_loss on device tensors (two launches + one for the gradient) against tools/nusc_shasta/train.py:200-211 written
+    in torch operations, value and gradients, under a scaled backward."""
+    from shasta_amd import training
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    m1 = torch.softmax(torch.randn(B, N, N + 2, generator=g), dim=2)
+    m2 = torch.softmax(torch.randn(B, N + 2, N, generator=g), dim=1)
+    gt = (torch.rand(B, N + 2, N + 2, generator=g) < 0.1).float()
+    gt[:, 0, 0] = 1.0
+    a1, a2 = m1.double().requires_grad_(True), m2.double().requires_grad_(True)
+    want = O.affinity_loss(a1, a2, gt.double())
+    (want * 3.0).backward()
+    d1, d2 = m1.to(dev).requires_grad_(True), m2.to(dev).requires_grad_(True)
+    got = training.affinity_loss(d1, d2, gt.to(dev))
+    assert got.shape == () and got.is_cuda
+    (got * 3.0).backward()
+    assert abs(float(got) - float(want)) <= 2e-6 * max(1.0, abs(float(want)))
+    _close("d m1", d1.grad, a1.grad, rtol=2e-6)
+    _close("d m2", d2.grad, a2.grad, rtol=2e-6)
+    # the same bits twice (fixed summation order)
+    again = training.affinity_loss(d1.detach(), d2.detach(), gt.to(dev))
+    assert torch.equal(again, got.detach())
+
+
 _PAIR_MLP_WIDTHS = {  # (kind, F) -> layer widths behind the factorised first layer (det3d/models/tracker/shasta.py:59-92)
     (0, 64): (8, 4, 2, 1), (1, 64): (32, 8, 1), (2, 64): (40, 10, 3), (0, 256): (32, 16, 8, 1), (1, 256): (32, 8, 1), (2, 256): (64, 16, 3),
     (0, 320): (40, 20, 10, 1), (1, 320): (32, 8, 1), (2, 320): (72, 18, 3)}
