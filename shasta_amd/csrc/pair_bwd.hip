@@ -57,6 +57,9 @@ constexpr size_t pb_lds_bytes(bool bwd) {
 }
 
 #define PB_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+#ifndef PB_ABL  // ablation builds only (tools/time_pair_mlp.py; wrong results): 1 no weight-gradient MFMAs, 2 no W2^T g2, 4 no sum over the lanes
+#define PB_ABL 0
+#endif
 
 // W2 (E2, E1), W3 (E3, E2), W4 (E4, E3): torch's nn.Linear layout; b2, b3, b4 their biases (W4, b4 unused when E4 == 0)
 template <class M, bool BWD>
@@ -149,12 +152,14 @@ __global__ __launch_bounds__(64 * PB_WPB) void pair_mlp_kernel(const float* __re
                 h1[kk] = relu_nan(u[kk] + uc[4 * kg + kk]);
                 if (BWD) L[(32 + M::H1 + 4 * kg + kk) * RS + lane] = h1[kk];
             }
+            // (consecutive MFMAs go to different accumulators: a 4x4x1 result is not back for the next issue slot)
+            f32x4 a2[KG2];
 #pragma unroll
-            for (int ob = 0; ob < KG2; ++ob) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(trow + M::T2F + (ob * KG1 + kg) * 16);
+            for (int ob = 0; ob < KG2; ++ob) a2[ob] = *reinterpret_cast<const f32x4*>(trow + M::T2F + (ob * KG1 + kg) * 16);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) z2[ob] = PB_MFMA4(a[kk], h1[kk], z2[ob]);
-            }
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int ob = 0; ob < KG2; ++ob) z2[ob] = PB_MFMA4(a2[ob][kk], h1[kk], z2[ob]);
         }
         float h2[E2P];
 #pragma unroll
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(64 * PB_WPB) void pair_mlp_kernel(const float* __re
                 const f32x4 a = *reinterpret_cast<const f32x4*>(trow + M::T3F + (qb * KG2 + og) * 16);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) z3[qb] = PB_MFMA4(a[kk], h2[4 * og + kk], z3[qb]);
-            }
+            }  // (short chains: KG3 <= 3 accumulators)
         float h3[E3P], res[NOUT];
 #pragma unroll
         for (int q = 0; q < E3P; ++q) h3[q] = z3[q / 4][q % 4];
@@ -234,37 +239,53 @@ __global__ __launch_bounds__(64 * PB_WPB) void pair_mlp_kernel(const float* __re
         }
         // ---- weight / bias gradients: sum over the 64 pairs of the tile on the matrix pipe ----
 #pragma unroll 8
-        for (int s = 0; s < 32; ++s) {
+        for (int s = 0; s < ((PB_ABL & 1) ? 0 : 32); ++s) {
             const float av = L[ka + 2 * s];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, L[(32 + 32 * nb) * RS + ka + 2 * s], acc[nb], 0, 0, 0);
         }
         // ---- first layer: gz1 = (W2^T g2) . [h1 > 0]; into this lane's gUC row, and over h1 in the tile for the sum over the lanes ----
+        constexpr int IG = (KG1 % 4 == 0) ? 4 : 2;  // input blocks in flight (KG1 = 2, 8, 10, 16, 18)
 #pragma unroll
-        for (int ib = 0; ib < KG1; ++ib) {
-            f32x4 gh = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ib0 = 0; ib0 < KG1; ib0 += IG) {
+            f32x4 gh[IG];
 #pragma unroll
-            for (int og = 0; og < KG2; ++og) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(trow + M::T2B + (ib * KG2 + og) * 16);
+            for (int j = 0; j < IG; ++j) gh[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) gh = PB_MFMA4(a[kk], g2[4 * og + kk], gh);
+            for (int og = 0; og < ((PB_ABL & 2) ? 0 : KG2); ++og) {
+                f32x4 a[IG];
+#pragma unroll
+                for (int j = 0; j < IG; ++j) a[j] = *reinterpret_cast<const f32x4*>(trow + M::T2B + ((ib0 + j) * KG2 + og) * 16);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int j = 0; j < IG; ++j) gh[j] = PB_MFMA4(a[j][kk], g2[4 * og + kk], gh[j]);
             }
-            const f32x4 u = *reinterpret_cast<const f32x4*>(upr + 4 * ib);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const float gz = (u[kk] + uc[4 * ib + kk]) > 0.0f ? gh[kk] : 0.0f;
-                guc[4 * ib + kk] += gz;
-                L[(32 + M::H1 + 4 * ib + kk) * RS + lane] = gz;
+            for (int j = 0; j < IG; ++j) {
+                const int ib = ib0 + j;
+                const f32x4 u = *reinterpret_cast<const f32x4*>(upr + 4 * ib);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const float gz = (u[kk] + uc[4 * ib + kk]) > 0.0f ? gh[j][kk] : 0.0f;
+                    guc[4 * ib + kk] += gz;
+                    L[(32 + M::H1 + 4 * ib + kk) * RS + lane] = gz;
+                }
             }
         }
 #pragma unroll
         for (int r0 = 0; r0 < E1; r0 += 64) {
             if (r0 + lane < E1) {
                 const float* row = L + (32 + M::H1 + r0 + lane) * RS;
-                float s = 0.0f;
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;  // four chains, combined in a fixed order
 #pragma unroll
-                for (int j = 0; j < 64; ++j) s += row[j];
-                gup_part[(((size_t)dt * B + b) * T + t) * E1 + r0 + lane] = s;
+                for (int j = 0; j < ((PB_ABL & 4) ? 4 : 64); j += 4) {
+                    s0 += row[j];
+                    s1 += row[j + 1];
+                    s2 += row[j + 2];
+                    s3 += row[j + 3];
+                }
+                gup_part[(((size_t)dt * B + b) * T + t) * E1 + r0 + lane] = (s0 + s1) + (s2 + s3);
             }
         }
     }
