@@ -638,10 +638,13 @@ def extra_train_step(bench, args, ex):
     from shasta_amd import training
     ts = {"note": "ms per step = forward (rows 4-16) + loss + backward + Adam; frame-pairs/s = B / step; fwd / bwd / adam from events on the stream"}
     ts["note"] += ("; *_dense: the four first-layer gradients of aug_shape written out and read back by Adam (36 B per parameter), the others: "
-                   "Adam straight from their factors (FusedAdam(lowrank_first_layers=model), 24 B per parameter)")
+                   "Adam straight from their factors (FusedAdam(lowrank_first_layers=model), 24 B per parameter); *_densepairs: the pair MLPs' "
+                   "backward in the dense formulation of round 4 (hidden activations of every pair in HBM, strided GEMMs: "
+                   "Shasta.dense_pair_backward), the others (fp32): recomputed and back-propagated per pair on chip (csrc/pair_bwd.hip); "
+                   "bf16: the GEMMs around them (first-layer tables, aff) with bf16 operands")
     for (cfg, B, steps) in ((CAR, 16, 10), (CAR, 64, 6), (HEADLINE, 8, 3)):
-        for prec in ("fp32", "bf16", "fp32_dense"):
-            if prec == "fp32_dense" and cfg is not HEADLINE:
+        for prec in ("fp32", "bf16", "fp32_dense", "fp32_densepairs"):
+            if prec.startswith("fp32_dense") and cfg is not HEADLINE:
                 continue
             key = "n%d_b%d_%s" % (cfg["max_obj"], B, prec)
             try:
@@ -651,6 +654,7 @@ def extra_train_step(bench, args, ex):
                         type="Shasta", reader=None, backbone=None, neck=None,
                         bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8), **cfg)).train()
                 model.train_precision = prec.split("_")[0]
+                model.dense_pair_backward = prec.endswith("_densepairs")
                 params = training.affinity_params(model)
                 opt = training.FusedAdam(params, lr=1e-4, lowrank_first_layers=None if prec.endswith("_dense") else model)
                 N = cfg["max_obj"]

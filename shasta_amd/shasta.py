@@ -159,8 +159,11 @@ class Shasta(BaseTrack):
         # 512 frame-pairs.  False keeps only the fp32 checkpoint tensors resident.
         self.precut_weight_stream = True
         # training backward (shasta_amd/training.py): "fp32" (parity path, like the reference's train.py:149) or "bf16": the GEMMs of
-        # the pair MLPs and of aff take bf16 operands with fp32 accumulation (BASELINE config 5's reduced-precision option)
+        # aff and of the pair MLPs' first-layer tables take bf16 operands with fp32 accumulation (BASELINE config 5's reduced-precision
+        # option); the pair MLPs' later layers run per pair on chip in fp32 either way, unless dense_pair_backward keeps the round-4
+        # formulation (every pair's hidden activations in HBM, strided GEMMs - with bf16 operands under the option)
         self.train_precision = "fp32"
+        self.dense_pair_backward = False
         self.keep_intermediates = False  # tests: also return residual / matched via self.last_intermediates
         self.last_intermediates = None
 

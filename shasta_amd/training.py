@@ -116,8 +116,8 @@ class _AffinityTrainFn(torch.autograd.Function):
         Dp = (D + 3) // 4 * 4
         P = B * T * D
         ws = torch.empty(64 * 1024 * 1024 // 4, device=dev)  # split-K scratch
-        # BASELINE config 5's reduced-precision option: the GEMMs of the pair MLPs and of `aff` (recomputation and gradients) take bf16
-        # operands with fp32 accumulation; parameters, their gradients, Adam and the anchor MLPs stay fp32
+        # BASELINE config 5's reduced-precision option: the GEMMs of `aff` and of the pair MLPs' first-layer tables (recomputation and
+        # gradients) take bf16 operands with fp32 accumulation; parameters, their gradients, Adam and the anchor MLPs stay fp32
         bf = getattr(model, "train_precision", "fp32") == "bf16"
         st = hip.stream_ptr
         g1 = g1.contiguous().float()
@@ -194,10 +194,11 @@ class _AffinityTrainFn(torch.autograd.Function):
                     _gemm(lib, gU, (E, 1), w0[:, col:], (1, kin), R, wd, E, gtab, ldc=ld, accum=True, bf16=bf)      # dX += gU W0 block
             return gW0, gb0
 
-        # The later layers of a pair MLP.  Default (fp32, F = 64 | 256 | 320): recomputed and back-propagated per pair on chip
-        # (csrc/pair_bwd.hip) - per pair only the MLP's output is written and its gradient read.  Otherwise (bf16 operands, other
-        # widths, Shasta.dense_pair_backward): the dense formulation - hidden activations of every pair materialised, strided GEMMs.
-        on_chip = (not bf) and bool(lib.shasta_pair_mlp_supported(F)) and not getattr(model, "dense_pair_backward", False)
+        # The later layers of a pair MLP.  Default (F = 64 | 256 | 320): recomputed and back-propagated per pair on chip in fp32
+        # (csrc/pair_bwd.hip) - per pair only the MLP's output is written and its gradient read; train_precision = "bf16" then shows in
+        # the GEMMs around them (first-layer tables, aff).  Otherwise (other widths, Shasta.dense_pair_backward): the dense formulation -
+        # hidden activations of every pair materialised, strided GEMMs (bf16 operands there too under the option).
+        on_chip = bool(lib.shasta_pair_mlp_supported(F)) and not getattr(model, "dense_pair_backward", False)
         kinds = {"fs": 0, "fd": 1, "rc": 2}
         tails, Hs, offs_, tabs, wts = {}, {}, {}, {}, {}
         outs = {}
