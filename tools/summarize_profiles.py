@@ -66,7 +66,8 @@ if __name__ == "__main__":
     os.makedirs(P, exist_ok=True)
     for name, dst in (("prof_default", "bench_default_b512"), ("prof_b1024", "bench_b1024"), ("prof_b128", "bench_b128"), ("prof_b64", "bench_b64"), ("prof_b1", "bench_b1"),
                       ("prof_pieces", "bench_pieces_b512"), ("prof_conv_b8", "shared_conv_b8"), ("prof_conv_b8_heads7", "shared_conv_b8_heads7"),
-                      ("prof_pair320_car", "pair_f320_car_b512"), ("prof_pair320_n500", "pair_f320_n500_b256")):
+                      ("prof_pair320_car", "pair_f320_car_b512"), ("prof_pair320_n500", "pair_f320_n500_b256"),
+                      ("prof_train_n500", "train_n500_b8"), ("prof_train_n90", "train_n90_b64")):
         src = os.path.join(G, SRC, name, "d_kernel_stats.csv")
         if os.path.exists(src):
             kernel_stats(src, os.path.join(P, "%s_kernel_stats_%s.csv" % (TAG, dst)))
@@ -81,6 +82,10 @@ if __name__ == "__main__":
             lines = [l for l in open(os.path.join(G, SRC, f)) if l.startswith("{")]
             if lines:
                 json.dump(json.loads(lines[-1]), open(os.path.join(P, TAG + "_" + f), "w"), indent=1)
+        if f in ("train_n500.log", "train_n90.log", "pair_mlp.log"):
+            lines = [l.rstrip() for l in open(os.path.join(G, SRC, f)) if "ms/step" in l or "fwd0" in l]
+            if lines:
+                open(os.path.join(P, TAG + "_" + f.replace(".log", ".txt")), "w").write("\n".join(lines) + "\n")
         if f == "stage_power.log":
             lines = [l for l in open(os.path.join(G, SRC, f)) if l.startswith("{")]
             if lines:
