@@ -12,12 +12,14 @@
 //   4 result registers of a lane are 4 features of ITS pair), the weights as A operands from LDS tables the workgroup builds once.
 //   (Weights as scalar operands of plain FMAs - the first form - do not survive the compiler: it hoists a thousand s_loads to the top
 //   of the unrolled body and spills the scalar registers into vector lanes; and scalar loads share lgkmcnt with the LDS traffic.)
-//   What sums over the LANES goes through a per-wave LDS tile [feature row][lane] (row stride 65 floats: conflict-free both ways):
-//     weight / bias gradients: v_mfma_f32_32x32x2_f32 with the pair index on the K axis - A = the rows [g2 | g3 | g4] (<= 32), B = the rows
-//     [h1 | h2 | h3 | 1] in blocks of 32 - accumulated over all pairs of the wave (the matrix pipe is otherwise idle here); the blocks
-//     hold every product row x row, the epilogue keeps g2 x h1, g3 x h2, g4 x h3 and the products with the row of ones (the biases);
+//   What sums over the LANES goes through a per-wave LDS tile [feature row][lane] (row stride 68 floats = 4 mod 32: the 16 rows x 4 pairs
+//   of an MFMA operand cover the banks once, a lane's b128 reads along its row are conflict-free too):
+//     weight / bias gradients: v_mfma_f32_16x16x4_f32 with the pair index on the K axis - A = 16 of the rows [g2 | g3 | g4], B = 16 of the
+//     rows [h1 | h2 | h3 | 1], only the blocks that hold a wanted product (g2 x h1, g3 x h2, g4 x h3, g x 1 = the biases: 7 of 12 blocks at
+//     F = 256's res_coeff) - accumulated over all pairs of the wave (the matrix pipe is otherwise idle);
 //     gUP[(b,t)][i] = sum over the tile's lanes of gz1: lane i sums row i of the tile (gz1 overwrites h1 after the MFMAs have read it;
-//     LDS operations of one wave execute in order, the tile is private to the wave: no barrier anywhere in the kernel).
+//     LDS operations of one wave execute in order, the tile is private to the wave: no barrier anywhere in the loop).
+//   The UP rows of the wave's tracks arrive a chunk (one 1 KB LDS-DMA) ahead of their use.
 //   Partial results - gUP per detection tile, gUC per track slice, the weight image per wave - are summed in a fixed order by
 //   sum_slices_kernel: every gradient is deterministic.
 #include "common.hpp"
@@ -31,17 +33,27 @@ struct PairMlp {
     static constexpr int NOUT = E4 ? E4 : E3;
     static constexpr int G2 = 0, G3 = E2, G4 = E2 + E3, EG = E2 + E3 + E4;                 // rows of the A tile
     static constexpr int H1 = 0, H2 = E1, H3 = E1 + E2, ONE = E1 + E2 + (E4 ? E3 : 0), EH = ONE + 1;  // rows of the B tile
-    static constexpr int NB = (EH + 31) / 32;
-    static constexpr int ROWS = 32 + 32 * NB, RS = 65;
+    // 16 x 16 x 4 tiles of the weight-gradient products: MB blocks of 16 gradient rows x NBH blocks of 16 activation rows, of which only
+    // the blocks that hold a wanted product (g2 x h1, g3 x h2, g4 x h3, any g x 1) are computed
+    static constexpr int MB = (EG + 15) / 16, NBH = (EH + 15) / 16;
+    static constexpr int ROWS = 32 + 16 * NBH, RS = 68;  // row stride = 4 mod 32 floats: the 16 rows x 4 pairs of an operand cover the banks once
     static constexpr int LDS_TILE = ROWS * RS;  // floats per wave
+    static constexpr bool overlap(int a0, int a1, int b0, int b1) { return a0 < b1 && b0 < a1; }
+    static constexpr bool needed(int mb, int nb) {
+        const int g0 = 16 * mb, g1 = g0 + 16, h0 = 16 * nb, h1 = h0 + 16;
+        const bool one = overlap(h0, h1, ONE, ONE + 1);
+        return (overlap(g0, g1, G2, G2 + E2) && (overlap(h0, h1, H1, H1 + E1) || one)) ||
+               (overlap(g0, g1, G3, G3 + E3) && (overlap(h0, h1, H2, H2 + E2) || one)) ||
+               (E4 > 0 && overlap(g0, g1, G4, G4 + E4) && (overlap(h0, h1, H3, H3 + E3) || one));
+    }
     // weight tables in LDS, shared by the workgroup: a layer W (OUT, IN) as A operands of v_mfma_f32_4x4x1_f32,
     //   forward form  [ob][kg][i][kk] = W[4 ob + i][4 kg + kk]        (4 output rows per block, K walks the inputs)
     //   backward form [ib][og][i][kk] = W[4 og + kk][4 ib + i]        (the same for W^T: 4 input rows per block, K walks the outputs)
     // lane l reads the 16 bytes of its row i = l & 3: four K steps of one block; zero where a width was rounded up
     static constexpr int T2F = 0, T2B = T2F + E2P * E1, T3F = T2B + E2P * E1, T3B = T3F + E3P * E2P, TB2 = T3B + E3P * E2P,
                          TB3 = TB2 + E2P, TW4 = TB3 + E3P, TB4 = TW4 + E3P, NTAB = TB4 + 4;
-    static constexpr int CH = 8;               // UP rows staged per wave at a time
-    static constexpr int LDS_UP = CH * E1;     // floats per wave
+    static constexpr int CH = 256 / E1;        // UP rows staged per wave at a time: one 1 KB LDS-DMA (64 lanes x 16 bytes)
+    static constexpr int LDS_UP = 2 * 256;     // floats per wave: the chunk in use and the next one on its way
     // the flat gradient image: [gW2 (E2, E1) | gb2 | gW3 (E3, E2) | gb3 | gW4 (E4, E3) | gb4], torch's (out, in) layout
     static constexpr int OW2 = 0, OB2 = E2 * E1, OW3 = OB2 + E2, OB3 = OW3 + E3 * E2, OW4 = OB3 + E3, OB4 = OW4 + E4 * E3, NE = OB4 + E4;
     static_assert(EG <= 32, "the gradient rows of one pair must fit one 32-row A tile");
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(64 * PB_WPB) void pair_mlp_kernel(const float* __re
                                                                const float* __restrict__ gout, float* __restrict__ out,
                                                                float* __restrict__ gup_part, float* __restrict__ guc_part,
                                                                float* __restrict__ w_part, int B, int T, int D, int tw) {
-    constexpr int E1 = M::E1, E2 = M::E2, E3 = M::E3, E4 = M::E4, E2P = M::E2P, E3P = M::E3P, NOUT = M::NOUT, RS = M::RS, NB = M::NB;
+    constexpr int E1 = M::E1, E2 = M::E2, E3 = M::E3, E4 = M::E4, E2P = M::E2P, E3P = M::E3P, NOUT = M::NOUT, RS = M::RS, MB = M::MB, NBH = M::NBH;
     constexpr int KG1 = E1 / 4, KG2 = E2P / 4, KG3 = E3P / 4;
     extern __shared__ __attribute__((aligned(16))) float s_pb[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -121,23 +133,32 @@ __global__ __launch_bounds__(64 * PB_WPB) void pair_mlp_kernel(const float* __re
     }
 #pragma unroll
     for (int i = 0; i < E1; ++i) guc[i] = 0.0f;
-    f32x16 acc[NB];
+    f32x4 acc[MB][NBH];  // (the blocks that are not needed are never touched: no registers)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+        for (int nb = 0; nb < NBH; ++nb) acc[mb][nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (BWD) L[(32 + M::ONE) * RS + lane] = 1.0f;
     __syncthreads();
-    const int ka = (lane & 31) * RS + (lane >> 5);  // this lane's element of a 32x32x2 operand: row lane % 32, pair 2 s + lane / 32
+    const int ka = (lane & 15) * RS + (lane >> 4);  // this lane's element of a 16x16x4 operand: row lane % 16, pair 4 s + lane / 16
+    // the UP rows of CH tracks at a time (contiguous in memory), fetched by one LDS-DMA per chunk into the half of the wave's buffer that is
+    // not in use, a chunk ahead: lane e brings floats 4 e .. 4 e + 3 of the chunk (lanes past its end: the chunk's first floats again)
+    auto fetch_up = [&](int t0, int half) __attribute__((always_inline)) {
+        const int nfl = min(M::CH, T - t0) * E1 / 4;
+        const float* src = UP + ((size_t)b * T + t0) * E1 + 4 * (lane < nfl ? lane : 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(Lup + 256 * half), 16, 0, 0);
+    };
+    if (t_beg < t_end) fetch_up(t_beg, 0);
     const float* trow = tab + (lane & 3) * 4;        // this lane's row of every 4x4x1 A block
 
     for (int t = t_beg; t < t_end; ++t) {
-        if (((t - t_beg) & (M::CH - 1)) == 0) {  // the UP rows of the next CH tracks (contiguous in memory), staged by the wave itself
-            const int nfl = min(M::CH, T - t) * E1 / 4;
-            const f32x4* src = reinterpret_cast<const f32x4*>(UP + ((size_t)b * T + t) * E1);
-            for (int e = lane; e < nfl; e += 64) reinterpret_cast<f32x4*>(Lup)[e] = src[e];
+        const int tc = t - t_beg, chunk = tc / M::CH, within = tc - chunk * M::CH;
+        if (within == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk has landed
+            if (t + M::CH < t_end) fetch_up(t + M::CH, (chunk + 1) & 1);
         }
-        const float* upr = Lup + ((t - t_beg) & (M::CH - 1)) * E1;
+        const float* upr = Lup + 256 * (chunk & 1) + within * E1;
         const size_t p = ((size_t)b * T + t) * D + dcl;
         // ---- forward ----
         f32x4 z2[KG2];
@@ -238,11 +259,18 @@ __global__ __launch_bounds__(64 * PB_WPB) void pair_mlp_kernel(const float* __re
             }
         }
         // ---- weight / bias gradients: sum over the 64 pairs of the tile on the matrix pipe ----
-#pragma unroll 8
-        for (int s = 0; s < ((PB_ABL & 1) ? 0 : 32); ++s) {
-            const float av = L[ka + 2 * s];
+#pragma unroll 4
+        for (int s = 0; s < ((PB_ABL & 1) ? 0 : 16); ++s) {
+            float av[MB], bv[NBH];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, L[(32 + 32 * nb) * RS + ka + 2 * s], acc[nb], 0, 0, 0);
+            for (int mb = 0; mb < MB; ++mb) av[mb] = L[16 * mb * RS + ka + 4 * s];
+#pragma unroll
+            for (int nb = 0; nb < NBH; ++nb) bv[nb] = L[(32 + 16 * nb) * RS + ka + 4 * s];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NBH; ++nb)
+                    if (M::needed(mb, nb)) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
         }
         // ---- first layer: gz1 = (W2^T g2) . [h1 > 0]; into this lane's gUC row, and over h1 in the tile for the sum over the lanes ----
         constexpr int IG = (KG1 % 4 == 0) ? 4 : 2;  // input blocks in flight (KG1 = 2, 8, 10, 16, 18)
@@ -276,16 +304,11 @@ __global__ __launch_bounds__(64 * PB_WPB) void pair_mlp_kernel(const float* __re
 #pragma unroll
         for (int r0 = 0; r0 < E1; r0 += 64) {
             if (r0 + lane < E1) {
-                const float* row = L + (32 + M::H1 + r0 + lane) * RS;
-                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;  // four chains, combined in a fixed order
+                const f32x4* row = reinterpret_cast<const f32x4*>(L + (32 + M::H1 + r0 + lane) * RS);
+                f32x4 s4 = {0.0f, 0.0f, 0.0f, 0.0f};  // four chains, combined in a fixed order
 #pragma unroll
-                for (int j = 0; j < ((PB_ABL & 4) ? 4 : 64); j += 4) {
-                    s0 += row[j];
-                    s1 += row[j + 1];
-                    s2 += row[j + 2];
-                    s3 += row[j + 3];
-                }
-                gup_part[(((size_t)dt * B + b) * T + t) * E1 + r0 + lane] = (s0 + s1) + (s2 + s3);
+                for (int j = 0; j < ((PB_ABL & 4) ? 1 : 16); ++j) s4 += row[j];
+                gup_part[(((size_t)dt * B + b) * T + t) * E1 + r0 + lane] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
             }
         }
     }
@@ -298,14 +321,17 @@ __global__ __launch_bounds__(64 * PB_WPB) void pair_mlp_kernel(const float* __re
             dst[i] = v;
         }
     }
-    // this wave's part of the weight image (D layout of 32x32 tiles: row = 8 (r / 4) + 4 (lane / 32) + r % 4, column = lane % 32)
+    // this wave's part of the weight image (D layout of a 16x16 tile: row = 4 (lane / 16) + r, column = lane % 16)
     float* wp = w_part + (((size_t)b * gridDim.x + dt) * nslice + slice) * M::NE;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int hrow = 32 * nb + (lane & 31);
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = 8 * (r / 4) + 4 * (lane >> 5) + (r % 4);
+    for (int nb = 0; nb < NBH; ++nb) {
+        if (!M::needed(mb, nb)) continue;
+        const int hrow = 16 * nb + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 16 * mb + 4 * (lane >> 4) + r;
             int idx = -1;
             if (m < E2) {
                 if (hrow < E1) idx = M::OW2 + m * E1 + hrow;
@@ -319,7 +345,7 @@ __global__ __launch_bounds__(64 * PB_WPB) void pair_mlp_kernel(const float* __re
                 if (hrow >= M::H3 && hrow < M::H3 + E3) idx = M::OW4 + r4 * E3 + (hrow - M::H3);
                 else if (hrow == M::ONE) idx = M::OB4 + r4;
             }
-            if (idx >= 0) wp[idx] = acc[nb][r];
+            if (idx >= 0) wp[idx] = acc[mb][nb][r];
         }
     }
 }
