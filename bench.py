@@ -638,13 +638,15 @@ def extra_train_step(bench, args, ex):
     from shasta_amd import training
     ts = {"note": "ms per step = forward (rows 4-16) + loss + backward + Adam; frame-pairs/s = B / step; fwd / bwd / adam from events on the stream"}
     ts["note"] += ("; *_dense: the four first-layer gradients of aug_shape written out and read back by Adam (36 B per parameter), the others: "
-                   "Adam straight from their factors (FusedAdam(lowrank_first_layers=model), 24 B per parameter); *_densepairs: the pair MLPs' "
+                   "Adam straight from their factors (FusedAdam(lowrank_first_layers=model), 24 B per parameter), fp32 / bf16: at steps of up to 16 frame-pairs "
+                   "inside loss.backward(), in the pass that also forms dx = ghid W1 (in_backward=True: that time is then in bwd_ms, adam_ms holds "
+                   "the other tensors); *_stepafter: the same with the update in step(); *_densepairs: the pair MLPs' "
                    "backward in the dense formulation of round 4 (hidden activations of every pair in HBM, strided GEMMs: "
                    "Shasta.dense_pair_backward), the others (fp32): recomputed and back-propagated per pair on chip (csrc/pair_bwd.hip); "
                    "bf16: the GEMMs around them (first-layer tables, aff) with bf16 operands")
     for (cfg, B, steps) in ((CAR, 16, 10), (CAR, 64, 6), (HEADLINE, 8, 3)):
-        for prec in ("fp32", "bf16", "fp32_dense", "fp32_densepairs"):
-            if prec.startswith("fp32_dense") and cfg is not HEADLINE:
+        for prec in ("fp32", "bf16", "fp32_stepafter", "fp32_dense", "fp32_densepairs"):
+            if prec.startswith(("fp32_dense", "fp32_stepafter")) and cfg is not HEADLINE:
                 continue
             key = "n%d_b%d_%s" % (cfg["max_obj"], B, prec)
             try:
@@ -656,7 +658,8 @@ def extra_train_step(bench, args, ex):
                 model.train_precision = prec.split("_")[0]
                 model.dense_pair_backward = prec.endswith("_densepairs")
                 params = training.affinity_params(model)
-                opt = training.FusedAdam(params, lr=1e-4, lowrank_first_layers=None if prec.endswith("_dense") else model)
+                opt = training.FusedAdam(params, lr=1e-4, lowrank_first_layers=None if prec.endswith("_dense") else model,
+                                         in_backward=prec in ("fp32", "bf16"))
                 N = cfg["max_obj"]
                 det0, prev = bench.boxes(cfg)
                 det0, prev, bev, pbev = det0[:B], prev[:B], bench.bev[:B], bench.pbev[:B]

@@ -269,8 +269,11 @@ def forward(w, bev_nchw, prev_bev_nchw, det_boxes, prev_det_boxes, num_feats, nu
 # --------------------------------------------------------------------------------------
 def affinity_loss(m1, m2, gt):
     gt1, gt2 = gt[:, :-2, :], gt[:, :, :-2]
-    lf = (gt1 * (-torch.log(m1 + 1e-10))).sum() / gt1.sum()
-    lb = (gt2 * (-torch.log(m2 + 1e-10))).sum() / gt2.sum()
+    lf, lb = (gt1 * (-torch.log(m1 + 1e-10))).sum(), (gt2 * (-torch.log(m2 + 1e-10))).sum()
+    if gt1.sum() > 0:  # (train.py:208-209: a direction without a ground-truth entry keeps its plain - zero - sum)
+        lf = lf / gt1.sum()
+    if gt2.sum() > 0:
+        lb = lb / gt2.sum()
     return (lf + lb) / 2
 
 

@@ -201,6 +201,7 @@ __global__ void combine_bwd_kernel(const float* __restrict__ gres, const float* 
 
 // ---- the training loss (tools/nusc_shasta/train.py:200-211) and its gradient ------------------------------------------------
 //   loss = (sum(gt1 . -log(m1 + 1e-10)) / sum(gt1) + sum(gt2 . -log(m2 + 1e-10)) / sum(gt2)) / 2,  gt1 = gt[:, :N, :], gt2 = gt[:, :, :N]
+//   (each quotient only where its sum(gt) > 0: train.py:208-209)
 // one block per row (b, t) of gt: the four sums of the row in a fixed order; loss_finish_kernel adds the rows in order.
 __global__ __launch_bounds__(256) void loss_rows_kernel(const float* __restrict__ m1, const float* __restrict__ m2, const float* __restrict__ gt,
                                                         int N, float* __restrict__ part) {
@@ -244,7 +245,8 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
         sums[threadIdx.x] = t;
     }
     __syncthreads();
-    if (threadIdx.x == 0) sums[4] = (sums[0] / sums[1] + sums[2] / sums[3]) * 0.5f;
+    // (train.py:208-209: a direction without a single ground-truth entry contributes its plain sum - zero - not 0 / 0)
+    if (threadIdx.x == 0) sums[4] = ((sums[1] > 0.0f ? sums[0] / sums[1] : sums[0]) + (sums[3] > 0.0f ? sums[2] / sums[3] : sums[2])) * 0.5f;
 }
 
 // g1 = dloss/dm1 = -gt1 / (m1 + 1e-10) * gloss / (2 sum(gt1)), g2 likewise; gloss read from device memory
@@ -260,12 +262,12 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
         const long bt = i / T;
         const long b = bt / N;
         const int t = bt - b * N;
-        g1[i] = -gt[((size_t)b * T + t) * T + d] / (m1[i] + 1e-10f) * (gl / sums[1]);
+        g1[i] = -gt[((size_t)b * T + t) * T + d] / (m1[i] + 1e-10f) * (sums[1] > 0.0f ? gl / sums[1] : gl);
     }
     {  // element i of m2 (B, T, N): the same count
         const int d = i % N;
         const long bt = i / N;
-        g2[i] = -gt[(size_t)bt * T + d] / (m2[i] + 1e-10f) * (gl / sums[3]);
+        g2[i] = -gt[(size_t)bt * T + d] / (m2[i] + 1e-10f) * (sums[3] > 0.0f ? gl / sums[3] : gl);
     }
 }
 
@@ -435,13 +437,20 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamMulti t, AdamArgs a
 // Adam pass - it is never written to memory and never read back.  24 bytes per parameter (p, m, v in and out) instead of the 36 of
 // "write the gradient, read it in the Adam kernel".  A thread owns COLS consecutive columns and keeps its R x COLS slice of X in
 // registers; G[r][h] is uniform over the workgroup (scalar loads).
-template <int RMAX, int COLS>
+// RDX > 0: the same pass also forms Y = Gdx . W with the weights as they are BEFORE the update (Gdx: (Rdx, H) at ldgdx; the backward's
+// dx = ghid . W1, which otherwise reads the matrix a second time: smallm_nn_kernel) - partial sums per row block into `part`
+// ([block][r][k], summed by smallm_finish_kernel).
+template <int RMAX, int COLS, int RDX = 0>
 __global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                            const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx, int R,
-                                                           int H, int K, int rows_per_block, AdamArgs a) {
+                                                           int H, int K, int rows_per_block, AdamArgs a, const float* __restrict__ Gdx = nullptr,
+                                                           int ldgdx = 0, int Rdx = 0, float* __restrict__ part = nullptr) {
     typedef float fv __attribute__((ext_vector_type(COLS)));
     const long k0 = ((long)blockIdx.x * 256 + threadIdx.x) * COLS;
     if (k0 >= K) return;
+    fv dacc[RDX > 0 ? RDX : 1];
+#pragma unroll
+    for (int r = 0; r < (RDX > 0 ? RDX : 1); ++r) dacc[r] = fv(0.0f);
     fv xv[RMAX];
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
@@ -451,7 +460,18 @@ __global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p
     const int h0 = blockIdx.y * rows_per_block, h1 = min(H, h0 + rows_per_block);
     for (int h = h0; h < h1; ++h) {
         const size_t at = (size_t)h * K + k0;
-        fv pp = *reinterpret_cast<const fv*>(p + at), mm = *reinterpret_cast<const fv*>(m + at), vv = *reinterpret_cast<const fv*>(v + at);
+        // (3 GB stream through once per step: non-temporal loads and stores, 1.06 -> 1.00 ms per 1 GB matrix = 6.1 TB/s over p, m, v in
+        // and out; unrolling the row loop on top of that: nothing)
+        fv pp = __builtin_nontemporal_load(reinterpret_cast<const fv*>(p + at)), mm = __builtin_nontemporal_load(reinterpret_cast<const fv*>(m + at)),
+           vv = __builtin_nontemporal_load(reinterpret_cast<const fv*>(v + at));
+        if (RDX > 0) {
+#pragma unroll
+            for (int r = 0; r < RDX; ++r) {
+                const float gd = r < Rdx ? Gdx[(size_t)r * ldgdx + h] : 0.0f;
+#pragma unroll
+                for (int c = 0; c < COLS; ++c) dacc[r][c] = fmaf(gd, pp[c], dacc[r][c]);
+            }
+        }
         fv g = fv(0.0f);
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
@@ -467,9 +487,12 @@ __global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p
             mm[c] = mk;
             vv[c] = vk;
         }
-        *reinterpret_cast<fv*>(p + at) = pp;
-        *reinterpret_cast<fv*>(m + at) = mm;
-        *reinterpret_cast<fv*>(v + at) = vv;
+        __builtin_nontemporal_store(pp, reinterpret_cast<fv*>(p + at));
+        __builtin_nontemporal_store(mm, reinterpret_cast<fv*>(m + at));
+        __builtin_nontemporal_store(vv, reinterpret_cast<fv*>(v + at));
+    }
+    if (RDX > 0) {
+        for (int r = 0; r < Rdx; ++r) *reinterpret_cast<fv*>(part + ((size_t)blockIdx.y * Rdx + r) * K + k0) = dacc[r];
     }
 }
 
@@ -778,6 +801,56 @@ extern "C" int shasta_adam_multi_f32(int count, float* const* param, const float
     return SHASTA_OK;
 }
 
+namespace {
+int adam_lowrank_rows_per_block(int H, int K, int cols) {
+    const int kblocks = shasta::cdiv(K / cols, 256);
+    return std::max(1, std::min(64, shasta::cdiv(H, std::max(1, 4096 / kblocks))));  // >= ~4096 workgroups, <= 64 rows each
+}
+}  // namespace
+
+extern "C" size_t shasta_adam_lowrank_dx_workspace_bytes(int H, int K, int Rdx) {
+    if (H <= 0 || K <= 0 || Rdx <= 0) return 0;
+    return (size_t)shasta::cdiv(H, adam_lowrank_rows_per_block(H, K, 4)) * Rdx * K * sizeof(float);
+}
+
+extern "C" int shasta_adam_lowrank_dx_f32(float* param, float* exp_avg, float* exp_avg_sq, int H, int K, const float* G, int ldg, const float* X,
+                                          int ldx, int R, const float* Gdx, int ldgdx, int Rdx, float* Y, long ldy, int accumulate, void* workspace,
+                                          size_t workspace_bytes, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                          shasta_stream_t stream) {
+    SHASTA_REQUIRE(param && exp_avg && exp_avg_sq && G && X && Gdx && Y && workspace && H >= 1 && K >= 4 && step >= 1, "adam_lowrank_dx: bad argument");
+    SHASTA_REQUIRE(R >= 1 && R <= 16 && Rdx >= 1 && Rdx <= 16, "adam_lowrank_dx: 1 <= R, Rdx <= 16");
+    SHASTA_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && ldg >= H && ldx >= K && ldgdx >= H, "adam_lowrank_dx: K and ldx multiples of 4, ldg, ldgdx >= H, ldx >= K");
+    SHASTA_REQUIRE((((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)X | (uintptr_t)workspace) & 15) == 0,
+                   "adam_lowrank_dx: 16-byte alignment");
+    if (workspace_bytes < shasta_adam_lowrank_dx_workspace_bytes(H, K, Rdx)) {
+        set_error_msg("adam_lowrank_dx: workspace too small");
+        return SHASTA_E_WORKSPACE;
+    }
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamArgs a;
+    a.lr_over_bc1 = (float)((double)lr / bc1);
+    a.beta1 = beta1;
+    a.beta2 = beta2;
+    a.eps = eps;
+    a.weight_decay = weight_decay;
+    a.rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const int kblocks = cdiv(K / 4, 256), rpb = adam_lowrank_rows_per_block(H, K, 4), chunks = cdiv(H, rpb);
+    float* part = static_cast<float*>(workspace);
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(kblocks, chunks), dim3(256), 0, as_stream(stream), param, exp_avg, exp_avg_sq, G, ldg, X, ldx, R, H, K, rpb, a,
+                           Gdx, ldgdx, Rdx, part);
+    };
+    if (R <= 8 && Rdx <= 8) launch(adam_lowrank_kernel<8, 4, 8>);
+    else if (R <= 8) launch(adam_lowrank_kernel<8, 4, 16>);
+    else if (Rdx <= 8) launch(adam_lowrank_kernel<16, 4, 8>);
+    else launch(adam_lowrank_kernel<16, 4, 16>);
+    int rc = check_launch("adam_lowrank_dx");
+    if (rc) return rc;
+    hipLaunchKernelGGL(smallm_finish_kernel, dim3((unsigned)(((long)Rdx * K + 255) / 256)), dim3(256), 0, as_stream(stream), part, chunks, Rdx, K, Y,
+                       ldy, accumulate);
+    return check_launch("adam_lowrank_dx finish");
+}
+
 extern "C" int shasta_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_sq, int H, int K, const float* G, int ldg, const float* X,
                                        int ldx, int R, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                        shasta_stream_t stream) {
@@ -796,9 +869,9 @@ extern "C" int shasta_adam_lowrank_f32(float* param, float* exp_avg, float* exp_
     a.rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
     auto launch = [&](auto kern, int cols) {
         const int kblocks = cdiv(K / cols, 256);
-        const int rpb = std::max(1, std::min(64, cdiv(H, std::max(1, 4096 / kblocks))));  // >= ~4096 workgroups, <= 64 rows each
+        const int rpb = adam_lowrank_rows_per_block(H, K, cols);
         hipLaunchKernelGGL(kern, dim3(kblocks, cdiv(H, rpb)), dim3(256), 0, as_stream(stream), param, exp_avg, exp_avg_sq, G, ldg, X, ldx, R, H, K,
-                           rpb, a);
+                           rpb, a, (const float*)nullptr, 0, 0, (float*)nullptr);
     };
     if (R <= 8) launch(adam_lowrank_kernel<8, 4>, 4);
     else if (R <= 16) launch(adam_lowrank_kernel<16, 4>, 4);

@@ -107,6 +107,8 @@ SYMBOLS = {
     "shasta_affinity_loss_f32": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "shasta_affinity_loss_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "shasta_adam_multi_f32": (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_long), _F, _F, _F, _F, _F, _I, _P]),
+    "shasta_adam_lowrank_dx_workspace_bytes": (_Z, [_I, _I, _I]),
+    "shasta_adam_lowrank_dx_f32": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, C.c_long, _I, _P, _Z, _F, _F, _F, _F, _F, _I, _P]),
     "shasta_adam_lowrank_f32": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _F, _F, _F, _F, _F, _I, _P]),
     "shasta_abs_f32": (_I, [_P, _P, _P, C.c_long, _I, _I, _I, _I, _P]),
     "shasta_bev_gather_bwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _I, _I, _P, _P]),

@@ -297,6 +297,11 @@ class _AffinityTrainFn(torch.autograd.Function):
         # model.lowrank_adam (set by FusedAdam(..., lowrank_first_layers=model)): the four 1 GB first-layer gradients are not formed at
         # all - their factors go to the optimizer, which builds the gradient in registers inside its pass (shasta_adam_lowrank_f32)
         lowrank = bool(getattr(model, "lowrank_adam", False)) and world * B <= 64 and (N * F) % 4 == 0
+        # FusedAdam(..., in_backward=True): the optimizer steps the four matrices HERE, in the pass that also forms dx = ghid W1 (with the
+        # weights as they are before the update): the 1 GB matrix is read once for both (shasta_adam_lowrank_dx_f32)
+        opt_ref = getattr(model, "_lowrank_adam_opt", None)
+        stepper = opt_ref() if opt_ref is not None else None
+        in_bwd = lowrank and stepper is not None and stepper.in_backward and world * B <= 16 and B <= 16 and N * F >= 4
         shape_grads, box_grads, ghids = [None] * 4, [None] * 4, [None] * 4
         for i in range(4):
             # aug_shape[i]: input = rows < N of feat (i<2) / prev_feat (i>=2); output row N + (i&1) of prev_feat (i<2) / feat (i>=2)
@@ -308,7 +313,7 @@ class _AffinityTrainFn(torch.autograd.Function):
             grads, ghid, w1 = anchor_bwd(model.aug_shape[i], x, T * F, N * F, g_out, 0, F, hid=hid, defer_w1=exchange or lowrank)
             shape_grads[i] = grads
             ghids[i] = ghid
-            if ghid is not None:  # dx = ghid W1 accumulated into the rows < N of the INPUT table's gradient
+            if ghid is not None and not in_bwd:  # dx = ghid W1 accumulated into the rows < N of the INPUT table's gradient
                 gin = dfeat if i < 2 else dprev_feat
                 if B <= 16 and (N * F) % 4 == 0:  # small batch: stream the 1 GB matrix once (csrc/train.hip)
                     nb = lib.shasta_smallm_nn_workspace_bytes(B, ghid.shape[1], N * F)
@@ -342,6 +347,12 @@ class _AffinityTrainFn(torch.autograd.Function):
         elif lowrank and ghids[0] is not None:
             for i in range(4):  # one rank: the local factors as they are (the input rows lie T * F apart in the feature table)
                 model.aug_shape[i][0].weight._shasta_grad_factors = (ghids[i], ghids[i].shape[1], S["feat"] if i < 2 else S["prev_feat"], T * F, B)
+
+        if in_bwd and ghids[0] is not None:
+            for i in range(4):
+                w1p = model.aug_shape[i][0].weight
+                gin = dfeat if i < 2 else dprev_feat
+                stepper.step_in_backward(w1p, w1p.__dict__.pop("_shasta_grad_factors"), ghids[i], ghids[i].shape[1], B, gin, T * F)
 
         # ---- gather (shasta.py:231-238) -> gradient of the two NHWC maps ----
         def gather_bwd(gtab, boxes):
@@ -464,8 +475,11 @@ def affinity_loss(m1, m2, gt):
             and tuple(m2.shape) == (m1.shape[0], N + 2, N) and tuple(gt.shape) == (m1.shape[0], N + 2, N + 2) and not gt.requires_grad):
         return _AffinityLossFn.apply(m1, m2, gt)
     gt1, gt2 = gt[:, :-2, :], gt[:, :, :-2]
-    lf = (gt1 * (-torch.log(m1 + 1e-10))).sum() / gt1.sum()
-    lb = (gt2 * (-torch.log(m2 + 1e-10))).sum() / gt2.sum()
+    lf, lb = (gt1 * (-torch.log(m1 + 1e-10))).sum(), (gt2 * (-torch.log(m2 + 1e-10))).sum()
+    if gt1.sum() > 0:  # (train.py:208-209: a direction without a ground-truth entry keeps its plain - zero - sum)
+        lf = lf / gt1.sum()
+    if gt2.sum() > 0:
+        lb = lb / gt2.sum()
     return (lf + lb) / 2
 
 
@@ -477,14 +491,50 @@ class FusedAdam(torch.optim.Optimizer):
 
     MULTI_MAX_NUMEL = 1 << 18  # tensors up to this size are updated together, 48 per launch
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lowrank_first_layers=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lowrank_first_layers=None, in_backward=False):
         """lowrank_first_layers = the Shasta model: its four aug_shape first-layer matrices (4 x 1 GB at N = 500) are updated straight from
         the FACTORS of their gradient (shasta_adam_lowrank_f32: 24 bytes per parameter instead of 36) - the backward then leaves their
         .grad None and hands the factors over on the parameter; same update, the gradient's sum over the step's frame-pairs in another
         order."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # in_backward (with lowrank_first_layers, steps of at most 16 frame-pairs over all ranks): those four matrices take their Adam
+        # update INSIDE loss.backward(), in the one pass over each that also forms the backward's dx = ghid W1 from the not-yet-updated
+        # weights (the matrix is read once instead of twice); step() then updates everything else.  Same weights after the step as
+        # without the option; for loops that are backward() -> step() like tools/nusc_shasta/train.py:213-215 (no gradient clipping or
+        # accumulation over several backward passes, whose updates must wait for step()).
+        self.in_backward = bool(in_backward) and lowrank_first_layers is not None
         if lowrank_first_layers is not None:
             lowrank_first_layers.lowrank_adam = True
+            import weakref
+            lowrank_first_layers._lowrank_adam_opt = weakref.ref(self)
+
+    def _state_of(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p)
+            st["exp_avg_sq"] = torch.zeros_like(p)
+        return st
+
+    @torch.no_grad()
+    def step_in_backward(self, p, factors, gdx, ldgdx, rdx, y, ldy):
+        """The Adam update of matrix p from the factors of its gradient, and y (+)= gdx . p (p before the update), in one pass."""
+        group = next((g for g in self.param_groups if any(q is p for q in g["params"])), None)
+        if group is None:
+            raise hip.ShastaHipError("FusedAdam(in_backward=True): the matrix is not one of this optimizer's parameters")
+        lib = hip.load()
+        st = self._state_of(p)
+        st["step"] = int(st["step"]) + 1
+        G, ldg, X, ldx, R = factors
+        H, K = p.shape
+        nb = lib.shasta_adam_lowrank_dx_workspace_bytes(H, K, rdx)
+        ws = torch.empty((nb + 3) // 4, device=p.device)
+        b1, b2 = group["betas"]
+        hip.check(lib.shasta_adam_lowrank_dx_f32(hip.ptr(p), hip.ptr(st["exp_avg"]), hip.ptr(st["exp_avg_sq"]), H, K, hip.ptr_view(G), ldg,
+                                                 hip.ptr_view(X), ldx, R, hip.ptr_view(gdx), ldgdx, rdx, hip.ptr_view(y), ldy, 1, hip.ptr(ws), nb,
+                                                 float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                                 st["step"], hip.stream_ptr()), "shasta_adam_lowrank_dx_f32")
+        torch.autograd.graph.increment_version(p)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -502,11 +552,7 @@ class FusedAdam(torch.optim.Optimizer):
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                     raise hip.ShastaHipError("FusedAdam needs contiguous fp32 device parameters (no CPU path)")
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p)
-                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st = self._state_of(p)
                 st["step"] = int(st["step"]) + 1
                 if p.grad is None:  # a matrix whose gradient is G^T X: formed inside the pass
                     G, ldg, X, ldx, R = factors

@@ -301,6 +301,15 @@ def test_fused_loss_matches_the_torch_formula(B, N):
     # the same bits twice (fixed summation order)
     again = training.affinity_loss(d1.detach(), d2.detach(), gt.to(dev))
     assert torch.equal(again, got.detach())
+    # no ground-truth entry in one direction (tools/nusc_shasta/train.py:208-209 keeps that direction's zero sum instead of 0 / 0)
+    gt0 = gt.clone()
+    gt0[:, :N, :] = 0.0
+    d1, d2 = m1.to(dev).requires_grad_(True), m2.to(dev).requires_grad_(True)
+    got0 = training.affinity_loss(d1, d2, gt0.to(dev))
+    want0 = O.affinity_loss(m1.double(), m2.double(), gt0.double())
+    assert torch.isfinite(got0) and abs(float(got0) - float(want0)) <= 2e-6 * max(1.0, abs(float(want0)))
+    got0.backward()
+    assert torch.isfinite(d1.grad).all() and torch.isfinite(d2.grad).all() and float(d1.grad.abs().max()) == 0.0
 
 
 _PAIR_MLP_WIDTHS = {  # (kind, F) -> layer widths behind the factorised first layer (det3d/models/tracker/shasta.py:59-92)
@@ -587,3 +596,85 @@ def test_train_steps_with_adam_from_the_factors_equal_the_dense_steps(exchange):
         assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(p.abs().max())), k
     moved = float((dense.aug_shape[0][0].weight - w["aug_shape.0.0.weight"].to(dev)).abs().max())
     assert moved > 1e-4  # the steps did something
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", [False, True])
+def test_adam_stepped_inside_the_backward_equals_the_step_after_it(exchange):
+    """FusedAdam(..., lowrank_first_layers=model, in_backward=True): the four aug_shape first-layer matrices take their update inside
+    loss.backward(), in the pass that also forms dx = ghid W1 from the not-yet-updated weights (shasta_adam_lowrank_dx_f32).  Three steps:
+    those matrices and their optimizer state bit for bit as with the update in step() (the same kernel arithmetic on the same factors),
+    everything else and the gradient of the BEV map up to the summation order of dx."""
+    import copy
+    import torch.distributed as dist
+    from shasta_amd import training
+    from tests.test_training_ddp import _free_port
+    c, model, w, a, b, det, prev, gt = _case(12, 7, 4, 3, seed=22)
+    dev = torch.device("cuda:0")
+    after = model.to(dev).train()
+    inside = copy.deepcopy(after)
+    gtd = gt.to(dev)
+    detd, prevd = det.to(dev).contiguous(), prev.to(dev).contiguous()
+    opts = [training.FusedAdam(after.parameters(), lr=1e-3, weight_decay=0.01, lowrank_first_layers=after),
+            training.FusedAdam(inside.parameters(), lr=1e-3, weight_decay=0.01, lowrank_first_layers=inside, in_backward=True)]
+    assert opts[1].in_backward and not opts[0].in_backward
+    if exchange:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    dbev = []
+    try:
+        for m, opt in zip((after, inside), opts):
+            m._force_factor_exchange = exchange
+            for it in range(3):
+                opt.zero_grad()
+                ad, bd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+                before = m.aug_shape[0][0].weight.detach().clone()
+                m1, m2 = training.affinity_train(m, ad, bd, detd.clone(), prevd)
+                training.affinity_loss(m1, m2, gtd).backward()
+                assert all(m.aug_shape[i][0].weight.grad is None for i in range(4))
+                moved_in_backward = not torch.equal(before, m.aug_shape[0][0].weight.detach())
+                assert moved_in_backward == (m is inside), "the matrices move inside backward() exactly when asked to"
+                training.allreduce_gradients(list(m.parameters()))
+                opt.step()
+                assert int(opt.state[m.aug_shape[0][0].weight]["step"]) == it + 1
+            dbev.append((ad.grad.clone(), bd.grad.clone()))
+    finally:
+        if exchange:
+            dist.destroy_process_group()
+    for i in range(4):
+        p, q = after.aug_shape[i][0].weight, inside.aug_shape[i][0].weight
+        assert torch.equal(p, q), "aug_shape.%d.0.weight" % i
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(opts[0].state[p][k], opts[1].state[q][k]), k
+    for (k, p), (_, q) in zip(after.named_parameters(), inside.named_parameters()):
+        assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(p.abs().max())), k
+    _close("d bev", dbev[1][0], dbev[0][0], rtol=1e-5)
+    _close("d prev_bev", dbev[1][1], dbev[0][1], rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,Rdx,H,K", [(1, 1, 5, 8), (8, 8, 70, 1032), (3, 16, 129, 260), (16, 5, 33, 4096)])
+def test_adam_lowrank_with_the_product_in_the_same_pass(R, Rdx, H, K):
+    """shasta_adam_lowrank_dx_f32 against shasta_adam_lowrank_f32 (the same update, bit for bit) and Gdx W in float64 (W before the update)."""
+    from shasta_amd import hip
+    lib = hip.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(R * 100 + H)
+    p0 = torch.randn(H, K, device=dev)
+    m0, v0 = torch.randn(H, K, device=dev) * 0.1, torch.rand(H, K, device=dev) * 0.01
+    G, X, Gdx = torch.randn(R, H + 3, device=dev), torch.randn(R, K + 4, device=dev), torch.randn(Rdx, H + 1, device=dev)
+    y0 = torch.randn(Rdx, K + 8, device=dev)
+    hyper = (3e-3, 0.9, 0.999, 1e-8, 0.01, 7)
+    pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+    hip.check(lib.shasta_adam_lowrank_f32(hip.ptr(pa), hip.ptr(ma), hip.ptr(va), H, K, hip.ptr(G), H + 3, hip.ptr(X), K + 4, R, *hyper, hip.stream_ptr()), "ref")
+    nb = lib.shasta_adam_lowrank_dx_workspace_bytes(H, K, Rdx)
+    for acc in (0, 1):
+        pb, mb, vb, y = p0.clone(), m0.clone(), v0.clone(), y0.clone()
+        ws = torch.full(((nb + 3) // 4,), float("nan"), device=dev)
+        hip.check(lib.shasta_adam_lowrank_dx_f32(hip.ptr(pb), hip.ptr(mb), hip.ptr(vb), H, K, hip.ptr(G), H + 3, hip.ptr(X), K + 4, R, hip.ptr(Gdx), H + 1, Rdx,
+                                                 hip.ptr(y), K + 8, acc, hip.ptr(ws), nb, *hyper, hip.stream_ptr()), "dx")
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+        want = Gdx[:, :H].double() @ p0.double() + (y0[:, :K].double() if acc else 0.0)
+        assert float((y[:, :K].double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+        assert torch.equal(y[:, K:], y0[:, K:]), "columns past K are not touched"
+    assert lib.shasta_adam_lowrank_dx_f32(hip.ptr(pb), hip.ptr(mb), hip.ptr(vb), H, K, hip.ptr(G), H + 3, hip.ptr(X), K + 4, R, hip.ptr(Gdx), H + 1, Rdx,
+                                          hip.ptr(y), K + 8, 0, hip.ptr(ws), nb - 4, *hyper, hip.stream_ptr()) != 0

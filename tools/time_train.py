@@ -21,6 +21,7 @@ ap.add_argument("--hw", type=int, default=180)
 ap.add_argument("--json", action="store_true", help="print one JSON line instead of text")
 ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused HIP step")
 ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32", help="Shasta.train_precision: operands of the pair / aff GEMMs of the backward")
+ap.add_argument("--in-backward", action="store_true", help="FusedAdam(in_backward=True): the first aug_shape layers step inside loss.backward()")
 a = ap.parse_args()
 rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
 torch.cuda.set_device(local_rank)
@@ -36,7 +37,7 @@ cfg = dict(type="Shasta", reader=None, backbone=None, neck=None,
 model = shasta_amd.build_simp_track(cfg).to(dev).train()
 model.train_precision = a.precision
 params = training.affinity_params(model)
-opt = torch.optim.Adam(params, lr=1e-4) if a.torch_adam else training.FusedAdam(params, lr=1e-4, lowrank_first_layers=model)
+opt = torch.optim.Adam(params, lr=1e-4) if a.torch_adam else training.FusedAdam(params, lr=1e-4, lowrank_first_layers=model, in_backward=a.in_backward)
 N, B = a.max_obj, a.batch
 g = torch.Generator(device="cpu").manual_seed(1 + rank)
 bev = torch.relu(torch.randn(B, a.hw, a.hw, 64, generator=g)).to(dev)
