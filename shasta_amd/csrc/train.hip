@@ -440,6 +440,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamMulti t, AdamArgs a
 // RDX > 0: the same pass also forms Y = Gdx . W with the weights as they are BEFORE the update (Gdx: (Rdx, H) at ldgdx; the backward's
 // dx = ghid . W1, which otherwise reads the matrix a second time: smallm_nn_kernel) - partial sums per row block into `part`
 // ([block][r][k], summed by smallm_finish_kernel).
+// (196 - 229 registers, two waves per SIMD; forced to three or four waves the pass is 5 - 10 % slower: 1.10 -> 1.18 / 1.22 ms per 1 GB matrix)
 template <int RMAX, int COLS, int RDX = 0>
 __global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                            const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx, int R,

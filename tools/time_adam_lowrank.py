@@ -14,6 +14,7 @@ ap.add_argument("--rows", type=int, default=2000)
 ap.add_argument("--cols", type=int, default=128000)
 ap.add_argument("--rank", type=int, default=8)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--dx", action="store_true", help="shasta_adam_lowrank_dx_f32: Y += Gdx W in the same pass")
 a = ap.parse_args()
 lib = hip.load()
 dev = torch.device("cuda:0")
@@ -24,7 +25,16 @@ vs = [torch.zeros(H, K, device=dev) for _ in range(2)]
 G, X = torch.randn(R, H, device=dev), torch.randn(R, K, device=dev)
 
 
+Y = torch.zeros(R, K, device=dev)
+nb = lib.shasta_adam_lowrank_dx_workspace_bytes(H, K, R)
+ws = torch.empty((nb + 3) // 4, device=dev)
+
+
 def step(i, n):
+    if a.dx:
+        hip.check(lib.shasta_adam_lowrank_dx_f32(hip.ptr(ps[i]), hip.ptr(ms[i]), hip.ptr(vs[i]), H, K, hip.ptr(G), H, hip.ptr(X), K, R, hip.ptr(G), H, R, hip.ptr(Y), K, 1,
+                                                 hip.ptr(ws), nb, 1e-4, 0.9, 0.999, 1e-8, 0.0, n, hip.stream_ptr()), "adam_lowrank_dx")
+        return
     hip.check(lib.shasta_adam_lowrank_f32(hip.ptr(ps[i]), hip.ptr(ms[i]), hip.ptr(vs[i]), H, K, hip.ptr(G), H, hip.ptr(X), K, R, 1e-4, 0.9, 0.999, 1e-8, 0.0,
                                           n, hip.stream_ptr()), "adam_lowrank")
 
@@ -38,4 +48,4 @@ for n in range(a.iters):
 e1.record()
 torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / a.iters
-print("%s: adam_lowrank (%d x %d, R = %d) %.3f ms = %.2f TB/s over p, m, v in and out" % (os.environ.get("SHASTA_HIP_LIB", "default").split("/")[-1], H, K, R, t, 24.0 * H * K / t / 1e9))
+print("%s: adam_lowrank%s (%d x %d, R = %d) %.3f ms = %.2f TB/s over p, m, v in and out" % (os.environ.get("SHASTA_HIP_LIB", "default").split("/")[-1], "_dx" if a.dx else "", H, K, R, t, 24.0 * H * K / t / 1e9))
