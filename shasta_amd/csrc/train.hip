@@ -448,17 +448,30 @@ __global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p
                                                            int ldgdx = 0, int Rdx = 0, float* __restrict__ part = nullptr) {
     typedef float fv __attribute__((ext_vector_type(COLS)));
     const long k0 = ((long)blockIdx.x * 256 + threadIdx.x) * COLS;
-    if (k0 >= K) return;
     fv dacc[RDX > 0 ? RDX : 1];
 #pragma unroll
     for (int r = 0; r < (RDX > 0 ? RDX : 1); ++r) dacc[r] = fv(0.0f);
+    // RMAX > 16 (the factors of a step over several ranks): G[r][h] for one h and all r lies in R different cache lines - as scalar loads
+    // they bound the pass (2.38 ms per 1 GB matrix at R = 64, 2.6 TB/s).  The block's (R, rows) slice of G goes through LDS instead,
+    // transposed to [row][r], and is read back as broadcasts.
+    constexpr bool G_LDS = RMAX > 16;
+    __shared__ __attribute__((aligned(16))) float s_g[G_LDS ? 64 * RMAX : 4];
     fv xv[RMAX];
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
         xv[r] = fv(0.0f);
-        if (r < R) xv[r] = *reinterpret_cast<const fv*>(X + (size_t)r * ldx + k0);
+        if (r < R && k0 < K) xv[r] = *reinterpret_cast<const fv*>(X + (size_t)r * ldx + k0);
     }
     const int h0 = blockIdx.y * rows_per_block, h1 = min(H, h0 + rows_per_block);
+    if (G_LDS) {  // (rows_per_block <= 64; every thread of the block gets here: threads past the last column leave after the barrier)
+        const int rows = h1 - h0;
+        for (int e = threadIdx.x; e < RMAX * rows; e += 256) {
+            const int r = e / rows, hl = e - r * rows;
+            s_g[hl * RMAX + r] = r < R ? G[(size_t)r * ldg + h0 + hl] : 0.0f;
+        }
+        __syncthreads();
+    }
+    if (k0 >= K) return;
     for (int h = h0; h < h1; ++h) {
         const size_t at = (size_t)h * K + k0;
         // (3 GB stream through once per step: non-temporal loads and stores, 1.06 -> 1.00 ms per 1 GB matrix = 6.1 TB/s over p, m, v in
@@ -476,7 +489,7 @@ __global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p
         fv g = fv(0.0f);
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
-            const float gr = r < R ? G[(size_t)r * ldg + h] : 0.0f;  // wave-uniform: scalar load
+            const float gr = G_LDS ? s_g[(h - h0) * RMAX + r] : (r < R ? G[(size_t)r * ldg + h] : 0.0f);  // wave-uniform: LDS broadcast / scalar load
 #pragma unroll
             for (int c = 0; c < COLS; ++c) g[c] = fmaf(gr, xv[r][c], g[c]);
         }
