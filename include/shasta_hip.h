@@ -526,7 +526,7 @@ int shasta_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_sq, int
 /* shasta_adam_lowrank_f32 and, in the same pass over the matrix, Y (+)= Gdx . W with the weights as they are BEFORE the update (Gdx: (Rdx, H)
  * at ldgdx, Y: (Rdx, K) at ldy; the backward's dx = ghid . W1 of a first aug_shape layer, which otherwise reads the 1 GB matrix once more:
  * shasta_smallm_nn_f32).  For an optimizer that steps these matrices inside the backward (training.FusedAdam(..., in_backward=True)).
- * 1 <= R, Rdx <= 16; workspace: shasta_adam_lowrank_dx_workspace_bytes(H, K, Rdx). */
+ * 1 <= R <= 64, 1 <= Rdx <= 16; workspace: shasta_adam_lowrank_dx_workspace_bytes(H, K, Rdx). */
 size_t shasta_adam_lowrank_dx_workspace_bytes(int H, int K, int Rdx);
 int shasta_adam_lowrank_dx_f32(float* param, float* exp_avg, float* exp_avg_sq, int H, int K, const float* G, int ldg, const float* X, int ldx,
                                int R, const float* Gdx, int ldgdx, int Rdx, float* Y, long ldy, int accumulate, void* workspace,

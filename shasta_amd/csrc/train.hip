@@ -824,7 +824,8 @@ int adam_lowrank_rows_per_block(int H, int K, int cols) {
 
 extern "C" size_t shasta_adam_lowrank_dx_workspace_bytes(int H, int K, int Rdx) {
     if (H <= 0 || K <= 0 || Rdx <= 0) return 0;
-    return (size_t)shasta::cdiv(H, adam_lowrank_rows_per_block(H, K, 4)) * Rdx * K * sizeof(float);
+    const int chunks = std::max(shasta::cdiv(H, adam_lowrank_rows_per_block(H, K, 4)), shasta::cdiv(H, adam_lowrank_rows_per_block(H, K, 2)));
+    return (size_t)chunks * Rdx * K * sizeof(float);  // (4 columns per thread up to rank 16, 2 above)
 }
 
 extern "C" int shasta_adam_lowrank_dx_f32(float* param, float* exp_avg, float* exp_avg_sq, int H, int K, const float* G, int ldg, const float* X,
@@ -832,7 +833,7 @@ extern "C" int shasta_adam_lowrank_dx_f32(float* param, float* exp_avg, float* e
                                           size_t workspace_bytes, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                           shasta_stream_t stream) {
     SHASTA_REQUIRE(param && exp_avg && exp_avg_sq && G && X && Gdx && Y && workspace && H >= 1 && K >= 4 && step >= 1, "adam_lowrank_dx: bad argument");
-    SHASTA_REQUIRE(R >= 1 && R <= 16 && Rdx >= 1 && Rdx <= 16, "adam_lowrank_dx: 1 <= R, Rdx <= 16");
+    SHASTA_REQUIRE(R >= 1 && R <= 64 && Rdx >= 1 && Rdx <= 16, "adam_lowrank_dx: 1 <= R <= 64, 1 <= Rdx <= 16");
     SHASTA_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && ldg >= H && ldx >= K && ldgdx >= H, "adam_lowrank_dx: K and ldx multiples of 4, ldg, ldgdx >= H, ldx >= K");
     SHASTA_REQUIRE((((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)X | (uintptr_t)workspace) & 15) == 0,
                    "adam_lowrank_dx: 16-byte alignment");
@@ -848,16 +849,17 @@ extern "C" int shasta_adam_lowrank_dx_f32(float* param, float* exp_avg, float* e
     a.eps = eps;
     a.weight_decay = weight_decay;
     a.rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    const int kblocks = cdiv(K / 4, 256), rpb = adam_lowrank_rows_per_block(H, K, 4), chunks = cdiv(H, rpb);
+    const int cols = R <= 16 ? 4 : 2;
+    const int kblocks = cdiv(K / cols, 256), rpb = adam_lowrank_rows_per_block(H, K, cols), chunks = cdiv(H, rpb);
     float* part = static_cast<float*>(workspace);
     auto launch = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(kblocks, chunks), dim3(256), 0, as_stream(stream), param, exp_avg, exp_avg_sq, G, ldg, X, ldx, R, H, K, rpb, a,
                            Gdx, ldgdx, Rdx, part);
     };
-    if (R <= 8 && Rdx <= 8) launch(adam_lowrank_kernel<8, 4, 8>);
-    else if (R <= 8) launch(adam_lowrank_kernel<8, 4, 16>);
-    else if (Rdx <= 8) launch(adam_lowrank_kernel<16, 4, 8>);
-    else launch(adam_lowrank_kernel<16, 4, 16>);
+    if (R <= 8) Rdx <= 8 ? launch(adam_lowrank_kernel<8, 4, 8>) : launch(adam_lowrank_kernel<8, 4, 16>);
+    else if (R <= 16) Rdx <= 8 ? launch(adam_lowrank_kernel<16, 4, 8>) : launch(adam_lowrank_kernel<16, 4, 16>);
+    else if (R <= 32) Rdx <= 8 ? launch(adam_lowrank_kernel<32, 2, 8>) : launch(adam_lowrank_kernel<32, 2, 16>);
+    else Rdx <= 8 ? launch(adam_lowrank_kernel<64, 2, 8>) : launch(adam_lowrank_kernel<64, 2, 16>);
     int rc = check_launch("adam_lowrank_dx");
     if (rc) return rc;
     hipLaunchKernelGGL(smallm_finish_kernel, dim3((unsigned)(((long)Rdx * K + 255) / 256)), dim3(256), 0, as_stream(stream), part, chunks, Rdx, K, Y,

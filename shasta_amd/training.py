@@ -301,7 +301,7 @@ class _AffinityTrainFn(torch.autograd.Function):
         # weights as they are before the update): the 1 GB matrix is read once for both (shasta_adam_lowrank_dx_f32)
         opt_ref = getattr(model, "_lowrank_adam_opt", None)
         stepper = opt_ref() if opt_ref is not None else None
-        in_bwd = lowrank and stepper is not None and stepper.in_backward and world * B <= 16 and B <= 16 and N * F >= 4
+        in_bwd = lowrank and stepper is not None and stepper.in_backward and world * B <= 64 and B <= 16 and N * F >= 4
         shape_grads, box_grads, ghids = [None] * 4, [None] * 4, [None] * 4
         for i in range(4):
             # aug_shape[i]: input = rows < N of feat (i<2) / prev_feat (i>=2); output row N + (i&1) of prev_feat (i<2) / feat (i>=2)
@@ -497,7 +497,7 @@ class FusedAdam(torch.optim.Optimizer):
         .grad None and hands the factors over on the parameter; same update, the gradient's sum over the step's frame-pairs in another
         order."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        # in_backward (with lowrank_first_layers, steps of at most 16 frame-pairs over all ranks): those four matrices take their Adam
+        # in_backward (with lowrank_first_layers, steps of at most 16 frame-pairs per rank and 64 over all ranks): those four matrices take their Adam
         # update INSIDE loss.backward(), in the one pass over each that also forms the backward's dx = ghid W1 from the not-yet-updated
         # weights (the matrix is read once instead of twice); step() then updates everything else.  Same weights after the step as
         # without the option; for loops that are backward() -> step() like tools/nusc_shasta/train.py:213-215 (no gradient clipping or

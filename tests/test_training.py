@@ -652,7 +652,7 @@ def test_adam_stepped_inside_the_backward_equals_the_step_after_it(exchange):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("R,Rdx,H,K", [(1, 1, 5, 8), (8, 8, 70, 1032), (3, 16, 129, 260), (16, 5, 33, 4096)])
+@pytest.mark.parametrize("R,Rdx,H,K", [(1, 1, 5, 8), (8, 8, 70, 1032), (3, 16, 129, 260), (16, 5, 33, 4096), (24, 8, 70, 516), (64, 8, 131, 1032), (33, 12, 64, 260)])
 def test_adam_lowrank_with_the_product_in_the_same_pass(R, Rdx, H, K):
     """shasta_adam_lowrank_dx_f32 against shasta_adam_lowrank_f32 (the same update, bit for bit) and Gdx W in float64 (W before the update)."""
     from shasta_amd import hip
