@@ -83,7 +83,7 @@ if __name__ == "__main__":
             if lines:
                 json.dump(json.loads(lines[-1]), open(os.path.join(P, TAG + "_" + f), "w"), indent=1)
         if f in ("train_n500.log", "train_n90.log", "pair_mlp.log"):
-            lines = [l.rstrip() for l in open(os.path.join(G, SRC, f)) if "ms/step" in l or "fwd0" in l]
+            lines = [l.rstrip() for l in open(os.path.join(G, SRC, f)) if "ms/step" in l or "fwd0" in l or "adam_lowrank" in l]
             if lines:
                 open(os.path.join(P, TAG + "_" + f.replace(".log", ".txt")), "w").write("\n".join(lines) + "\n")
         if f == "stage_power.log":
