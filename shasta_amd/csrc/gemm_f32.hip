@@ -553,8 +553,10 @@ int launch_gemm_strided(const float* A, long sa_m, long sa_k, const float* W, lo
     int nz = 1;
     // long reductions with few output tiles (weight gradients): split the reduction over grid.z
     // (bias and activation then belong to the sum of the slices: gemm_reduce_kernel applies them)
-    if (splitk_ws && K >= 1024 && tiles < 128 && !mask && (act & 4) == 0) {
-        nz = min(min(512, cdiv(1024, tiles)), cdiv(K, 256));
+    // (from K = 256 in slices of at least 128: a few-row GEMM with K = 450 ... 630 in ONE workgroup took 30 - 36 us of the car
+    // configuration's training step, four times per step)
+    if (splitk_ws && K >= 256 && tiles < 128 && !mask && (act & 4) == 0) {
+        nz = min(min(512, cdiv(1024, tiles)), cdiv(K, 128));
         while (nz > 1 && (size_t)nz * M * N * sizeof(float) > splitk_ws_bytes) --nz;
     }
     if (nz <= 1) {

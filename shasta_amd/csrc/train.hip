@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
     __shared__ float red[4][64];
     const int k = threadIdx.x & 3, q = threadIdx.x >> 2;
     float s = 0.0f;
+#pragma unroll 8
     for (int r = q; r < rows; r += 64) s += part[(size_t)r * 4 + k];
     red[k][q] = s;
     __syncthreads();
