@@ -70,6 +70,21 @@ inline size_t aux_maxima_bytes(size_t H) { return align_up(4 * H * sizeof(unsign
 inline size_t aux_stats_bytes(size_t H) { return align_up(4 * H * sizeof(float) + 64, 256); }
 inline size_t aux_image_offset(size_t H) { return aux_maxima_bytes(H) + aux_stats_bytes(H); }
 
+// XCD-aware tile order.  Workgroups go to the 8 XCDs (each with its own L2) round-robin by their linear id, x fastest: with the tiles
+// of one frame along x, every XCD sees every frame and fetches that frame's shared rows into its own L2 (the pair kernel at 1024
+// frame-pairs: 2.7 GB fetched for 0.6 GB of tables).  This returns the block index of the LOGICAL tile for the calling workgroup such
+// that the workgroups of one XCD take consecutive logical tiles - the tiles of a frame share an L2.  (A pure relabelling: which
+// workgroup computes a tile has no influence on the tile's result.)
+__device__ __forceinline__ void xcd_logical_block(int& bx, int& by, int& bz) {
+    const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+    unsigned L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const unsigned per = total >> 3;
+    if (L < per * 8) L = (L & 7) * per + (L >> 3);
+    bx = (int)(L % nx);
+    by = (int)((L / nx) % ny);
+    bz = (int)(L / (nx * ny));
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

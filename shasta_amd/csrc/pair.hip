@@ -313,7 +313,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4))) v
 #ifdef PAIR_STAMP
     const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int b = blockIdx.z, d0 = blockIdx.x * DT;
+    int lbx, lby, b;
+    xcd_logical_block(lbx, lby, b);  // the detection tiles of a frame on one XCD (common.hpp)
+    const int d0 = lbx * DT;
     const int d = d0 + dlane, dcl = min(d, D - 1);
     const PackedLayout P(0, 0, F);
     {
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4))) v
     const unsigned abias_base = (unsigned)(unsigned long long)(s_a4 + (lane & 3));
     const f32x4 zero4 = {0, 0, 0, 0};
 
-    const int t_beg = (blockIdx.y * WPB + wid) * TW;
+    const int t_beg = (lby * WPB + wid) * TW;
     const int t_end = min(T, t_beg + TW);
     float* my_up = s_up + wid * (RING * 256);
     // lanes [0, ET/4): the UP row; the next 4 lanes: the 16-float hand row of the same track (lands right behind it); the

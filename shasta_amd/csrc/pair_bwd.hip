@@ -87,8 +87,10 @@ __global__ __launch_bounds__(64 * PB_WPB) void pair_mlp_kernel(const float* __re
     extern __shared__ __attribute__((aligned(16))) float s_pb[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, dt = blockIdx.x, d = dt * 64 + lane, dcl = min(d, D - 1);
-    const int slice = blockIdx.y * PB_WPB + wid, nslice = gridDim.y * PB_WPB;
+    int dt, lby, b;
+    xcd_logical_block(dt, lby, b);  // the tiles and track slices of a frame on one XCD: its UP / UC rows come from HBM once (common.hpp)
+    const int d = dt * 64 + lane, dcl = min(d, D - 1);
+    const int slice = lby * PB_WPB + wid, nslice = gridDim.y * PB_WPB;
     const int t_beg = slice * tw, t_end = min(T, t_beg + tw);
     float* tab = s_pb;
     float* Lup = s_pb + M::NTAB + wid * M::LDS_UP;

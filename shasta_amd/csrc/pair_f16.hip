@@ -187,8 +187,14 @@ __global__ __launch_bounds__(64 * WPB) void pair_f16_kernel(const float* __restr
 #endif
     // (Placing the 8 detection tiles of a frame-pair on ONE XCD - they all read that frame-pair's UP / hand tables, 265 KB, which with
     // the plain order is fetched into eight L2s - was measured: 1.5 % less energy per step, pair kernel 4.21 - 4.30 -> 4.35 ms; not kept.)
+#ifdef PAIR_NO_XCD_ORDER
     const int b = blockIdx.z, d0 = blockIdx.x * 64;
     const int by = blockIdx.y;
+#else
+    int lbx, by, b;
+    xcd_logical_block(lbx, by, b);  // the detection tiles of a frame on one XCD: its UP / UC rows come from HBM once
+    const int d0 = lbx * 64;
+#endif
     const int d = d0 + lane, dcl = min(d, D - 1);
     const PackedLayout P(0, 0, F);
     {

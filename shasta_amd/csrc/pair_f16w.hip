@@ -194,7 +194,9 @@ __global__ __launch_bounds__(64 * PWK_WPB) __attribute__((amdgpu_waves_per_eu(2,
     wu4* s_w = reinterpret_cast<wu4*>(s_up + PWK_WPB * 6 * PWK_SLOT);  // [piece][fragment][lane] second-layer weight pieces
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, d0 = blockIdx.x * 32, by = blockIdx.y;
+    int lbx, by, b;
+    xcd_logical_block(lbx, by, b);  // the detection tiles of a frame on one XCD (common.hpp)
+    const int d0 = lbx * 32;
     const int n = lane & 31, kb = lane >> 5;
     const int d = d0 + n, dcl = min(d, D - 1);
     const PackedLayout P(0, 0, F);
