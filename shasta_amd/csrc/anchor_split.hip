@@ -665,7 +665,9 @@ __global__ __launch_bounds__(512) void anchor_l1_wide_kernel(AnchorSplitArgs a) 
         if (idx == 0) {
             const char* base = wub + (size_t)(t >> 1) * 4096 + (size_t)(t & 1) * 2048;
             const uint32_t dst = lds0 + (uint32_t)((slot * SLOT + wid * 256) * 4);
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(loff), "s"(base), "s"(dst) : "memory", "m0");
+            // (no `nt`: the workgroup of the other 512-item block reads the same fragments at about the same time on this XCD - without the
+            // hint more of its reads hit the L2: 6.62 -> 6.23 GB fetched per 1024 frame-pairs, the launch time unchanged)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(loff), "s"(base), "s"(dst) : "memory", "m0");
         } else {
             const int f = 4 * wid + idx - 1, u = f >> 1, pc = f & 1;  // fragment (item block u, piece) of the slot
             const char* base = xub + (size_t)(t >> 1) * (4 * XT * 1024) + (size_t)(((u * 2 + (t & 1)) * 2 + pc) * 1024);
