@@ -171,7 +171,9 @@ def anchor_shape(w, i, table):
 def anchor_box(w, i, boxes7):
     """boxes7 (B,N,7) -> (B,1,7) with dims [3:6] abs'd."""
     B = boxes7.shape[0]
-    a = _mlp(w, f"aug_dets.{i}", boxes7.reshape(B, -1)).reshape(B, 1, 7)
+    # (.clone(): at max_obj = 1 the reshape is a VIEW of the box table, which the back-projection then writes in place - autograd
+    # refuses the saved input; for every other size the reshape copies anyway)
+    a = _mlp(w, f"aug_dets.{i}", boxes7.reshape(B, -1).clone()).reshape(B, 1, 7)
     return torch.cat([a[:, :, :3], torch.abs(a[:, :, 3:6]), a[:, :, 6:]], dim=-1)
 
 

@@ -1,6 +1,8 @@
-"""Seeded random configurations of the whole path against the oracle: table sizes, feature counts, point counts, batch sizes,
+"""Seeded random configurations of the whole path against the oracle (SHASTA_FUZZ_SEED / SHASTA_FUZZ_CASES and SHASTA_FUZZ_GRAD_SEED /
+SHASTA_FUZZ_GRAD_CASES widen the forward / backward sweeps for a one-off run): table sizes, feature counts, point counts, batch sizes,
 padding, map sizes, convolution shapes.  The fixed-shape tests cover the shipped configurations; this sweep is there for the
 seams between kernel variants (batch-size and width thresholds, partial tiles, odd sizes)."""
+import os
 import random
 
 import numpy as np
@@ -43,7 +45,7 @@ BIGGER = [(90, 3, 5, 17, 40, 180, 1), (100, 7, 4, 33, None, 90, 2), (130, 5, 1, 
           (200, 7, 1, 16, 150, 180, 10), (40, 4, 4, 48, 39, 45, 11)]
 
 
-@pytest.mark.parametrize("N,nf,npnt,B,n_real,hw,seed", _cases(28, 2024) + BIGGER)
+@pytest.mark.parametrize("N,nf,npnt,B,n_real,hw,seed", _cases(int(os.environ.get("SHASTA_FUZZ_CASES", 28)), int(os.environ.get("SHASTA_FUZZ_SEED", 2024))) + BIGGER)
 def test_forward_random_configs_vs_oracle(N, nf, npnt, B, n_real, hw, seed):
     dev = torch.device("cuda:0")
     stride = 8 * 180 // hw  # the map always spans the same metric extent
@@ -92,10 +94,11 @@ def test_shared_conv_random_shapes_vs_oracle(B, cin, H, W, seed):
 
 def _grad_cases(n, seed):
     rnd = random.Random(seed)
-    return [(rnd.choice([1, 3, 5, 9, 16, 21]), rnd.randint(1, 7), rnd.choice([1, 4, 5]), rnd.choice([1, 2, 5, 17]), 4000 + k) for k in range(n)]
+    sizes = [1, 3, 5, 9, 16, 21] + ([33, 47, 62, 63, 64, 65, 90, 127, 129] if os.environ.get("SHASTA_FUZZ_GRAD_BIG") else [])  # (one-off sweeps: tile seams of pair_bwd.hip)
+    return [(rnd.choice(sizes), rnd.randint(1, 7), rnd.choice([1, 4, 5]), rnd.choice([1, 2, 5, 17]), 4000 + k) for k in range(n)]
 
 
-@pytest.mark.parametrize("N,nf,npnt,B,seed", _grad_cases(8, 9) + [(100, 7, 4, 2, 4100), (130, 3, 5, 3, 4101), (64, 7, 1, 20, 4102)])
+@pytest.mark.parametrize("N,nf,npnt,B,seed", _grad_cases(int(os.environ.get("SHASTA_FUZZ_GRAD_CASES", 8)), int(os.environ.get("SHASTA_FUZZ_GRAD_SEED", 9))) + [(100, 7, 4, 2, 4100), (130, 3, 5, 3, 4101), (64, 7, 1, 20, 4102)])
 def test_backward_random_configs_vs_oracle_autograd(N, nf, npnt, B, seed):
     from shasta_amd import training
     dev = torch.device("cuda:0")
