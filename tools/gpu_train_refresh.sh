@@ -1,3 +1,6 @@
+#!/bin/bash
+# Re-collects the training files of a measurement pass (kernel stats of a training step at N=500 B=8 and at the car configuration x 64, the
+# per-pair MLP kernels and the low-rank Adam pass alone) and the driver line into gpurun_out/r5m3.  usage (GPU box): bash tools/gpu_train_refresh.sh
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r5m3
 mkdir -p $O

@@ -1,3 +1,6 @@
+#!/bin/bash
+# A/B of the XCD-aware tile order of the pair kernel: time (tools/pair_time.py) and FETCH_SIZE with the default library and with
+# tools/probes/_bin/libshasta_noxcd.so (python tools/build_variant.py noxcd pair_f16.hip -DPAIR_NO_XCD_ORDER).  usage (GPU box): bash tools/gpu_xcd_ab.sh
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for lib in "" tools/probes/_bin/libshasta_noxcd.so; do
