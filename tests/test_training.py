@@ -319,7 +319,8 @@ _PAIR_MLP_WIDTHS = {  # (kind, F) -> layer widths behind the factorised first la
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,F,B,T,D", [(0, 64, 2, 5, 7), (2, 64, 1, 22, 22), (1, 64, 3, 66, 65), (0, 256, 2, 92, 92), (2, 256, 1, 130, 70),
-                                          (1, 256, 2, 9, 200), (0, 320, 1, 33, 129), (2, 320, 2, 92, 92), (2, 256, 3, 1, 1)])
+                                          (1, 256, 2, 9, 200), (0, 320, 1, 33, 129), (2, 320, 2, 92, 92), (2, 256, 3, 1, 1), (2, 256, 1, 602, 602), (0, 320, 1, 700, 333),
+                                          (1, 64, 40, 17, 65)])
 def test_pair_mlp_on_chip_matches_autograd(kind, F, B, T, D):
     """csrc/pair_bwd.hip: a pair MLP behind its factorised first layer, forward and backward per pair on chip, against torch autograd of
     the dense formulation in float64: the output, the gradients of both first-layer tables (sums over the detections / the tracks) and
@@ -366,13 +367,43 @@ def test_pair_mlp_on_chip_matches_autograd(kind, F, B, T, D):
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b), "the gradients are sums in a fixed order"
     gUP, gUC, img = res[0]
-    _close("gUP", gUP, UPd.grad, rtol=1e-5)
-    _close("gUC", gUC, UCd.grad, rtol=1e-5)
+    # From ~10^5 pairs on, a few of the P x (E2 + E3) later-layer units sit within fp32 rounding of their ReLU kink, and the float64
+    # reference takes the other branch there (expected count ~ units x 1e-6): such a flip moves one track row of gUP and one detection
+    # row of gUC by O(|gout| |W|) and every weight gradient by one pair's share.  Small cases: every entry within 1e-5 of the range;
+    # large cases (a flip touches a whole row of gUP / gUC: ~15 flips at 602 x 602 = 2.5 % of the rows): at least 85 % of the entries within
+    # 1e-5 of the range, the median deviation below 1e-6, the largest below 3 %.
+    big = B * T * D > 100000
+
+    def close(name, got, want):
+        if not big:
+            return _close(name, got, want, rtol=1e-5)
+        got, want = got.detach().double().cpu(), want.detach().double().cpu()
+        scale = max(float(want.abs().max()), 1e-7)
+        err = (got - want).abs() / scale
+        assert float(err.max()) <= 3e-2, "%s: max |diff| %.3e of the range" % (name, float(err.max()))
+        assert float((err > 1e-5).double().mean()) <= 0.15, "%s: %.2e of the entries off by more than 1e-5 of the range" % (name, float((err > 1e-5).double().mean()))
+        assert float(err.flatten().median()) <= 1e-6, "%s: median deviation %.2e of the range" % (name, float(err.flatten().median()))
+
+    close("gUP", gUP, UPd.grad)
+    close("gUC", gUC, UCd.grad)
     o = 0
     for i, (w, b) in enumerate(ld):
-        _close("gW%d" % (i + 2), img[o:o + w.numel()].view_as(w), w.grad, rtol=1e-5)
-        _close("gb%d" % (i + 2), img[o + w.numel():o + w.numel() + b.numel()], b.grad, rtol=1e-5)
+        close("gW%d" % (i + 2), img[o:o + w.numel()].view_as(w), w.grad)
+        close("gb%d" % (i + 2), img[o + w.numel():o + w.numel() + b.numel()], b.grad)
         o += w.numel() + b.numel()
+    if big:
+        # linearity in the incoming gradient at the full size (the ReLU masks belong to the forward, which does not see gout): no kink
+        # ambiguity here - backward(2.5 g1 + g2) = 2.5 backward(g1) + backward(g2) up to fp32 summation
+        def run(gm):
+            ws = torch.empty((nb + 3) // 4, device=dev)
+            a_, b_, c_ = torch.empty_like(UPg), torch.empty_like(UCg), torch.empty(nimg, device=dev)
+            hip.check(lib.shasta_pair_mlp_backward_f32(kind, F, hip.ptr(UPg), hip.ptr(UCg), wt, hip.ptr(gm), B, T, D, hip.ptr(a_), hip.ptr(b_), hip.ptr(c_),
+                                                       hip.ptr(ws), nb, hip.stream_ptr()), "pair_mlp_backward")
+            return a_.double(), b_.double(), c_.double()
+        g2 = torch.randn(goutg.shape, generator=torch.Generator().manual_seed(7)).to(dev)
+        r1, r2, r12 = run(goutg), run(g2), run(2.5 * goutg + g2)
+        for name, x, y, z in zip(("gUP", "gUC", "weight image"), r1, r2, r12):
+            _close("linearity of " + name, z, 2.5 * x + y, rtol=2e-6)
     # too small a workspace, an unsupported width: errors, not writes
     assert lib.shasta_pair_mlp_backward_f32(kind, F, hip.ptr(UPg), hip.ptr(UCg), wt, hip.ptr(goutg), B, T, D, hip.ptr(gUP.to(dev)), hip.ptr(gUC.to(dev)),
                                             hip.ptr(img.to(dev)), hip.ptr(ws), nb - 4, hip.stream_ptr()) != 0
