@@ -630,8 +630,8 @@ def test_train_steps_with_adam_from_the_factors_equal_the_dense_steps(exchange):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exchange", [False, True])
-def test_adam_stepped_inside_the_backward_equals_the_step_after_it(exchange):
+@pytest.mark.parametrize("exchange,size", [(False, (12, 7, 4, 3)), (True, (12, 7, 4, 3)), (False, (500, 7, 4, 2))])
+def test_adam_stepped_inside_the_backward_equals_the_step_after_it(exchange, size):
     """FusedAdam(..., lowrank_first_layers=model, in_backward=True): the four aug_shape first-layer matrices take their update inside
     loss.backward(), in the pass that also forms dx = ghid W1 from the not-yet-updated weights (shasta_adam_lowrank_dx_f32).  Three steps:
     those matrices and their optimizer state bit for bit as with the update in step() (the same kernel arithmetic on the same factors),
@@ -640,7 +640,7 @@ def test_adam_stepped_inside_the_backward_equals_the_step_after_it(exchange):
     import torch.distributed as dist
     from shasta_amd import training
     from tests.test_training_ddp import _free_port
-    c, model, w, a, b, det, prev, gt = _case(12, 7, 4, 3, seed=22)
+    c, model, w, a, b, det, prev, gt = _case(*size, seed=22)  # (the last one: the configuration the metric is quoted on, 4 x 1 GB matrices)
     dev = torch.device("cuda:0")
     after = model.to(dev).train()
     inside = copy.deepcopy(after)
@@ -709,3 +709,39 @@ def test_adam_lowrank_with_the_product_in_the_same_pass(R, Rdx, H, K):
         assert torch.equal(y[:, K:], y0[:, K:]), "columns past K are not touched"
     assert lib.shasta_adam_lowrank_dx_f32(hip.ptr(pb), hip.ptr(mb), hip.ptr(vb), H, K, hip.ptr(G), H + 3, hip.ptr(X), K + 4, R, hip.ptr(Gdx), H + 1, Rdx,
                                           hip.ptr(y), K + 8, 0, hip.ptr(ws), nb - 4, *hyper, hip.stream_ptr()) != 0
+
+
+@pytest.mark.gpu
+def test_backward_at_the_headline_size_twice_the_same_bits():
+    """N = M = 500, F = 256, nf = 7 (the configuration the metric is quoted on), two frame-pairs: every parameter gradient of rows 6-16 is
+    a sum in a fixed order (per-pair kernels, split-K slices, partial-sum passes) - two backward passes over the same inputs give the same
+    bits - finite, and not all zero; only the scatter-add into the BEV maps' gradient uses float atomics (agreement to fp32 rounding)."""
+    import shasta_amd
+    from shasta_amd import training
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    with torch.device(dev):
+        model = shasta_amd.build_simp_track(dict(type="Shasta", reader=None, backbone=None, neck=None,
+                                                 bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
+                                                 max_obj=500, num_feats=7, num_point=4, in_channels=512)).train()
+    B, N = 2, 500
+    g = torch.Generator().manual_seed(5)
+    bev = torch.relu(torch.randn(B, 180, 180, 64, generator=g)).to(dev)
+    pbev = torch.relu(torch.randn(B, 180, 180, 64, generator=g)).to(dev)
+    det, prev = O.synth_boxes(g, B, N, None).to(dev), O.synth_boxes(g, B, N, N - 40).to(dev)
+    gt = (torch.rand(B, N + 2, N + 2, generator=g) < 0.01).float().to(dev)
+    gt[:, 0, 0] = 1.0
+    runs = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        a, b = bev.clone().requires_grad_(True), pbev.clone().requires_grad_(True)
+        m1, m2 = training.affinity_train(model, a, b, det.clone(), prev.clone())
+        training.affinity_loss(m1, m2, gt).backward()
+        runs.append(({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, a.grad.clone(), b.grad.clone()))
+    assert len(runs[0][0]) == 2 * (8 + 4 + 8 + 3 + 3 + 6)
+    for k, v in runs[0][0].items():
+        assert torch.isfinite(v).all(), k
+        assert torch.equal(v, runs[1][0][k]), k
+    assert sum(float(v.abs().max()) > 0 for v in runs[0][0].values()) >= 60
+    for x, y in ((runs[0][1], runs[1][1]), (runs[0][2], runs[1][2])):
+        assert float((x - y).abs().max()) <= 1e-5 * max(float(x.abs().max()), 1e-12)
