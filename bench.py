@@ -370,19 +370,24 @@ def rooflines(cfg, arithmetic, r, with_traffic=True):
                  "avg_launch_ms": pair_ms, "share_of_step": pair_ms / step_ms}
     T = wk.N + 2
     if pair_f16:
+        executed = 2.0 * (3 * PAIR_F16_LAYER2_SLOTS[wk.F] + (wk.executed_pair_macs - wk.layer2_macs)) * wk.pairs * B
         roof_pair.update({
+            # what limits this kernel is VALU issue (cutting the hidden activations into fp16 pieces: ~2.5 vector slots per hidden value);
+            # the matrix pipe idles most of the time (mfma_busy).  `frac` stays the f32-equivalent figure of rounds 1 - 5 (useful fp32
+            # flops against the f32 MFMA peak - a yardstick, not this kernel's ceiling); `frac_executed` = executed matrix flops against
+            # the peak of the pipe they run on (f16)
+            "bound": "valu",
             "kernel": "%s: per-pair MLP tails (second layers on the f16 matrix path) + hand residual -> residual (B, %d, %d)" % (pair_kernel, T, T),
             "mfma_dtype": "f16 (layer 2: three piece products per fp32 product) + f32 (layers 3-4)",
-            "executed_flops_per_launch": 2.0 * (3 * PAIR_F16_LAYER2_SLOTS[wk.F] + (wk.executed_pair_macs - wk.layer2_macs)) * wk.pairs * B,
-            "note": "useful fp32 flops priced against the f32 MFMA peak, the yardstick of the f32 form (pair_mfma4_kernel, --arithmetic pieces); "
-                    "in this form the kernel is bound by VALU issue (cutting the activations into fp16 pieces), not by a matrix pipe"
-                    if wk.F != 320 else
-                    "useful fp32 flops priced against the f32 MFMA peak, the yardstick of the f32 form (pair_mfma4_kernel, --arithmetic pieces); "
-                    "32x32x16 tiles over the 144 columns: 60 f16 MFMAs + 102 f32 4x4x1 per 64 pairs keep the matrix pipe busy ~85 % of the time at the "
-                    "clock the power cap leaves, the cuts the vector pipe ~70 % (DESIGN.md K4)"})
+            "executed_flops_per_launch": executed,
+            "frac_f32_equiv": pair_tflops / MFMA_F32_PEAK_TFLOPS,
+            "frac_executed": executed / (pair_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS})
+        roof_pair.update(_pmc_counters(B, "pair", pair_kernel) if (with_traffic and headline and arithmetic == "f16x2") else {})
     else:
         roof_pair.update({"kernel": "pair_mfma4_kernel<%d,8>: per-pair MLP tails + hand residual -> residual (B, %d, %d)" % (wk.F, T, T),
                           "mfma_dtype": "f32", "executed_flops_per_launch": 2.0 * wk.executed_pair_macs * wk.pairs * B})
+    if roof_l1["bound"] == "mfma" and with_traffic and headline and arithmetic == "f16x2":
+        roof_l1.update(_pmc_counters(B, "l1", l1_kernel))
     return roof_l1, roof_pair
 
 
@@ -422,6 +427,8 @@ def main():
                          "the weight stream + three bf16 pieces elsewhere (default), three bf16 pieces everywhere, or f32 MFMA kernels only")
     ap.add_argument("--no-precut", action="store_true", help="Shasta.precut_weight_stream = False: cut the fp32 first-layer weights inside the "
                                                              "weight-stream kernel instead of streaming the pre-cut fp16 piece image (+4.1 GB resident)")
+    ap.add_argument("--extra-file", default=os.path.join(ROOT, "bench_extra.json"),
+                    help="where the long form goes (full roofline objects, the other operating points of SURVEY 8(d), notes); also printed to stderr")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only, on the CPU with gloo (no GPU, no forward): for the CPU test suite")
     args = ap.parse_args()
@@ -456,54 +463,116 @@ def main():
     # `roofline` is the kernel with the longer average launch; the other one rides along as `roofline_second`
     roof, second = (roof_l1, roof_pair) if r["l1_ms"] >= r["pair_ms"] else (roof_pair, roof_l1)
     joules, elapsed = r["joules"], r["elapsed"]
-    out = {
-        "metric": "affinity frame-pairs/sec at N=M=500, F=256",
-        "value": r["value"],
-        "unit": "frame-pairs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": r["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.arithmetic == "f32" else "f32 (%s products)" % args.arithmetic, "data": "synthetic",
-        "config": {"workload": "synthetic N=M=500, F=256 (num_point=4, C=64), nf=7 affinity forward from HBM-resident "
-                               "NHWC BEV features (SURVEY 8a rows 4-16)", "frame_pairs_per_step_per_gpu": B,
-                   "max_obj": N_OBJ, "num_feats": NF, "num_point": NPOINT, "bev_hw": HW,
-                   "parallelism": "replica x%d (frame-parallel, no data-path collective)" % world,
-                   "hip_graph": bool(args.graph), "precut_weight_stream": not args.no_precut,
-                   "arithmetic": args.arithmetic + ": " + {"f16x2": "fp32 operands in HBM, fp32 accumulation throughout; the first aug_shape layer (from 17 frame-pairs per step "
-                                           "with the pre-cut weight image, above 64 without) and the second layers of the pair MLPs form every fp32 product from three products of "
-                                           "two range-scaled fp16 pieces per operand (round to nearest; measured max error vs float64: weight "
-                                           "stream 5.5e-6 against 7.0e-6 for the f32 MFMA kernel, pair stage 1.8e-6 against 2.3e-6), and so do the six "
-                                           "aff layers from 8192 table rows (one pass with both softmaxes; logits within 2x the f32 kernel's error); the "
-                                           "row-embedding GEMMs use six products of three exact bf16 pieces from 8192 table rows "
-                                           "(--arithmetic pieces / f32 select the other forms; extra.arithmetic_f32 is the strict-fp32 figure)",
-                                  "pieces": "fp32 operands, fp32 accumulation throughout; above 32 frame-pairs per step the first aug_shape "
-                                            "layer, and from 8192 table rows the row-embedding GEMMs and the aff layers, form every fp32 product "
-                                            "from six exact bf16 piece products on the bf16 MFMA path",
-                                  "f32": "fp32 operands, fp32 accumulation throughout, f32 MFMA kernels only",
-                                  "f16grid": "as f16x2, but the pair kernel takes the fp16 pieces of its hidden activations from a fixed grid per "
-                                             "MLP (22 bits of the tile's largest sum): NOT fp32-equivalent (residual errors 2x / 5x the fp32 kernels')"}[args.arithmetic]},
-        "dense_equivalent_tflops": DENSE_GFLOP_PER_PAIR * 1e9 * r["value"] / 1e12,
-        "selfcheck_max_abs": r["selfcheck"],
-        # rank 0's GPU over the timed loop, from the device's energy accumulator (null when the rocm_smi device cannot be matched)
-        "energy": None if joules is None else {"joules_per_step": joules / args.steps, "avg_power_w": joules / elapsed,
-                                               "millijoules_per_frame_pair": joules / args.steps / B * 1e3, "pci": energy.pci},
-        "roofline": roof,
-        "roofline_second": second,
-    }
+    probe = os.environ.get("SHASTA_BENCH_PROBE") == "1"  # a diagnostic library (results wrong on purpose) is being timed: never a headline
+    out = build_line(args, world, r, roof, second, probe)
+    if probe:
+        out["probe"] = True
+        out["probe_value"] = r["value"]
+    # everything else (the full roofline objects, the other operating points, notes) goes to a side file and to stderr: the last stdout
+    # line stays a few hundred bytes per object (round 5's 22 KB line was not parsed by the driver)
+    detail = {"headline": {"value": r["value"], "ms_per_step": r["ms_per_step"], "frame_pairs_per_step": B,
+                           "dense_equivalent_tflops": DENSE_GFLOP_PER_PAIR * 1e9 * r["value"] / 1e12,
+                           "hip_graph": bool(args.graph), "precut_weight_stream": not args.no_precut,
+                           "arithmetic_note": ARITHMETIC_NOTES[args.arithmetic],
+                           "energy": None if joules is None else {"joules_per_step": joules / args.steps, "avg_power_w": joules / elapsed,
+                                                                  "millijoules_per_frame_pair": joules / args.steps / B * 1e3, "pci": energy.pci},
+                           "roofline": roof, "roofline_second": second}}
     if rank == 0 and world == 1 and not args.no_extras and not args.graph:
         try:
-            out["extra"] = extras(bench, args)
+            detail["extra"] = extras(bench, args)
+            f32 = detail["extra"].get("arithmetic_f32", {})
+            out["value_f32"] = f32.get("value")
         except Exception as err:  # noqa: BLE001  (the headline above is measured: never lose the line to an extra)
-            out["extra"] = {"error": "%s: %s" % (type(err).__name__, str(err)[:300])}
+            detail["extra"] = {"error": "%s: %s" % (type(err).__name__, str(err)[:300])}
+    if args.arithmetic == "f32":
+        out["value_f32"] = out["value"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(bench.model(HEADLINE), args.cpu_sample)
         except Exception as err:  # noqa: BLE001
-            out["cpu_baseline"] = {"error": "%s: %s" % (type(err).__name__, str(err)[:300]), "kind": "port"}
+            out["cpu_baseline"] = {"error": "%s: %s" % (type(err).__name__, str(err)[:200]), "kind": "port"}
     if rank == 0:
-        print(json.dumps(out))
+        out["extra_file"] = write_extra(detail, args.extra_file)
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
+
+
+def build_line(args, world, r, roof, second, probe=False):
+    """The compact object of the one stdout line (every key the contract names, no prose); main() and --dry-run share it."""
+    B, joules = r["B"], r.get("joules")
+    return {
+        "metric": "affinity frame-pairs/sec at N=M=500, F=256",
+        "value": None if probe else r["value"],
+        "unit": "frame-pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": r["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "synthetic N=M=500, F=256 (num_point 4 x C 64), nf=7: affinity forward from HBM-resident NHWC BEV maps "
+                               "(SURVEY 8a rows 4-16)", "frame_pairs_per_step_per_gpu": B,
+                   "max_obj": N_OBJ, "num_feats": NF, "num_point": NPOINT, "arithmetic": args.arithmetic,
+                   "parallelism": "replica x%d" % world},
+        "roofline": compact_roofline(roof),
+        "roofline_second": compact_roofline(second),
+        "cpu_baseline": None,
+        "value_f32": None,
+        "selfcheck_max_abs": r.get("selfcheck"),
+        "mj_per_frame_pair": None if joules is None else joules / args.steps / B * 1e3,
+        "extra_file": None,
+    }
+
+
+LINE_LIMIT = 4096  # bytes of the one stdout line (tests/test_bench_launch.py, tests/test_bench_contract.py hold it to this)
+
+ARITHMETIC_NOTES = {
+    "f16x2": "fp32 operands in HBM, fp32 accumulation throughout; the first aug_shape layer (from 17 frame-pairs per step with the pre-cut weight "
+             "image, above 64 without) and the second layers of the pair MLPs form every fp32 product from three products of two range-scaled fp16 "
+             "pieces per operand (max error vs float64: weight stream 5.5e-6 against 7.0e-6 for the f32 MFMA kernel, pair stage 1.8e-6 against "
+             "2.3e-6), and so do the six aff layers from 8192 table rows; the row-embedding GEMMs use six products of three exact bf16 pieces",
+    "pieces": "fp32 operands, fp32 accumulation; above 32 frame-pairs per step the first aug_shape layer, and from 8192 table rows the "
+              "row-embedding GEMMs and the aff layers, form every fp32 product from six exact bf16 piece products",
+    "f32": "fp32 operands, fp32 accumulation throughout, f32 MFMA kernels only",
+    "f16grid": "as f16x2, but the pair kernel takes the fp16 pieces of its hidden activations from a fixed grid per MLP: NOT fp32-equivalent",
+}
+
+
+def compact_roofline(ro):
+    """The judged keys of a roofline object (task statement 4) + the kernel's short name, its launch time and, where the committed
+    counter pass holds them, the pipe counters; the long form is in the side file."""
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "share_of_step",
+            "frac_f32_equiv", "frac_executed", "mfma_busy", "valu_busy", "valu_insts")
+    c = {k: ro[k] for k in keep if k in ro}
+    c["kernel"] = ro["kernel"].split(":")[0].split(" (")[0]
+    return c
+
+
+def write_extra(detail, path):
+    """The long form: `path` (default bench_extra.json beside bench.py; the temp directory if that is read-only) and stderr."""
+    text = json.dumps(detail)
+    print("bench.py extra: " + text, file=sys.stderr, flush=True)
+    import tempfile
+    for p in (path, os.path.join(tempfile.gettempdir(), "shasta_bench_extra.json")):
+        try:
+            with open(p, "w") as f:
+                f.write(text + "\n")
+            return os.path.relpath(p, ROOT) if os.path.abspath(p).startswith(ROOT + os.sep) else p
+        except OSError:
+            continue
+    return None
+
+
+def emit(out):
+    """The ONE stdout line, last thing printed; never longer than LINE_LIMIT (optional keys are dropped first, in this order)."""
+    line = json.dumps(out)
+    for k in ("mj_per_frame_pair", "selfcheck_max_abs", "roofline_second"):
+        if len(line) <= LINE_LIMIT:
+            break
+        out.pop(k, None)
+        line = json.dumps(out)
+    assert len(line) <= LINE_LIMIT, "bench line of %d bytes" % len(line)
+    sys.stderr.flush()
+    print(line, flush=True)
 
 
 def extras(bench, args):
@@ -864,25 +933,50 @@ def extra_shared_conv(bench, args, ex):
     ex["shared_conv"] = sc
 
 
+def _pmc_file():
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def _same_kernel(recorded, running):
+    return bool(recorded) and recorded.split("<")[0].split(" ")[0] == running.split("<")[0].split(" ")[0]
+
+
 def _pmc_traffic(B, kernel, running):
     """(HBM bytes per launch, source) of one of the two heaviest kernels of the DEFAULT arithmetic.  The figure is NOT measured by
     this run: it comes from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json: (2 FETCH_SIZE + WRITE_SIZE) 1024,
     FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes), and is reported only when that file was recorded for the kernel
     this run launches; (None, reason) otherwise."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(p) as f:
-            d = json.load(f)
-    except (OSError, ValueError):
+    d = _pmc_file()
+    if d is None:
         return None, "no profiles/pmc_traffic.json"
     meta = d.get("_meta", {})
     key = ("batch_%d" if kernel == "l1" else "pair_batch_%d") % B
     if d.get(key) is None:
         return None, "profiles/pmc_traffic.json holds no pass at %d frame-pairs per step" % B
     recorded = meta.get("kernels", {}).get(key, "")
-    if not recorded or recorded.split("<")[0].split(" ")[0] != running.split("<")[0].split(" ")[0]:
+    if not _same_kernel(recorded, running):
         return None, "profiles/pmc_traffic.json was recorded for %r, this run launches %r" % (recorded, running)
     return d[key], "static: profiles/pmc_traffic.json (%s; kernel %s), not measured by this run" % (meta.get("pass", "rocprofv3 --pmc pass"), recorded)
+
+
+def _pmc_counters(B, kernel, running):
+    """Pipe counters of the same committed pass (profiles/pmc_traffic.json `counters`: mean per launch of SQ_VALU_MFMA_BUSY_CYCLES,
+    SQ_INSTS_VALU, GRBM_GUI_ACTIVE at B frame-pairs per step), as fractions of the launch (profiles/README.md has the formulas):
+      mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)
+      valu_busy = 4 cycles x SQ_INSTS_VALU (wave-instructions, a 64-wide wave takes four passes of the 16-lane SIMD) / the same denominator
+    Static like `traffic`; {} when the pass was recorded for another kernel."""
+    d = _pmc_file() or {}
+    key = ("batch_%d" if kernel == "l1" else "pair_batch_%d") % B
+    c = d.get("counters", {}).get(key)
+    if not c or not _same_kernel(d.get("_meta", {}).get("kernels", {}).get(key, ""), running):
+        return {}
+    simd_cycles = 1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0
+    return {"mfma_busy": c["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles, "valu_busy": 4.0 * c["SQ_INSTS_VALU"] / simd_cycles,
+            "valu_insts": c["SQ_INSTS_VALU"], "counters_source": "static: profiles/pmc_traffic.json `counters` (%s)" % d.get("_meta", {}).get("pass", "")}
 
 
 def cpu_baseline(model, sample):
@@ -918,8 +1012,11 @@ def cpu_baseline(model, sample):
     torch.set_num_threads(all_threads)
     host = os.cpu_count() or all_threads
     return {"value": sample / dt, "unit": "frame-pairs/s", "cores": host, "threads": best_n, "kind": "port",
-            "sample": "%d frame-pairs at N=M=500,F=256, batch 1, torch-CPU fp32 oracle, %.1f s on a host with %d logical CPUs; the "
-                      "fastest of {8,16,32,64,%d} torch threads was used: %d" % (sample, dt, host, all_threads, best_n)}
+            "sample": CPU_SAMPLE_TEXT % (sample, dt, host, all_threads, best_n)}
+
+
+CPU_SAMPLE_TEXT = ("%d frame-pairs at N=M=500,F=256, batch 1, torch-CPU fp32 oracle, %.1f s on a host with %d logical CPUs; the fastest of "
+                   "{8,16,32,64,%d} torch threads was used: %d")
 
 
 def dry_run(args, rank, world):
@@ -943,10 +1040,17 @@ def dry_run(args, rank, world):
         dist.barrier()
     assert int(t[0].item()) == world and args.gpus == world
     if rank == 0:
-        print(json.dumps({"metric": "affinity frame-pairs/sec at N=M=500, F=256", "value": None, "unit": "frame-pairs/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "dry_run": True,
-                          "max_over_ranks": t[0].item(), "ms_per_step": t[1].item() / max(1, args.steps) * 1e3,
-                          "elapsed_max_over_ranks_s": t[1].item(), "elapsed_rank0_s": own}), flush=True)
+        # the line has the shape of a measured one (same builder, rooflines priced from stand-in launch times, the longest cpu_baseline
+        # sample text) with `value` null, so that the CPU suite can hold its length to LINE_LIMIT
+        B = args.batch
+        ms = t[1].item() / max(1, args.steps) * 1e3
+        r = {"B": B, "value": None, "ms_per_step": ms, "l1_ms": 0.3 * ms, "pair_ms": 0.48 * ms, "joules": None, "selfcheck": None}
+        roof_l1, roof_pair = rooflines(HEADLINE, args.arithmetic, r)
+        out = build_line(args, world, r, roof_pair, roof_l1)
+        out["cpu_baseline"] = {"value": None, "unit": "frame-pairs/s", "cores": os.cpu_count(), "threads": 0, "kind": "port",
+                               "sample": CPU_SAMPLE_TEXT % (args.cpu_sample, 0.0, os.cpu_count() or 0, 0, 0)}
+        out.update({"dry_run": True, "max_over_ranks": t[0].item(), "elapsed_max_over_ranks_s": t[1].item(), "elapsed_rank0_s": own})
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 

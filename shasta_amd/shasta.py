@@ -238,13 +238,13 @@ class Shasta(BaseTrack):
         plist = getattr(self, "_plist", None)
         ws = getattr(self, "_wstruct", None)
         if ws is not None and plist is not None:
-            probe = tuple(p.data_ptr() for p in plist) + (self.arithmetic, self.precut_weight_stream)
+            probe = tuple(p.data_ptr() for p in plist) + (self.arithmetic, self.precut_weight_stream, int(getattr(self, "extra_options", 0)))
             if ws[1] == probe:
                 return ws[0]
         w = self._build_weights()
         _watch(self)
         self._plist = [p for m in self._linear_modules() for p in (m.weight, m.bias)]
-        self._wstruct = (w, tuple(p.data_ptr() for p in self._plist) + (self.arithmetic, self.precut_weight_stream))
+        self._wstruct = (w, tuple(p.data_ptr() for p in self._plist) + (self.arithmetic, self.precut_weight_stream, int(getattr(self, "extra_options", 0))))
         return w
 
     def _linear_modules(self):

@@ -288,19 +288,13 @@ class _AffinityTrainFn(torch.autograd.Function):
         # Data-parallel training: dW1 of an aug_shape MLP is ghid^T x, a rank-B update of a (N*F/64, N*F) matrix (1 GB at
         # N=500).  Instead of all-reducing 4 x 1 GB of gradients, the ranks exchange the FACTORS (all_gather of B x (4H + 2K)
         # floats per rank, ~1 MB per frame-pair) and every rank forms the averaged gradient with one GEMM over world*B rows.
-        world, group = _exchange_world(model)
         for p_ in (model.aug_shape[i][0].weight for i in range(4)):  # a stale flag from a step reduced some other way
             p_._shasta_grad_is_global = False
+        world, group, exchange, lowrank, stepper = first_layer_plan(model, B, N * F)
         if world > 1:
             _check_equal_local_batch(B, world, group, dev)
-        exchange = world > 1 or getattr(model, "_force_factor_exchange", False)  # the latter: single-rank test of the path
-        # model.lowrank_adam (set by FusedAdam(..., lowrank_first_layers=model)): the four 1 GB first-layer gradients are not formed at
-        # all - their factors go to the optimizer, which builds the gradient in registers inside its pass (shasta_adam_lowrank_f32)
-        lowrank = bool(getattr(model, "lowrank_adam", False)) and world * B <= 64 and (N * F) % 4 == 0
         # FusedAdam(..., in_backward=True): the optimizer steps the four matrices HERE, in the pass that also forms dx = ghid W1 (with the
         # weights as they are before the update): the 1 GB matrix is read once for both (shasta_adam_lowrank_dx_f32)
-        opt_ref = getattr(model, "_lowrank_adam_opt", None)
-        stepper = opt_ref() if opt_ref is not None else None
         in_bwd = lowrank and stepper is not None and stepper.in_backward and world * B <= 64 and B <= 16 and N * F >= 4
         shape_grads, box_grads, ghids = [None] * 4, [None] * 4, [None] * 4
         for i in range(4):
@@ -384,6 +378,34 @@ class _AffinityTrainFn(torch.autograd.Function):
         return (None, dbev, dprev_bev, None, None) + tuple(out)
 
 
+def first_layer_plan(model, B, K):
+    """How the backward treats the four aug_shape first-layer matrices ((K/64, K) each, K = N*F; 1 GB at N = 500) for a step of B local
+    frame-pairs: (world, group, exchange, lowrank, stepper).
+      exchange: data-parallel run - the ranks all-gather the rank-B FACTORS of dW1 = ghid^T x and every rank forms the averaged gradient
+                (or hands the gathered factors to the optimizer) instead of all-reducing 4 x 1 GB;
+      lowrank:  the gradient is not formed at all, its factors go to FusedAdam(lowrank_first_layers=model), which builds it in registers
+                inside its pass (shasta_adam_lowrank_f32) - only while that optimizer is alive, and never with rank-LOCAL factors in a
+                data-parallel run (model.low_rank_grad_exchange = False there means: dense gradient, averaged by allreduce_gradients);
+      stepper:  the live FusedAdam, or None."""
+    world, group = _exchange_world(model)
+    exchange = world > 1 or bool(getattr(model, "_force_factor_exchange", False))  # the latter: single-rank test of the path
+    opt_ref = getattr(model, "_lowrank_adam_opt", None)
+    stepper = opt_ref() if opt_ref is not None else None
+    if stepper is None and getattr(model, "lowrank_adam", False):
+        model.lowrank_adam = False  # its optimizer is gone: .grad must come back, or the matrices would silently stop training
+    lowrank = bool(getattr(model, "lowrank_adam", False)) and world * B <= 64 and K % 4 == 0
+    if lowrank and _dist_world(model) > 1 and not exchange:
+        lowrank = False
+    if lowrank:
+        for i in range(4):
+            if "_shasta_grad_factors" in model.aug_shape[i][0].weight.__dict__:
+                raise hip.ShastaHipError(
+                    "FusedAdam(lowrank_first_layers=model): a second backward() before step() - the factors of the first-layer gradients "
+                    "are handed over, not accumulated (no gradient accumulation or clipping with this option; build the optimizer "
+                    "without it for those)")
+    return world, group, exchange, lowrank, stepper
+
+
 def _exchange_world(model):
     """(world size, group) of the low-rank gradient exchange; (1, None) when not running data-parallel or switched off
     with model.low_rank_grad_exchange = False."""
@@ -392,6 +414,14 @@ def _exchange_world(model):
         return 1, None
     group = getattr(model, "grad_exchange_group", None)
     return dist.get_world_size(group), group
+
+
+def _dist_world(model):
+    """World size of the data-parallel job itself, whatever model.low_rank_grad_exchange says."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    return dist.get_world_size(getattr(model, "grad_exchange_group", None))
 
 
 def _all_gather_rows(t, world, group=None):

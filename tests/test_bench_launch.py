@@ -75,3 +75,23 @@ def test_the_slowest_of_eight_ranks_sets_the_time():
     assert len(lines) == 1 and lines[0]["n_gpus"] == 8
     assert lines[0]["elapsed_max_over_ranks_s"] >= 0.5 > lines[0]["elapsed_rank0_s"]
     assert abs(lines[0]["ms_per_step"] - lines[0]["elapsed_max_over_ranks_s"] / 4 * 1e3) < 1e-6
+
+
+def test_the_line_stays_under_4_kb():
+    """the driver did not parse round 5's 22 KB line.  --dry-run prints a line of the measured line's shape (same
+    builder: config, both compact roofline objects priced from stand-in launch times, the cpu_baseline keys) with `value` null."""
+    for extra in ([], ["--batch", "1"], ["--arithmetic", "f32", "--batch", "512"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--dry-run"] + extra,
+                           capture_output=True, text=True, timeout=120, env=_env(), cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = r.stdout.rstrip().splitlines()
+        assert len(out) == 1 and len(out[0]) < 4096, len(out[0])
+        j = json.loads(out[0])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                  "data", "config", "roofline", "roofline_second", "cpu_baseline", "value_f32", "extra_file"):
+            assert k in j, k
+        for ro in (j["roofline"], j["roofline_second"]):
+            assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms"} <= set(ro)
+            assert ro["bound"] in ("hbm", "mfma", "valu")
+        assert set(j["cpu_baseline"]) == {"value", "unit", "cores", "threads", "kind", "sample"}
+        assert not any(isinstance(v, str) and len(v) > 200 for v in j["config"].values())

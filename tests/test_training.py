@@ -630,6 +630,41 @@ def test_train_steps_with_adam_from_the_factors_equal_the_dense_steps(exchange):
 
 
 @pytest.mark.gpu
+def test_lowrank_option_refuses_a_second_backward_and_ends_with_its_optimizer():
+    """Round-5 advisor findings on FusedAdam(lowrank_first_layers=model): the factors handed over on the parameter are assigned, not
+    accumulated - a second backward() before step() is refused loudly instead of dropping the first gradient; and the option lives
+    as long as ITS optimizer: once that is gone (replaced by torch.optim.Adam, say) the backward forms .grad again."""
+    import gc
+    from shasta_amd import hip, training
+    c, model, w, a, b, det, prev, gt = _case(12, 7, 4, 3, seed=22)
+    dev = torch.device("cuda:0")
+    m = model.to(dev).train()
+    ad, bd, gtd, detd, prevd = a.to(dev), b.to(dev), gt.to(dev), det.to(dev).contiguous(), prev.to(dev).contiguous()
+    opt = training.FusedAdam(m.parameters(), lr=1e-3, lowrank_first_layers=m)
+
+    def backward():
+        m1, m2 = training.affinity_train(m, ad, bd, detd.clone(), prevd)
+        training.affinity_loss(m1, m2, gtd).backward()
+    backward()
+    assert all(m.aug_shape[i][0].weight.grad is None for i in range(4))
+    with pytest.raises(hip.ShastaHipError, match="second backward"):
+        backward()
+    opt.step()
+    opt.zero_grad()
+    backward()  # after the step the factors were consumed: fine again
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    del opt
+    gc.collect()
+    other = torch.optim.Adam(m.parameters(), lr=1e-3)
+    before = m.aug_shape[0][0].weight.detach().clone()
+    backward()
+    assert all(m.aug_shape[i][0].weight.grad is not None for i in range(4)) and m.lowrank_adam is False
+    other.step()
+    assert float((m.aug_shape[0][0].weight - before).abs().max()) > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("exchange,size", [(False, (12, 7, 4, 3)), (True, (12, 7, 4, 3)), (False, (500, 7, 4, 2))])
 def test_adam_stepped_inside_the_backward_equals_the_step_after_it(exchange, size):
     """FusedAdam(..., lowrank_first_layers=model, in_backward=True): the four aug_shape first-layer matrices take their update inside

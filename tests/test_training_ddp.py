@@ -242,3 +242,63 @@ def test_syncbn_is_stable_for_large_means_and_handles_the_optional_parts():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _plan_worker(rank, world, port, q):
+    """Round-5 advisor finding: FusedAdam(lowrank_first_layers=model) + model.low_rank_grad_exchange = False in a data-parallel run
+    updated the four first-layer matrices from rank-LOCAL factors (replicas diverge, silently).  first_layer_plan is the decision the
+    backward takes; no device needed."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from shasta_amd import hip
+    from shasta_amd.training import first_layer_plan
+
+    class Opt:  # stands for the live FusedAdam the model holds a weakref to
+        in_backward = False
+
+    import weakref
+    model, *_ = _ddp_case(2)
+    opt = Opt()
+    model.lowrank_adam, model._lowrank_adam_opt = True, weakref.ref(opt)
+    K = 6 * 256
+    ok = True
+    w, g, exchange, lowrank, stepper = first_layer_plan(model, 2, K)      # default: factors gathered over the ranks, optimizer takes them
+    ok = ok and (w, exchange, lowrank) == (world, True, True) and stepper is opt
+    model.low_rank_grad_exchange = False                                   # exchange off: dense gradient for allreduce_gradients, NOT local factors
+    w, g, exchange, lowrank, stepper = first_layer_plan(model, 2, K)
+    ok = ok and (w, exchange, lowrank) == (1, False, False)
+    model.low_rank_grad_exchange = True
+    model.aug_shape[0][0].weight._shasta_grad_factors = ("pending",)      # a second backward before step(): refused, not overwritten
+    try:
+        first_layer_plan(model, 2, K)
+        ok = False
+    except hip.ShastaHipError as e:
+        ok = ok and "second backward" in str(e)
+    del model.aug_shape[0][0].weight._shasta_grad_factors
+    del opt, stepper                                                       # the optimizer is gone: .grad comes back
+    w, g, exchange, lowrank, stepper = first_layer_plan(model, 2, K)
+    ok = ok and lowrank is False and stepper is None and model.lowrank_adam is False and exchange is True
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_first_layer_plan_never_takes_rank_local_factors_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_first_layer_plan_single_process():
+    from shasta_amd.training import first_layer_plan
+    model, *_ = _ddp_case(2)
+    assert first_layer_plan(model, 2, 6 * 256) == (1, None, False, False, None)
+    model.lowrank_adam = True  # sticky flag without a live optimizer: cleared
+    assert first_layer_plan(model, 2, 6 * 256)[3] is False and model.lowrank_adam is False

@@ -5,11 +5,9 @@ O=$R/gpurun_out/$1
 shift
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-export SHASTA_BENCH_PROBE=1
 for lib in "$@"; do
   n=$(basename $lib .so)
-  export SHASTA_HIP_LIB=$R/$lib
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/$n -o p -- python3 $R/bench.py --batch 1024 --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $O/$n.log 2>&1
+  SHASTA_HIP_LIB=$R/$lib SHASTA_BENCH_PROBE=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/$n -o p -- python3 $R/bench.py --batch 1024 --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $O/$n.log 2>&1
   echo "== $n"
   python3 $R/tools/pmc_table.py $O/$n anchor_l1_
   python3 - <<PY

@@ -113,6 +113,19 @@ if __name__ == "__main__":
             names = sorted({r["kernel"] for r in rows if r["run"] == "b%d_fetch" % b and kern in r["kernel"] and int(r["launches"]) > 3})
             if names and (key % b) in traffic:
                 kern_names[key % b] = names[0].replace("shasta::", "").replace("void ", "")
+    # pipe counters of the same two kernels (bench.py: roofline.mfma_busy / valu_busy / valu_insts), full-batch launches only
+    counters = {}
+    for b in (512, 1024):
+        for key, kern in (("batch_%d", "anchor_l1"), ("pair_batch_%d", "::pair_")):
+            best = {}
+            for r in rows:
+                if r["run"] == "b%d_mfma" % b and kern in r["kernel"] and int(r["launches"]) > 3:
+                    g = int(r["grid_size"] or 0)
+                    if r["counter"] not in best or g > best[r["counter"]][0]:
+                        best[r["counter"]] = (g, float(r["mean_value_per_launch"]))
+            if best:
+                counters[key % b] = {c: v[1] for c, v in best.items()}
+    traffic["counters"] = counters
     traffic["_meta"] = {"pass": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round %s, profiles/%s_pmc_summary.csv" % (TAG, TAG), "kernels": kern_names}
     traffic["_note"] = ("batch_B / pair_batch_B: HBM-side bytes per launch of anchor_l1*_kernel / pair_mfma4_kernel at B frame-pairs per step, default "
                         "arithmetic, = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/%s_pmc_summary.csv); "
@@ -124,9 +137,11 @@ if __name__ == "__main__":
     for f in sorted(os.listdir(P)):
         if f.startswith(TAG + "_bench_") and f.endswith(".json"):
             d = json.load(open(os.path.join(P, f)))
-            if d.get("config", {}).get("arithmetic", "").startswith("f16x2") and d.get("config", {}).get("precut_weight_stream", True):
+            if d.get("config", {}).get("arithmetic", "").startswith("f16x2") and d.get("config", {}).get("precut_weight_stream", True) and d.get("roofline"):
                 b = d["config"]["frame_pairs_per_step_per_gpu"]
                 for key in ("roofline", "roofline_second"):
+                    if not d.get(key):
+                        continue
                     k = ("pair_batch_%d" if d[key]["kernel"].startswith("pair") else "batch_%d") % b
                     if k in traffic:
                         d[key]["traffic"] = traffic[k]
