@@ -326,6 +326,17 @@ int shasta_aff_softmax_f32(const shasta_weights* w, const void* packed, int B, c
                            int ld_residual, float* matched1, float* matched2, float* matched_out,
                            void* workspace, size_t workspace_bytes, shasta_stream_t stream);
 
+/* Status of the most recent aff stage launched on a workspace - asynchronous failures the launching call could not report (it had
+ * returned SHASTA_OK before the kernel ran).  *status = 0, or bit 0: a row group of the one-pass aff kernel (layers + both softmaxes
+ * of shasta.py:323-325 in one launch, from 8192 table rows) gave up waiting for the column statistics of its sibling row groups;
+ * its rows of matched2 are NaN.  Both calls synchronise on `stream`.  shasta_aff_status: `workspace` / `ld_residual` as passed to
+ * shasta_aff_softmax_f32; shasta_forward_status: `workspace` as passed to shasta_affinity_forward_f32 / _from_bev_f32 / _train_f32
+ * (valid until the next forward on that workspace). */
+int shasta_aff_status(const shasta_weights* w, int B, int ld_residual, const void* workspace, size_t workspace_bytes,
+                      int* status, shasta_stream_t stream);
+int shasta_forward_status(const shasta_weights* w, int B, const void* workspace, size_t workspace_bytes, int* status,
+                          shasta_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Rotated 3-D IoU / GIoU distance matrix (float64, like the reference)
  * replaces mot_3d/association.py:108-120 (`compute_iou_distance`): dist[d][t] = 1 - iou3d(det_d, trk_t)[1]

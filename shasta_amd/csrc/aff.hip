@@ -280,6 +280,31 @@ int launch_aff_frame(const shasta_weights* w, const float* packed_pieces, const 
 int launch_aff_pieces(const shasta_weights* w, const float* packed_pieces, const float* residual, int ld, float* matched, int ldm,
                       float* m1, int M, hipStream_t st);
 
+// the piece forms of the six layers serve this call (and, unless SHASTA_OPT_TWO_PASS_AFF, the one-pass kernel with its sibling wait)
+static bool aff_piece_form(const shasta_weights* w, int B, int ld, const void* residual, const void* ws) {
+    const int M = B * (w->max_obj + 2);
+    return (M >= 8192 || (w->options & SHASTA_OPT_ONE_PASS_AFF)) && !(w->options & SHASTA_OPT_F32_AFF) && aff_pieces_serves(w->max_obj + 2) && ld % 4 == 0 &&
+           (uintptr_t)residual % 16 == 0 && (uintptr_t)ws % 16 == 0;
+}
+
+// Status word of the most recent aff launch on workspace `ws` (aff_workspace_bytes): 0, or bit 0 = a row group's wait for its siblings
+// timed out (those rows of matched2 are NaN).  Only the one-pass form has something to report; the other forms give 0.  Synchronises
+// on the stream.  `ld`: the residual's leading dimension of that launch.
+int aff_status(const shasta_weights* w, int B, int ld, const void* ws, int* status, hipStream_t st) {
+    *status = 0;
+    if (B == 0 || !aff_piece_form(w, B, ld, nullptr, ws) || (w->options & SHASTA_OPT_TWO_PASS_AFF)) return SHASTA_OK;
+    unsigned word = 0;
+    const char* src = static_cast<const char*>(ws) + aff_matched_bytes(B, w->max_obj);
+    hipError_t e = hipMemcpyAsync(&word, src, sizeof(word), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        set_error("aff_status", e);
+        return SHASTA_E_LAUNCH;
+    }
+    *status = (int)word;
+    return SHASTA_OK;
+}
+
 int aff_softmax(const shasta_weights* w, const float* packed, int B, const float* residual, int ld, float* m1,
                 float* m2, float* matched_out, void* ws, size_t ws_bytes, hipStream_t st) {
     const int N = w->max_obj, T = N + 2, D = N + 2, Dp = (T + 3) / 4 * 4;
@@ -304,8 +329,7 @@ int aff_softmax(const shasta_weights* w, const float* packed, int B, const float
     // From 8192 residual rows up the six layers run as exact bf16 piece products (aff_pieces.hip: 2.7 x fewer matrix cycles per
     // fp32 product) for tables up to 512 columns whose rows are 16-byte aligned; SHASTA_OPT_F32_AFF keeps the f32
     // kernel.  Small batches stay on the f32 kernel (16-row workgroups: more parallelism, less latency).
-    const bool pieces = (M >= 8192 || (w->options & SHASTA_OPT_ONE_PASS_AFF)) && !(w->options & SHASTA_OPT_F32_AFF) && aff_pieces_serves(D) && ld % 4 == 0 &&
-                        (uintptr_t)residual % 16 == 0 && (uintptr_t)ws % 16 == 0;
+    const bool pieces = aff_piece_form(w, B, ld, residual, ws);
     // ... and, unless SHASTA_OPT_TWO_PASS_AFF asks for the two-kernel form, with both softmaxes in the same pass (aff_frame_kernel):
     // `matched` is then written only when the caller wants it
     if (pieces && !(w->options & SHASTA_OPT_TWO_PASS_AFF)) {

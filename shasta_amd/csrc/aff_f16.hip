@@ -486,7 +486,8 @@ __global__ __launch_bounds__(64 * WAVES) void aff_frame16_kernel(AffFrameArgs fa
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = fa.G;
-    const int b = blockIdx.x / G, q = blockIdx.x - b * G;
+    const int tile = (int)ap_take_ticket(fa, reinterpret_cast<unsigned*>(smem));
+    const int b = tile / G, q = tile - b * G;
     const int nrows = min(ROWS, a.T - q * ROWS), g0 = b * a.T + q * ROWS;
     f32x16 acc[NFW][RB];
     float rs[RB];
@@ -500,10 +501,13 @@ template <int ROWS, int WAVES>
 static int launch_aff_frame16_shape(AffFrameArgs& fa, int B, void* ws, hipStream_t st) {
     using S = AqShape<ROWS, WAVES>;
     fa.G = cdiv(fa.p.T, ROWS);
-    fa.part = static_cast<float*>(ws);
-    fa.arrive = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + align_up((size_t)B * fa.G * 1024 * sizeof(float), 256));
-    if (fa.G > 1 && hipMemsetAsync(fa.arrive, 0, (size_t)B * sizeof(unsigned), st) != hipSuccess) {
-        set_error_msg("aff_frame16: memset of the arrival counters failed");
+    unsigned* ctrl = static_cast<unsigned*>(ws);  // [status, ticket, arrive[B]]
+    fa.status = ctrl;
+    fa.ticket = ctrl + 1;
+    fa.arrive = ctrl + 2;
+    fa.part = reinterpret_cast<float*>(static_cast<char*>(ws) + aff_frame_ctrl_bytes(B));
+    if (hipMemsetAsync(ctrl, 0, (size_t)(B + 2) * sizeof(unsigned), st) != hipSuccess) {
+        set_error_msg("aff_frame16: memset of the control words failed");
         return SHASTA_E_LAUNCH;
     }
     if (hipFuncSetAttribute((const void*)aff_frame16_kernel<ROWS, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS) != hipSuccess) {

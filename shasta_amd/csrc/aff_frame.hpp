@@ -59,9 +59,15 @@ struct AffPiecesArgs {
 //   * matched2 = softmax over the T rows of a column: every workgroup reduces its rows to (max, sum of exp(x - max)) per column,
 //     publishes the 2 x D floats, counts itself on the frame's arrival counter and waits for its G - 1 siblings; all of them then
 //     combine the G partials in the same fixed order and write their rows of matched2 straight from the registers.
-// Waiting is safe: workgroups are dispatched in block-id order (per XCD), so the siblings of a resident workgroup are resident,
-// finished or next in line, never behind a workgroup that waits (the lowest unfinished frame always has all its workgroups on the
-// chip).  A wait that nevertheless outlasts ~2 s poisons this workgroup's rows of matched2 with NaN instead of hanging the device.
+// Waiting is safe by construction: a workgroup does not take its row group from blockIdx but from a TICKET (one atomic counter per
+// launch, ap_take_ticket): tickets are handed out in the order the workgroups actually start, whatever order the hardware dispatches
+// block ids in, so the siblings of a running workgroup (the tickets of the same frame) are running, finished, or the very next ones
+// to start - never queued behind a workgroup that waits (the look-back scans of rocPRIM / CUB number their tiles the same way).
+// A wait that nevertheless outlasts ~2 s poisons this workgroup's rows of matched2 with NaN instead of hanging the device AND sets
+// bit 0 of the launch's status word (shasta_aff_status / shasta_forward_status read it): the C call has long returned SHASTA_OK.
+// Ordering of the exchange: every thread's partial stores are agent-scope atomics and complete (s_waitcnt vmcnt(0)) before the
+// workgroup barrier; thread 0 then counts the workgroup in with a RELEASE fence at agent scope in front of the read-modify-write
+// and puts an ACQUIRE fence behind the poll that saw all G arrivals; the barrier that follows hands that edge to the other threads.
 // Partials cross the XCDs' L2s as agent-scope (sc1) stores / loads - no cache-wide write-back or invalidate.
 // exp(x - m) = v_exp_f32(fma(x, log2 e, c)), c = fl(-m log2 e): the rounding of c is common to a whole row (column), i.e. it cancels
 // between the sum and the terms; the G column partials are rescaled by exp2(c_frame - c_group) with the very same constants.
@@ -70,8 +76,27 @@ struct AffFrameArgs {
     float* m2;         // (B, T, N)
     float* part;       // [B][G][2][512]: per row group the column maxima, then the column sums
     unsigned* arrive;  // [B], zero on entry
+    unsigned* ticket;  // [1], zero on entry: the next logical tile (b, q) = (ticket / G, ticket % G)
+    unsigned* status;  // [1], zero on entry: bit 0 = a sibling wait timed out (rows of matched2 are NaN)
     int G;
 };
+
+// control words of a one-pass launch at the head of its workspace: [status, ticket, arrive[B]] (one memset per launch)
+__host__ __device__ inline size_t aff_frame_ctrl_bytes(int B) { return ((size_t)(B + 2) * sizeof(unsigned) + 255) / 256 * 256; }
+
+// the logical tile of this workgroup: tickets in start order when row groups wait for each other (G > 1), else the block id.
+// `slot`: four bytes of LDS nobody else touches until the second barrier.
+__device__ __forceinline__ unsigned ap_take_ticket(const AffFrameArgs& fa, unsigned* slot) {
+    if (fa.G <= 1) return blockIdx.x;
+#ifdef SHASTA_AFF_NO_TICKET  // A/B diagnostic only (tools/gpu_aff_ab.sh): block ids as tiles, i.e. trust in-order dispatch
+    return blockIdx.x;
+#endif
+    if (threadIdx.x == 0) *slot = __hip_atomic_fetch_add(fa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned t = *slot;
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(t);
+}
 
 constexpr float AP_LOG2E = 1.44269504088896340736f;
 
@@ -284,16 +309,32 @@ __device__ __forceinline__ void ap_frame_tail(const AffFrameArgs& fa, char* smem
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (tid == 0) {
+#ifdef SHASTA_AFF_FORCE_TIMEOUT  // test build (tests/test_aff_stage.py): row group 0 never counts itself in, everybody's wait runs out quickly
+                    constexpr unsigned SPIN_LIMIT = 1u << 8;
+                    const unsigned mine = q == 0 ? 0u : 1u;
+#else
+                    constexpr unsigned SPIN_LIMIT = 1u << 21;
+                    const unsigned mine = 1u;
+#endif
+                    // release: the partials of this workgroup (complete, see above) are ordered before the count the siblings poll
+#ifndef SHASTA_AFF_NO_FENCE  // (A/B diagnostic only, tools/gpu_aff_ab.sh)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
                     // polled with the same read-modify-write path that counts the arrivals
-                    unsigned seen = __hip_atomic_fetch_add(fa.arrive + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u, spins = 0;
+                    unsigned seen = __hip_atomic_fetch_add(fa.arrive + b, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine, spins = 0;
                     while (seen < (unsigned)G) {
                         __builtin_amdgcn_s_sleep(16);
                         seen = __hip_atomic_fetch_add(fa.arrive + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (++spins > (1u << 21)) {
+                        if (++spins > SPIN_LIMIT) {
                             poisoned = true;
                             break;
                         }
                     }
+                    // acquire: the siblings' partials are read after the count that announced them
+#ifndef SHASTA_AFF_NO_FENCE
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+                    if (poisoned) __hip_atomic_fetch_or(fa.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     cinv[511] = poisoned ? 1.0f : 0.0f;  // column 511 is never a column of matched2
                 }
                 __syncthreads();

@@ -475,7 +475,8 @@ __global__ __launch_bounds__(64 * WAVES) void aff_frame_kernel(AffFrameArgs fa) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = fa.G;
-    const int b = blockIdx.x / G, q = blockIdx.x - b * G;
+    const int tile = (int)ap_take_ticket(fa, reinterpret_cast<unsigned*>(smem));
+    const int b = tile / G, q = tile - b * G;
     const int nrows = min(ROWS, a.T - q * ROWS), g0 = b * a.T + q * ROWS;
     f32x16 acc[NFW][RB];
     ap_mlp<ROWS, WAVES>(a, smem, g0, g0 + nrows - 1, tid, lane, wid, acc);
@@ -497,7 +498,7 @@ static int launch_aff_pieces_shape(const AffPiecesArgs& a, hipStream_t st) {
 
 size_t aff_frame_workspace_bytes(int B, int N) {
     const int T = N + 2, G = cdiv(T, 64);  // the 64-row shape needs the most partials
-    return align_up((size_t)B * G * 1024 * sizeof(float), 256) + align_up((size_t)B * sizeof(unsigned), 256);
+    return aff_frame_ctrl_bytes(B) + align_up((size_t)B * G * 1024 * sizeof(float), 256);
 }
 
 template <int ROWS, int WAVES>
@@ -505,10 +506,13 @@ static int launch_aff_frame_shape(AffFrameArgs& fa, int B, void* ws, hipStream_t
     using S = ApShape<ROWS, WAVES>;
     const size_t lds = (size_t)S::ABYTES + S::BBYTES;
     fa.G = cdiv(fa.p.T, ROWS);
-    fa.part = static_cast<float*>(ws);
-    fa.arrive = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + align_up((size_t)B * fa.G * 1024 * sizeof(float), 256));
-    if (fa.G > 1 && hipMemsetAsync(fa.arrive, 0, (size_t)B * sizeof(unsigned), st) != hipSuccess) {
-        set_error_msg("aff_frame: memset of the arrival counters failed");
+    unsigned* ctrl = static_cast<unsigned*>(ws);  // [status, ticket, arrive[B]]
+    fa.status = ctrl;
+    fa.ticket = ctrl + 1;
+    fa.arrive = ctrl + 2;
+    fa.part = reinterpret_cast<float*>(static_cast<char*>(ws) + aff_frame_ctrl_bytes(B));
+    if (hipMemsetAsync(ctrl, 0, (size_t)(B + 2) * sizeof(unsigned), st) != hipSuccess) {
+        set_error_msg("aff_frame: memset of the control words failed");
         return SHASTA_E_LAUNCH;
     }
     if (hipFuncSetAttribute((const void*)aff_frame_kernel<ROWS, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {

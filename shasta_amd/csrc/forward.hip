@@ -28,6 +28,7 @@ int anchor_stage_fused(const shasta_weights* w, int B, float* feat, float* prev_
 int pair_residual(const shasta_weights* w, const float* packed, int B, const float* feat, const float* prev_feat,
                   const float* det_tab, const float* prev_tab, float* residual, int ld, void* ws, size_t ws_bytes,
                   hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+int aff_status(const shasta_weights* w, int B, int ld, const void* ws, int* status, hipStream_t st);
 int aff_softmax(const shasta_weights* w, const float* packed, int B, const float* residual, int ld, float* m1,
                 float* m2, float* matched_out, void* ws, size_t ws_bytes, hipStream_t st);
 int pack_weights(const shasta_weights* w, float* packed, hipStream_t st);
@@ -199,6 +200,32 @@ extern "C" int shasta_aff_softmax_f32(const shasta_weights* w, const void* packe
     SHASTA_REQUIRE(ld_residual >= w->max_obj + 2, "aff_softmax: ld_residual < N+2");
     return aff_softmax(w, static_cast<const float*>(packed), B, residual, ld_residual, matched1, matched2, matched_out,
                        workspace, workspace_bytes, as_stream(stream));
+}
+
+extern "C" int shasta_aff_status(const shasta_weights* w, int B, int ld_residual, const void* workspace, size_t workspace_bytes,
+                                 int* status, shasta_stream_t stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    SHASTA_REQUIRE(B >= 0 && workspace && status, "aff_status: bad argument");
+    if (workspace_bytes < aff_workspace_bytes(B, w->max_obj)) {
+        set_error_msg("aff_status: workspace too small");
+        return SHASTA_E_WORKSPACE;
+    }
+    return aff_status(w, B, ld_residual, workspace, status, as_stream(stream));
+}
+
+extern "C" int shasta_forward_status(const shasta_weights* w, int B, const void* workspace, size_t workspace_bytes, int* status,
+                                     shasta_stream_t stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    SHASTA_REQUIRE(B >= 0 && workspace && status, "forward_status: bad argument");
+    const int N = w->max_obj, T = N + 2, Dp = (T + 3) / 4 * 4;
+    const FwdWs L(B, N, w->feat_dim);
+    if (workspace_bytes < L.total) {
+        set_error_msg("forward_status: workspace too small");
+        return SHASTA_E_WORKSPACE;
+    }
+    return aff_status(w, B, Dp, static_cast<const char*>(workspace) + L.residual, status, as_stream(stream));
 }
 
 struct BevSource {

@@ -9,7 +9,7 @@ import os
 
 import torch
 
-ABI_VERSION = 11  # must equal shasta_abi_version() of the loaded library
+ABI_VERSION = 12  # must equal shasta_abi_version() of the loaded library
 # SHASTA_HIP_LIB: load another build of the same ABI (A/B timing of kernel variants on one box)
 _LIB_PATH = os.environ.get("SHASTA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libshasta_hip.so")
 _lib = None
@@ -86,6 +86,8 @@ SYMBOLS = {
     "shasta_anchor_boxes_f32": (_I, [_WP, _I, _P, _P, _I, _P, _P, _P, _Z, _P]),
     "shasta_pair_residual_f32": (_I, [_WP, _P, _I, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "shasta_aff_softmax_f32": (_I, [_WP, _P, _I, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    "shasta_aff_status": (_I, [_WP, _I, _I, _P, _Z, C.POINTER(C.c_int), _P]),
+    "shasta_forward_status": (_I, [_WP, _I, _P, _Z, C.POINTER(C.c_int), _P]),
     "shasta_iou3d_distance_f64": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     "shasta_hand_dist_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "shasta_hand_dist_bwd_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),

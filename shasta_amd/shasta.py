@@ -522,6 +522,7 @@ class Shasta(BaseTrack):
                 hip.ptr(res), hip.ptr(mat), hip.ptr(anch), hip.ptr(bufs["ws"]), bufs["ws_bytes"], hip.stream_ptr(), evs),
                 "shasta_affinity_from_bev_f32")
             self.newborn, self.fp, self.dead_trk, self.fn = anch[:, 0:1], anch[:, 1:2], anch[:, 2:3], anch[:, 3:4]
+        self._last_forward = (w, B, bufs["ws"], bufs["ws_bytes"])
         if _train_keep is not None:
             # shasta.py:260-267 leaves the four anchor boxes on the module as fresh tensors: the training entry has no output for them,
             # so they are copied out of the work buffers (two small copies), which the next forward overwrites
@@ -532,6 +533,18 @@ class Shasta(BaseTrack):
             self.last_intermediates = dict(feature=bufs["feat"], prev_feature=bufs["prev_feat"], residual=res,
                                            matched=mat, det_tab=bufs["det_tab"], prev_tab=bufs["prev_tab"])
         return m1, m2
+
+    def forward_status(self):
+        """Asynchronous status of this module's most recent forward (shasta_forward_status): 0, or bit 0 = a row group of the one-pass aff
+        kernel timed out waiting for its siblings and wrote NaN into its rows of matched2 (the launch itself had returned SHASTA_OK).
+        Synchronises the current stream; raises nothing - callers that read results on the host anyway can afford the check."""
+        last = getattr(self, "_last_forward", None)
+        if last is None:
+            return 0
+        w, B, ws, ws_bytes = last
+        st = C.c_int(0)
+        hip.check(hip.load().shasta_forward_status(C.byref(w), B, hip.ptr(ws), ws_bytes, C.byref(st), hip.stream_ptr()), "shasta_forward_status")
+        return st.value
 
     def forward(self, example, train_mode=True, **kwargs):
         det = example["det_boxes"]

@@ -69,6 +69,14 @@ class _Aff:
                                                   self.nws, hip.stream_ptr()), "shasta_aff_softmax_f32")
         return self.logits.clone() if want_logits else None, self.m1.clone(), self.m2.clone()
 
+    def status(self, options):
+        """shasta_aff_status of the last call on this workspace (0 = nothing to report)"""
+        w = hip.Weights.from_buffer_copy(self.w)
+        w.options = options
+        st = C.c_int(-1)
+        hip.check(self.lib.shasta_aff_status(C.byref(w), self.B, self.Dp, hip.ptr(self.ws), self.nws, C.byref(st), hip.stream_ptr()), "shasta_aff_status")
+        return st.value
+
 
 def _residual(B, N, dev, seed, scale=1.0):
     T = N + 2
@@ -99,6 +107,7 @@ def test_aff_forms_against_float64(B, N, gain):
         lg, m1, m2 = aff(res, opt)
         out[name] = (lg, m1, m2)
         assert torch.isfinite(m1).all() and torch.isfinite(m2).all(), name
+        assert aff.status(opt) == 0, name
         err[name] = float((lg.double().cpu() - ref).abs().max())
         # softmaxes against the float64 softmax of the form's OWN logits: the exchange / reduction machinery, free of layer rounding
         own = lg.double().cpu()
@@ -192,3 +201,63 @@ def test_one_pass_aff_on_two_streams_at_once():
         torch.cuda.synchronize()
         for i in range(2):
             assert torch.equal(affs[i].m1, want[i][1]) and torch.equal(affs[i].m2, want[i][2]), i
+
+
+_TIMEOUT_SCRIPT = r"""
+import ctypes as C, sys, torch
+sys.path.insert(0, %r)
+from shasta_amd import hip
+from tests.test_aff_stage import _Aff, _model, _residual, FORMS
+dev = torch.device("cuda", 0)
+N, B = 500, 3
+m = _model(N, 1.0, dev)
+aff = _Aff(m, B, dev)
+res = _residual(B, N, dev, seed=5)
+for name in ("bf16 pieces one-pass", "fp16 pieces one-pass"):
+    _, m1, m2 = aff(res, FORMS[name], want_logits=False)   # the call itself returns SHASTA_OK (hip.check would raise)
+    torch.cuda.synchronize()
+    assert torch.isfinite(m1).all(), name                    # the row softmax needs no sibling
+    assert torch.isnan(m2).all(), name                       # every row group of every frame gave up: all of matched2 poisoned
+    assert aff.status(FORMS[name]) == 1, (name, aff.status(FORMS[name]))
+    _, m1, m2 = aff(res, hip.OPT_F32_AFF, want_logits=False)  # a form without a wait on the same workspace: nothing to report
+    assert aff.status(hip.OPT_F32_AFF) == 0 and torch.isfinite(m2).all()
+print("timeout-reported")
+"""
+
+
+def test_a_sibling_wait_that_times_out_is_reported_in_the_status_word(tmp_path):
+    """VERDICT r5 / advisor: on a time-out of the sibling wait the one-pass kernel poisons its rows of matched2 with NaN while the C call has
+    long returned SHASTA_OK - the launch's status word (shasta_aff_status / shasta_forward_status) now says so.  A build of the two aff
+    sources with -DSHASTA_AFF_FORCE_TIMEOUT (row group 0 of a frame never counts itself in, the spin limit is 256) is loaded in a child
+    process through SHASTA_HIP_LIB."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "build_variant.py"), "afftimeout", "aff_f16.hip,aff_pieces.hip",
+                        "-DSHASTA_AFF_FORCE_TIMEOUT"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lib = r.stdout.strip().splitlines()[-1]
+    r = subprocess.run([sys.executable, "-c", _TIMEOUT_SCRIPT % root], capture_output=True, text=True, timeout=600, cwd=root,
+                       env=dict(os.environ, SHASTA_HIP_LIB=lib))
+    assert r.returncode == 0 and "timeout-reported" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+    # the shipped library on the same case: status 0
+    dev = _dev()
+    m = _model(500, 1.0, dev)
+    aff = _Aff(m, 3, dev)
+    _, _, m2 = aff(_residual(3, 500, dev, seed=5), FORMS["fp16 pieces one-pass"], want_logits=False)
+    assert torch.isfinite(m2).all() and aff.status(FORMS["fp16 pieces one-pass"]) == 0
+
+
+def test_forward_status_of_the_module():
+    """Shasta.forward_status(): 0 after a forward through the one-pass form (10 040 table rows) and after one below its threshold."""
+    dev = _dev()
+    m = _model(500, 1.0, dev).eval()
+    m.arithmetic = "f16x2"
+    g = torch.Generator().manual_seed(3)
+    for B in (20, 2):
+        bev, pbev = (torch.relu(torch.randn(B, 24, 24, 64, generator=g)).to(dev) for _ in range(2))
+        det, prev = (torch.rand(B, 500, 11, generator=g).to(dev) for _ in range(2))
+        with torch.no_grad():
+            m1, m2 = m.affinity_from_bev(bev, pbev, det, prev)
+        assert m.forward_status() == 0 and torch.isfinite(m2).all()

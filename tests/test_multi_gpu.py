@@ -110,3 +110,63 @@ def test_rccl_train_step_equals_the_single_process_step(world):
             assert float((torch.from_numpy(res[r][n]) - g).abs().max()) <= 2e-3 * scale + 1e-7, (n, r)  # HIP backward vs autograd: 2e-3 as in test_training.py
     assert torch.allclose(torch.from_numpy(res[0]["__running_mean"]), model.shared_conv[1].running_mean, rtol=1e-4, atol=1e-6)
     assert all((res[0]["__running_mean"] == res[r]["__running_mean"]).all() for r in range(1, world))
+
+
+def _nccl_chain_worker(rank, world, port, root, work, backend="nccl"):
+    """BASELINE config 4 on real GPUs: this rank's scenes through the HIP chain on its own GPU, per-class results gathered on rank 0
+    over RCCL (replica.gather_decoded -> dist.gather_object), rank 0 merges, tracks and writes the reference CLIs' files."""
+    from shasta_amd import pipeline, scenes
+    from tests.test_pipeline import _models
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    gpu = rank if backend == "nccl" else 0  # gloo: the ranks share GPU 0 (1-GPU lease)
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    paths = scenes.split_paths(root)
+    meta = json.load(open(paths["frames_meta_path"]))["frames"]
+    sc, cur = [], None
+    for fr in meta:
+        if fr["first"]:
+            cur = ("scene-%04d" % len(sc), [])
+            sc.append(cur)
+        cur[1].append(fr["token"])
+    models = {n: m.to(dev) for n, m in _models().items()}
+    res = pipeline.run_split(models, paths, sc, scenes.TokenBev(), dev, work_dir=work if rank == 0 else None, batch_pairs=3, rank=rank,
+                             world=world)
+    assert (res is None) == (rank != 0)
+    dist.destroy_process_group()
+
+
+def test_two_process_chain_on_one_gpu_equals_single_rank(tmp_path):
+    """The same comparison on a 1-GPU lease: two processes share GPU 0 and exchange over gloo - everything of the multi-rank device
+    chain (sharding, HIP forward + decode per rank, gather, merge, whole-scene tracker on rank 0, the files) except RCCL itself."""
+    _chain_equals_single_rank(2, tmp_path, "gloo")
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rccl_scene_sharded_chain_equals_single_rank(world, tmp_path):
+    """pipeline.run_split(rank, world) over `nccl` - scenes sharded over the GPUs (uneven: 11 scenes of 2 to 5
+    frames), decoded results gathered on rank 0, whose merged_cp_val.json / tracking_result.json are byte-equal to the files of the
+    one-rank run on one GPU (tools/nusc_shasta/eval.py:175-181 is the post-pass the gather feeds, pub_test.py:88-162 the tracker)."""
+    _need(world)
+    _chain_equals_single_rank(world, tmp_path, "nccl")
+
+
+def _chain_equals_single_rank(world, tmp_path, backend):
+    from shasta_amd import pipeline, scenes
+    from tests.test_pipeline import _models
+    lengths = [3, 5, 2, 4, 3, 2, 5, 3, 4, 2, 3]
+    root = str(tmp_path / "split")
+    paths, sc = scenes.write_synthetic_split(root, n_scenes=len(lengths), frames_per_scene=lengths, seed=7)
+    many, one = str(tmp_path / "many"), str(tmp_path / "one")
+    mp.spawn(_nccl_chain_worker, args=(world, _free_port(), root, many, backend), nprocs=world, join=True)
+    dev = torch.device("cuda", 0)
+    models = {n: m.to(dev) for n, m in _models().items()}
+    pipeline.run_split(models, paths, sc, scenes.TokenBev(), dev, work_dir=one, batch_pairs=3)
+    for f in ("merged_cp_val.json", "tracking_result.json", "car/cp_val.json"):
+        with open(os.path.join(many, f), "rb") as a, open(os.path.join(one, f), "rb") as b:
+            assert a.read() == b.read(), f
