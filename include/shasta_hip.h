@@ -160,6 +160,55 @@ int shasta_shared_conv_multi_f32(const float* x, const float* x_prev, int B, int
                                  shasta_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K0 in train() mode (csrc/shared_conv_train.hip): what autograd does for `self.shared_conv(bev_map)` when the reference trains it -
+ * tools/nusc_shasta/train.py:183-191 freezes children 1, 2 (backbone, neck) only and keeps every BatchNorm in train mode; the
+ * optimizer (:143-147) holds shared_conv.0.{weight,bias} and shared_conv.1.{weight,bias}.  The neck is frozen: no input gradient.
+ *
+ * Forward of one BatchNorm call (= one map: det3d/models/tracker/shasta.py:223-228 calls shared_conv on the current map, then on the
+ * previous one):
+ *   1. y = conv(x) + bias, NHWC: shasta_shared_conv_multi_f32 / shasta_shared_conv_f32 on a RAW pack (shasta_shared_conv_pack_raw_*:
+ *      the epilogue writes conv + bias as is - no BatchNorm, no ReLU); the fp16 form leaves the image maxima at the head of its
+ *      workspace (2B uint32 bit patterns), which the weight gradient takes over
+ *   2. shasta_bn_stats_f32: mean_m2[0:64] = batch mean, [64:128] = sum of squared deviations (float64 accumulation) over the
+ *      M = maps x H x W pixels of y; a synchronised BatchNorm merges these over the ranks (shasta_amd/sync_bn.py) before step 3
+ *   3. shasta_bn_finalize_f32: stat[0:64] = mean, [64:128] = 1 / sqrt(M2 / n + eps); running statistics (NULL to skip) updated as
+ *      nn.BatchNorm2d does (momentum, unbiased variance), *num_batches_tracked += 1
+ *   4. shasta_bn_relu_apply_f32: out = relu((y - mean) invstd gamma + beta)
+ * Backward, per BatchNorm call, given gout = d loss / d out (M, 64):
+ *   5. shasta_bn_relu_bwd_reduce_f32: sums[0:64] = sum g', [64:128] = sum g' xhat (g' = gout where out > 0; = dbeta, dgamma of this
+ *      rank), [128:192] = max |g'|, [192:256] = max |xhat|; a synchronised BatchNorm all-reduces sums[0:128] into sums_global
+ *   6. shasta_bn_relu_bwd_dy_f16x2: dy = gamma invstd (g' - sums_global[0] / n - xhat sums_global[1] / n) for images
+ *      [img0, img0 + nimg) of the `nimg_total` maps of the step, written as range-scaled fp16 pieces in the fragment order of the
+ *      weight-gradient kernel into `dy` (shasta_conv_dy_bytes(nimg_total, H, W)); edy[0:64] = this call's scale exponents; dbias[0:64]
+ *      (+)= sum dy
+ *   7. shasta_conv_wgrad_f16x2, once for all maps of the step: dweight (64, Cin, 3, 3) = sum over pixels and maps of dy x shifted x, three
+ *      fp16 piece products per fp32 product, fp32 accumulation, fixed summation order (same bits on every run).  xmax: the image maxima
+ *      of step 1 in the order [current maps of the B frame pairs, previous maps]; edy: [2][64] (current call, previous call).
+ * shasta_conv_train_supported: maps up to 287 columns wide (any Cin, H). */
+int shasta_conv_train_supported(int in_channels, int H, int W);
+int shasta_shared_conv_pack_raw_f32(const float* weight, const float* bias, int in_channels, void* packed, size_t packed_bytes,
+                                    shasta_stream_t stream);
+int shasta_shared_conv_pack_raw_f16x2(const float* weight, const float* bias, int in_channels, void* packed, size_t packed_bytes,
+                                      shasta_stream_t stream);
+size_t shasta_bn_workspace_bytes(void);
+int shasta_bn_stats_f32(const float* y, long M, float* mean_m2, void* workspace, size_t workspace_bytes, shasta_stream_t stream);
+int shasta_bn_finalize_f32(const float* mean_m2, double n, float eps, float momentum, float* stat, float* running_mean,
+                           float* running_var, long* num_batches_tracked, shasta_stream_t stream);
+int shasta_bn_relu_apply_f32(const float* y, long M, const float* stat, const float* gamma, const float* beta, float* out,
+                             shasta_stream_t stream);
+int shasta_bn_relu_bwd_reduce_f32(const float* y, const float* gout, long M, const float* stat, const float* gamma,
+                                  const float* beta, float* sums, void* workspace, size_t workspace_bytes, shasta_stream_t stream);
+size_t shasta_conv_dy_bytes(int nimg, int H, int W);
+int shasta_bn_relu_bwd_dy_f16x2(const float* y, const float* gout, int nimg, int img0, int nimg_total, int H, int W, const float* stat,
+                                const float* gamma, const float* beta, const float* sums_global, const float* sums_local,
+                                double n_global, void* dy, size_t dy_bytes, float* edy, float* dbias, int accumulate_dbias,
+                                shasta_stream_t stream);
+size_t shasta_conv_wgrad_workspace_bytes(int nimg, int in_channels, int H, int W);
+int shasta_conv_wgrad_f16x2(const float* x, const float* x_prev, int B, int in_channels, int H, int W, const unsigned* xmax,
+                            const void* dy, const float* edy, float* dweight, void* workspace, size_t workspace_bytes,
+                            shasta_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Weights of the affinity network, raw nn.Linear layout (out_features, in_features) row major,
  * exactly the tensors of the reference state_dict (det3d/models/tracker/shasta.py:49-106).
  * ------------------------------------------------------------------------------------------ */

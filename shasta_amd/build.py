@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libshasta_hip.so")
 SOURCES = ["abi.hip", "bev_gather.hip", "gemm_f32.hip", "gemm_pieces.hip", "anchor.hip", "anchor_mfma.hip", "anchor_split.hip", "pair.hip", "pair_f16.hip", "pair_f16w.hip", "embed_rows.hip", "aff.hip", "aff_pieces.hip", "aff_f16.hip", "forward.hip",
-           "voxelize.hip", "shared_conv.hip", "shared_conv_f16.hip", "iou3d.hip", "decode.hip", "train.hip", "pair_bwd.hip", "track.hip", "nms.hip"]
+           "voxelize.hip", "shared_conv.hip", "shared_conv_f16.hip", "shared_conv_train.hip", "iou3d.hip", "decode.hip", "train.hip", "pair_bwd.hip", "track.hip", "nms.hip"]
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fmaf(); products that the
 # reference rounds separately stay separately rounded (parity with the PyTorch fp32 forward).
 # -fvisibility=hidden: the .so exports exactly the extern "C" functions include/shasta_hip.h declares (its visibility pragma)
@@ -24,6 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 EXTRA_FLAGS = {"pair.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "gemm_pieces.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "aff_pieces.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "aff_f16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "pair_f16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "embed_rows.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# (shared_conv_train.hip keeps its 144 accumulators per wave in AGPRs: default form)
 
 
 def _hipcc():

@@ -23,11 +23,11 @@ constexpr int CV_WT = CV_CK * 9 * 64;          // 4608 floats
 constexpr int CV_IN_PT = (CV_IN + 255) / 256;  // 7 staged input floats per thread
 constexpr int CV_WT_PT = (CV_WT / 4 + 255) / 256;  // 5 staged weight float4 per thread
 
-// packed layout: [Cin/8][72][64] weights, then alpha[64], beta'[64], bias[64]
+// packed layout: [Cin/8][72][64] weights, then alpha[64], beta'[64], bias[64], then [192] = 1.0 for a RAW pack (conv + bias, no BN, no ReLU)
 __global__ void shared_conv_pack_kernel(const float* __restrict__ w, const float* __restrict__ bias,
                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                         const float* __restrict__ mean, const float* __restrict__ var, float eps, int Cin,
-                                        float* __restrict__ out) {
+                                        float* __restrict__ out, int raw) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     const int total = Cin * 9 * 64;
     for (int e = tid; e < total; e += nth) {
@@ -36,11 +36,11 @@ __global__ void shared_conv_pack_kernel(const float* __restrict__ w, const float
         out[e] = w[((size_t)n * Cin + c) * 9 + tap];
     }
     for (int n = tid; n < 64; n += nth) {
-        const float invstd = 1.0f / sqrtf(var[n] + eps);
-        const float alpha = invstd * gamma[n];
+        const float alpha = raw ? 1.0f : (1.0f / sqrtf(var[n] + eps)) * gamma[n];
         out[total + n] = alpha;
-        out[total + 64 + n] = beta[n] - mean[n] * alpha;
+        out[total + 64 + n] = raw ? 0.0f : beta[n] - mean[n] * alpha;
         out[total + 128 + n] = bias[n];
+        if (n == 0) out[total + 192] = raw ? 1.0f : 0.0f;
     }
 }
 
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void shared_conv_kernel(const float* __restric
     const int gy = y0 + wv;
     if (gy >= H) return;
     const float* par = packed + (size_t)Cin * 9 * 64;
+    const bool raw = par[192] != 0.0f;  // uniform
     float* orow = out + (((size_t)b * H + gy) * W) * 64;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void shared_conv_kernel(const float* __restric
             if (px < W) {
                 const float a = nb ? acc1[r] : acc0[r];
                 const float v = (a + bias) * alpha + beta2;
-                orow[(size_t)px * 64 + chn] = relu_nan(v);
+                orow[(size_t)px * 64 + chn] = raw ? v : relu_nan(v);
             }
         }
     }
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(256) void shared_conv_flat_kernel(const float* __re
         compute(s_in0, s_w0);
     }
     const float* par = packed + (size_t)Cin * 9 * 64;
+    const bool raw = par[192] != 0.0f;  // uniform
     float* obase = out + (size_t)b * npix * 64;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(256) void shared_conv_flat_kernel(const float* __re
             if (pp < npix) {
                 const float a = nb ? acc1[r] : acc0[r];
                 const float v = (a + bias) * alpha + beta2;
-                obase[(size_t)pp * 64 + chn] = relu_nan(v);
+                obase[(size_t)pp * 64 + chn] = raw ? v : relu_nan(v);
             }
         }
     }
@@ -299,7 +301,7 @@ using namespace shasta;
 
 extern "C" size_t shasta_shared_conv_packed_bytes(int in_channels) {
     if (in_channels <= 0 || in_channels % CV_CK) return 0;
-    return ((size_t)in_channels * 9 * 64 + 192) * sizeof(float);
+    return ((size_t)in_channels * 9 * 64 + 256) * sizeof(float);
 }
 
 extern "C" int shasta_shared_conv_pack_f32(const float* weight, const float* bias, const float* bn_weight,
@@ -313,8 +315,22 @@ extern "C" int shasta_shared_conv_pack_f32(const float* weight, const float* bia
         return SHASTA_E_WORKSPACE;
     }
     hipLaunchKernelGGL(shared_conv_pack_kernel, dim3(256), dim3(256), 0, as_stream(stream), weight, bias, bn_weight, bn_bias,
-                       bn_mean, bn_var, bn_eps, in_channels, static_cast<float*>(packed));
+                       bn_mean, bn_var, bn_eps, in_channels, static_cast<float*>(packed), 0);
     return check_launch("shared_conv_pack");
+}
+
+extern "C" int shasta_shared_conv_pack_raw_f32(const float* weight, const float* bias, int in_channels, void* packed, size_t packed_bytes,
+                                               shasta_stream_t stream) {
+    SHASTA_REQUIRE(weight && bias && packed, "shared_conv_pack_raw: null pointer");
+    SHASTA_REQUIRE(in_channels > 0 && in_channels % CV_CK == 0, "shared_conv_pack_raw: in_channels must be a multiple of 8");
+    SHASTA_REQUIRE((uintptr_t)packed % 16 == 0, "shared_conv_pack_raw: packed buffer must be 16-byte aligned");
+    if (packed_bytes < shasta_shared_conv_packed_bytes(in_channels)) {
+        set_error_msg("shared_conv_pack_raw: packed buffer too small");
+        return SHASTA_E_WORKSPACE;
+    }
+    hipLaunchKernelGGL(shared_conv_pack_kernel, dim3(256), dim3(256), 0, as_stream(stream), weight, bias, nullptr, nullptr, nullptr, nullptr,
+                       0.0f, in_channels, static_cast<float*>(packed), 1);
+    return check_launch("shared_conv_pack_raw");
 }
 
 extern "C" int shasta_shared_conv_f32(const float* x, const float* x_prev, int B, int in_channels, int H, int W,

@@ -43,7 +43,8 @@ constexpr int C16_INBUF = 4 * C16_PLANE;       // [piece 2][octet 2] planes
 constexpr int C16_WBUF = 9 * 2 * 2 * 1024;     // [tap 9][channel block 2][piece 2] fragments of 1 KB
 constexpr int C16_LDS = 2 * C16_WBUF + 2 * C16_INBUF;  // 155 648 bytes: one workgroup per CU
 constexpr int C16_MAXH = 8;                    // class heads per launch
-constexpr int C16_PARAMS = 256;                // floats behind the fragments: alpha[64], beta'[64], bias[64], 2^-e[64]
+constexpr int C16_PARAMS = 320;                // floats behind the fragments: alpha[64], beta'[64], bias[64], 2^-e[64], then [256] = 1.0 for a RAW head
+                                               // (train mode: conv + bias as is, no BatchNorm, no ReLU - shared_conv_train.hip takes it from there)
 
 __device__ __forceinline__ void cut2(float a, _Float16& h, _Float16& l) {
     h = (_Float16)a;
@@ -77,7 +78,7 @@ __device__ __forceinline__ uint32_t pack2h(_Float16 even, _Float16 odd) {
 __global__ __launch_bounds__(256) void conv16_pack_kernel(const float* __restrict__ w, const float* __restrict__ bias,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ mean, const float* __restrict__ var, float eps, int Cin,
-                                                          char* __restrict__ out) {
+                                                          char* __restrict__ out, int raw) {
     __shared__ float red[4];
     const int n = blockIdx.x, tid = threadIdx.x, K = Cin * 9;
     const float* wn = w + (size_t)n * K;
@@ -107,12 +108,12 @@ __global__ __launch_bounds__(256) void conv16_pack_kernel(const float* __restric
     }
     if (tid == 0) {
         float* par = reinterpret_cast<float*>(out + (size_t)nchunk * C16_WBUF);
-        const float invstd = 1.0f / sqrtf(var[n] + eps);
-        const float alpha = invstd * gamma[n];
+        const float alpha = raw ? 1.0f : (1.0f / sqrtf(var[n] + eps)) * gamma[n];
         par[n] = alpha;
-        par[64 + n] = beta[n] - mean[n] * alpha;
+        par[64 + n] = raw ? 0.0f : beta[n] - mean[n] * alpha;
         par[128 + n] = bias[n];
         par[192 + n] = __builtin_ldexpf(1.0f, -e);
+        if (n == 0) par[256] = raw ? 1.0f : 0.0f;
     }
 }
 
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(512 / PB, PB == 1 ? 2 : 1) void shared_conv_f16_ker
     // epilogue: D[pixel][channel]: lane = channel (32 nb + li), pixel = (r & 3) + 8 (r >> 2) + 4 h of the block's 32
     const float* par = reinterpret_cast<const float*>(wsrc + (size_t)nchunk * C16_WBUF);
     const float back = __builtin_ldexpf(1.0f, -eimg);
+    const bool raw = par[256] != 0.0f;  // uniform
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
         const int pblk = p0 + 32 * (PB * wv + pb);
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(512 / PB, PB == 1 ? 2 : 1) void shared_conv_f16_ker
                 if (pp < npix) {
                     const float sv = acc[pb][nb][rr] * un;
                     const float v = (sv + bias) * alpha + beta2;
-                    out[(size_t)pp * 64 + chn] = relu_nan(v);
+                    out[(size_t)pp * 64 + chn] = raw ? v : relu_nan(v);
                 }
             }
         }
@@ -702,6 +704,7 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16w_kernel(Conv16Args a) 
     // epilogue: D[pixel][channel]: lane = channel (32 nb + li), pixel = (r & 3) + 8 (r >> 2) + 4 h of the block's 32
     const float* par = reinterpret_cast<const float*>(wsrc + (size_t)nchunk * C16_WBUF);
     const float back = __builtin_ldexpf(1.0f, -eimg);
+    const bool raw = par[256] != 0.0f;  // uniform
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
         const int pblk = p0 + 32 * (PB * wv + pb);
@@ -716,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16w_kernel(Conv16Args a) 
                 if (pp < npix) {
                     const float sv = acc[pb][nb][rr] * un;
                     const float v = (sv + bias) * alpha + beta2;
-                    out[(size_t)pp * 64 + chn] = relu_nan(v);
+                    out[(size_t)pp * 64 + chn] = raw ? v : relu_nan(v);
                 }
             }
         }
@@ -924,6 +927,7 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16p_kernel(Conv16pArgs pa
     // epilogue: D[pixel][channel]: lane = channel (32 nb + li), pixel = (r & 3) + 8 (r >> 2) + 4 h of the block's 32
     const float* par = reinterpret_cast<const float*>(wsrc + (size_t)nchunk * C16_WBUF);
     const float back = __builtin_ldexpf(1.0f, -eimg);
+    const bool raw = par[256] != 0.0f;  // uniform
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
         const int pblk = p0 + 32 * (PB * wv + pb);
@@ -938,7 +942,7 @@ __global__ __launch_bounds__(512, 2) void shared_conv_f16p_kernel(Conv16pArgs pa
                 if (pp < npix) {
                     const float sv = acc[pb][nb][rr] * un;
                     const float v = (sv + bias) * alpha + beta2;
-                    out[(size_t)pp * 64 + chn] = relu_nan(v);
+                    out[(size_t)pp * 64 + chn] = raw ? v : relu_nan(v);
                 }
             }
         }
@@ -1002,8 +1006,22 @@ extern "C" int shasta_shared_conv_pack_f16x2(const float* weight, const float* b
         return SHASTA_E_WORKSPACE;
     }
     hipLaunchKernelGGL(conv16_pack_kernel, dim3(64), dim3(256), 0, as_stream(stream), weight, bias, bn_weight, bn_bias, bn_mean, bn_var,
-                       bn_eps, in_channels, static_cast<char*>(packed));
+                       bn_eps, in_channels, static_cast<char*>(packed), 0);
     return check_launch("shared_conv_pack_f16x2");
+}
+
+extern "C" int shasta_shared_conv_pack_raw_f16x2(const float* weight, const float* bias, int in_channels, void* packed, size_t packed_bytes,
+                                                 shasta_stream_t stream) {
+    SHASTA_REQUIRE(weight && bias && packed, "shared_conv_pack_raw_f16x2: null pointer");
+    SHASTA_REQUIRE(in_channels > 0 && in_channels % 16 == 0, "shared_conv_pack_raw_f16x2: in_channels must be a multiple of 16");
+    SHASTA_REQUIRE((uintptr_t)packed % 16 == 0, "shared_conv_pack_raw_f16x2: packed buffer must be 16-byte aligned");
+    if (packed_bytes < shasta_shared_conv_f16x2_packed_bytes(in_channels)) {
+        set_error_msg("shared_conv_pack_raw_f16x2: packed buffer too small");
+        return SHASTA_E_WORKSPACE;
+    }
+    hipLaunchKernelGGL(conv16_pack_kernel, dim3(64), dim3(256), 0, as_stream(stream), weight, bias, nullptr, nullptr, nullptr, nullptr, 0.0f,
+                       in_channels, static_cast<char*>(packed), 1);
+    return check_launch("shared_conv_pack_raw_f16x2");
 }
 
 extern "C" size_t shasta_shared_conv_multi_workspace_bytes(int B) { return B <= 0 ? 0 : align_up((size_t)2 * B * sizeof(unsigned), 256); }

@@ -68,6 +68,18 @@ SYMBOLS = {
     "shasta_shared_conv_multi_workspace_bytes_for": (_Z, [_I, _I, _I, _I, _I, _I]),
     "shasta_shared_conv_multi_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _Z, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, _Z, _P]),
     "shasta_shared_conv_multi_bounded_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _Z, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, _Z, _F, _P]),
+    "shasta_conv_train_supported": (_I, [_I, _I, _I]),
+    "shasta_shared_conv_pack_raw_f32": (_I, [_P, _P, _I, _P, _Z, _P]),
+    "shasta_shared_conv_pack_raw_f16x2": (_I, [_P, _P, _I, _P, _Z, _P]),
+    "shasta_bn_workspace_bytes": (_Z, []),
+    "shasta_bn_stats_f32": (_I, [_P, C.c_long, _P, _P, _Z, _P]),
+    "shasta_bn_finalize_f32": (_I, [_P, C.c_double, _F, _F, _P, _P, _P, _P, _P]),
+    "shasta_bn_relu_apply_f32": (_I, [_P, C.c_long, _P, _P, _P, _P, _P]),
+    "shasta_bn_relu_bwd_reduce_f32": (_I, [_P, _P, C.c_long, _P, _P, _P, _P, _P, _Z, _P]),
+    "shasta_conv_dy_bytes": (_Z, [_I, _I, _I]),
+    "shasta_bn_relu_bwd_dy_f16x2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, C.c_double, _P, _Z, _P, _P, _I, _P]),
+    "shasta_conv_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "shasta_conv_wgrad_f16x2": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "shasta_packed_bytes": (_Z, [_I, _I, _I]),
     "shasta_pack_weights_f32": (_I, [_WP, _P, _Z, _P]),
     "shasta_aug_shape_aux_bytes": (_Z, [_I, _I, _I]),

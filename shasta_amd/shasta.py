@@ -158,6 +158,9 @@ class Shasta(BaseTrack):
         # tensors inside the kernel (SHASTA_OPT_PRECUT_WEIGHT_STREAM): bit-identical results, weight-stream kernel 2.75 -> 2.56 ms at
         # 512 frame-pairs.  False keeps only the fp32 checkpoint tensors resident.
         self.precut_weight_stream = True
+        # train() mode: shared_conv forward (batch-statistics BatchNorm) and backward by the hand-written kernels (shared_conv_train.py);
+        # False keeps the module's own nn.Sequential (MIOpen / ATen + autograd), e.g. to time the two against each other
+        self.hand_written_train_conv = True
         # training backward (shasta_amd/training.py): "fp32" (parity path, like the reference's train.py:149) or "bf16": the GEMMs of
         # aff and of the pair MLPs' first-layer tables take bf16 operands with fp32 accumulation (BASELINE config 5's reduced-precision
         # option); the pair MLPs' later layers run per pair on chip in fp32 either way, unless dense_pair_backward keeps the round-4
@@ -394,8 +397,15 @@ class Shasta(BaseTrack):
         needs_grad = torch.is_grad_enabled() and (any(t.requires_grad for t in maps) or
                                                    any(p.requires_grad for p in self.shared_conv.parameters()))
         if self.training or needs_grad:
-            # Training (train.py:193 keeps every BN in train() mode: batch statistics) and frozen-BN fine-tuning with autograd
-            # on are the reference's own differentiable nn.Sequential; the hand-written kernel is the inference operator.
+            # Training (train.py:191 keeps every BN in train() mode: batch statistics; :183-189 freeze backbone and neck only, so
+            # shared_conv trains): conv + batch-statistics BatchNorm (+ the exchange of a synchronised one) + ReLU -> NHWC and the
+            # backward for its four parameters, hand-written (shared_conv_train.py / csrc/shared_conv_train.hip).  What stays on the
+            # module's own nn.Sequential: a map that itself requires grad (somebody trains the neck), an eval-mode BatchNorm under
+            # autograd (frozen-BN fine-tuning), a single map, maps wider than the weight-gradient kernel holds (287 columns).
+            from . import shared_conv_train as sct
+            if (prev_bev_map is not None and self.hand_written_train_conv and sct.supported(self, bev_map) and
+                    not prev_bev_map.requires_grad):
+                return sct.shared_conv_train(self, bev_map, prev_bev_map)
             outs = [self.shared_conv(t).permute(0, 2, 3, 1).contiguous() for t in maps]
             return outs[0] if prev_bev_map is None else tuple(outs)
         if self.arithmetic in ("f16x2", "f16grid"):  # products from two fp16 pieces per operand (csrc/shared_conv_f16.hip)
