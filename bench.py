@@ -712,7 +712,9 @@ def extra_train_step(bench, args, ex):
                    "the other tensors); *_stepafter: the same with the update in step(); *_densepairs: the pair MLPs' "
                    "backward in the dense formulation of round 4 (hidden activations of every pair in HBM, strided GEMMs: "
                    "Shasta.dense_pair_backward), the others (fp32): recomputed and back-propagated per pair on chip (csrc/pair_bwd.hip); "
-                   "bf16: the GEMMs around them (first-layer tables, aff) with bf16 operands")
+                   "bf16: the GEMMs around them (first-layer tables, aff) with bf16 operands; *_from_neck: the whole step of the reference "
+                   "(Shasta.forward from two (B, 512, 180, 180) neck outputs: shared_conv in train() mode hand-written, forward + backward + "
+                   "its four parameters in the update), *_from_neck_miopen: the same with shared_conv through nn.Sequential")
     for (cfg, B, steps) in ((CAR, 16, 10), (CAR, 64, 6), (HEADLINE, 8, 3)):
         for prec in ("fp32", "bf16", "fp32_stepafter", "fp32_dense", "fp32_densepairs"):
             if prec.startswith(("fp32_dense", "fp32_stepafter")) and cfg is not HEADLINE:
@@ -761,6 +763,47 @@ def extra_train_step(bench, args, ex):
                 ts[key] = {"ms_per_step": ms, "frame_pairs_per_s": B / ms * 1e3,
                            "fwd_ms": sum(e[0].elapsed_time(e[1]) for e in evs) / steps, "bwd_ms": sum(e[1].elapsed_time(e[2]) for e in evs) / steps,
                            "adam_ms": sum(e[2].elapsed_time(e[3]) for e in evs) / steps}
+                if prec == "fp32":
+                    # the step as the reference runs it (tools/nusc_shasta/train.py:198-218 through Shasta.forward): from the frozen neck's
+                    # outputs, i.e. with shared_conv in train() mode - conv + batch-statistics BatchNorm + ReLU forward, BatchNorm / ReLU
+                    # backward and the weight gradient - hand-written (csrc/shared_conv_train.hip) and, beside it, through the module's
+                    # own nn.Sequential (MIOpen conv + wgrad, ATen BatchNorm, autograd)
+                    x = torch.relu(torch.randn(B, 512, HW, HW, device=dev, generator=bench.gen))
+                    xp = torch.relu(torch.randn(B, 512, HW, HW, device=dev, generator=bench.gen))
+                    conv_params = list(model.shared_conv.parameters())
+                    opt2 = training.FusedAdam(conv_params, lr=1e-4)
+                    for hand in (True, False):
+                        model.hand_written_train_conv = hand
+
+                        def neck_step(ev=None):
+                            opt.zero_grad(set_to_none=True)
+                            opt2.zero_grad(set_to_none=True)
+                            if ev:
+                                ev[0].record()
+                            m1, m2, _ = model(dict(det_boxes=det0.clone(), prev_det_boxes=prev.clone(), bev_map=x, prev_bev_map=xp), train_mode=True)
+                            loss = training.affinity_loss(m1, m2, gt)
+                            if ev:
+                                ev[1].record()
+                            loss.backward()
+                            if ev:
+                                ev[2].record()
+                            opt.step()
+                            opt2.step()
+                            if ev:
+                                ev[3].record()
+                        for _ in range(2):
+                            neck_step()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for i in range(steps):
+                            neck_step(evs[i])
+                        torch.cuda.synchronize()
+                        ms = (time.perf_counter() - t0) / steps * 1e3
+                        ts[key + ("_from_neck" if hand else "_from_neck_miopen")] = {
+                            "ms_per_step": ms, "frame_pairs_per_s": B / ms * 1e3,
+                            "fwd_ms": sum(e[0].elapsed_time(e[1]) for e in evs) / steps, "bwd_ms": sum(e[1].elapsed_time(e[2]) for e in evs) / steps,
+                            "adam_ms": sum(e[2].elapsed_time(e[3]) for e in evs) / steps}
+                    del x, xp, opt2
                 del model, params, opt
                 torch.cuda.empty_cache()
             except Exception as err:  # noqa: BLE001

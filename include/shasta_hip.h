@@ -184,7 +184,7 @@ int shasta_shared_conv_multi_f32(const float* x, const float* x_prev, int B, int
  *   7. shasta_conv_wgrad_f16x2, once for all maps of the step: dweight (64, Cin, 3, 3) = sum over pixels and maps of dy x shifted x, three
  *      fp16 piece products per fp32 product, fp32 accumulation, fixed summation order (same bits on every run).  xmax: the image maxima
  *      of step 1 in the order [current maps of the B frame pairs, previous maps]; edy: [2][64] (current call, previous call).
- * shasta_conv_train_supported: maps up to 287 columns wide (any Cin, H). */
+ * shasta_conv_train_supported: maps up to 255 columns wide (any Cin, H). */
 int shasta_conv_train_supported(int in_channels, int H, int W);
 int shasta_shared_conv_pack_raw_f32(const float* weight, const float* bias, int in_channels, void* packed, size_t packed_bytes,
                                     shasta_stream_t stream);

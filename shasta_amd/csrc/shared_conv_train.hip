@@ -193,7 +193,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_final_kernel(const double*
 // ---- backward, pass 2: dy of one image row, scaled per channel, cut into fp16 pieces, written in the fragment order of the weight-
 // gradient kernel: block ((row id * KS + k) * 2 + channel block) * 2 + piece, 1 KB each: lane (m = channel in the block, h) holds
 // columns 16 k + 8 h .. + 7.  grid = rows of all images of this BatchNorm call; row id = img0 * H + blockIdx.x -------------------------
-constexpr int DY_MAXPW = 288;
+constexpr int DY_MAXPW = 256;
 __global__ __launch_bounds__(256) void bn_bwd_dy_kernel(const float* __restrict__ y, const float* __restrict__ gout, int H, int W, int PW,
                                                         long row0, const float* __restrict__ stat, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ sums_global,
@@ -277,7 +277,8 @@ struct WgradArgs {
     int B, nimg, Cin, H, W, PW, KS, ROWB, cblocks, rsplit, rows_per_split, total;
 };
 
-template <int MAXKQ>  // k-steps of a wave per image row at most: 3 serves rows of up to 191 columns (12 k-steps), 5 up to 287
+template <int MAXKQ>  // k-steps of a wave per image row = padded row width / 64 (rows are padded to whole multiples of 64 columns, so
+                      // that every wave runs the same branch-free sequence): 3 for the 180-column maps
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -306,36 +307,33 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
     }
     // staging role: channel tid >> 4 of the block, column pairs (tid & 15) + 16 i
     const int sc = tid >> 4, sl = tid & 15;
-    const int npair = (W + 1) >> 1, NI = (npair + 15) >> 4;
     const bool c_ok = cb * WG_CB + sc < Cin;
     const float* xc = xin + (size_t)(cb * WG_CB + (c_ok ? sc : 0)) * H * W;
-    constexpr int MAXNI = MAXKQ == 3 ? 6 : 9;  // column pairs of a lane: W <= 192 / W <= 288
+    constexpr int MAXNI = 2 * MAXKQ;  // column pairs of a lane
     float sv[MAXNI][2];
+    // (straight-line: every load is issued, from a clamped address - a branch per load would make each wait for the one before)
     auto load_row = [&](int row) __attribute__((always_inline)) {
         const bool ok = c_ok && row >= 0 && row < H;
-        const float* xr = xc + (size_t)(ok ? row : 0) * W;
+        const float* xr = xc + (size_t)min(max(row, 0), H - 1) * W;
 #pragma unroll
         for (int i = 0; i < MAXNI; ++i) {
-            if (i < NI) {
-                const int p = 2 * (sl + 16 * i);
-                sv[i][0] = (ok && p < W) ? xr[p] : 0.0f;
-                sv[i][1] = (ok && p + 1 < W) ? xr[p + 1] : 0.0f;
-            }
+            const int p = 2 * (sl + 16 * i);
+            const float v0 = xr[min(p, W - 1)], v1 = xr[min(p + 1, W - 1)];
+            sv[i][0] = (ok && p < W) ? v0 : 0.0f;
+            sv[i][1] = (ok && p + 1 < W) ? v1 : 0.0f;
         }
     };
     auto store_row = [&](int row) __attribute__((always_inline)) {
         char* dst = lds + ((row + 1) & 3) * SLOT + sc * ROWB + 16;
 #pragma unroll
         for (int i = 0; i < MAXNI; ++i) {
-            if (i < NI) {
-                const int p = 2 * (sl + 16 * i);
-                if (p < W) {  // (the odd column beyond an odd W holds a zero: it is a padding column)
-                    _Float16 h0, l0, h1, l1;
-                    tr_cut2(sv[i][0] * xscale, h0, l0);
-                    tr_cut2(sv[i][1] * xscale, h1, l1);
-                    *reinterpret_cast<uint32_t*>(dst + 2 * p) = tr_pack2h(h0, h1);
-                    *reinterpret_cast<uint32_t*>(dst + PIECE + 2 * p) = tr_pack2h(l0, l1);
-                }
+            const int p = 2 * (sl + 16 * i);
+            if (p < W) {  // (the odd column beyond an odd W holds a zero: it is a padding column)
+                _Float16 h0, l0, h1, l1;
+                tr_cut2(sv[i][0] * xscale, h0, l0);
+                tr_cut2(sv[i][1] * xscale, h1, l1);
+                *reinterpret_cast<uint32_t*>(dst + 2 * p) = tr_pack2h(h0, h1);
+                *reinterpret_cast<uint32_t*>(dst + PIECE + 2 * p) = tr_pack2h(l0, l1);
             }
         }
     };
@@ -346,7 +344,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
     }
 
     const int n = lane & 31, h = lane >> 5;
-    const int nk = (KS - kq + 3) >> 2;
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     f32x16 acc[9];
 #pragma unroll
@@ -361,16 +358,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
         al[i] = *reinterpret_cast<const t16x8*>(f + 1024);
     };
 #pragma unroll
-    for (int i = 0; i < MAXKQ; ++i)
-        if (i < nk) load_a(r0, i);
+    for (int i = 0; i < MAXKQ; ++i) load_a(r0, i);
     __syncthreads();
     const int b_lane = n * ROWB + 16 + 16 * h;
     for (int r = r0; r < r1; ++r) {
-        const bool more = r + 1 < r1;
-        if (more) load_row(r + 2);
+        // (unconditional: the last iteration stages a row and requests fragments nobody uses - cheaper than branches around loads)
+        const int rnext = min(r + 1, r1 - 1);
+        load_row(r + 2);
+        __builtin_amdgcn_sched_barrier(0);  // the row's loads are issued HERE (left alone the scheduler sinks them to their first use)
 #pragma unroll
         for (int i = 0; i < MAXKQ; ++i) {
-            if (i >= nk) continue;
             const int k = kq + 4 * i;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
@@ -398,9 +395,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) acc[3 * ky + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[kx], acc[3 * ky + kx], 0, 0, 0);
             }
-            if (more) load_a(r + 1, i);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(rnext, i);  // next row's fragments of this k-step: requested now, used a row's worth of MFMAs later
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) store_row(r + 2);  // into the slot of row r - 2, which nobody reads any more
+        store_row(r + 2);  // into the slot of row r - 2, which nobody reads any more
         __syncthreads();
     }
 
@@ -439,7 +438,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
     dw[i] = s;
 }
 
-static int wgrad_pw(int W) { return (W + 1 + 15) / 16 * 16; }
+static int wgrad_pw(int W) { return (W + 1 + 63) / 64 * 64; }  // whole multiples of 64 columns: 4 waves x 16 columns per round of k-steps
 static int wgrad_rowb(int PW) {
     int b = 2 * PW + 32;
     if ((b / 16) % 2 == 0) b += 16;  // an odd number of 16-byte units per channel row: the 16-byte reads of 16 consecutive channels cover all banks
@@ -459,7 +458,7 @@ static void wgrad_split(int nimg, int Cin, int H, int& cblocks, int& rsplit, int
 using namespace shasta;
 
 extern "C" int shasta_conv_train_supported(int in_channels, int H, int W) {
-    if (in_channels <= 0 || H <= 0 || W <= 0 || W > DY_MAXPW - 1) return 0;
+    if (in_channels <= 0 || H <= 0 || W <= 0 || W > DY_MAXPW - 1) return 0;  // 255 columns: four rounds of k-steps per row
     if ((long)in_channels * H * W >= (1L << 31)) return 0;
     const int PW = wgrad_pw(W);
     return WG_RING * 2 * WG_CB * wgrad_rowb(PW) <= 150 * 1024 && (size_t)(PW * 65 + 4 * BN_C) * sizeof(float) <= 96 * 1024;
@@ -578,16 +577,24 @@ extern "C" int shasta_conv_wgrad_f16x2(const float* x, const float* x_prev, int 
     a.total = a.cblocks * nimg * a.rsplit;
     const int lds_ring = WG_RING * 2 * WG_CB * a.ROWB, lds_red = 8 * 16 * 64 * (int)sizeof(float);
     const int lds = lds_ring > lds_red ? lds_ring : lds_red;
-    const bool narrow = a.KS <= 12;
-    const void* fn = narrow ? (const void*)conv_wgrad_kernel<3> : (const void*)conv_wgrad_kernel<5>;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-        (void)hipGetLastError();
-        set_error_msg("conv_wgrad: the device refuses the LDS ring");
-        return SHASTA_E_LAUNCH;
-    }
     hipStream_t st = as_stream(stream);
-    if (narrow) hipLaunchKernelGGL(conv_wgrad_kernel<3>, dim3((unsigned)a.total), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<5>, dim3((unsigned)a.total), dim3(512), lds, st, a);
+    bool launched = false;
+#define SHASTA_WGRAD(NK)                                                                                                             \
+    if (a.KS == 4 * NK) {                                                                                                            \
+        if (hipFuncSetAttribute((const void*)conv_wgrad_kernel<NK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) { \
+            (void)hipGetLastError();                                                                                                 \
+            set_error_msg("conv_wgrad: the device refuses the LDS ring");                                                            \
+            return SHASTA_E_LAUNCH;                                                                                                  \
+        }                                                                                                                            \
+        hipLaunchKernelGGL(conv_wgrad_kernel<NK>, dim3((unsigned)a.total), dim3(512), lds, st, a);                                   \
+        launched = true;                                                                                                             \
+    }
+    SHASTA_WGRAD(1)
+    SHASTA_WGRAD(2)
+    SHASTA_WGRAD(3)
+    SHASTA_WGRAD(4)
+#undef SHASTA_WGRAD
+    SHASTA_REQUIRE(launched, "conv_wgrad: map width not served");
     int rc = check_launch("conv_wgrad");
     if (rc) return rc;
     const long count = (long)BN_C * in_channels * 9;

@@ -401,7 +401,7 @@ class Shasta(BaseTrack):
             # shared_conv trains): conv + batch-statistics BatchNorm (+ the exchange of a synchronised one) + ReLU -> NHWC and the
             # backward for its four parameters, hand-written (shared_conv_train.py / csrc/shared_conv_train.hip).  What stays on the
             # module's own nn.Sequential: a map that itself requires grad (somebody trains the neck), an eval-mode BatchNorm under
-            # autograd (frozen-BN fine-tuning), a single map, maps wider than the weight-gradient kernel holds (287 columns).
+            # autograd (frozen-BN fine-tuning), a single map, maps wider than the weight-gradient kernel holds (255 columns).
             from . import shared_conv_train as sct
             if (prev_bev_map is not None and self.hand_written_train_conv and sct.supported(self, bev_map) and
                     not prev_bev_map.requires_grad):
