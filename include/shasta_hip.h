@@ -75,6 +75,20 @@ int shasta_voxelize_mean_f32(const float* points, int num_points, int ndim, cons
                              int32_t* num_voxels, int32_t* cell_map, void* workspace,
                              size_t workspace_bytes, shasta_stream_t stream);
 
+/* A batch of clouds in ONE chain of launches: the reference voxelises the current and the previous cloud of every sample
+ * (datasets/pipelines/preprocess.py:179-208: `Voxelization.__call__` runs the generator on res["lidar"]["points"] and on
+ * res["lidar"]["prev_points"]), one cloud per DataLoader worker call.  `points` holds the clouds back to back ((sum P, ndim) fp32),
+ * h_offsets[0..num_clouds] (HOST) their first rows; num_clouds <= 32.  Every output has a leading cloud axis:
+ * voxels (num_clouds, max_voxels, max_points, ndim), coors (num_clouds, max_voxels, 3), num_points (num_clouds, max_voxels),
+ * mean (num_clouds, max_voxels, ndim) or NULL, num_voxels (num_clouds,) int32 ON THE DEVICE (no host read inside the call).
+ * cell_maps: num_clouds dense maps back to back (num_clouds x shasta_voxelize_cell_map_bytes), all-empty on entry and on exit.
+ * Cloud c's results are bit for bit those of shasta_voxelize_mean_f32 on that cloud alone. */
+size_t shasta_voxelize_batch_workspace_bytes(const int* h_offsets, int num_clouds, int max_voxels, int max_points);
+int shasta_voxelize_mean_batch_f32(const float* points, const int* h_offsets, int num_clouds, int ndim, const float* h_range6,
+                                   const float* h_voxel3, int max_points, int max_voxels, float* voxels, int32_t* coors,
+                                   int32_t* num_points_per_voxel, float* mean, int32_t* num_voxels, int32_t* cell_maps,
+                                   void* workspace, size_t workspace_bytes, shasta_stream_t stream);
+
 /* The reader alone, for callers that already hold voxelised input (det3d/models/readers/voxel_encoder.py:18-28 as called from
  * Shasta.extract_feat, det3d/models/tracker/shasta.py:178-179): out (V, num_features) = sum over the max_points slots of
  * voxels (V, max_points, ndim)[..., :num_features] / num_points.  num_points_f32: (V,) fp32 - example_to_device

@@ -56,6 +56,8 @@ SYMBOLS = {
     "shasta_voxelize_cell_map_init": (_I, [_P, _Z, _P]),
     "shasta_voxelize_workspace_bytes": (_Z, [_I, _I, _I]),
     "shasta_voxelize_mean_f32": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "shasta_voxelize_batch_workspace_bytes": (_Z, [_P, _I, _I, _I]),
+    "shasta_voxelize_mean_batch_f32": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "shasta_voxel_mean_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "shasta_bev_gather_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P, _I, _I, _P]),
     "shasta_shared_conv_packed_bytes": (_Z, [_I]),

@@ -21,15 +21,20 @@ class _CellMaps:
     def __init__(self):
         self._maps = {}
 
-    def get(self, device, rng, vs):
+    def get(self, device, rng, vs, clouds=1):
+        """`clouds` maps back to back (a batch call gives every cloud its own: 332 MB each for the nuScenes grid - 5.3 GB for the 16
+        clouds of 8 samples, allocated once and kept all-empty by the kernels)."""
         lib = hip.load()
         key = (str(device), tuple(float(x) for x in rng), tuple(float(x) for x in vs))
-        if key not in self._maps:
-            nbytes = lib.shasta_voxelize_cell_map_bytes(rng.ctypes.data_as(C.c_void_p), vs.ctypes.data_as(C.c_void_p))
-            if nbytes == 0:
-                raise hip.ShastaHipError("voxelize: empty or invalid grid")
-            m = torch.empty(nbytes // 4, dtype=torch.int32, device=device)
-            hip.check(lib.shasta_voxelize_cell_map_init(hip.ptr(m), nbytes, hip.stream_ptr()), "cell_map_init")
+        nbytes = lib.shasta_voxelize_cell_map_bytes(rng.ctypes.data_as(C.c_void_p), vs.ctypes.data_as(C.c_void_p))
+        if nbytes == 0:
+            raise hip.ShastaHipError("voxelize: empty or invalid grid")
+        cur = self._maps.get(key)
+        if cur is None or cur.numel() * 4 < clouds * nbytes:
+            self._maps.pop(key, None)
+            cur = None
+            m = torch.empty(clouds * nbytes // 4, dtype=torch.int32, device=device)
+            hip.check(lib.shasta_voxelize_cell_map_init(hip.ptr(m), clouds * nbytes, hip.stream_ptr()), "cell_map_init")
             self._maps[key] = m
         return self._maps[key]
 
@@ -67,6 +72,45 @@ def points_to_voxel_device(points, voxel_size, coors_range, max_points=35, max_v
     return out
 
 
+def points_to_voxel_batch_device(clouds, voxel_size, coors_range, max_points=35, max_voxels=20000, with_mean=True):
+    """The clouds of a batch (the current and the previous cloud of every sample: preprocess.py:179-208 voxelises both) in ONE chain of
+    launches, nothing read back.  clouds: list of (P_i, ndim) fp32 device tensors, or a tuple (points (sum P, ndim), offsets) with the
+    clouds back to back and `offsets` a host sequence of len(clouds) + 1 row indices.  Returns device tensors with a leading cloud axis:
+    voxels (n, max_voxels, max_points, ndim), coors (n, max_voxels, 3) zyx, num_points (n, max_voxels), mean (n, max_voxels, ndim) or
+    None, num_voxels (n,) int32 - rows >= num_voxels[c] of cloud c are not written.  Up to 32 clouds per call."""
+    lib = hip.load()
+    if isinstance(clouds, tuple):
+        points, offsets = clouds
+        offsets = [int(o) for o in offsets]
+    else:
+        offsets = [0]
+        for c in clouds:
+            offsets.append(offsets[-1] + int(c.shape[0]))
+        points = torch.cat([c.float() for c in clouds], dim=0) if len(clouds) > 1 else clouds[0]
+    if not points.is_cuda:
+        raise hip.ShastaHipError("points_to_voxel_batch_device needs device tensors (no CPU path)")
+    points = points.float().contiguous()
+    n, ndim = len(offsets) - 1, points.shape[1]
+    if not 1 <= n <= 32:
+        raise ValueError("1 to 32 clouds per call")
+    vs = np.ascontiguousarray(voxel_size, np.float32)
+    rg = np.ascontiguousarray(coors_range, np.float32)
+    dev = points.device
+    cmap = _cell_maps.get(dev, rg, vs, clouds=n)
+    voxels = torch.empty(n, max_voxels, max_points, ndim, device=dev)
+    coors = torch.empty(n, max_voxels, 3, dtype=torch.int32, device=dev)
+    num = torch.empty(n, max_voxels, dtype=torch.int32, device=dev)
+    mean = torch.empty(n, max_voxels, ndim, device=dev) if with_mean else None
+    nv = torch.empty(n, dtype=torch.int32, device=dev)
+    off = (C.c_int * (n + 1))(*offsets)
+    wsb = lib.shasta_voxelize_batch_workspace_bytes(off, n, max_voxels, max_points)
+    ws = torch.empty((wsb + 3) // 4, dtype=torch.int32, device=dev)
+    hip.check(lib.shasta_voxelize_mean_batch_f32(hip.ptr(points), off, n, ndim, rg.ctypes.data_as(C.c_void_p), vs.ctypes.data_as(C.c_void_p),
+                                                 max_points, max_voxels, hip.ptr(voxels), hip.ptr(coors), hip.ptr(num), hip.ptr(mean),
+                                                 hip.ptr(nv), hip.ptr(cmap), hip.ptr(ws), wsb, hip.stream_ptr()), "shasta_voxelize_mean_batch_f32")
+    return voxels, coors, num, mean, nv
+
+
 def points_to_voxel(points, voxel_size, coors_range, max_points=35, reverse_index=True, max_voxels=20000):
     """Drop-in for the reference function: numpy in, numpy out (voxels, coordinates zyx, num_points_per_voxel)."""
     if not reverse_index:
@@ -100,6 +144,13 @@ class VoxelGenerator:
             max_voxels = self._max_voxels
         return points_to_voxel_device(points, self._voxel_size, self._point_cloud_range, self._max_num_points,
                                       max_voxels, with_mean)
+
+    def generate_batch_device(self, clouds, max_voxels=-1, with_mean=True):
+        """Every cloud of a batch (current + previous cloud of every sample) in one chain of launches; the voxel counts stay on the
+        device (points_to_voxel_batch_device): no host synchronisation unless the caller reads them."""
+        if max_voxels == -1:
+            max_voxels = self._max_voxels
+        return points_to_voxel_batch_device(clouds, self._voxel_size, self._point_cloud_range, self._max_num_points, max_voxels, with_mean)
 
     @property
     def voxel_size(self):

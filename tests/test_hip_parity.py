@@ -943,6 +943,52 @@ def test_voxelize_vs_oracle_full_size(P, mp, mv, seed):
         assert np.array_equal(cell[:, ::-1], rc)
 
 
+def _cloud(rng, P):
+    pts = np.zeros((P, 5), np.float32)
+    if P:
+        r = np.abs(rng.normal(0, 18, size=P)).astype(np.float32)
+        th = rng.uniform(0, 2 * np.pi, size=P).astype(np.float32)
+        pts[:, 0], pts[:, 1] = r * np.cos(th), r * np.sin(th)
+        pts[:, 2] = rng.normal(-1.5, 0.6, size=P)
+        pts[:, 3] = rng.uniform(0, 255, size=P)
+        pts[:, 4] = rng.integers(0, 10, size=P) * 0.05
+        pts[: P // 50] = pts[P // 2: P // 2 + P // 50]  # exact duplicates
+    return pts
+
+
+@pytest.mark.parametrize("sizes,mp,mv", [((300000, 280000, 1, 0, 257, 256, 120000, 300000), 10, 160000), ((5000, 90000, 70000), 10, 20000),
+                                         ((40, 0, 0, 13), 3, 6), ((1000,) * 32, 5, 700)])
+def test_voxelize_batch_equals_cloud_by_cloud_and_the_c_oracle(sizes, mp, mv):
+    """shasta_voxelize_mean_batch_f32: the clouds of a batch (current + previous cloud of every sample, preprocess.py:179-208) in one
+    chain of launches with the voxel counts left on the device - every cloud bit for bit what the one-cloud call and the C twin of the
+    reference's serial loop give for it; empty clouds, clouds that end on a workgroup boundary, the voxel cap hit in some clouds only;
+    a second call finds every cloud's cell map restored; the list and the (points, offsets) forms agree."""
+    from oracle import voxelize_oracle as VO
+    from shasta_amd.voxel_generator import points_to_voxel_batch_device, points_to_voxel_device
+    dev = _dev()
+    rng = np.random.default_rng(len(sizes) * 7 + mp)
+    clouds = [_cloud(rng, P) for P in sizes]
+    dclouds = [torch.from_numpy(c).to(dev) for c in clouds]
+    for rep in range(2):
+        if rep == 0:
+            v, c, n, mean, nv = points_to_voxel_batch_device(dclouds, VS, RG, mp, mv, with_mean=True)
+        else:
+            offs = np.concatenate([[0], np.cumsum(sizes)])
+            v, c, n, mean, nv = points_to_voxel_batch_device((torch.cat(dclouds), offs), VS, RG, mp, mv, with_mean=True)
+        assert nv.is_cuda and nv.dtype == torch.int32 and v.shape[:2] == (len(sizes), mv)
+        nvh = nv.cpu().numpy()
+        for i, pts in enumerate(clouds):
+            rv, rc, rn, rmean = VO.points_to_voxel(pts, VS, RG, mp, mv, with_mean=True)
+            V = int(nvh[i])
+            assert V == rv.shape[0], i
+            assert np.array_equal(c[i, :V].cpu().numpy(), rc) and np.array_equal(n[i, :V].cpu().numpy(), rn), i
+            assert np.array_equal(v[i, :V].cpu().numpy(), rv), i
+            np.testing.assert_allclose(mean[i, :V].cpu().numpy(), rmean, rtol=1e-6, atol=1e-6)
+            if rep == 0 and i < 4:
+                sv, sc, sn, sm = points_to_voxel_device(dclouds[i], VS, RG, mp, mv, with_mean=True)
+                assert torch.equal(sv, v[i, :V]) and torch.equal(sc, c[i, :V]) and torch.equal(sn, n[i, :V]) and torch.equal(sm, mean[i, :V])
+
+
 @pytest.mark.parametrize("name,B", [("small_32_7_4", 40), ("small_32_7_4", 100), ("car_90_3_5", 48), ("bicycle_50_3_5", 70), ("truck_60_3_5", 150)])
 def test_f32_arithmetic_option_matches_oracle_and_pieces(name, B):
     """The three settings of Shasta.arithmetic (shasta_weights.options) against the oracle on the same inputs: "f16x2" (default:
