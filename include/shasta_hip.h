@@ -60,20 +60,17 @@ const char* shasta_last_error(void);
  *  coors       (max_voxels, 3) int32 z,y,x
  *  num_points  (max_voxels,) int32
  *  mean        (max_voxels, ndim) fp32 or NULL        -- sum over slots / count
- *  num_voxels  (1,) int32 device scalar (V); rows >= V of the outputs are left zeroed
- *  cell_map    (gz*gy*gx,) int32, must hold 0x7fffffff everywhere on entry (see
- *              shasta_voxelize_cell_map_bytes / _init); restored to that state on exit, so one
- *              map serves every call on the stream (the reference allocates 331 MB per call).
- *  workspace   shasta_voxelize_workspace_bytes(P, max_voxels, max_points) bytes
+ *  num_voxels  (1,) int32 device scalar (V); rows >= V of `voxels` are zero, of the other outputs unspecified
+ *  workspace   shasta_voxelize_workspace_bytes(P, max_voxels, max_points) bytes.  It holds, besides the per-point scratch, the
+ *              cell -> first point map: the reference allocates a dense (gz, gy, gx) int32 map per call (331 MB for the nuScenes
+ *              grid, point_cloud_ops.py:150); a cloud of P points touches at most P cells, so here it is an open-addressing hash
+ *              table of 2^ceil(log2(2 P)) entries (8 MB for 3e5 points), cleared by one memset inside the call.
  * ------------------------------------------------------------------------------------------ */
-size_t shasta_voxelize_cell_map_bytes(const float* h_range6, const float* h_voxel3);
-int shasta_voxelize_cell_map_init(int32_t* cell_map, size_t bytes, shasta_stream_t stream);
 size_t shasta_voxelize_workspace_bytes(int num_points, int max_voxels, int max_points);
 int shasta_voxelize_mean_f32(const float* points, int num_points, int ndim, const float* h_range6,
                              const float* h_voxel3, int max_points, int max_voxels, float* voxels,
                              int32_t* coors, int32_t* num_points_per_voxel, float* mean,
-                             int32_t* num_voxels, int32_t* cell_map, void* workspace,
-                             size_t workspace_bytes, shasta_stream_t stream);
+                             int32_t* num_voxels, void* workspace, size_t workspace_bytes, shasta_stream_t stream);
 
 /* A batch of clouds in ONE chain of launches: the reference voxelises the current and the previous cloud of every sample
  * (datasets/pipelines/preprocess.py:179-208: `Voxelization.__call__` runs the generator on res["lidar"]["points"] and on
@@ -81,13 +78,13 @@ int shasta_voxelize_mean_f32(const float* points, int num_points, int ndim, cons
  * h_offsets[0..num_clouds] (HOST) their first rows; num_clouds <= 32.  Every output has a leading cloud axis:
  * voxels (num_clouds, max_voxels, max_points, ndim), coors (num_clouds, max_voxels, 3), num_points (num_clouds, max_voxels),
  * mean (num_clouds, max_voxels, ndim) or NULL, num_voxels (num_clouds,) int32 ON THE DEVICE (no host read inside the call).
- * cell_maps: num_clouds dense maps back to back (num_clouds x shasta_voxelize_cell_map_bytes), all-empty on entry and on exit.
+ * workspace: shasta_voxelize_batch_workspace_bytes (per-point scratch + one hash table per cloud, sized for the largest cloud).
  * Cloud c's results are bit for bit those of shasta_voxelize_mean_f32 on that cloud alone. */
 size_t shasta_voxelize_batch_workspace_bytes(const int* h_offsets, int num_clouds, int max_voxels, int max_points);
 int shasta_voxelize_mean_batch_f32(const float* points, const int* h_offsets, int num_clouds, int ndim, const float* h_range6,
                                    const float* h_voxel3, int max_points, int max_voxels, float* voxels, int32_t* coors,
-                                   int32_t* num_points_per_voxel, float* mean, int32_t* num_voxels, int32_t* cell_maps,
-                                   void* workspace, size_t workspace_bytes, shasta_stream_t stream);
+                                   int32_t* num_points_per_voxel, float* mean, int32_t* num_voxels, void* workspace,
+                                   size_t workspace_bytes, shasta_stream_t stream);
 
 /* The reader alone, for callers that already hold voxelised input (det3d/models/readers/voxel_encoder.py:18-28 as called from
  * Shasta.extract_feat, det3d/models/tracker/shasta.py:178-179): out (V, num_features) = sum over the max_points slots of

@@ -8,14 +8,16 @@
 //     would open a new voxel are dropped, points of existing voxels are still accepted;
 //   * each voxel keeps its first max_points points, in input order.
 // Parallel formulation (all integer, no float atomics, order independent -> bitwise reproducible):
-//   1. key[i] = z*gy*gx + y*gx + x ; cell_map[key] = min(point index)              (atomicMin)
-//   2. owner(i) = cell_map[key[i]] (one random read per point); creator(i) = owner(i) == i ; voxel id = exclusive prefix count of
+//   1. key[i] = z*gy*gx + y*gx + x ; cell[key] = min(point index)                  (atomicMin)
+//   2. owner(i) = cell[key[i]] (one random read per point); creator(i) = owner(i) == i ; voxel id = exclusive prefix count of
 //      creators (scan); the creator takes slot 0
 //   3. rounds r = 1..max_points-1: every still unplaced point atomicMin's its index into slot[vid][r];
 //      the winner takes slot r.  After max_points rounds the rest is dropped, exactly the points the serial loop would have skipped.
-//   4. per (voxel, slot): zero-fill the empty slots, the last filled one names the count; mean = (sum over slots) / count.
-// The dense cell map (40x1440x1440 int32 = 332 MB for the nuScenes grid) is allocated once by the caller and
-// restored to its all-empty state before the call returns; the reference re-allocates it on every call.
+//   4. the voxel rows are cleared up front (one memset: the padding), the filled slots counted per voxel; mean = (sum over slots) / count.
+// cell[.]: the reference keeps a dense (40, 1440, 1440) int32 map of the grid (332 MB for nuScenes, allocated on every call,
+// point_cloud_ops.py:150).  A cloud of P points touches at most P cells: here the map is an open-addressing hash table of
+// 2^ceil(log2(2 P)) (key, first point) entries per cloud (8 MB for 3e5 points), cleared by one memset per call - random accesses over
+// 5.3 GB of dense maps (16 clouds) were most of the chain's time (TLB and DRAM page misses on every point).
 #include "common.hpp"
 #include <math.h>
 #include <limits.h>
@@ -44,10 +46,10 @@ static VoxGrid make_grid(const float* r, const float* v) {
 // A batch of clouds in one chain of launches (the reference voxelises the current and the previous cloud of every sample:
 // datasets/pipelines/preprocess.py:179-208).  The clouds lie back to back in `pts`; a workgroup of 256 points never straddles two
 // clouds (block b of the launch belongs to cloud c with boff[c] <= b < boff[c + 1] and covers points off[c] + 256 (b - boff[c]) ...),
-// every cloud has its own dense cell map (cell_map + c * cells) and its own rows of the outputs.
+// every cloud has its own hash table (table + c * 2^tbits entries) and its own rows of the outputs.
 constexpr int kMaxClouds = 32;
 struct VoxBatch {
-    int n;
+    int n, tbits;              // clouds; log2 of the entries of a cloud's hash table
     int off[kMaxClouds + 1];   // first point of every cloud (+ the total)
     int boff[kMaxClouds + 1];  // first block of every cloud (+ the total)
 };
@@ -59,8 +61,36 @@ __device__ __forceinline__ void vox_locate(const VoxBatch& B, int b, int t, int&
     if (i >= B.off[c + 1] - B.off[c]) i = -1;
 }
 
-__global__ __launch_bounds__(256) void vox_key_kernel(const float* __restrict__ pts, VoxBatch B, int ndim, VoxGrid G, long cells,
-                                                      int* __restrict__ keys, int* __restrict__ cell_map) {
+// cell -> first point: one 64-bit word per entry, (key << 32) | point index, empty = all ones (what the clearing memset leaves).
+// ONE atomic per probe: atomicMin of the packed pair.  Same key in the slot -> the smaller point index stays (the map's purpose).  Another
+// key in the slot: the numerically smaller pair stays and the larger one - ours, or the one we just displaced - moves on to the next
+// slot (linear probing; an entry only ever moves forward along its own probe path, so a look-up that walks from the key's home slot
+// finds it).  Tables are at most half full.
+typedef unsigned long long VoxCell;
+__device__ __forceinline__ unsigned vox_hash(unsigned key, int bits) { return (key * 2654435761u) >> (32 - bits); }
+__device__ __forceinline__ void vox_insert(VoxCell* __restrict__ t, int bits, unsigned key, unsigned i) {
+    const unsigned mask = (1u << bits) - 1u;
+    unsigned h = vox_hash(key, bits);
+    VoxCell mine = ((VoxCell)key << 32) | i;
+    for (;;) {
+        const VoxCell old = atomicMin(&t[h], mine);
+        if (old == ~0ull || (unsigned)(old >> 32) == (unsigned)(mine >> 32)) return;  // took an empty slot / merged with our key
+        if (old > mine) mine = old;  // we displaced another key's entry: carry it on
+        h = (h + 1) & mask;
+    }
+}
+__device__ __forceinline__ int vox_lookup(const VoxCell* __restrict__ t, int bits, unsigned key) {
+    const unsigned mask = (1u << bits) - 1u;
+    unsigned h = vox_hash(key, bits);
+    for (;;) {
+        const VoxCell e = t[h];
+        if ((unsigned)(e >> 32) == key) return (int)(unsigned)e;
+        h = (h + 1) & mask;  // (the key is in the table: every point was inserted by the pass before)
+    }
+}
+
+__global__ __launch_bounds__(256) void vox_key_kernel(const float* __restrict__ pts, VoxBatch B, int ndim, VoxGrid G,
+                                                      int* __restrict__ keys, VoxCell* __restrict__ table) {
     int c, i;
     vox_locate(B, blockIdx.x, threadIdx.x, c, i);
     if (i < 0) return;
@@ -76,14 +106,14 @@ __global__ __launch_bounds__(256) void vox_key_kernel(const float* __restrict__ 
     int key = -1;
     if (ok) {
         key = (cc[2] * G.g[1] + cc[1]) * G.g[0] + cc[0];
-        atomicMin(&cell_map[(size_t)c * cells + key], i);
+        vox_insert(table + ((size_t)c << B.tbits), B.tbits, (unsigned)key, (unsigned)i);
     }
     keys[gi] = key;
 }
 
-// owner[i] = the first point of point i's cell (the point that creates the voxel) or -1 for a dropped point - the ONE random read of
-// the cell map per point; the block's number of creators for the scan
-__global__ __launch_bounds__(256) void vox_owner_kernel(const int* __restrict__ keys, const int* __restrict__ cell_map, VoxBatch B, long cells,
+// owner[i] = the first point of point i's cell (the point that creates the voxel) or -1 for a dropped point - the ONE look-up of the
+// table per point; the block's number of creators for the scan
+__global__ __launch_bounds__(256) void vox_owner_kernel(const int* __restrict__ keys, const VoxCell* __restrict__ table, VoxBatch B,
                                                         int* __restrict__ owner, int* __restrict__ block_sums) {
     int c, i;
     vox_locate(B, blockIdx.x, threadIdx.x, c, i);
@@ -91,7 +121,7 @@ __global__ __launch_bounds__(256) void vox_owner_kernel(const int* __restrict__ 
     if (i >= 0) {
         const size_t gi = (size_t)B.off[c] + i;
         const int key = keys[gi];
-        const int o = key >= 0 ? cell_map[(size_t)c * cells + key] : -1;
+        const int o = key >= 0 ? vox_lookup(table + ((size_t)c << B.tbits), B.tbits, (unsigned)key) : -1;
         owner[gi] = o;
         flag = o == i;
     }
@@ -158,18 +188,16 @@ __global__ __launch_bounds__(256) void vox_assign_kernel(const int* __restrict__
 }
 
 // Every point learns its voxel (pvid, in place over `owner`; -1 = dropped or placed); creators copy themselves into slot 0 and retire,
-// the others bid for slot 1.  Every cell-map read is done by now: the map is restored to all-empty here.
+// the others bid for slot 1.
 __global__ __launch_bounds__(256) void vox_place_kernel(const float* __restrict__ pts, VoxBatch B, int ndim, int max_voxels, int max_points,
-                                                        long cells, const int* __restrict__ keys, const int* __restrict__ vid_of_point,
-                                                        int* __restrict__ pvid, int* __restrict__ cell_map, int* __restrict__ slot_idx,
-                                                        float* __restrict__ voxels) {
+                                                        const int* __restrict__ vid_of_point, int* __restrict__ pvid,
+                                                        int* __restrict__ slot_idx, float* __restrict__ voxels) {
     int c, i;
     vox_locate(B, blockIdx.x, threadIdx.x, c, i);
     if (i < 0) return;
     const size_t base = (size_t)B.off[c], gi = base + i;
     const int o = pvid[gi];
     if (o < 0) return;
-    if (o == i) cell_map[(size_t)c * cells + keys[gi]] = kEmpty;  // every touched cell has exactly one owner: one random write per cell
     const int v = vid_of_point[base + o];
     if (v >= max_voxels) {
         pvid[gi] = -1;
@@ -211,40 +239,37 @@ __global__ __launch_bounds__(256) void vox_round_kernel(const float* __restrict_
     }
 }
 
-// one thread per (voxel, slot): empty slots are zero-filled (consecutive threads = consecutive slots: whole lines), the last filled slot
-// names the count (filled slots are contiguous from 0: a point only bids for r + 1 after losing r).  grid.y = cloud
-__global__ __launch_bounds__(256) void vox_finalize_kernel(const int* __restrict__ slot_idx, const int* __restrict__ num_voxels, int max_voxels,
-                                                           int max_points, int ndim, float* __restrict__ voxels, int* __restrict__ num_points) {
+// Eight lanes per voxel (lane = channel; a loop beyond 8 channels).  The voxel rows were cleared by ONE memset in front of the chain
+// (a streaming fill of the zero-padded (max_voxels, max_points, ndim) output - most of it stays padding), the placed points written
+// over it; here the filled slots (contiguous from 0: a point only bids for r + 1 after losing r) are counted and, for the reader
+// (voxel_encoder.py:18-28), summed in slot order / their number - straight from the cloud through the slots' point indices, so the
+// padded output is not read back.  grid.y = cloud
+__global__ __launch_bounds__(256) void vox_finalize_kernel(const float* __restrict__ pts, VoxBatch B, const int* __restrict__ slot_idx,
+                                                           const int* __restrict__ num_voxels, int max_voxels, int max_points, int ndim,
+                                                           int* __restrict__ num_points, float* __restrict__ mean) {
     const int c = blockIdx.y;
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    const int v = (int)(t / max_points), r = (int)(t - (long)v * max_points);
+    const int v = blockIdx.x * 32 + (threadIdx.x >> 3), k0 = threadIdx.x & 7;
     if (v >= num_voxels[c]) return;
     const size_t row = (size_t)c * max_voxels + v;
     const int* sl = slot_idx + row * max_points;
-    if (sl[r] == kSlotEmpty) {
-        float* dst = voxels + (row * max_points + r) * ndim;
-        for (int k = 0; k < ndim; ++k) dst[k] = 0.0f;
-    } else if (r + 1 == max_points || sl[r + 1] == kSlotEmpty) {
-        num_points[row] = r + 1;
+    const float* cloud = pts + (size_t)B.off[c] * ndim;
+    int cnt = 0;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // channels k0, k0 + 8, ... (ndim <= 32)
+    for (int r = 0; r < max_points; ++r) {
+        const int idx = sl[r];
+        if (idx == kSlotEmpty) break;
+        ++cnt;
+        if (mean) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + 8 * j < ndim) s[j] += cloud[(size_t)idx * ndim + k0 + 8 * j];
+        }
     }
-}
-
-// one thread per (voxel, channel), eight channel lanes per voxel (a loop beyond 8 channels): the filled slots summed in order / their
-// number.  (Folded into the finalize pass - the thread of the last filled slot summing all channels - it ran 140 us slower per 16
-// clouds: one lane per voxel walks the slots while its 63 neighbours wait.)
-__global__ __launch_bounds__(256) void vox_mean_kernel(const float* __restrict__ voxels, const int* __restrict__ num_points,
-                                                       const int* __restrict__ num_voxels, int max_voxels, int max_points, int ndim,
-                                                       float* __restrict__ mean) {
-    const int c = blockIdx.y;
-    const int v = blockIdx.x * 32 + (threadIdx.x >> 3);
-    if (v >= num_voxels[c]) return;
-    const size_t row = (size_t)c * max_voxels + v;
-    const int cnt = num_points[row];
-    const float* src = voxels + row * max_points * ndim;
-    for (int k = threadIdx.x & 7; k < ndim; k += 8) {
-        float s = 0.0f;
-        for (int r = 0; r < cnt; ++r) s += src[r * ndim + k];
-        mean[row * ndim + k] = s / (float)cnt;
+    if (k0 == 0) num_points[row] = cnt;
+    if (mean) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + 8 * j < ndim) mean[row * ndim + k0 + 8 * j] = s[j] / (float)cnt;
     }
 }
 
@@ -260,9 +285,15 @@ __global__ void voxel_mean_kernel(const float* __restrict__ voxels, const float*
     out[i] = s / counts[v];
 }
 
+static int vox_table_bits(int max_cloud_points) {
+    int bits = 10;
+    while (bits < 30 && (1L << bits) < 2L * max_cloud_points) ++bits;
+    return bits;
+}
+
 struct VoxWs {
-    size_t keys, pvid, vidp, bsum, slots, total;
-    VoxWs(long P, int nblocks, int nclouds, int max_voxels, int max_points) {
+    size_t keys, pvid, vidp, bsum, slots, table, total;
+    VoxWs(long P, int nblocks, int nclouds, int max_voxels, int max_points, int tbits) {
         size_t o = 0;
         const size_t p = align_up((size_t)(P > 0 ? P : 1) * sizeof(int), 256);
         keys = o; o += p;
@@ -270,18 +301,21 @@ struct VoxWs {
         vidp = o; o += p;
         bsum = o; o += align_up((size_t)(nblocks + 1) * sizeof(int), 256);
         slots = o; o += align_up((size_t)nclouds * max_voxels * max_points * sizeof(int), 256);
+        table = o; o += ((size_t)nclouds << tbits) * sizeof(VoxCell);
         total = o;
     }
 };
 
 static int vox_batch(const float* points, const int* h_offsets, int n, int ndim, const VoxGrid& G, int max_points, int max_voxels,
-                     float* voxels, int32_t* coors, int32_t* num_points_per_voxel, float* mean, int32_t* num_voxels, int32_t* cell_map,
+                     float* voxels, int32_t* coors, int32_t* num_points_per_voxel, float* mean, int32_t* num_voxels,
                      void* workspace, size_t workspace_bytes, hipStream_t st) {
     VoxBatch B;
     B.n = n;
     B.off[0] = B.boff[0] = 0;
+    int pmax = 0;
     for (int c = 0; c < n; ++c) {
         const int pc = h_offsets[c + 1] - h_offsets[c];
+        pmax = pc > pmax ? pc : pmax;
         if (pc < 0) {
             set_error_msg("voxelize: offsets must not decrease");
             return SHASTA_E_ARG;
@@ -292,8 +326,8 @@ static int vox_batch(const float* points, const int* h_offsets, int n, int ndim,
     for (int c = n + 1; c <= kMaxClouds; ++c) B.off[c] = B.off[n], B.boff[c] = B.boff[n];
     const long P = B.off[n];
     const int nb = B.boff[n];
-    const long cells = (long)G.g[0] * G.g[1] * G.g[2];
-    const VoxWs L(P, nb, n, max_voxels, max_points);
+    B.tbits = vox_table_bits(pmax);
+    const VoxWs L(P, nb, n, max_voxels, max_points, B.tbits);
     if (workspace_bytes < L.total) {
         set_error_msg("voxelize: workspace too small");
         return SHASTA_E_WORKSPACE;
@@ -304,35 +338,34 @@ static int vox_batch(const float* points, const int* h_offsets, int n, int ndim,
     int* vidp = reinterpret_cast<int*>(ws + L.vidp);
     int* bsum = reinterpret_cast<int*>(ws + L.bsum);
     int* slots = reinterpret_cast<int*>(ws + L.slots);
+    VoxCell* table = reinterpret_cast<VoxCell*>(ws + L.table);
     hipError_t e = hipMemsetAsync(num_voxels, 0, (size_t)n * sizeof(int32_t), st);  // (clouds without points never write theirs)
+    if (e == hipSuccess && nb > 0 && max_voxels > 0) e = hipMemsetAsync(table, 0xff, ((size_t)n << B.tbits) * sizeof(VoxCell), st);
     if (e == hipSuccess && nb > 0 && max_voxels > 0) e = hipMemsetAsync(slots, 0x7f, (size_t)n * max_voxels * max_points * sizeof(int), st);
+    // the zero padding of the voxel rows (slots nobody takes): one streaming fill instead of scattered 20-byte stores
+    if (e == hipSuccess && nb > 0 && max_voxels > 0) e = hipMemsetAsync(voxels, 0, (size_t)n * max_voxels * max_points * ndim * sizeof(float), st);
     if (e != hipSuccess) {
         set_error("voxelize: memset", e);
         return SHASTA_E_LAUNCH;
     }
     if (nb == 0 || max_voxels == 0) return SHASTA_OK;
     int rc;
-    hipLaunchKernelGGL(vox_key_kernel, dim3(nb), dim3(256), 0, st, points, B, ndim, G, cells, keys, cell_map);
+    hipLaunchKernelGGL(vox_key_kernel, dim3(nb), dim3(256), 0, st, points, B, ndim, G, keys, table);
     if ((rc = check_launch("vox_key"))) return rc;
-    hipLaunchKernelGGL(vox_owner_kernel, dim3(nb), dim3(256), 0, st, keys, cell_map, B, cells, pvid, bsum);
+    hipLaunchKernelGGL(vox_owner_kernel, dim3(nb), dim3(256), 0, st, keys, table, B, pvid, bsum);
     if ((rc = check_launch("vox_owner"))) return rc;
     hipLaunchKernelGGL(vox_scan_kernel, dim3(1), dim3(1024), 0, st, bsum, nb);
     if ((rc = check_launch("vox_scan"))) return rc;
     hipLaunchKernelGGL(vox_assign_kernel, dim3(nb), dim3(256), 0, st, keys, pvid, B, bsum, G, max_voxels, max_points, vidp, coors, num_voxels, slots);
     if ((rc = check_launch("vox_assign"))) return rc;
-    hipLaunchKernelGGL(vox_place_kernel, dim3(nb), dim3(256), 0, st, points, B, ndim, max_voxels, max_points, cells, keys, vidp, pvid, cell_map,
-                       slots, voxels);
+    hipLaunchKernelGGL(vox_place_kernel, dim3(nb), dim3(256), 0, st, points, B, ndim, max_voxels, max_points, vidp, pvid, slots, voxels);
     if ((rc = check_launch("vox_place"))) return rc;
     for (int r = 1; r < max_points; ++r) {
         hipLaunchKernelGGL(vox_round_kernel, dim3(cdiv(nb, 4)), dim3(256), 0, st, points, B, ndim, r, max_voxels, max_points, nb, pvid, slots, voxels);
         if ((rc = check_launch("vox_round"))) return rc;
     }
-    hipLaunchKernelGGL(vox_finalize_kernel, dim3((unsigned)(((long)max_voxels * max_points + 255) / 256), n), dim3(256), 0, st, slots, num_voxels,
-                       max_voxels, max_points, ndim, voxels, num_points_per_voxel);
-    if ((rc = check_launch("vox_finalize"))) return rc;
-    if (mean)
-        hipLaunchKernelGGL(vox_mean_kernel, dim3((unsigned)cdiv(max_voxels, 32), n), dim3(256), 0, st, voxels, num_points_per_voxel,
-                           num_voxels, max_voxels, max_points, ndim, mean);
+    hipLaunchKernelGGL(vox_finalize_kernel, dim3((unsigned)cdiv(max_voxels, 32), n), dim3(256), 0, st, points, B, slots, num_voxels, max_voxels,
+                       max_points, ndim, num_points_per_voxel, mean);
     return check_launch("vox_finalize");
 }
 
@@ -340,70 +373,60 @@ static int vox_batch(const float* points, const int* h_offsets, int n, int ndim,
 
 using namespace shasta;
 
-extern "C" size_t shasta_voxelize_cell_map_bytes(const float* h_range6, const float* h_voxel3) {
-    if (!h_range6 || !h_voxel3) return 0;
-    const VoxGrid G = make_grid(h_range6, h_voxel3);
-    if (G.g[0] <= 0 || G.g[1] <= 0 || G.g[2] <= 0) return 0;
-    return (size_t)G.g[0] * G.g[1] * G.g[2] * sizeof(int32_t);
-}
-
-extern "C" int shasta_voxelize_cell_map_init(int32_t* cell_map, size_t bytes, shasta_stream_t stream) {
-    SHASTA_REQUIRE(cell_map, "cell_map_init: null pointer");
-    // 0x7fffffff is not a byte pattern: fill with a kernel-free 32-bit memset
-    hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cell_map), kEmpty, bytes / 4, as_stream(stream));
-    if (e != hipSuccess) {
-        set_error("cell_map_init", e);
-        return SHASTA_E_LAUNCH;
-    }
-    return SHASTA_OK;
-}
-
 extern "C" size_t shasta_voxelize_workspace_bytes(int num_points, int max_voxels, int max_points) {
     if (num_points < 0 || max_voxels < 0 || max_points < 1) return 0;
-    return VoxWs(num_points, cdiv(num_points > 0 ? num_points : 1, 256), 1, max_voxels, max_points).total;
+    return VoxWs(num_points, cdiv(num_points > 0 ? num_points : 1, 256), 1, max_voxels, max_points, vox_table_bits(num_points)).total;
+}
+
+static int vox_check_grid(const VoxGrid& G) {
+    SHASTA_REQUIRE(G.g[0] > 0 && G.g[1] > 0 && G.g[2] > 0, "voxelize: empty grid");
+    SHASTA_REQUIRE((double)G.g[0] * G.g[1] * G.g[2] < 2147483647.0, "voxelize: grid too large for int32 keys");
+    return SHASTA_OK;
 }
 
 extern "C" int shasta_voxelize_mean_f32(const float* points, int P, int ndim, const float* h_range6,
                                         const float* h_voxel3, int max_points, int max_voxels, float* voxels,
                                         int32_t* coors, int32_t* num_points_per_voxel, float* mean,
-                                        int32_t* num_voxels, int32_t* cell_map, void* workspace, size_t workspace_bytes,
+                                        int32_t* num_voxels, void* workspace, size_t workspace_bytes,
                                         shasta_stream_t stream) {
-    SHASTA_REQUIRE(h_range6 && h_voxel3 && num_voxels && cell_map && workspace, "voxelize: null pointer");
-    SHASTA_REQUIRE(P >= 0 && ndim >= 3 && max_points >= 1 && max_voxels >= 0, "voxelize: bad size");
+    SHASTA_REQUIRE(h_range6 && h_voxel3 && num_voxels && workspace, "voxelize: null pointer");
+    SHASTA_REQUIRE(P >= 0 && ndim >= 3 && ndim <= 32 && max_points >= 1 && max_voxels >= 0, "voxelize: bad size");
     SHASTA_REQUIRE(P == 0 || points, "voxelize: null points");
     SHASTA_REQUIRE(max_voxels == 0 || (voxels && coors && num_points_per_voxel), "voxelize: null outputs");
     const VoxGrid G = make_grid(h_range6, h_voxel3);
-    SHASTA_REQUIRE(G.g[0] > 0 && G.g[1] > 0 && G.g[2] > 0, "voxelize: empty grid");
-    SHASTA_REQUIRE((double)G.g[0] * G.g[1] * G.g[2] < 2147483647.0, "voxelize: grid too large for int32 keys");
+    int rc = vox_check_grid(G);
+    if (rc) return rc;
     const int off[2] = {0, P};
-    return vox_batch(points, off, 1, ndim, G, max_points, max_voxels, voxels, coors, num_points_per_voxel, mean, num_voxels, cell_map, workspace,
+    return vox_batch(points, off, 1, ndim, G, max_points, max_voxels, voxels, coors, num_points_per_voxel, mean, num_voxels, workspace,
                      workspace_bytes, as_stream(stream));
 }
 
 extern "C" size_t shasta_voxelize_batch_workspace_bytes(const int* h_offsets, int num_clouds, int max_voxels, int max_points) {
     if (!h_offsets || num_clouds < 1 || num_clouds > kMaxClouds || max_voxels < 0 || max_points < 1) return 0;
-    int nb = 0;
+    int nb = 0, pmax = 0;
     for (int c = 0; c < num_clouds; ++c) {
-        if (h_offsets[c + 1] < h_offsets[c]) return 0;
-        nb += cdiv(h_offsets[c + 1] - h_offsets[c], 256);
+        const int pc = h_offsets[c + 1] - h_offsets[c];
+        if (pc < 0) return 0;
+        nb += cdiv(pc, 256);
+        pmax = pc > pmax ? pc : pmax;
     }
-    return VoxWs((long)h_offsets[num_clouds] - h_offsets[0], nb, num_clouds, max_voxels, max_points).total;
+    return VoxWs((long)h_offsets[num_clouds] - h_offsets[0], nb, num_clouds, max_voxels, max_points, vox_table_bits(pmax)).total;
 }
 
 extern "C" int shasta_voxelize_mean_batch_f32(const float* points, const int* h_offsets, int num_clouds, int ndim, const float* h_range6,
                                               const float* h_voxel3, int max_points, int max_voxels, float* voxels, int32_t* coors,
-                                              int32_t* num_points_per_voxel, float* mean, int32_t* num_voxels, int32_t* cell_maps,
-                                              void* workspace, size_t workspace_bytes, shasta_stream_t stream) {
-    SHASTA_REQUIRE(h_offsets && h_range6 && h_voxel3 && num_voxels && cell_maps && workspace, "voxelize_batch: null pointer");
+                                              int32_t* num_points_per_voxel, float* mean, int32_t* num_voxels, void* workspace,
+                                              size_t workspace_bytes, shasta_stream_t stream) {
+    SHASTA_REQUIRE(h_offsets && h_range6 && h_voxel3 && num_voxels && workspace, "voxelize_batch: null pointer");
     SHASTA_REQUIRE(num_clouds >= 1 && num_clouds <= kMaxClouds, "voxelize_batch: 1 to 32 clouds per call");
-    SHASTA_REQUIRE(ndim >= 3 && max_points >= 1 && max_voxels >= 0 && h_offsets[0] >= 0, "voxelize_batch: bad size");
+    SHASTA_REQUIRE(ndim >= 3 && ndim <= 32 && max_points >= 1 && max_voxels >= 0 && h_offsets[0] >= 0, "voxelize_batch: bad size");
     SHASTA_REQUIRE(h_offsets[num_clouds] == h_offsets[0] || points, "voxelize_batch: null points");
     SHASTA_REQUIRE(max_voxels == 0 || (voxels && coors && num_points_per_voxel), "voxelize_batch: null outputs");
     const VoxGrid G = make_grid(h_range6, h_voxel3);
-    SHASTA_REQUIRE(G.g[0] > 0 && G.g[1] > 0 && G.g[2] > 0, "voxelize_batch: empty grid");
-    SHASTA_REQUIRE((double)G.g[0] * G.g[1] * G.g[2] < 2147483647.0, "voxelize_batch: grid too large for int32 keys");
+    int rc = vox_check_grid(G);
+    if (rc) return rc;
     return vox_batch(points ? points + (size_t)h_offsets[0] * ndim : nullptr, h_offsets, num_clouds, ndim, G, max_points, max_voxels, voxels, coors,
-                     num_points_per_voxel, mean, num_voxels, cell_maps, workspace, workspace_bytes, as_stream(stream));
+                     num_points_per_voxel, mean, num_voxels, workspace, workspace_bytes, as_stream(stream));
 }
 
 extern "C" int shasta_voxel_mean_f32(const float* voxels, const float* num_points_f32, int num_voxels, int max_points, int ndim,

@@ -9,7 +9,7 @@ import os
 
 import torch
 
-ABI_VERSION = 12  # must equal shasta_abi_version() of the loaded library
+ABI_VERSION = 13  # must equal shasta_abi_version() of the loaded library
 # SHASTA_HIP_LIB: load another build of the same ABI (A/B timing of kernel variants on one box)
 _LIB_PATH = os.environ.get("SHASTA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libshasta_hip.so")
 _lib = None
@@ -52,12 +52,10 @@ SYMBOLS = {
     "shasta_abi_version": (_I, []),
     "shasta_build_info": (C.c_char_p, []),
     "shasta_last_error": (C.c_char_p, []),
-    "shasta_voxelize_cell_map_bytes": (_Z, [_P, _P]),
-    "shasta_voxelize_cell_map_init": (_I, [_P, _Z, _P]),
     "shasta_voxelize_workspace_bytes": (_Z, [_I, _I, _I]),
-    "shasta_voxelize_mean_f32": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "shasta_voxelize_mean_f32": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "shasta_voxelize_batch_workspace_bytes": (_Z, [_P, _I, _I, _I]),
-    "shasta_voxelize_mean_batch_f32": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "shasta_voxelize_mean_batch_f32": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "shasta_voxel_mean_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "shasta_bev_gather_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P, _I, _I, _P]),
     "shasta_shared_conv_packed_bytes": (_Z, [_I]),

@@ -3,8 +3,10 @@
 Mirrors det3d/core/input/voxel_generator.py:5-46 and det3d/ops/point_cloud/point_cloud_ops.py:112-184
 (`points_to_voxel(points, voxel_size, coors_range, max_points, reverse_index=True, max_voxels)`), the CPU numba loop
 that the reference runs in 48 DataLoader workers.  Here the scatter (and the per-voxel mean of
-VoxelFeatureExtractorV3, det3d/models/readers/voxel_encoder.py:18-28) is one call of `shasta_voxelize_mean_f32`;
-outputs are bit-identical to the serial loop (voxel order, kept points, coordinates, counts).
+VoxelFeatureExtractorV3, det3d/models/readers/voxel_encoder.py:18-28) is one call of `shasta_voxelize_mean_f32` - or, for the
+current and previous clouds of a whole batch, of `shasta_voxelize_mean_batch_f32`; outputs are bit-identical to the serial loop
+(voxel order, kept points, coordinates, counts).  The reference's dense cell map (332 MB per call) is a hash table of 8 MB per
+cloud inside the call's workspace.
 """
 import ctypes as C
 
@@ -12,34 +14,6 @@ import numpy as np
 import torch
 
 from . import hip
-
-
-class _CellMaps:
-    """One persistent dense cell map per (device, grid): allocated once (332 MB for the nuScenes grid; the reference
-    allocates it on every call), kept all-empty between calls by the kernels themselves."""
-
-    def __init__(self):
-        self._maps = {}
-
-    def get(self, device, rng, vs, clouds=1):
-        """`clouds` maps back to back (a batch call gives every cloud its own: 332 MB each for the nuScenes grid - 5.3 GB for the 16
-        clouds of 8 samples, allocated once and kept all-empty by the kernels)."""
-        lib = hip.load()
-        key = (str(device), tuple(float(x) for x in rng), tuple(float(x) for x in vs))
-        nbytes = lib.shasta_voxelize_cell_map_bytes(rng.ctypes.data_as(C.c_void_p), vs.ctypes.data_as(C.c_void_p))
-        if nbytes == 0:
-            raise hip.ShastaHipError("voxelize: empty or invalid grid")
-        cur = self._maps.get(key)
-        if cur is None or cur.numel() * 4 < clouds * nbytes:
-            self._maps.pop(key, None)
-            cur = None
-            m = torch.empty(clouds * nbytes // 4, dtype=torch.int32, device=device)
-            hip.check(lib.shasta_voxelize_cell_map_init(hip.ptr(m), clouds * nbytes, hip.stream_ptr()), "cell_map_init")
-            self._maps[key] = m
-        return self._maps[key]
-
-
-_cell_maps = _CellMaps()
 
 
 def points_to_voxel_device(points, voxel_size, coors_range, max_points=35, max_voxels=20000, with_mean=False):
@@ -53,7 +27,6 @@ def points_to_voxel_device(points, voxel_size, coors_range, max_points=35, max_v
     vs = np.ascontiguousarray(voxel_size, np.float32)
     rg = np.ascontiguousarray(coors_range, np.float32)
     dev = points.device
-    cmap = _cell_maps.get(dev, rg, vs)
     voxels = torch.empty(max_voxels, max_points, ndim, device=dev)
     coors = torch.empty(max_voxels, 3, dtype=torch.int32, device=dev)
     num = torch.empty(max_voxels, dtype=torch.int32, device=dev)
@@ -63,7 +36,7 @@ def points_to_voxel_device(points, voxel_size, coors_range, max_points=35, max_v
     ws = torch.empty((wsb + 3) // 4, dtype=torch.int32, device=dev)
     hip.check(lib.shasta_voxelize_mean_f32(hip.ptr(points), P, ndim, rg.ctypes.data_as(C.c_void_p),
                                            vs.ctypes.data_as(C.c_void_p), max_points, max_voxels, hip.ptr(voxels),
-                                           hip.ptr(coors), hip.ptr(num), hip.ptr(mean), hip.ptr(nv), hip.ptr(cmap),
+                                           hip.ptr(coors), hip.ptr(num), hip.ptr(mean), hip.ptr(nv),
                                            hip.ptr(ws), wsb, hip.stream_ptr()), "shasta_voxelize_mean_f32")
     V = int(nv.item())
     out = (voxels[:V], coors[:V], num[:V])
@@ -96,7 +69,6 @@ def points_to_voxel_batch_device(clouds, voxel_size, coors_range, max_points=35,
     vs = np.ascontiguousarray(voxel_size, np.float32)
     rg = np.ascontiguousarray(coors_range, np.float32)
     dev = points.device
-    cmap = _cell_maps.get(dev, rg, vs, clouds=n)
     voxels = torch.empty(n, max_voxels, max_points, ndim, device=dev)
     coors = torch.empty(n, max_voxels, 3, dtype=torch.int32, device=dev)
     num = torch.empty(n, max_voxels, dtype=torch.int32, device=dev)
@@ -107,7 +79,7 @@ def points_to_voxel_batch_device(clouds, voxel_size, coors_range, max_points=35,
     ws = torch.empty((wsb + 3) // 4, dtype=torch.int32, device=dev)
     hip.check(lib.shasta_voxelize_mean_batch_f32(hip.ptr(points), off, n, ndim, rg.ctypes.data_as(C.c_void_p), vs.ctypes.data_as(C.c_void_p),
                                                  max_points, max_voxels, hip.ptr(voxels), hip.ptr(coors), hip.ptr(num), hip.ptr(mean),
-                                                 hip.ptr(nv), hip.ptr(cmap), hip.ptr(ws), wsb, hip.stream_ptr()), "shasta_voxelize_mean_batch_f32")
+                                                 hip.ptr(nv), hip.ptr(ws), wsb, hip.stream_ptr()), "shasta_voxelize_mean_batch_f32")
     return voxels, coors, num, mean, nv
 
 
