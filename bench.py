@@ -689,6 +689,20 @@ def extra_voxelize(bench, args, ex):
     alg = P * 5 * 4 + V * (10 * 5 * 4 + 3 * 4 + 4 + 5 * 4)
     e = {"points": P, "voxels": V, "ms": ms, "note": "one call incl. output allocation and the host read of the voxel count",
          "algorithmic_bytes": alg, "algorithmic_gbs": alg / ms / 1e6, "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS, "clouds_per_s": 1e3 / ms}
+    # the clouds of a batch in one chain of launches (current + previous cloud of 8 samples: preprocess.py:179-208 voxelises both), the voxel
+    # counts left on the device: no host read inside the timed loop
+    from shasta_amd.voxel_generator import points_to_voxel_batch_device
+    n = 16
+    allp = torch.cat([d[torch.randperm(P, device=dev, generator=bench.gen)] for _ in range(n)])
+    offs = [P * i for i in range(n + 1)]
+    nv = points_to_voxel_batch_device((allp, offs), VS, RG, 10, 160000, with_mean=True)[4]
+    msb = timed_ms(torch, lambda: points_to_voxel_batch_device((allp, offs), VS, RG, 10, 160000, with_mean=True), 10)
+    Vb = int(nv.sum())
+    algb = n * P * 5 * 4 + Vb * (10 * 5 * 4 + 3 * 4 + 4 + 5 * 4)
+    e["batch16"] = {"clouds": n, "points_per_cloud": P, "voxels": Vb, "ms": msb, "clouds_per_s": n / msb * 1e3, "algorithmic_bytes": algb,
+                    "algorithmic_gbs": algb / msb / 1e6, "hbm_frac": algb / msb / 1e6 / HBM_PEAK_GBS,
+                    "note": "shasta_voxelize_mean_batch_f32: one chain of 15 launches for 16 clouds, num_voxels stays on the device"}
+    del allp
     if not args.no_cpu_baseline:
         from oracle import voxelize_oracle as VO  # the checker's C twin of the serial reference loop, timed on one host core
         VO.points_to_voxel(pts, VS, RG, 10, 160000)

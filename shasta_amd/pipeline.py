@@ -391,6 +391,12 @@ def _run_split(models, paths, scenes, bev, device, work_dir=None, split="val", m
             per_class[name] = replica.gather_decoded(decs[name], dst=0, group=group)
     if rank != 0:
         return None
+    if world > 1:
+        # the gather appended the other ranks' tokens behind rank 0's own: put every class's dictionary back into the split's frame
+        # order, so that the files rank 0 writes are byte for byte those of a one-rank run
+        for name, cp in per_class.items():
+            res = cp["results"]
+            cp["results"] = {t: res[t] for t in all_tokens if t in res}
     with timer.stage("merge"):
         merged = merge_results(per_class)
         if forward_override is not None:

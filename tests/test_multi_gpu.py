@@ -48,13 +48,17 @@ def test_bench_replicas_on_several_gpus(gpus):
     assert 0.8 * gpus * one["value"] <= many["value"] <= 1.15 * gpus * one["value"], (one["value"], many["value"])
 
 
-def _nccl_train_worker(rank, world, port, q):
+def _nccl_train_worker(rank, world, port, q, backend="nccl"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    gpu = rank if backend == "nccl" else 0  # gloo: the ranks share GPU 0 (1-GPU lease)
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from shasta_amd import training
     from shasta_amd.sync_bn import convert_syncbn_model
     model, bev, pbev, det, prev, gt = _ddp_case(2 * world)
@@ -75,13 +79,25 @@ def _nccl_train_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_two_process_train_step_on_one_gpu_equals_the_single_process_step():
+    """The data-parallel step on a 1-GPU lease: two processes share GPU 0 and exchange over gloo - the hand-written train-mode
+    shared_conv with a synchronised BatchNorm (statistics all-gathered in the forward, sums all-reduced in the backward), the factor
+    all-gather inside the HIP backward, allreduce_gradients: everything of the multi-rank step except RCCL itself."""
+    _need(1)
+    _train_step_equals_single(2, "gloo")
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_rccl_train_step_equals_the_single_process_step(world):
     _need(world)
+    _train_step_equals_single(world, "nccl")
+
+
+def _train_step_equals_single(world, backend):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_nccl_train_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_nccl_train_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in procs)
@@ -144,6 +160,7 @@ def _nccl_chain_worker(rank, world, port, root, work, backend="nccl"):
 def test_two_process_chain_on_one_gpu_equals_single_rank(tmp_path):
     """The same comparison on a 1-GPU lease: two processes share GPU 0 and exchange over gloo - everything of the multi-rank device
     chain (sharding, HIP forward + decode per rank, gather, merge, whole-scene tracker on rank 0, the files) except RCCL itself."""
+    _need(1)
     _chain_equals_single_rank(2, tmp_path, "gloo")
 
 

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/${1:-final}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err   # the driver's line: headline + extra.{batch_sweep, arithmetic_*, car_90_320_3} + cpu_baseline
+python3 $R/bench.py --extra-file $O/bench_extra.json > $O/bench_default.json 2> $O/bench_default.err   # the driver's line (compact) + the long form: extra.{batch_sweep, arithmetic_*, car_90_320_3, ...}
 for b in 1 64 128 512; do
   python3 $R/bench.py --batch $b --no-cpu-baseline --no-extras > $O/bench_b$b.json 2> /dev/null
 done
@@ -51,6 +51,11 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train_n500 -o d -- python3 $R/tools/time_train.py --max-obj 500 --feats 7 --points 4 --batch 8 --steps 8 --in-backward > $O/train_n500.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train_n90 -o d -- python3 $R/tools/time_train.py --max-obj 90 --feats 3 --points 5 --batch 64 --steps 8 --in-backward > $O/train_n90.log 2>&1
 (cd $R && python3 tools/time_pair_mlp.py > $O/pair_mlp.log 2>&1; python3 tools/time_adam_lowrank.py >> $O/pair_mlp.log 2>&1; python3 tools/time_adam_lowrank.py --dx >> $O/pair_mlp.log 2>&1; python3 tools/time_adam_lowrank.py --rank 64 >> $O/pair_mlp.log 2>&1)
+# round 6: K0 in train() mode (kernel stats + counters of the weight-gradient kernel at 8 frame pairs), K1 one cloud / a batch of 16
+bash $R/tools/gpu_pmc_convtrain.sh ${1:-final} 8 > $O/convtrain_pmc.log 2>&1
+(cd $R && python3 tools/time_conv_train.py --batch 8 > $O/conv_train.jsonl 2>/dev/null; python3 tools/time_conv_train.py --batch 2 >> $O/conv_train.jsonl 2>/dev/null; python3 tools/time_conv_train.py --batch 64 --iters 4 >> $O/conv_train.jsonl 2>/dev/null)
+VOX_ITERS=5 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_voxelize -o d -- python3 $R/tools/time_voxelize.py > $O/voxelize_prof.log 2>&1
+(cd $R && python3 tools/time_voxelize.py > $O/voxelize.log 2>&1)
 grep -h '^{' $O/bench_default.json $O/bench_b1.json $O/bench_b64.json $O/bench_b128.json $O/bench_b512.json $O/bench_pieces.json $O/bench_f32.json $O/bench_torchrun.json | cut -c1-230
 grep time $O/conv_check.jsonl | cut -c1-200; tail -1 $O/pipeline.log | cut -c1-400; grep -h "^{" $O/pair320_car.log $O/pair320_n500.log
 ls $O

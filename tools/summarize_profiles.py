@@ -67,7 +67,8 @@ if __name__ == "__main__":
     for name, dst in (("prof_default", "bench_default_b512"), ("prof_b1024", "bench_b1024"), ("prof_b128", "bench_b128"), ("prof_b64", "bench_b64"), ("prof_b1", "bench_b1"),
                       ("prof_pieces", "bench_pieces_b512"), ("prof_conv_b8", "shared_conv_b8"), ("prof_conv_b8_heads7", "shared_conv_b8_heads7"),
                       ("prof_pair320_car", "pair_f320_car_b512"), ("prof_pair320_n500", "pair_f320_n500_b256"),
-                      ("prof_train_n500", "train_n500_b8"), ("prof_train_n90", "train_n90_b64")):
+                      ("prof_train_n500", "train_n500_b8"), ("prof_train_n90", "train_n90_b64"),
+                      ("prof_convtrain_b8", "shared_conv_train_b8"), ("prof_voxelize", "voxelize")):
         src = os.path.join(G, SRC, name, "d_kernel_stats.csv")
         if os.path.exists(src):
             kernel_stats(src, os.path.join(P, "%s_kernel_stats_%s.csv" % (TAG, dst)))
@@ -90,7 +91,11 @@ if __name__ == "__main__":
             lines = [l for l in open(os.path.join(G, SRC, f)) if l.startswith("{")]
             if lines:
                 json.dump(json.loads(lines[-1]), open(os.path.join(P, TAG + "_stage_power.json"), "w"), indent=1)
-        if f in ("conv_check.jsonl", "pipeline.log", "pipeline_sync.log", "pair320_car.log", "pair320_n500.log"):
+        if f == "bench_extra.json":
+            json.dump(json.load(open(os.path.join(G, SRC, f))), open(os.path.join(P, TAG + "_bench_extra.json"), "w"), indent=1)
+        if f == "voxelize.log":
+            shutil.copy(os.path.join(G, SRC, f), os.path.join(P, TAG + "_voxelize.txt"))
+        if f in ("conv_check.jsonl", "pipeline.log", "pipeline_sync.log", "pair320_car.log", "pair320_n500.log", "conv_train.jsonl"):
             rows = [json.loads(l) for l in open(os.path.join(G, SRC, f)) if l.startswith("{")]
             json.dump(rows, open(os.path.join(P, TAG + "_" + f.split(".")[0] + ".json"), "w"), indent=1)
         if f.startswith("l1_check_") and f.endswith(".json"):
