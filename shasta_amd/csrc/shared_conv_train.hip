@@ -77,11 +77,21 @@ __device__ __forceinline__ void combine_slices(const double* __restrict__ part, 
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = 0.0;
-    for (int i = g; i < nslice; i += 16) {
+    // (eight slices' loads in flight at a time: the adds keep their order, the loop is otherwise one memory latency per slice)
+    for (int i0 = g; i0 < nslice; i0 += 16 * 8) {
+        double t[8][NV];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const double t = part[(size_t)i * stride + k * BN_C + c];
-            v[k] = is_max[k] ? fmax(v[k], t) : v[k] + t;
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + 16 * u, nslice - 1);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) t[u][k] = part[(size_t)i * stride + k * BN_C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + 16 * u < nslice) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) v[k] = is_max[k] ? fmax(v[k], t[u][k]) : v[k] + t[u][k];
+            }
         }
     }
 #pragma unroll
