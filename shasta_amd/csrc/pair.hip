@@ -126,11 +126,78 @@ struct RowPrepArgs {
     float* emb[2];        // [0] UP, [1] UC             (B, T, ET)
     float* hand[2];       // (B, T, 16)
     float* denom;         // (B, D)
-    int B, T, N, nf, F, nrow_blocks, nhand_blocks, dblocks;
+    int B, T, N, nf, F, nrow_blocks, nhand_blocks, dblocks, dper;  // dper: detections per thread of the column-norm role (1 or 4)
 };
 
+// column norms (shasta.py:278-279) of 16 * ND detections of one frame per workgroup: ND per thread - a track read from LDS serves ND
+// detections and the frame's previous boxes are staged once per 16 ND columns (ND = 4 from 2048 workgroups on: the staging latency was
+// most of a block's time; ND = 1 keeps small batches spread over more workgroups)
+template <int ND, int NF>  // NF: num_feats as a compile-time constant (no branch per column in the inner loop), 0 = read it from the arguments
+__device__ __forceinline__ void col_norm_block(const RowPrepArgs& a, int cb, int tid) {
+    const int T = a.T, D = a.T, nf = NF ? NF : a.nf;
+    const int b = cb / a.dblocks, dl = tid & 15, tg = tid >> 4;
+    const int d0 = (cb % a.dblocks) * (16 * ND) + dl;  // this thread's detections: d0, d0 + 16, ...
+    float db[ND][7];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const f32x4* h = reinterpret_cast<const f32x4*>(a.tab[1] + ((size_t)b * D + min(d0 + 16 * j, D - 1)) * 8);
+        const f32x4 x = h[0], c = h[1];
+        db[j][0] = x[0]; db[j][1] = x[1]; db[j][2] = x[2]; db[j][3] = x[3]; db[j][4] = c[0]; db[j][5] = c[1]; db[j][6] = c[2];
+    }
+    // the frame's previous boxes pass through LDS in chunks of 512 rows (one coalesced copy per chunk, then broadcast reads)
+    __shared__ __attribute__((aligned(16))) f32x4 sp[2 * 512];
+    const f32x4* hp = reinterpret_cast<const f32x4*>(a.tab[0] + (size_t)b * T * 8);
+    // Two tracks per step as the halves of packed fp32 operations (v_pk_add / v_pk_mul).  Every product and sum is rounded separately
+    // exactly as in the scalar form; a column's sum of squares is the sum of the two halves' running sums (tracks tg, tg + 32, ... and
+    // tg + 16, tg + 48, ...), then of the 16 track groups in order.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 ssq2[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) ssq2[j] = f2{0.0f, 0.0f};
+    for (int t0 = 0; t0 < T; t0 += 512) {
+        const int nt = min(512, T - t0);
+        if (t0) __syncthreads();
+        for (int e = tid; e < 2 * nt; e += 256) sp[e] = hp[(size_t)t0 * 2 + e];
+        __syncthreads();
+        for (int t = tg; t < nt; t += 32) {
+            const int tb = t + 16;
+            const bool two = tb < nt;
+            const f32x4 x0 = sp[2 * t], c0 = sp[2 * t + 1];
+            const f32x4 x1 = sp[2 * (two ? tb : t)], c1 = sp[2 * (two ? tb : t) + 1];
+            const f2 p[7] = {f2{x0[0], x1[0]}, f2{x0[1], x1[1]}, f2{x0[2], x1[2]}, f2{x0[3], x1[3]}, f2{c0[0], c1[0]}, f2{c0[1], c1[1]},
+                             f2{c0[2], c1[2]}};
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                f2 d2 = {0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    if (k < nf) {  // (columns >= nf take no part; the former multiplication by a 1.0 / 0.0 mask gave the same bits)
+                        const f2 df = p[k] - f2{db[j][k], db[j][k]};
+                        d2 += df * df;
+                    }
+                }
+                f2 sq = d2 * d2;
+                if (!two) sq[1] = 0.0f;
+                ssq2[j] += sq;
+            }
+        }
+    }
+    __shared__ float red4[ND][16][17];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) red4[j][dl][tg] = ssq2[j][0] + ssq2[j][1];
+    __syncthreads();
+    if (tid < 16 * ND) {
+        const int j = tid >> 4, l = tid & 15, dd = (cb % a.dblocks) * (16 * ND) + 16 * j + l;
+        if (dd < D) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tot += red4[j][l][i];  // fixed order
+            a.denom[(size_t)b * D + dd] = fmaxf(sqrtf(tot), 1e-12f);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void row_prep_kernel(RowPrepArgs a) {
-    __shared__ float red[16][17];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < a.nrow_blocks) {
         // 32 table rows per block (4 rounds of 8 rows x 32 threads).  The (R1+32) x 8 box-column weights of this side are staged
@@ -213,49 +280,13 @@ __global__ __launch_bounds__(256) void row_prep_kernel(RowPrepArgs a) {
         return;
     }
     // ---- column norms ----
-    const int T = a.T, D = a.T, nf = a.nf;
     const int cb = blockIdx.x - a.nrow_blocks - a.nhand_blocks;
-    const int b = cb / a.dblocks, dl = tid & 15, tg = tid >> 4;
-    const int dd = (cb % a.dblocks) * 16 + dl;
-    float db[8];
-    {
-        const f32x4* h = reinterpret_cast<const f32x4*>(a.tab[1] + ((size_t)b * D + min(dd, D - 1)) * 8);
-        const f32x4 x = h[0], c = h[1];
-        db[0] = x[0]; db[1] = x[1]; db[2] = x[2]; db[3] = x[3]; db[4] = c[0]; db[5] = c[1]; db[6] = c[2]; db[7] = 0.0f;
-    }
-    float mask[7];  // columns >= nf do not take part: zero both sides
-#pragma unroll
-    for (int k = 0; k < 7; ++k) mask[k] = k < nf ? 1.0f : 0.0f;
-    // the frame's previous boxes pass through LDS in chunks of 512 rows (one coalesced copy per chunk, then broadcast reads):
-    // straight from global memory every thread paid a load latency per four tracks
-    __shared__ __attribute__((aligned(16))) f32x4 sp[2 * 512];
-    const f32x4* hp = reinterpret_cast<const f32x4*>(a.tab[0] + (size_t)b * T * 8);
-    float ssq = 0.0f;
-    for (int t0 = 0; t0 < T; t0 += 512) {
-        const int nt = min(512, T - t0);
-        if (t0) __syncthreads();
-        for (int e = tid; e < 2 * nt; e += 256) sp[e] = hp[(size_t)t0 * 2 + e];
-        __syncthreads();
-#pragma unroll 4
-        for (int t = tg; t < nt; t += 16) {  // the same tracks, in the same order, as a loop over t0 + t = tg, tg + 16, ...
-            const f32x4 x = sp[2 * t], c = sp[2 * t + 1];
-            const float p[7] = {x[0], x[1], x[2], x[3], c[0], c[1], c[2]};
-            float d2 = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const float df = (p[k] - db[k]) * mask[k];
-                d2 += df * df;
-            }
-            ssq += d2 * d2;
-        }
-    }
-    red[dl][tg] = ssq;
-    __syncthreads();
-    if (tg == 0 && dd < D) {
-        float tot = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) tot += red[dl][i];  // fixed order
-        a.denom[(size_t)b * D + dd] = fmaxf(sqrtf(tot), 1e-12f);
+    if (a.dper == 4) {
+        // (num_feats stays a run-time value: with it compiled in - no branch per column - the kernel took 0.27 instead of 0.21 ms per
+        // 1024 frame-pairs in an alternating A/B on one box, tools/gpu_kernel_ab.sh)
+        col_norm_block<4, 0>(a, cb, tid);
+    } else {
+        col_norm_block<1, 0>(a, cb, tid);
     }
 }
 
@@ -549,7 +580,8 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     rp.F = F;
     rp.nrow_blocks = fused ? 0 : 2 * cdiv(B * T, 32);  // the fused kernel has added the box columns already
     rp.nhand_blocks = cdiv(2 * B * T, 256);
-    rp.dblocks = cdiv(D, 16);
+    rp.dper = cdiv(D, 16) * B >= 2048 ? 4 : 1;
+    rp.dblocks = cdiv(D, 16 * rp.dper);
     hipLaunchKernelGGL(row_prep_kernel, dim3(rp.nrow_blocks + rp.nhand_blocks + rp.dblocks * B), dim3(256), 0, st, rp);
     rc = check_launch("row_prep");
     if (rc) return rc;
