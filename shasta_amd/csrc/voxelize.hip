@@ -24,7 +24,6 @@
 
 namespace shasta {
 
-constexpr int kEmpty = 0x7fffffff;
 constexpr int kSlotEmpty = 0x7f7f7f7f;  // what hipMemsetAsync(0x7f) leaves
 
 struct VoxGrid {
