@@ -16,9 +16,10 @@ import torch
 from . import hip
 
 
-def points_to_voxel_device(points, voxel_size, coors_range, max_points=35, max_voxels=20000, with_mean=False):
+def points_to_voxel_device(points, voxel_size, coors_range, max_points=35, max_voxels=20000, with_mean=False, sync=True):
     """points: (P, ndim) fp32 DEVICE tensor.  Returns device tensors (voxels (V,max_points,ndim), coors (V,3) zyx int32,
-    num_points (V,) int32[, mean (V,ndim)]) -- one host sync to read V."""
+    num_points (V,) int32[, mean (V,ndim)]) -- one host sync to read V.  sync=False: nothing is read back - the tensors come with all
+    max_voxels rows and the count as a (1,) int32 device tensor appended (rows >= V: zero in `voxels`, unspecified elsewhere)."""
     lib = hip.load()
     if not points.is_cuda:
         raise hip.ShastaHipError("points_to_voxel_device needs a device tensor (no CPU path)")
@@ -38,6 +39,8 @@ def points_to_voxel_device(points, voxel_size, coors_range, max_points=35, max_v
                                            vs.ctypes.data_as(C.c_void_p), max_points, max_voxels, hip.ptr(voxels),
                                            hip.ptr(coors), hip.ptr(num), hip.ptr(mean), hip.ptr(nv),
                                            hip.ptr(ws), wsb, hip.stream_ptr()), "shasta_voxelize_mean_f32")
+    if not sync:
+        return (voxels, coors, num) + ((mean,) if with_mean else ()) + (nv,)
     V = int(nv.item())
     out = (voxels[:V], coors[:V], num[:V])
     if with_mean:
@@ -111,11 +114,12 @@ class VoxelGenerator:
             max_voxels = self._max_voxels
         return points_to_voxel(points, self._voxel_size, self._point_cloud_range, self._max_num_points, True, max_voxels)
 
-    def generate_device(self, points, max_voxels=-1, with_mean=True):
+    def generate_device(self, points, max_voxels=-1, with_mean=True, sync=True):
+        """sync=False: the voxel count stays on the device (last element of the returned tuple), the tensors keep all max_voxels rows."""
         if max_voxels == -1:
             max_voxels = self._max_voxels
         return points_to_voxel_device(points, self._voxel_size, self._point_cloud_range, self._max_num_points,
-                                      max_voxels, with_mean)
+                                      max_voxels, with_mean, sync=sync)
 
     def generate_batch_device(self, clouds, max_voxels=-1, with_mean=True):
         """Every cloud of a batch (current + previous cloud of every sample) in one chain of launches; the voxel counts stay on the

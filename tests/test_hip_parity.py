@@ -904,7 +904,11 @@ def test_voxelize_matches_reference_golden(case):
     z = np.load(__import__("os").path.join(__import__("tests.helpers", fromlist=["GOLDEN"]).GOLDEN, "voxelize.npz"))
     mp, mv = (int(x) for x in z[case + "_cfg"])
     pts = torch.from_numpy(z[case + "_points"]).to(dev)
-    for _ in range(2):  # second call checks that the persistent cell map was restored
+    # sync=False: nothing read back, the count is a device tensor
+    fv, fc, fn_, fm, nv = points_to_voxel_device(pts, VS, RG, mp, mv, with_mean=True, sync=False)
+    assert nv.is_cuda and fv.shape[0] == mv and int(nv) == z[case + "_coors"].shape[0]
+    assert np.array_equal(fv[:int(nv)].cpu().numpy(), z[case + "_voxels"]) and not bool(fv[int(nv):].any())
+    for _ in range(2):  # second call: nothing of the first call's scratch state survives
         v, c, n, mean = points_to_voxel_device(pts, VS, RG, mp, mv, with_mean=True)
         assert np.array_equal(c.cpu().numpy(), z[case + "_coors"])
         assert np.array_equal(n.cpu().numpy(), z[case + "_num"])
