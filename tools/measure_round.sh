@@ -59,3 +59,6 @@ VOX_ITERS=5 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_voxe
 grep -h '^{' $O/bench_default.json $O/bench_b1.json $O/bench_b64.json $O/bench_b128.json $O/bench_b512.json $O/bench_pieces.json $O/bench_f32.json $O/bench_torchrun.json | cut -c1-230
 grep time $O/conv_check.jsonl | cut -c1-200; tail -1 $O/pipeline.log | cut -c1-400; grep -h "^{" $O/pair320_car.log $O/pair320_n500.log
 ls $O
+# K1 HBM traffic (round 6): FETCH_SIZE / WRITE_SIZE of the voxeliser's kernels, one cloud and the batch of 16
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_voxfetch_b16 -o p -- python3 $R/tools/time_voxelize.py > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_voxwrite_b16 -o p -- python3 $R/tools/time_voxelize.py > /dev/null 2>&1
