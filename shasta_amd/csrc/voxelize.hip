@@ -11,9 +11,11 @@
 //   1. key[i] = z*gy*gx + y*gx + x ; cell[key] = min(point index)                  (atomicMin)
 //   2. owner(i) = cell[key[i]] (one random read per point); creator(i) = owner(i) == i ; voxel id = exclusive prefix count of
 //      creators (scan); the creator takes slot 0
-//   3. rounds r = 1..max_points-1: every still unplaced point atomicMin's its index into slot[vid][r];
-//      the winner takes slot r.  After max_points rounds the rest is dropped, exactly the points the serial loop would have skipped.
-//   4. the voxel rows are cleared up front (one memset: the padding), the filled slots counted per voxel; mean = (sum over slots) / count.
+//   3. every other point inserts itself into the voxel's slots 1..max_points-1, kept sorted by point index (atomicMin leaves the
+//      smaller value in the slot, the larger one moves on): the slots end up with the first max_points points, exactly the ones the
+//      serial loop keeps
+//   4. the voxel rows are cleared up front (one memset: the padding); per voxel the filled slots are counted, their points copied
+//      in, mean = (sum over slots) / count.
 // cell[.]: the reference keeps a dense (40, 1440, 1440) int32 map of the grid (332 MB for nuScenes, allocated on every call,
 // point_cloud_ops.py:150).  A cloud of P points touches at most P cells: here the map is an open-addressing hash table of
 // 2^ceil(log2(2 P)) (key, first point) entries per cloud (8 MB for 3e5 points), cleared by one memset per call - random accesses over
@@ -186,82 +188,63 @@ __global__ __launch_bounds__(256) void vox_assign_kernel(const int* __restrict__
     if ((int)blockIdx.x == B.boff[c] && threadIdx.x == 0) num_voxels[c] = min(block_sums[B.boff[c + 1]] - block_sums[B.boff[c]], max_voxels);
 }
 
-// Every point learns its voxel (pvid, in place over `owner`; -1 = dropped or placed); creators copy themselves into slot 0 and retire,
-// the others bid for slot 1.
-__global__ __launch_bounds__(256) void vox_place_kernel(const float* __restrict__ pts, VoxBatch B, int ndim, int max_voxels, int max_points,
-                                                        const int* __restrict__ vid_of_point, int* __restrict__ pvid,
-                                                        int* __restrict__ slot_idx, float* __restrict__ voxels) {
+// Every point that did not create its voxel inserts itself into the voxel's slots 1 .. max_points - 1, kept SORTED by point index:
+// at slot r it leaves the smaller of (itself, the slot's content) there - one atomicMin - and carries the larger one on to slot r + 1;
+// a value that meets an empty slot stays, one that runs off the end is dropped.  Whatever the arrival order, slot r ends up with the
+// (r + 1)-th smallest point index of the voxel: every value but the smallest passes on from slot 0, so slot 1 collects the minimum of
+// the rest, and so on - exactly the points, in the order, the serial loop keeps.  A point whose index is already above the last slot's
+// content can never get in (slots only decrease) and leaves after one read: crowded voxels stop costing atomics once they hold small
+// indices.  This one pass replaces the placement pass and max_points - 1 bidding rounds of rounds 1 - 5 (an atomic per live point and
+// round).  The creator sits in slot 0 since vox_assign.
+__global__ __launch_bounds__(256) void vox_insert_kernel(VoxBatch B, int max_voxels, int max_points, const int* __restrict__ owner,
+                                                         const int* __restrict__ vid_of_point, int* __restrict__ slot_idx) {
     int c, i;
     vox_locate(B, blockIdx.x, threadIdx.x, c, i);
     if (i < 0) return;
-    const size_t base = (size_t)B.off[c], gi = base + i;
-    const int o = pvid[gi];
-    if (o < 0) return;
+    const size_t base = (size_t)B.off[c];
+    const int o = owner[base + i];
+    if (o < 0 || o == i) return;
     const int v = vid_of_point[base + o];
-    if (v >= max_voxels) {
-        pvid[gi] = -1;
-        return;
-    }
-    if (o == i) {
-        float* dst = voxels + ((size_t)c * max_voxels + v) * max_points * ndim;
-        for (int k = 0; k < ndim; ++k) dst[k] = pts[gi * ndim + k];
-        pvid[gi] = -1;
-    } else {
-        pvid[gi] = v;
-        if (max_points > 1) atomicMin(&slot_idx[((size_t)c * max_voxels + v) * max_points + 1], i);
-    }
-}
-
-// round r >= 1: a point that won slot r (slot_idx == i) copies itself into voxels[vid][r] and retires; every other live point bids
-// for slot r + 1
-__global__ __launch_bounds__(256) void vox_round_kernel(const float* __restrict__ pts, VoxBatch B, int ndim, int r, int max_voxels, int max_points,
-                                                        int nblocks, int* __restrict__ pvid, int* __restrict__ slot_idx, float* __restrict__ voxels) {
-    // four 256-point blocks per workgroup: most points have retired after the first rounds, a workgroup then only reads 4 KB of pvid
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int b = blockIdx.x * 4 + j;
-        if (b >= nblocks) return;
-        int c, i;
-        vox_locate(B, b, threadIdx.x, c, i);
-        if (i < 0) continue;
-        const size_t gi = (size_t)B.off[c] + i;
-        const int v = pvid[gi];
-        if (v < 0) continue;
-        int* slots = slot_idx + ((size_t)c * max_voxels + v) * max_points;
-        if (slots[r] == i) {
-            float* dst = voxels + (((size_t)c * max_voxels + v) * max_points + r) * ndim;
-            for (int k = 0; k < ndim; ++k) dst[k] = pts[gi * ndim + k];
-            pvid[gi] = -1;
-        } else if (r + 1 < max_points) {
-            atomicMin(&slots[r + 1], i);
-        }
+    if (v >= max_voxels) return;
+    int* slots = slot_idx + ((size_t)c * max_voxels + v) * max_points;
+    int p = i;
+    if (__hip_atomic_load(&slots[max_points - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p) return;
+    for (int r = 1; r < max_points; ++r) {
+        const int old = atomicMin(&slots[r], p);
+        if (old == kSlotEmpty) return;
+        if (old > p) p = old;
     }
 }
 
 // Eight lanes per voxel (lane = channel; a loop beyond 8 channels).  The voxel rows were cleared by ONE memset in front of the chain
-// (a streaming fill of the zero-padded (max_voxels, max_points, ndim) output - most of it stays padding), the placed points written
-// over it; here the filled slots (contiguous from 0: a point only bids for r + 1 after losing r) are counted and, for the reader
-// (voxel_encoder.py:18-28), summed in slot order / their number - straight from the cloud through the slots' point indices, so the
-// padded output is not read back.  grid.y = cloud
+// (a streaming fill of the zero-padded (max_voxels, max_points, ndim) output - most of it stays padding); here the filled slots
+// (contiguous from 0) are counted, their points copied from the cloud into the voxel's rows and, for the reader
+// (voxel_encoder.py:18-28), summed in slot order / their number.  grid.y = cloud
 __global__ __launch_bounds__(256) void vox_finalize_kernel(const float* __restrict__ pts, VoxBatch B, const int* __restrict__ slot_idx,
                                                            const int* __restrict__ num_voxels, int max_voxels, int max_points, int ndim,
-                                                           int* __restrict__ num_points, float* __restrict__ mean) {
+                                                           float* __restrict__ voxels, int* __restrict__ num_points, float* __restrict__ mean) {
     const int c = blockIdx.y;
     const int v = blockIdx.x * 32 + (threadIdx.x >> 3), k0 = threadIdx.x & 7;
     if (v >= num_voxels[c]) return;
     const size_t row = (size_t)c * max_voxels + v;
     const int* sl = slot_idx + row * max_points;
     const float* cloud = pts + (size_t)B.off[c] * ndim;
+    float* dst = voxels + row * max_points * ndim;
+    // (slot r, its point, slot r + 1, ...: a form with all slot loads and gathers of a voxel in flight at once - indices handed round the
+    // eight lanes by shuffles - ran 3 % slower per batch in an alternating A/B on one box)
     int cnt = 0;
-    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // channels k0, k0 + 8, ... (ndim <= 32)
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int r = 0; r < max_points; ++r) {
         const int idx = sl[r];
         if (idx == kSlotEmpty) break;
         ++cnt;
-        if (mean) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k0 + 8 * j < ndim) s[j] += cloud[(size_t)idx * ndim + k0 + 8 * j];
+        for (int j = 0; j < 4; ++j) {
+            if (k0 + 8 * j < ndim) {
+                const float val = cloud[(size_t)idx * ndim + k0 + 8 * j];
+                dst[r * ndim + k0 + 8 * j] = val;
+                s[j] += val;
+            }
         }
     }
     if (k0 == 0) num_points[row] = cnt;
@@ -357,14 +340,12 @@ static int vox_batch(const float* points, const int* h_offsets, int n, int ndim,
     if ((rc = check_launch("vox_scan"))) return rc;
     hipLaunchKernelGGL(vox_assign_kernel, dim3(nb), dim3(256), 0, st, keys, pvid, B, bsum, G, max_voxels, max_points, vidp, coors, num_voxels, slots);
     if ((rc = check_launch("vox_assign"))) return rc;
-    hipLaunchKernelGGL(vox_place_kernel, dim3(nb), dim3(256), 0, st, points, B, ndim, max_voxels, max_points, vidp, pvid, slots, voxels);
-    if ((rc = check_launch("vox_place"))) return rc;
-    for (int r = 1; r < max_points; ++r) {
-        hipLaunchKernelGGL(vox_round_kernel, dim3(cdiv(nb, 4)), dim3(256), 0, st, points, B, ndim, r, max_voxels, max_points, nb, pvid, slots, voxels);
-        if ((rc = check_launch("vox_round"))) return rc;
+    if (max_points > 1) {
+        hipLaunchKernelGGL(vox_insert_kernel, dim3(nb), dim3(256), 0, st, B, max_voxels, max_points, pvid, vidp, slots);
+        if ((rc = check_launch("vox_insert"))) return rc;
     }
     hipLaunchKernelGGL(vox_finalize_kernel, dim3((unsigned)cdiv(max_voxels, 32), n), dim3(256), 0, st, points, B, slots, num_voxels, max_voxels,
-                       max_points, ndim, num_points_per_voxel, mean);
+                       max_points, ndim, voxels, num_points_per_voxel, mean);
     return check_launch("vox_finalize");
 }
 
