@@ -151,3 +151,58 @@ def test_no_grad_train_mode_forward_and_fallbacks():
     o3, _ = m3.shared_conv_nhwc(xg, xp)
     o3.sum().backward()
     assert xg.grad is not None and getattr(m3, "_conv_raw", None) is None
+
+
+def test_training_from_the_neck_follows_the_sequential_path_step_by_step():
+    """The reference's training step from the neck outputs (Shasta.forward in train mode -> loss -> backward -> Adam on every trainable
+    tensor incl. shared_conv.0 / .1) with K0 hand-written and, beside it, through nn.Sequential: the same losses and the same weights
+    after eight steps (the two paths differ by summation order only, Adam amplifies nothing at this step size)."""
+    import shasta_amd
+    from shasta_amd import training
+    dev = _dev()
+    torch.manual_seed(5)
+    cfg = dict(type="Shasta", reader=None, backbone=None, neck=None,
+               bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
+               max_obj=12, num_feats=3, num_point=5, in_channels=32)
+    a = shasta_amd.build_simp_track(cfg).to(dev).train()
+    b = copy.deepcopy(a)
+    b.hand_written_train_conv = False
+    g = torch.Generator().manual_seed(6)
+    B, N, HW = 3, 12, 180
+    x = torch.relu(torch.randn(B, 32, HW, HW, generator=g)).to(dev)
+    xp = torch.relu(torch.randn(B, 32, HW, HW, generator=g)).to(dev)
+
+    def boxes():
+        t = torch.zeros(B, N, 11)
+        t[:, :, :2] = (torch.rand(B, N, 2, generator=g) - 0.5) * 100
+        t[:, :, 2] = torch.randn(B, N, generator=g)
+        t[:, :, 3:6] = torch.rand(B, N, 3, generator=g) * 3 + 0.5
+        t[:, :, 6] = (torch.rand(B, N, generator=g) - 0.5) * 6.28
+        t[:, :, 7:9] = torch.randn(B, N, 2, generator=g)
+        t[:, :, 9] = 0.5
+        return t.to(dev)
+    det, prev = boxes(), boxes()
+    gt = torch.zeros(B, N + 2, N + 2)
+    perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B)])
+    gt[torch.arange(B)[:, None], torch.arange(N)[None, :], perm] = 1.0
+    gt = gt.to(dev)
+    losses = []
+    for m in (a, b):
+        opt = training.FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+        ls = []
+        for _ in range(8):
+            opt.zero_grad(set_to_none=True)
+            m1, m2, _ = m(dict(det_boxes=det.clone(), prev_det_boxes=prev.clone(), bev_map=x, prev_bev_map=xp), train_mode=True)
+            loss = training.affinity_loss(m1, m2, gt)
+            loss.backward()
+            opt.step()
+            ls.append(float(loss.detach()))
+        losses.append(ls)
+    assert getattr(a, "_conv_raw", None) is not None and getattr(b, "_conv_raw", None) is None
+    assert losses[0][-1] < losses[0][0]  # it learns
+    for la, lb in zip(*losses):
+        assert abs(la - lb) <= 1e-4 * max(1.0, abs(lb)), losses
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert float((p - q).abs().max()) <= 2e-4 * max(1.0, float(q.abs().max())), k
+    for k in ("running_mean", "running_var"):
+        assert torch.allclose(getattr(a.shared_conv[1], k), getattr(b.shared_conv[1], k), rtol=1e-3, atol=1e-5)
