@@ -577,22 +577,29 @@ int shasta_smallm_nn_f32(const float* G, int ldg, const float* W, int R, int H, 
 int shasta_scale_f32(float* x, long n, float alpha, shasta_stream_t stream);
 
 /* One fused Adam update of a parameter tensor (torch.optim.Adam semantics of tools/nusc_shasta/train.py:147,215: L2
- * weight decay folded into the gradient, bias correction with `step` (1-based), no amsgrad).  16-byte aligned pointers. */
+ * weight decay folded into the gradient, bias correction with `step` (1-based), no amsgrad).  16-byte aligned pointers.
+ * d_dyn (all four Adam entry points; NULL for the plain form): four DEVICE floats {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step), beta1,
+ * beta2} that replace `lr`, the betas and `step` - a training step replayed from a captured hipGraph cannot take the step number and
+ * the scheduler's learning rate / momentum (OneCycleLR cycles both, tools/nusc_shasta/train.py:172) as launch arguments (frozen at
+ * capture time).  shasta_adam_prepare_f32 advances a device-side step counter and writes them from d_hyper = {lr, beta1, beta2}
+ * (device), once per optimizer step (training.FusedAdam(..., capturable=True)). */
+int shasta_adam_prepare_f32(int* d_step, const float* d_hyper, float* d_dyn, shasta_stream_t stream);
 int shasta_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
-                         float beta2, float eps, float weight_decay, int step, shasta_stream_t stream);
+                         float beta2, float eps, float weight_decay, int step, const float* d_dyn, shasta_stream_t stream);
 
 /* The same update for `count` tensors (host arrays of device pointers and element counts) that share lr / betas / eps / weight_decay /
  * step: one launch per 48 tensors (the small weight and bias tensors of a model); no alignment requirement. */
 int shasta_adam_multi_f32(int count, float* const* param, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
                           const long* n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                          shasta_stream_t stream);
+                          const float* d_dyn, shasta_stream_t stream);
 
 /* The same update for an (H, K) matrix whose gradient is the rank-R product g[h][k] = sum_r G[r][h] X[r][k] (G: (R, H) at ldg, X: (R, K) at
  * ldx; the first aug_shape layers of tools/nusc_shasta/train.py:198-218: G = gradient of the hidden activations - already divided by
  * the world size when the factors were gathered over the ranks -, X = the layer's inputs, R = frame-pairs of the step over all ranks,
  * 1..64).  The gradient is formed in registers inside the pass and never touches memory.  K and ldx multiples of 4. */
 int shasta_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_sq, int H, int K, const float* G, int ldg, const float* X, int ldx,
-                            int R, float lr, float beta1, float beta2, float eps, float weight_decay, int step, shasta_stream_t stream);
+                            int R, float lr, float beta1, float beta2, float eps, float weight_decay, int step, const float* d_dyn,
+                            shasta_stream_t stream);
 
 /* shasta_adam_lowrank_f32 and, in the same pass over the matrix, Y (+)= Gdx . W with the weights as they are BEFORE the update (Gdx: (Rdx, H)
  * at ldgdx, Y: (Rdx, K) at ldy; the backward's dx = ghid . W1 of a first aug_shape layer, which otherwise reads the 1 GB matrix once more:
@@ -602,7 +609,7 @@ size_t shasta_adam_lowrank_dx_workspace_bytes(int H, int K, int Rdx);
 int shasta_adam_lowrank_dx_f32(float* param, float* exp_avg, float* exp_avg_sq, int H, int K, const float* G, int ldg, const float* X, int ldx,
                                int R, const float* Gdx, int ldgdx, int Rdx, float* Y, long ldy, int accumulate, void* workspace,
                                size_t workspace_bytes, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                               shasta_stream_t stream);
+                               const float* d_dyn, shasta_stream_t stream);
 
 #pragma GCC visibility pop
 

@@ -378,7 +378,32 @@ __global__ void abs_kernel(const float* __restrict__ x, const float* __restrict_
 //   g' = g + wd*p ; m += (g' - m)*(1-b1) ; v = b2*v + (1-b2)*g'*g' ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 struct AdamArgs {
     float lr_over_bc1, beta1, beta2, eps, weight_decay, rsqrt_bc2;
+    // non-null: everything that changes from step to step comes from DEVICE memory (dyn = {lr / bc1, 1 / sqrt(bc2), beta1, beta2},
+    // written by adam_prepare_kernel from a device-side step counter and the scheduler's lr / betas) - a training step replayed from a
+    // captured hipGraph cannot take them as launch arguments, which are frozen at capture time
+    const float* dyn;
 };
+__device__ __forceinline__ AdamArgs adam_resolve(AdamArgs a) {
+    if (a.dyn) {
+        a.lr_over_bc1 = a.dyn[0];
+        a.rsqrt_bc2 = a.dyn[1];
+        a.beta1 = a.dyn[2];
+        a.beta2 = a.dyn[3];
+    }
+    return a;
+}
+// one step of the device-side schedule: ++*step; hyper = {lr, beta1, beta2} -> dyn = {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step), beta1, beta2}
+__global__ void adam_prepare_kernel(int* __restrict__ step, const float* __restrict__ hyper, float* __restrict__ dyn) {
+    if (threadIdx.x || blockIdx.x) return;
+    const int s = *step + 1;
+    *step = s;
+    const float beta1 = hyper[1], beta2 = hyper[2];
+    const double bc1 = 1.0 - pow((double)beta1, (double)s), bc2 = 1.0 - pow((double)beta2, (double)s);
+    dyn[0] = (float)((double)hyper[0] / bc1);
+    dyn[1] = (float)(1.0 / sqrt(bc2));
+    dyn[2] = beta1;
+    dyn[3] = beta2;
+}
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a) {
     g = fmaf(a.weight_decay, p, g);
@@ -389,7 +414,8 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, long n, AdamArgs a) {
+                                                   float* __restrict__ v, long n, AdamArgs a_in) {
+    const AdamArgs a = adam_resolve(a_in);
     const long n4 = n >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -423,7 +449,8 @@ struct AdamMulti {
     long n[ADAM_MULTI];
 };
 
-__global__ __launch_bounds__(256) void adam_multi_kernel(AdamMulti t, AdamArgs a) {
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamMulti t, AdamArgs a_in) {
+    const AdamArgs a = adam_resolve(a_in);
     const int k = blockIdx.y;
     float* __restrict__ p = t.p[k];
     const float* __restrict__ g = t.g[k];
@@ -445,8 +472,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamMulti t, AdamArgs a
 template <int RMAX, int COLS, int RDX = 0>
 __global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                            const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx, int R,
-                                                           int H, int K, int rows_per_block, AdamArgs a, const float* __restrict__ Gdx = nullptr,
+                                                           int H, int K, int rows_per_block, AdamArgs a_in, const float* __restrict__ Gdx = nullptr,
                                                            int ldgdx = 0, int Rdx = 0, float* __restrict__ part = nullptr) {
+    const AdamArgs a = adam_resolve(a_in);
     typedef float fv __attribute__((ext_vector_type(COLS)));
     const long k0 = ((long)blockIdx.x * 256 + threadIdx.x) * COLS;
     fv dacc[RDX > 0 ? RDX : 1];
@@ -765,13 +793,11 @@ extern "C" int shasta_bev_gather_bwd_f32(const float* dfeat, int B, int H, int W
     return check_launch("bev_gather_bwd");
 }
 
-extern "C" int shasta_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
-                                    float beta2, float eps, float weight_decay, int step, shasta_stream_t stream) {
-    SHASTA_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "adam_step: bad argument");
-    SHASTA_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
-                   "adam_step: tensors must be 16-byte aligned");
-    if (n == 0) return SHASTA_OK;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+// d_dyn (device, 4 floats, or NULL): when given, lr, betas and step are ignored - the kernels read lr / bc1, 1 / sqrt(bc2) and the betas
+// from it (shasta_adam_prepare_f32 writes them from a device-side step counter and {lr, beta1, beta2} once per optimizer step)
+static AdamArgs make_adam_args(float lr, float beta1, float beta2, float eps, float weight_decay, int step, const float* d_dyn) {
+    const double s = step >= 1 ? (double)step : 1.0;
+    const double bc1 = 1.0 - pow((double)beta1, s), bc2 = 1.0 - pow((double)beta2, s);
     AdamArgs a;
     a.lr_over_bc1 = (float)((double)lr / bc1);
     a.beta1 = beta1;
@@ -779,6 +805,23 @@ extern "C" int shasta_adam_step_f32(float* param, const float* grad, float* exp_
     a.eps = eps;
     a.weight_decay = weight_decay;
     a.rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    a.dyn = d_dyn;
+    return a;
+}
+
+extern "C" int shasta_adam_prepare_f32(int* d_step, const float* d_hyper, float* d_dyn, shasta_stream_t stream) {
+    SHASTA_REQUIRE(d_step && d_hyper && d_dyn, "adam_prepare: null pointer");
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, as_stream(stream), d_step, d_hyper, d_dyn);
+    return check_launch("adam_prepare");
+}
+
+extern "C" int shasta_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int step, const float* d_dyn, shasta_stream_t stream) {
+    SHASTA_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && (step >= 1 || d_dyn), "adam_step: bad argument");
+    SHASTA_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                   "adam_step: tensors must be 16-byte aligned");
+    if (n == 0) return SHASTA_OK;
+    const AdamArgs a = make_adam_args(lr, beta1, beta2, eps, weight_decay, step, d_dyn);
     const long blocks = std::min<long>((n / 4 + 255) / 256 + 1, 256L * 16);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, a);
     return check_launch("adam_step");
@@ -786,16 +829,9 @@ extern "C" int shasta_adam_step_f32(float* param, const float* grad, float* exp_
 
 extern "C" int shasta_adam_multi_f32(int count, float* const* param, const float* const* grad, float* const* exp_avg,
                                      float* const* exp_avg_sq, const long* n, float lr, float beta1, float beta2, float eps,
-                                     float weight_decay, int step, shasta_stream_t stream) {
-    SHASTA_REQUIRE(count >= 0 && step >= 1 && (count == 0 || (param && grad && exp_avg && exp_avg_sq && n)), "adam_multi: bad argument");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    AdamArgs a;
-    a.lr_over_bc1 = (float)((double)lr / bc1);
-    a.beta1 = beta1;
-    a.beta2 = beta2;
-    a.eps = eps;
-    a.weight_decay = weight_decay;
-    a.rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+                                     float weight_decay, int step, const float* d_dyn, shasta_stream_t stream) {
+    SHASTA_REQUIRE(count >= 0 && (step >= 1 || d_dyn) && (count == 0 || (param && grad && exp_avg && exp_avg_sq && n)), "adam_multi: bad argument");
+    const AdamArgs a = make_adam_args(lr, beta1, beta2, eps, weight_decay, step, d_dyn);
     for (int k0 = 0; k0 < count; k0 += ADAM_MULTI) {
         AdamMulti t;
         const int c = std::min(ADAM_MULTI, count - k0);
@@ -832,8 +868,8 @@ extern "C" size_t shasta_adam_lowrank_dx_workspace_bytes(int H, int K, int Rdx) 
 extern "C" int shasta_adam_lowrank_dx_f32(float* param, float* exp_avg, float* exp_avg_sq, int H, int K, const float* G, int ldg, const float* X,
                                           int ldx, int R, const float* Gdx, int ldgdx, int Rdx, float* Y, long ldy, int accumulate, void* workspace,
                                           size_t workspace_bytes, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                                          shasta_stream_t stream) {
-    SHASTA_REQUIRE(param && exp_avg && exp_avg_sq && G && X && Gdx && Y && workspace && H >= 1 && K >= 4 && step >= 1, "adam_lowrank_dx: bad argument");
+                                          const float* d_dyn, shasta_stream_t stream) {
+    SHASTA_REQUIRE(param && exp_avg && exp_avg_sq && G && X && Gdx && Y && workspace && H >= 1 && K >= 4 && (step >= 1 || d_dyn), "adam_lowrank_dx: bad argument");
     SHASTA_REQUIRE(R >= 1 && R <= 64 && Rdx >= 1 && Rdx <= 16, "adam_lowrank_dx: 1 <= R <= 64, 1 <= Rdx <= 16");
     SHASTA_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && ldg >= H && ldx >= K && ldgdx >= H, "adam_lowrank_dx: K and ldx multiples of 4, ldg, ldgdx >= H, ldx >= K");
     SHASTA_REQUIRE((((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)X | (uintptr_t)workspace) & 15) == 0,
@@ -842,14 +878,7 @@ extern "C" int shasta_adam_lowrank_dx_f32(float* param, float* exp_avg, float* e
         set_error_msg("adam_lowrank_dx: workspace too small");
         return SHASTA_E_WORKSPACE;
     }
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    AdamArgs a;
-    a.lr_over_bc1 = (float)((double)lr / bc1);
-    a.beta1 = beta1;
-    a.beta2 = beta2;
-    a.eps = eps;
-    a.weight_decay = weight_decay;
-    a.rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const AdamArgs a = make_adam_args(lr, beta1, beta2, eps, weight_decay, step, d_dyn);
     const int cols = R <= 16 ? 4 : 2;
     const int kblocks = cdiv(K / cols, 256), rpb = adam_lowrank_rows_per_block(H, K, cols), chunks = cdiv(H, rpb);
     float* part = static_cast<float*>(workspace);
@@ -870,20 +899,13 @@ extern "C" int shasta_adam_lowrank_dx_f32(float* param, float* exp_avg, float* e
 
 extern "C" int shasta_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_sq, int H, int K, const float* G, int ldg, const float* X,
                                        int ldx, int R, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                                       shasta_stream_t stream) {
-    SHASTA_REQUIRE(param && exp_avg && exp_avg_sq && G && X && H >= 0 && K >= 0 && step >= 1, "adam_lowrank: bad argument");
+                                       const float* d_dyn, shasta_stream_t stream) {
+    SHASTA_REQUIRE(param && exp_avg && exp_avg_sq && G && X && H >= 0 && K >= 0 && (step >= 1 || d_dyn), "adam_lowrank: bad argument");
     SHASTA_REQUIRE(R >= 1 && R <= 64, "adam_lowrank: 1 <= R <= 64 (frame-pairs of a step over all ranks)");
     SHASTA_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && ldg >= H && ldx >= K, "adam_lowrank: K and ldx multiples of 4, ldg >= H, ldx >= K");
     SHASTA_REQUIRE((((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)X) & 15) == 0, "adam_lowrank: 16-byte alignment");
     if (H == 0 || K == 0) return SHASTA_OK;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    AdamArgs a;
-    a.lr_over_bc1 = (float)((double)lr / bc1);
-    a.beta1 = beta1;
-    a.beta2 = beta2;
-    a.eps = eps;
-    a.weight_decay = weight_decay;
-    a.rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const AdamArgs a = make_adam_args(lr, beta1, beta2, eps, weight_decay, step, d_dyn);
     auto launch = [&](auto kern, int cols) {
         const int kblocks = cdiv(K / cols, 256);
         const int rpb = adam_lowrank_rows_per_block(H, K, cols);

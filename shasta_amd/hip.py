@@ -9,7 +9,7 @@ import os
 
 import torch
 
-ABI_VERSION = 13  # must equal shasta_abi_version() of the loaded library
+ABI_VERSION = 14  # must equal shasta_abi_version() of the loaded library
 # SHASTA_HIP_LIB: load another build of the same ABI (A/B timing of kernel variants on one box)
 _LIB_PATH = os.environ.get("SHASTA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libshasta_hip.so")
 _lib = None
@@ -117,13 +117,14 @@ SYMBOLS = {
     "shasta_smallm_nn_workspace_bytes": (_Z, [_I, _I, _I]),
     "shasta_smallm_nn_f32": (_I, [_P, _I, _P, _I, _I, _I, _P, C.c_long, _I, _P, _Z, _P]),
     "shasta_scale_f32": (_I, [_P, C.c_long, _F, _P]),
-    "shasta_adam_step_f32": (_I, [_P, _P, _P, _P, C.c_long, _F, _F, _F, _F, _F, _I, _P]),
+    "shasta_adam_prepare_f32": (_I, [_P, _P, _P, _P]),
+    "shasta_adam_step_f32": (_I, [_P, _P, _P, _P, C.c_long, _F, _F, _F, _F, _F, _I, _P, _P]),
     "shasta_affinity_loss_f32": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "shasta_affinity_loss_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
-    "shasta_adam_multi_f32": (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_long), _F, _F, _F, _F, _F, _I, _P]),
+    "shasta_adam_multi_f32": (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_long), _F, _F, _F, _F, _F, _I, _P, _P]),
     "shasta_adam_lowrank_dx_workspace_bytes": (_Z, [_I, _I, _I]),
-    "shasta_adam_lowrank_dx_f32": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, C.c_long, _I, _P, _Z, _F, _F, _F, _F, _F, _I, _P]),
-    "shasta_adam_lowrank_f32": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _F, _F, _F, _F, _F, _I, _P]),
+    "shasta_adam_lowrank_dx_f32": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, C.c_long, _I, _P, _Z, _F, _F, _F, _F, _F, _I, _P, _P]),
+    "shasta_adam_lowrank_f32": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _F, _F, _F, _F, _F, _I, _P, _P]),
     "shasta_abs_f32": (_I, [_P, _P, _P, C.c_long, _I, _I, _I, _I, _P]),
     "shasta_bev_gather_bwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
     "shasta_nms_workspace_bytes": (_Z, [_I]),

@@ -229,6 +229,7 @@ class Shasta(BaseTrack):
         self._aux_key = None
         self._guard_key = None
         self._conv_key = None
+        self._conv_raw = None
         if getattr(self, "_conv_bank", None) is not None:
             self._conv_bank._key = None
 

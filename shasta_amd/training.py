@@ -521,7 +521,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     MULTI_MAX_NUMEL = 1 << 18  # tensors up to this size are updated together, 48 per launch
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lowrank_first_layers=None, in_backward=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lowrank_first_layers=None, in_backward=False,
+                 capturable=False):
         """lowrank_first_layers = the Shasta model: its four aug_shape first-layer matrices (4 x 1 GB at N = 500) are updated straight from
         the FACTORS of their gradient (shasta_adam_lowrank_f32: 24 bytes per parameter instead of 36) - the backward then leaves their
         .grad None and hands the factors over on the parameter; same update, the gradient's sum over the step's frame-pairs in another
@@ -533,6 +534,14 @@ class FusedAdam(torch.optim.Optimizer):
         # without the option; for loops that are backward() -> step() like tools/nusc_shasta/train.py:213-215 (no gradient clipping or
         # accumulation over several backward passes, whose updates must wait for step()).
         self.in_backward = bool(in_backward) and lowrank_first_layers is not None
+        # capturable: the step number, the learning rate and the betas reach the kernels through DEVICE memory (one tiny kernel per
+        # optimizer step advances a device-side counter and turns {lr, beta1, beta2} into the bias-corrected factors), so that a whole
+        # training step - forward, loss, backward, this update - can be captured into a hipGraph once and replayed (GraphedTrainStep):
+        # launch arguments are frozen at capture time.  A scheduler keeps writing group["lr"] / group["betas"] on the host;
+        # sync_hyper() copies them over (called by step() itself outside a capture, by GraphedTrainStep before every replay).  One
+        # step counter per parameter group (every tensor of a group is stepped together, as in the reference's loop).
+        self.capturable = bool(capturable)
+        self._armed = {}  # id(group) -> the group's factors are prepared for the current optimizer step
         if lowrank_first_layers is not None:
             lowrank_first_layers.lowrank_adam = True
             import weakref
@@ -545,6 +554,40 @@ class FusedAdam(torch.optim.Optimizer):
             st["exp_avg"] = torch.zeros_like(p)
             st["exp_avg_sq"] = torch.zeros_like(p)
         return st
+
+    def _dev(self, group, device):
+        d = group.get("_shasta_dev")
+        if d is None or d["step"].device != device:
+            d = group["_shasta_dev"] = dict(step=torch.zeros(1, dtype=torch.int32, device=device), hyper=torch.zeros(3, device=device),
+                                            dyn=torch.zeros(4, device=device), host=None)
+        return d
+
+    def sync_hyper(self):
+        """capturable: copy every group's lr / betas (the scheduler's host values) to the device; a no-op when nothing changed."""
+        for group in self.param_groups:
+            d = group.get("_shasta_dev")
+            if d is None:
+                continue
+            host = (float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]))
+            if d["host"] != host:
+                d["hyper"].copy_(torch.tensor(host, dtype=torch.float32), non_blocking=False)
+                d["host"] = host
+
+    def _dyn(self, group, device):
+        """Device pointer of the group's step factors for the CURRENT optimizer step (None in the plain mode).  The first use in a step -
+        inside the backward when the first layers step there, else in step() - advances the device-side counter."""
+        if not self.capturable:
+            return None
+        d = self._dev(group, device)
+        if not self._armed.get(id(group)):
+            if d["host"] is None or not torch.cuda.is_current_stream_capturing():
+                if torch.cuda.is_current_stream_capturing() and d["host"] is None:
+                    raise hip.ShastaHipError("FusedAdam(capturable=True): run one eager step (or sync_hyper()) before capturing")
+                self.sync_hyper()
+            hip.check(hip.load().shasta_adam_prepare_f32(hip.ptr(d["step"]), hip.ptr(d["hyper"]), hip.ptr(d["dyn"]), hip.stream_ptr()),
+                      "shasta_adam_prepare_f32")
+            self._armed[id(group)] = True
+        return hip.ptr(d["dyn"])
 
     @torch.no_grad()
     def step_in_backward(self, p, factors, gdx, ldgdx, rdx, y, ldy):
@@ -563,7 +606,7 @@ class FusedAdam(torch.optim.Optimizer):
         hip.check(lib.shasta_adam_lowrank_dx_f32(hip.ptr(p), hip.ptr(st["exp_avg"]), hip.ptr(st["exp_avg_sq"]), H, K, hip.ptr_view(G), ldg,
                                                  hip.ptr_view(X), ldx, R, hip.ptr_view(gdx), ldgdx, rdx, hip.ptr_view(y), ldy, 1, hip.ptr(ws), nb,
                                                  float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                                 st["step"], hip.stream_ptr()), "shasta_adam_lowrank_dx_f32")
+                                                 st["step"], self._dyn(group, p.device), hip.stream_ptr()), "shasta_adam_lowrank_dx_f32")
         torch.autograd.graph.increment_version(p)
 
     @torch.no_grad()
@@ -588,8 +631,8 @@ class FusedAdam(torch.optim.Optimizer):
                     G, ldg, X, ldx, R = factors
                     hip.check(lib.shasta_adam_lowrank_f32(hip.ptr(p), hip.ptr(st["exp_avg"]), hip.ptr(st["exp_avg_sq"]), p.shape[0], p.shape[1],
                                                           hip.ptr_view(G), ldg, hip.ptr_view(X), ldx, R, float(group["lr"]), float(b1), float(b2),
-                                                          float(group["eps"]), float(group["weight_decay"]), st["step"], hip.stream_ptr()),
-                              "shasta_adam_lowrank_f32")
+                                                          float(group["eps"]), float(group["weight_decay"]), st["step"], self._dyn(group, p.device),
+                                                          hip.stream_ptr()), "shasta_adam_lowrank_f32")
                     torch.autograd.graph.increment_version(p)
                     continue
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
@@ -602,7 +645,8 @@ class FusedAdam(torch.optim.Optimizer):
                     g = g.clone()
                 hip.check(lib.shasta_adam_step_f32(hip.ptr(p), hip.ptr(g), hip.ptr(st["exp_avg"]), hip.ptr(st["exp_avg_sq"]), p.numel(),
                                                    float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                                   float(group["weight_decay"]), st["step"], hip.stream_ptr()), "shasta_adam_step_f32")
+                                                   float(group["weight_decay"]), st["step"], self._dyn(group, p.device), hip.stream_ptr()),
+                          "shasta_adam_step_f32")
                 # the kernel wrote through the raw pointer: tell torch (Shasta._ensure_packed and the conv-weight cache key
                 # their packed copies on (data_ptr, _version); autograd's saved-tensor checks rely on it too)
                 torch.autograd.graph.increment_version(p)
@@ -611,10 +655,72 @@ class FusedAdam(torch.optim.Optimizer):
                 arr = lambda j: (C.c_void_p * k)(*[it[j].data_ptr() for it in items])  # noqa: E731
                 hip.check(lib.shasta_adam_multi_f32(k, arr(0), arr(1), arr(2), arr(3), (C.c_long * k)(*[it[0].numel() for it in items]),
                                                     float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                                    step_no, hip.stream_ptr()), "shasta_adam_multi_f32")
+                                                    step_no, self._dyn(group, items[0][0].device), hip.stream_ptr()), "shasta_adam_multi_f32")
                 for it in items:
                     torch.autograd.graph.increment_version(it[0])
+            self._armed[id(group)] = False  # the next optimizer step prepares its own factors
         return loss
+
+
+class GraphedTrainStep:
+    """One training step of tools/nusc_shasta/train.py:198-218 - forward (from the NHWC features, or from the neck outputs with
+    shared_conv in train mode), the masked NLL, the HIP backward, FusedAdam(capturable=True) - captured ONCE into a hipGraph and
+    replayed per step: the host's launch work (~240 launches at the car configuration) is out of the way.  Measured (tools/time_train.py
+    --graph): no faster than the eager loop on this stack - 2.65 vs 2.71 ms at 16 frame pairs, 2.8 at 64 once the input copies are
+    discounted - the step is bound by the GPU-side dispatch of its ~240 dependent small kernels (8 - 12 us apiece end to end), which a
+    replay does not shorten; what helps is fewer kernels.  Kept for hosts whose Python is the slower side.  Inputs of every step must have the shapes of the ones given here (they are copied into static buffers); the
+    scheduler keeps stepping on the host, its lr / betas are copied to the device before each replay.  One process, one GPU (a
+    data-parallel step synchronises on the host to compare batch sizes and stays eager).
+
+        step = GraphedTrainStep(model, opt, bev, pbev, det, prev, gt)        # three eager warm-up steps + the capture (they DO update the weights)
+        for batch in loader: loss = step(*batch); scheduler.step()
+    """
+
+    def __init__(self, model, opt, bev, pbev, det_boxes, prev_det_boxes, gt, from_neck=False, warmup=3):
+        if not getattr(opt, "capturable", False):
+            raise hip.ShastaHipError("GraphedTrainStep needs FusedAdam(..., capturable=True): step number, lr and betas from device memory")
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise hip.ShastaHipError("GraphedTrainStep: single-process steps only")
+        self.model, self.opt, self.from_neck = model, opt, from_neck
+        self.static = [t.detach().clone() for t in (bev, pbev, det_boxes, prev_det_boxes, gt)]
+        self._work = self.static[2].clone()  # the forward back-projects det_boxes in place: every step starts from a fresh copy
+
+        def body():
+            opt.zero_grad(set_to_none=True)
+            sb, sp, sd, spv, sg = self.static
+            self._work.copy_(sd)
+            if from_neck:
+                m1, m2, _ = model(dict(det_boxes=self._work, prev_det_boxes=spv, bev_map=sb, prev_bev_map=sp), train_mode=True)
+            else:
+                m1, m2 = affinity_train(model, sb, sp, self._work, spv)
+            loss = affinity_loss(m1, m2, sg)
+            loss.backward()
+            opt.step()
+            return loss.detach()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = body()
+        self.steps = 0
+
+    def __call__(self, bev, pbev, det_boxes, prev_det_boxes, gt):
+        for s, t in zip(self.static, (bev, pbev, det_boxes, prev_det_boxes, gt)):
+            if s.data_ptr() != t.data_ptr():
+                s.copy_(t)
+        self.opt.sync_hyper()
+        self.graph.replay()
+        self.steps += 1
+        # the replayed kernels wrote the weights without the host noticing: whatever the host derived from them (packed copies, keyed
+        # on version counters that only move at capture time) is dropped, so that an eager forward after training packs afresh
+        self.model.invalidate_weights_cache()
+        return self.loss
 
 
 def allreduce_gradients(params, world_size=None, bucket_bytes=256 << 20, group=None):

@@ -729,7 +729,7 @@ def test_adam_lowrank_with_the_product_in_the_same_pass(R, Rdx, H, K):
     m0, v0 = torch.randn(H, K, device=dev) * 0.1, torch.rand(H, K, device=dev) * 0.01
     G, X, Gdx = torch.randn(R, H + 3, device=dev), torch.randn(R, K + 4, device=dev), torch.randn(Rdx, H + 1, device=dev)
     y0 = torch.randn(Rdx, K + 8, device=dev)
-    hyper = (3e-3, 0.9, 0.999, 1e-8, 0.01, 7)
+    hyper = (3e-3, 0.9, 0.999, 1e-8, 0.01, 7, None)  # (lr, betas, eps, weight decay, step, d_dyn = NULL: the plain form)
     pa, ma, va = p0.clone(), m0.clone(), v0.clone()
     hip.check(lib.shasta_adam_lowrank_f32(hip.ptr(pa), hip.ptr(ma), hip.ptr(va), H, K, hip.ptr(G), H + 3, hip.ptr(X), K + 4, R, *hyper, hip.stream_ptr()), "ref")
     nb = lib.shasta_adam_lowrank_dx_workspace_bytes(H, K, Rdx)
@@ -780,3 +780,69 @@ def test_backward_at_the_headline_size_twice_the_same_bits():
     assert sum(float(v.abs().max()) > 0 for v in runs[0][0].values()) >= 60
     for x, y in ((runs[0][1], runs[1][1]), (runs[0][2], runs[1][2])):
         assert float((x - y).abs().max()) <= 1e-5 * max(float(x.abs().max()), 1e-12)
+
+
+@pytest.mark.gpu
+def test_capturable_adam_and_the_graphed_step_equal_the_eager_loop():
+    """FusedAdam(capturable=True): step number, lr and betas reach the kernels through device memory (shasta_adam_prepare_f32) - the same
+    weights as the plain optimizer under OneCycleLR (which cycles lr AND beta1), with the first-layer update inside the backward; and
+    training.GraphedTrainStep: the whole step (forward, loss, HIP backward, Adam) captured into a hipGraph once and replayed gives the
+    weights of the eager loop, step for step - the schedule moves between replays although launch arguments are frozen."""
+    import copy
+    from shasta_amd import training
+    c, model, w, a, b, det, prev, gt = _case(12, 7, 4, 3, seed=23)
+    dev = torch.device("cuda:0")
+    base = model.to(dev).train()
+    ad, bd, gtd, detd, prevd = a.to(dev), b.to(dev), gt.to(dev), det.to(dev).contiguous(), prev.to(dev).contiguous()
+    total = 9
+
+    def make(capturable):
+        m = copy.deepcopy(base)
+        opt = training.FusedAdam(m.parameters(), lr=1e-3, weight_decay=0.01, lowrank_first_layers=m, in_backward=True, capturable=capturable)
+        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=5e-3, total_steps=total + 1)
+        return m, opt, sched
+
+    def eager(m, opt, sched, steps, losses):
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            m1, m2 = training.affinity_train(m, ad, bd, detd.clone(), prevd)
+            loss = training.affinity_loss(m1, m2, gtd)
+            loss.backward()
+            opt.step()
+            sched.step()
+            losses.append(float(loss.detach()))
+    plain, cap, graphed = make(False), make(True), make(True)
+    lp, lc, lg = [], [], []
+    eager(*plain, total, lp)
+    eager(*cap, total, lc)
+    # the graphed loop: GraphedTrainStep's three warm-up steps run at the schedule's first value (no scheduler step between them), so
+    # the comparison loop does the same: three eager steps without moving the schedule, then one scheduler step per training step
+    ref = make(True)
+    for _ in range(3):
+        ref[1].zero_grad(set_to_none=True)
+        m1, m2 = training.affinity_train(ref[0], ad, bd, detd.clone(), prevd)
+        training.affinity_loss(m1, m2, gtd).backward()
+        ref[1].step()
+    lr_ = []
+    eager(*ref, total - 3, lr_)
+    step = training.GraphedTrainStep(graphed[0], graphed[1], ad, bd, detd, prevd, gtd, warmup=3)
+    for _ in range(total - 3):
+        lg.append(float(step(ad, bd, detd, prevd, gtd)))
+        graphed[2].step()
+    assert lp[-1] < lp[0]
+    for x, y in zip(lp, lc):
+        assert abs(x - y) <= 1e-6 * max(1.0, abs(x)), (lp, lc)
+    for (k, p), (_, q) in zip(plain[0].named_parameters(), cap[0].named_parameters()):
+        assert float((p - q).abs().max()) <= 1e-6 * max(1.0, float(p.abs().max())), k
+    for x, y in zip(lr_, lg):
+        assert abs(x - y) <= 1e-6 * max(1.0, abs(x)), (lr_, lg)
+    for (k, p), (_, q) in zip(ref[0].named_parameters(), graphed[0].named_parameters()):
+        assert float((p - q).abs().max()) <= 1e-6 * max(1.0, float(p.abs().max())), k
+    # the device-side step counter moved with the replays; an eager forward after training sees the trained weights
+    assert int(graphed[1].param_groups[0]["_shasta_dev"]["step"]) == total
+    graphed[0].eval()
+    ref[0].eval()
+    with torch.no_grad():
+        e1, _ = graphed[0].affinity_from_bev(ad, bd, detd.clone(), prevd)
+        r1, _ = ref[0].affinity_from_bev(ad, bd, detd.clone(), prevd)
+    assert float((e1 - r1).abs().max()) <= 1e-6

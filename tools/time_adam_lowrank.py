@@ -33,10 +33,10 @@ ws = torch.empty((nb + 3) // 4, device=dev)
 def step(i, n):
     if a.dx:
         hip.check(lib.shasta_adam_lowrank_dx_f32(hip.ptr(ps[i]), hip.ptr(ms[i]), hip.ptr(vs[i]), H, K, hip.ptr(G), H, hip.ptr(X), K, R, hip.ptr(G), H, R, hip.ptr(Y), K, 1,
-                                                 hip.ptr(ws), nb, 1e-4, 0.9, 0.999, 1e-8, 0.0, n, hip.stream_ptr()), "adam_lowrank_dx")
+                                                 hip.ptr(ws), nb, 1e-4, 0.9, 0.999, 1e-8, 0.0, n, None, hip.stream_ptr()), "adam_lowrank_dx")
         return
     hip.check(lib.shasta_adam_lowrank_f32(hip.ptr(ps[i]), hip.ptr(ms[i]), hip.ptr(vs[i]), H, K, hip.ptr(G), H, hip.ptr(X), K, R, 1e-4, 0.9, 0.999, 1e-8, 0.0,
-                                          n, hip.stream_ptr()), "adam_lowrank")
+                                          n, None, hip.stream_ptr()), "adam_lowrank")
 
 
 for n in range(1, 4):

@@ -22,6 +22,7 @@ ap.add_argument("--json", action="store_true", help="print one JSON line instead
 ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused HIP step")
 ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32", help="Shasta.train_precision: operands of the pair / aff GEMMs of the backward")
 ap.add_argument("--in-backward", action="store_true", help="FusedAdam(in_backward=True): the first aug_shape layers step inside loss.backward()")
+ap.add_argument("--graph", action="store_true", help="the whole step captured into a hipGraph and replayed (training.GraphedTrainStep, FusedAdam(capturable=True))")
 a = ap.parse_args()
 rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
 torch.cuda.set_device(local_rank)
@@ -37,7 +38,8 @@ cfg = dict(type="Shasta", reader=None, backbone=None, neck=None,
 model = shasta_amd.build_simp_track(cfg).to(dev).train()
 model.train_precision = a.precision
 params = training.affinity_params(model)
-opt = torch.optim.Adam(params, lr=1e-4) if a.torch_adam else training.FusedAdam(params, lr=1e-4, lowrank_first_layers=model, in_backward=a.in_backward)
+opt = torch.optim.Adam(params, lr=1e-4) if a.torch_adam else training.FusedAdam(params, lr=1e-4, lowrank_first_layers=model, in_backward=a.in_backward,
+                                                                                capturable=a.graph)
 N, B = a.max_obj, a.batch
 g = torch.Generator(device="cpu").manual_seed(1 + rank)
 bev = torch.relu(torch.randn(B, a.hw, a.hw, 64, generator=g)).to(dev)
@@ -58,7 +60,14 @@ def boxes():
 det0, prev0 = boxes(), boxes()
 gt = (torch.rand(B, N + 2, N + 2, generator=g) < 0.02).float().to(dev)
 gt[:, 0, 0] = 1
-for it in range(a.steps + 2):
+if a.graph:
+    step = training.GraphedTrainStep(model, opt, bev, pbev, det0, prev0, gt)
+    for it in range(a.steps + 2):
+        if it == 2:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        loss = step(bev, pbev, det0, prev0, gt)
+for it in range(0 if a.graph else a.steps + 2):
     if it == 2:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
