@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void vox_key_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const float f = floorf(__fdiv_rn(__fsub_rn(pts[gi * ndim + j], G.lo[j]), G.vs[j]));
-        if (f < 0.0f || f >= (float)G.g[j]) ok = false;
+        if (!(f >= 0.0f && f < (float)G.g[j])) ok = false;  // a NaN coordinate drops the point (undefined in the reference: its int cast indexes the map)
         cc[j] = ok ? (int)f : 0;
     }
     int key = -1;

@@ -993,6 +993,74 @@ def test_voxelize_batch_equals_cloud_by_cloud_and_the_c_oracle(sizes, mp, mv):
                 assert torch.equal(sv, v[i, :V]) and torch.equal(sc, c[i, :V]) and torch.equal(sn, n[i, :V]) and torch.equal(sm, mean[i, :V])
 
 
+@pytest.mark.parametrize("kind", ["one_cell", "few_cells", "edges", "non_finite", "descending"])
+def test_voxelize_adversarial_clouds(kind):
+    """The cases the hash table and the sorted slot insertion are most exposed to, bit for bit against the C twin of the serial loop:
+    2e5 points in ONE cell (every insertion meets the same max_points slots), 2e5 points in 37 cells (long same-key chains in the
+    table), points exactly on the faces of the range and of cells (floor((p - lo) / vs) in fp32 decides, upper faces are outside),
+    infinite and NaN coordinates (dropped: -inf / +inf fail the range test in the reference too; NaN is undefined there - its integer
+    cast indexes the dense map - and is dropped here), and a cloud whose cells appear in descending key order with the cap hit."""
+    from oracle import voxelize_oracle as VO
+    from shasta_amd.voxel_generator import points_to_voxel_batch_device, points_to_voxel_device
+    dev = _dev()
+    rng = np.random.default_rng(11)
+    mp, mv = 10, 160000
+    if kind == "one_cell":
+        P = 200000
+        pts = rng.normal(0, 1, (P, 5)).astype(np.float32)
+        pts[:, :3] = np.array([10.0, -3.0, -1.0], np.float32) + rng.uniform(0.001, 0.045, (P, 3)).astype(np.float32)
+    elif kind == "few_cells":
+        P = 200000
+        pts = rng.normal(0, 1, (P, 5)).astype(np.float32)
+        cell = rng.integers(0, 37, P)
+        pts[:, 0] = (cell * 0.075 + 0.03).astype(np.float32)
+        pts[:, 1] = 0.01
+        pts[:, 2] = -1.0
+    elif kind == "edges":
+        g = np.arange(-54, 54.0001, 0.075, dtype=np.float32)
+        xs = np.concatenate([g, np.nextafter(g, np.float32(100)), np.nextafter(g, np.float32(-100))])
+        P = xs.size * 3
+        pts = np.zeros((P, 5), np.float32)
+        pts[:, 3] = np.arange(P)
+        pts[: xs.size, 0], pts[: xs.size, 1], pts[: xs.size, 2] = xs, 0.5, -1.0
+        pts[xs.size: 2 * xs.size, 0], pts[xs.size: 2 * xs.size, 1], pts[xs.size: 2 * xs.size, 2] = 0.5, xs, -1.0
+        zs = np.resize(np.concatenate([np.arange(-5, 3.0001, 0.2, dtype=np.float32), np.float32([3.0, -5.0, 2.9999998, -5.0000005])]), xs.size)
+        pts[2 * xs.size:, 0], pts[2 * xs.size:, 1], pts[2 * xs.size:, 2] = -20.0, 20.0, zs
+    elif kind == "non_finite":
+        P = 50000
+        pts = _cloud(rng, P)
+        bad = rng.choice(P, 3000, replace=False)
+        vals = np.float32([np.nan, np.inf, -np.inf, -np.nan])
+        pts[bad, rng.integers(0, 3, bad.size)] = vals[rng.integers(0, 4, bad.size)]
+        pts[bad[:50], 3] = np.nan  # a NaN in a payload channel is just data
+    else:
+        P, mv = 60000, 5000
+        pts = np.zeros((P, 5), np.float32)
+        k = (P - 1 - np.arange(P)) // 3  # three points per cell, cells from far to near
+        pts[:, 0] = ((k % 1400) * 0.075 - 52).astype(np.float32)
+        pts[:, 1] = ((k // 1400) * 0.075 - 52).astype(np.float32)
+        pts[:, 2] = -1.0
+        pts[:, 3] = np.arange(P)
+    if kind == "non_finite":
+        keep = np.isfinite(pts[:, :3]).all(axis=1)
+        rv, rc, rn, rmean = VO.points_to_voxel(np.ascontiguousarray(pts[keep]), VS, RG, mp, mv, with_mean=True)
+    else:
+        rv, rc, rn, rmean = VO.points_to_voxel(pts, VS, RG, mp, mv, with_mean=True)
+    d = torch.from_numpy(pts).to(dev)
+    v, c, n, mean = points_to_voxel_device(d, VS, RG, mp, mv, with_mean=True)
+    assert v.shape[0] == rv.shape[0] and v.shape[0] > 0
+    assert np.array_equal(c.cpu().numpy(), rc) and np.array_equal(n.cpu().numpy(), rn)
+    assert np.array_equal(v.cpu().numpy(), rv, equal_nan=True)
+    np.testing.assert_allclose(mean.cpu().numpy(), rmean, rtol=1e-6, atol=1e-6, equal_nan=True)
+    # the same cloud twice in one batch call
+    bv, bc, bn, bm, nv = points_to_voxel_batch_device([d, d], VS, RG, mp, mv, with_mean=True)
+    V = v.shape[0]
+    assert nv.tolist() == [V, V]
+    for i in range(2):
+        assert torch.equal(bc[i, :V], c) and torch.equal(bn[i, :V], n)
+        assert np.array_equal(bv[i, :V].cpu().numpy(), rv, equal_nan=True)
+
+
 @pytest.mark.parametrize("name,B", [("small_32_7_4", 40), ("small_32_7_4", 100), ("car_90_3_5", 48), ("bicycle_50_3_5", 70), ("truck_60_3_5", 150)])
 def test_f32_arithmetic_option_matches_oracle_and_pieces(name, B):
     """The three settings of Shasta.arithmetic (shasta_weights.options) against the oracle on the same inputs: "f16x2" (default:
