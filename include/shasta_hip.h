@@ -60,7 +60,7 @@ const char* shasta_last_error(void);
  *  coors       (max_voxels, 3) int32 z,y,x
  *  num_points  (max_voxels,) int32
  *  mean        (max_voxels, ndim) fp32 or NULL        -- sum over slots / count
- *  num_voxels  (1,) int32 device scalar (V); rows >= V of `voxels` are zero, of the other outputs unspecified
+ *  num_voxels  (1,) int32 device scalar (V); rows >= V of every output are not written (the reference returns the first V rows)
  *  workspace   shasta_voxelize_workspace_bytes(P, max_voxels, max_points) bytes.  It holds, besides the per-point scratch, the
  *              cell -> first point map: the reference allocates a dense (gz, gy, gx) int32 map per call (331 MB for the nuScenes
  *              grid, point_cloud_ops.py:150); a cloud of P points touches at most P cells, so here it is an open-addressing hash

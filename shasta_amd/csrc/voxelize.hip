@@ -14,8 +14,8 @@
 //   3. every other point inserts itself into the voxel's slots 1..max_points-1, kept sorted by point index (atomicMin leaves the
 //      smaller value in the slot, the larger one moves on): the slots end up with the first max_points points, exactly the ones the
 //      serial loop keeps
-//   4. the voxel rows are cleared up front (one memset: the padding); per voxel the filled slots are counted, their points copied
-//      in, mean = (sum over slots) / count.
+//   4. per voxel the filled slots are counted, their points copied in and the other slots zeroed (whole rows, put together in LDS),
+//      mean = (sum over slots) / count.
 // cell[.]: the reference keeps a dense (40, 1440, 1440) int32 map of the grid (332 MB for nuScenes, allocated on every call,
 // point_cloud_ops.py:150).  A cloud of P points touches at most P cells: here the map is an open-addressing hash table of
 // 2^ceil(log2(2 P)) (key, first point) entries per cloud (8 MB for 3e5 points), cleared by one memset per call - random accesses over
@@ -216,13 +216,76 @@ __global__ __launch_bounds__(256) void vox_insert_kernel(VoxBatch B, int max_vox
     }
 }
 
-// Eight lanes per voxel (lane = channel; a loop beyond 8 channels).  The voxel rows were cleared by ONE memset in front of the chain
-// (a streaming fill of the zero-padded (max_voxels, max_points, ndim) output - most of it stays padding); here the filled slots
-// (contiguous from 0) are counted, their points copied from the cloud into the voxel's rows and, for the reader
-// (voxel_encoder.py:18-28), summed in slot order / their number.  grid.y = cloud
+// The outputs of 32 voxels per workgroup.  The filled slots of a voxel (contiguous from 0) name its points, the other slots are the
+// zero padding of the reference's np.zeros output; for the reader (voxel_encoder.py:18-28) all max_points slots are summed in slot
+// order - padding included, as points.sum(dim=1) does - and divided by the count.  The 32 complete rows (max_points * ndim floats each,
+// back to back in the output) are put together in LDS: one thread per (voxel, slot) - the slot words of the 32 voxels are one linear
+// run, and every point fetch of the workgroup is in flight at once (a loop over the slots per voxel is a chain of max_points dependent
+// slot -> point loads: 0.25 ms per 16 clouds, latency bound) - then eight lanes per voxel count and sum, and the rows leave as one
+// linear run of 16-byte stores.  Rounds 1 - 6a cleared the whole (max_voxels, max_points, ndim) output with a memset in front of the
+// chain (512 MB per 16 clouds) and stored the kept points over it in 20-byte pieces.  Rows >= V are not written.  grid.y = cloud
+template <int NDIM>
+__device__ __forceinline__ void vox_copy_point(const float* __restrict__ src, float* dst, int ndim, bool filled) {
+    if (NDIM > 0) {
+        float v[NDIM > 0 ? NDIM : 1];
+#pragma unroll
+        for (int k = 0; k < NDIM; ++k) v[k] = filled ? src[k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < NDIM; ++k) dst[k] = v[k];
+    } else {
+        for (int k = 0; k < ndim; ++k) dst[k] = filled ? src[k] : 0.0f;
+    }
+}
+template <int NDIM>
 __global__ __launch_bounds__(256) void vox_finalize_kernel(const float* __restrict__ pts, VoxBatch B, const int* __restrict__ slot_idx,
-                                                           const int* __restrict__ num_voxels, int max_voxels, int max_points, int ndim,
+                                                           const int* __restrict__ num_voxels, int max_voxels, int max_points, int ndim_rt,
                                                            float* __restrict__ voxels, int* __restrict__ num_points, float* __restrict__ mean) {
+    extern __shared__ __attribute__((aligned(16))) float vox_tile[];  // [32][max_points][ndim]
+    const int ndim = NDIM > 0 ? NDIM : ndim_rt;
+    const int c = blockIdx.y, V = num_voxels[c], v0 = blockIdx.x * 32;
+    if (v0 >= V) return;  // the whole workgroup
+    const int nv = min(32, V - v0), rowlen = max_points * ndim;
+    const size_t row0 = (size_t)c * max_voxels + v0;
+    const int* sl = slot_idx + row0 * max_points;
+    const float* cloud = pts + (size_t)B.off[c] * ndim;
+    for (int p = threadIdx.x; p < nv * max_points; p += 256) {
+        const int idx = sl[p];
+        const bool filled = idx != kSlotEmpty;
+        vox_copy_point<NDIM>(cloud + (size_t)(filled ? idx : 0) * ndim, vox_tile + (size_t)p * ndim, ndim, filled);
+    }
+    __syncthreads();
+    const int g = threadIdx.x >> 3, k0 = threadIdx.x & 7;
+    if (g < nv) {
+        int cnt = 0;
+        for (int r = k0; r < max_points; r += 8) cnt += sl[g * max_points + r] != kSlotEmpty;
+        cnt += __shfl_xor(cnt, 1, 64);
+        cnt += __shfl_xor(cnt, 2, 64);
+        cnt += __shfl_xor(cnt, 4, 64);
+        if (k0 == 0) num_points[row0 + g] = cnt;
+        if (mean) {
+            for (int k = k0; k < ndim; k += 8) {
+                float s = 0.0f;
+                for (int r = 0; r < max_points; ++r) s += vox_tile[g * rowlen + r * ndim + k];
+                mean[(row0 + g) * ndim + k] = s / (float)cnt;
+            }
+        }
+    }
+    const int nfl = nv * rowlen;
+    float* out = voxels + row0 * rowlen;
+    int done = 0;
+    if (((uintptr_t)out & 15) == 0) {
+        for (int i = threadIdx.x; i < nfl / 4; i += 256)
+            __builtin_nontemporal_store(reinterpret_cast<const f32x4*>(vox_tile)[i], reinterpret_cast<f32x4*>(out) + i);
+        done = nfl & ~3;
+    }
+    for (int i = done + threadIdx.x; i < nfl; i += 256) out[i] = vox_tile[i];
+}
+
+// The same for rows too long for LDS (32 x max_points x ndim floats above 64 KB): eight lanes per voxel (lane = channel; a loop beyond
+// 8 channels) walk the slots and store straight into the output.
+__global__ __launch_bounds__(256) void vox_finalize_direct_kernel(const float* __restrict__ pts, VoxBatch B, const int* __restrict__ slot_idx,
+                                                                  const int* __restrict__ num_voxels, int max_voxels, int max_points, int ndim,
+                                                                  float* __restrict__ voxels, int* __restrict__ num_points, float* __restrict__ mean) {
     const int c = blockIdx.y;
     const int v = blockIdx.x * 32 + (threadIdx.x >> 3), k0 = threadIdx.x & 7;
     if (v >= num_voxels[c]) return;
@@ -230,18 +293,17 @@ __global__ __launch_bounds__(256) void vox_finalize_kernel(const float* __restri
     const int* sl = slot_idx + row * max_points;
     const float* cloud = pts + (size_t)B.off[c] * ndim;
     float* dst = voxels + row * max_points * ndim;
-    // (slot r, its point, slot r + 1, ...: a form with all slot loads and gathers of a voxel in flight at once - indices handed round the
-    // eight lanes by shuffles - ran 3 % slower per batch in an alternating A/B on one box)
     int cnt = 0;
+    bool live = true;
     float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int r = 0; r < max_points; ++r) {
-        const int idx = sl[r];
-        if (idx == kSlotEmpty) break;
-        ++cnt;
+        const int idx = live ? sl[r] : kSlotEmpty;
+        if (idx == kSlotEmpty) live = false;
+        else ++cnt;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (k0 + 8 * j < ndim) {
-                const float val = cloud[(size_t)idx * ndim + k0 + 8 * j];
+                const float val = live ? cloud[(size_t)idx * ndim + k0 + 8 * j] : 0.0f;
                 dst[r * ndim + k0 + 8 * j] = val;
                 s[j] += val;
             }
@@ -324,8 +386,6 @@ static int vox_batch(const float* points, const int* h_offsets, int n, int ndim,
     hipError_t e = hipMemsetAsync(num_voxels, 0, (size_t)n * sizeof(int32_t), st);  // (clouds without points never write theirs)
     if (e == hipSuccess && nb > 0 && max_voxels > 0) e = hipMemsetAsync(table, 0xff, ((size_t)n << B.tbits) * sizeof(VoxCell), st);
     if (e == hipSuccess && nb > 0 && max_voxels > 0) e = hipMemsetAsync(slots, 0x7f, (size_t)n * max_voxels * max_points * sizeof(int), st);
-    // the zero padding of the voxel rows (slots nobody takes): one streaming fill instead of scattered 20-byte stores
-    if (e == hipSuccess && nb > 0 && max_voxels > 0) e = hipMemsetAsync(voxels, 0, (size_t)n * max_voxels * max_points * ndim * sizeof(float), st);
     if (e != hipSuccess) {
         set_error("voxelize: memset", e);
         return SHASTA_E_LAUNCH;
@@ -344,8 +404,20 @@ static int vox_batch(const float* points, const int* h_offsets, int n, int ndim,
         hipLaunchKernelGGL(vox_insert_kernel, dim3(nb), dim3(256), 0, st, B, max_voxels, max_points, pvid, vidp, slots);
         if ((rc = check_launch("vox_insert"))) return rc;
     }
-    hipLaunchKernelGGL(vox_finalize_kernel, dim3((unsigned)cdiv(max_voxels, 32), n), dim3(256), 0, st, points, B, slots, num_voxels, max_voxels,
-                       max_points, ndim, voxels, num_points_per_voxel, mean);
+    const size_t tile = (size_t)32 * max_points * ndim * sizeof(float);  // 6.4 KB for 10 x 5
+    const dim3 fgrid((unsigned)cdiv(max_voxels, 32), n);
+    if (tile > 64 * 1024)
+        hipLaunchKernelGGL(vox_finalize_direct_kernel, fgrid, dim3(256), 0, st, points, B, slots, num_voxels, max_voxels, max_points, ndim, voxels,
+                           num_points_per_voxel, mean);
+    else if (ndim == 5)
+        hipLaunchKernelGGL(vox_finalize_kernel<5>, fgrid, dim3(256), tile, st, points, B, slots, num_voxels, max_voxels, max_points, ndim, voxels,
+                           num_points_per_voxel, mean);
+    else if (ndim == 4)
+        hipLaunchKernelGGL(vox_finalize_kernel<4>, fgrid, dim3(256), tile, st, points, B, slots, num_voxels, max_voxels, max_points, ndim, voxels,
+                           num_points_per_voxel, mean);
+    else
+        hipLaunchKernelGGL(vox_finalize_kernel<0>, fgrid, dim3(256), tile, st, points, B, slots, num_voxels, max_voxels, max_points, ndim, voxels,
+                           num_points_per_voxel, mean);
     return check_launch("vox_finalize");
 }
 

@@ -19,7 +19,7 @@ from . import hip
 def points_to_voxel_device(points, voxel_size, coors_range, max_points=35, max_voxels=20000, with_mean=False, sync=True):
     """points: (P, ndim) fp32 DEVICE tensor.  Returns device tensors (voxels (V,max_points,ndim), coors (V,3) zyx int32,
     num_points (V,) int32[, mean (V,ndim)]) -- one host sync to read V.  sync=False: nothing is read back - the tensors come with all
-    max_voxels rows and the count as a (1,) int32 device tensor appended (rows >= V: zero in `voxels`, unspecified elsewhere)."""
+    max_voxels rows and the count as a (1,) int32 device tensor appended (rows >= V are not written)."""
     lib = hip.load()
     if not points.is_cuda:
         raise hip.ShastaHipError("points_to_voxel_device needs a device tensor (no CPU path)")
