@@ -167,6 +167,47 @@ def test_voxelizer_random_clouds_bit_exact_vs_c_oracle(P, ndim, mp, mv, grid, se
     np.testing.assert_allclose(mean.cpu().numpy(), rmean, rtol=1e-6, atol=1e-6)
 
 
+def _vox_batch_cases(n, seed):
+    rnd = random.Random(seed)
+    out = []
+    for k in range(n):
+        nc = rnd.choice([1, 2, 3, 7, 16, 32])
+        sizes = tuple(rnd.choice([0, 1, 255, 256, 257, 3000, 20000]) for _ in range(nc))
+        out.append((sizes, rnd.choice([3, 4, 5, 6, 9]), rnd.choice([1, 2, 10, 35]), rnd.choice([1, 50, 4000]), rnd.choice(["nusc", "coarse", "tiny"]), 7000 + k))
+    return out
+
+
+@pytest.mark.parametrize("sizes,ndim,mp,mv,grid,seed", _vox_batch_cases(10, 77))
+def test_voxelizer_random_batches_bit_exact_vs_c_oracle(sizes, ndim, mp, mv, grid, seed):
+    """shasta_voxelize_mean_batch_f32 on random batches: 1 - 32 clouds of random sizes (empty ones, ones that end on a workgroup
+    boundary), point widths 3 - 9, capacities and grids; every cloud bit for bit the serial C restatement, counts on the device."""
+    from oracle import voxelize_oracle as VO
+    from shasta_amd.voxel_generator import points_to_voxel_batch_device
+    dev = torch.device("cuda:0")
+    vs, rg = {"nusc": ([0.075, 0.075, 0.2], [-54, -54, -5, 54, 54, 3]), "coarse": ([0.5, 0.5, 8.0], [-20, -30, -5, 20, 30, 3]),
+              "tiny": ([1.0, 2.0, 4.0], [0, 0, 0, 4, 6, 4])}[grid]
+    vs, rg = np.array(vs, np.float32), np.array(rg, np.float32)
+    rng = np.random.default_rng(seed)
+    clouds = []
+    for P in sizes:
+        pts = rng.normal(0, 1, (P, ndim)).astype(np.float32)
+        pts[:, :3] = (rg[:3] + (rg[3:] - rg[:3]) * rng.uniform(-0.1, 1.1, (P, 3))).astype(np.float32)
+        if P > 10:
+            pts[: P // 7] = pts[P // 2: P // 2 + P // 7]
+        clouds.append(pts)
+    if sum(sizes) == 0:
+        clouds[0] = np.zeros((0, ndim), np.float32)
+    v, c, n, mean, nv = points_to_voxel_batch_device([torch.from_numpy(x).to(dev) for x in clouds], vs, rg, mp, mv, with_mean=True)
+    nvh = nv.cpu().numpy()
+    for i, pts in enumerate(clouds):
+        rv, rc, rn, rmean = VO.points_to_voxel(pts, vs, rg, mp, mv, with_mean=True)
+        V = int(nvh[i])
+        assert V == rv.shape[0], i
+        assert np.array_equal(c[i, :V].cpu().numpy(), rc) and np.array_equal(n[i, :V].cpu().numpy(), rn), i
+        assert np.array_equal(v[i, :V].cpu().numpy(), rv), i
+        np.testing.assert_allclose(mean[i, :V].cpu().numpy(), rmean, rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("npnt,seed", [(1, 1), (4, 2), (5, 3)])
 def test_boxes_outside_the_map_follow_the_reference_clamping(npnt, seed):
     """bilinear_interpolate_torch clamps the corner INDICES to the map but takes the weights from the clamped indices
