@@ -559,7 +559,9 @@ int shasta_colsum_f32(const float* Y, int ldy, int M, int N, float* out, float* 
 /* columns [c0,c1) of rows of width `cols`: forward out = |x|, backward out = g*sign(x); other columns pass through */
 int shasta_abs_f32(const float* x, const float* g, float* out, long n, int cols, int c0, int c1, int backward,
                    shasta_stream_t stream);
-/* gradient of shasta_bev_gather_f32 w.r.t. the BEV map (scatter-add with float atomics; dbev must be zeroed by the caller) */
+/* gradient of shasta_bev_gather_f32 w.r.t. the BEV map, ADDED to dbev (zeroed by the caller).  H * W < 2^17 (the reference's 180 x 180):
+ * the terms of a pixel are summed in a fixed order - one workgroup per batch item sorts its N * num_point * 4 contributions by pixel in
+ * LDS - so the result is bit-reproducible; larger maps: scatter-add with float atomics (equal to fp32 rounding only). */
 int shasta_bev_gather_bwd_f32(const float* dfeat, int B, int H, int W, int C, const float* boxes, int N, int box_stride,
                               int box_batch_stride, int num_point, float pc_x0, float pc_y0, float vs_x, float vs_y,
                               float out_stride, int row_stride, int batch_stride, float* dbev, shasta_stream_t stream);

@@ -604,20 +604,21 @@ __global__ __launch_bounds__(256) void smallm_finish_kernel(const float* __restr
     *y = accumulate ? *y + s : s;
 }
 
-// gather backward: dBEV[b, y, x, :] += w * dfeat[b, n, pt*C : (pt+1)*C] for the four corners of every point (atomics)
-__global__ __launch_bounds__(256) void bev_gather_bwd_kernel(const float* __restrict__ dfeat, int H, int W, int C,
-                                                             const float* __restrict__ boxes, int N, int box_stride,
-                                                             int box_batch_stride, int num_point, float pc_x0, float pc_y0,
-                                                             float vs_x, float vs_y, float out_stride_px, int row_stride,
-                                                             int batch_stride, int total_points, float* __restrict__ dbev) {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (wave >= total_points) return;
-    const int pt = wave % num_point, n = (wave / num_point) % N, b = wave / (num_point * N);
-    const float* box = boxes + (size_t)b * box_batch_stride + (size_t)n * box_stride;
+// ---- gather backward: dBEV[b, y, x, :] += w * dfeat[b, n, pt*C : (pt+1)*C] for the four corners of every point ---------------------
+struct GatherBwdArgs {
+    const float* dfeat;
+    const float* boxes;
+    float* dbev;
+    int H, W, C, N, box_stride, box_batch_stride, num_point, row_stride, batch_stride;
+    float pc_x0, pc_y0, vs_x, vs_y, out_stride_px;
+};
+// the four corner pixels (y0 x0, y1 x0, y0 x1, y1 x1 - the order of the forward's terms) and weights of point `pt` of box n of item b:
+// the forward's arithmetic (bev_gather_kernel, center_utils.py:92-121), operation for operation
+__device__ __forceinline__ void gather_bwd_corners(const GatherBwdArgs& a, int b, int n, int pt, int (&pix)[4], float (&wgt)[4]) {
+    const float* box = a.boxes + (size_t)b * a.box_batch_stride + (size_t)n * a.box_stride;
     const float cx = box[0], cy = box[1];
     float px = cx, py = cy;
-    const int edge = (num_point == 5) ? pt - 1 : (num_point == 4 ? pt : -1);
+    const int edge = (a.num_point == 5) ? pt - 1 : (a.num_point == 4 ? pt : -1);
     if (edge >= 0) {
         const float w = box[3], l = box[4], yaw = box[6];
         const float s = sinf(yaw), c = cosf(yaw);
@@ -634,26 +635,176 @@ __global__ __launch_bounds__(256) void bev_gather_bwd_kernel(const float* __rest
         px = __fdiv_rn(__fadd_rn(qx[0], qx[1]), 2.0f);
         py = __fdiv_rn(__fadd_rn(qy[0], qy[1]), 2.0f);
     }
-    const float x = __fdiv_rn(__fdiv_rn(__fsub_rn(px, pc_x0), vs_x), out_stride_px);
-    const float y = __fdiv_rn(__fdiv_rn(__fsub_rn(py, pc_y0), vs_y), out_stride_px);
+    const float x = __fdiv_rn(__fdiv_rn(__fsub_rn(px, a.pc_x0), a.vs_x), a.out_stride_px);
+    const float y = __fdiv_rn(__fdiv_rn(__fsub_rn(py, a.pc_y0), a.vs_y), a.out_stride_px);
     auto clampi = [](float f, int hi) -> int {
         if (!(f > -2.0f)) return -1;
         if (f > (float)(hi + 1)) return hi + 1;
         return (int)f;
     };
-    int x0 = clampi(floorf(x), W), y0 = clampi(floorf(y), H);
+    int x0 = clampi(floorf(x), a.W), y0 = clampi(floorf(y), a.H);
     int x1 = x0 + 1, y1 = y0 + 1;
-    x0 = min(max(x0, 0), W - 1); x1 = min(max(x1, 0), W - 1);
-    y0 = min(max(y0, 0), H - 1); y1 = min(max(y1, 0), H - 1);
-    const float wa = (x1 - x) * (y1 - y), wb = (x1 - x) * (y - y0), wc = (x - x0) * (y1 - y), wd = (x - x0) * (y - y0);
-    float* im = dbev + (size_t)b * H * W * C;
-    const float* g = dfeat + (size_t)b * batch_stride + (size_t)n * row_stride + (size_t)pt * C;
-    for (int ch = lane; ch < C; ch += 64) {
+    x0 = min(max(x0, 0), a.W - 1); x1 = min(max(x1, 0), a.W - 1);
+    y0 = min(max(y0, 0), a.H - 1); y1 = min(max(y1, 0), a.H - 1);
+    wgt[0] = (x1 - x) * (y1 - y); wgt[1] = (x1 - x) * (y - y0); wgt[2] = (x - x0) * (y1 - y); wgt[3] = (x - x0) * (y - y0);
+    pix[0] = y0 * a.W + x0; pix[1] = y1 * a.W + x0; pix[2] = y0 * a.W + x1; pix[3] = y1 * a.W + x1;
+}
+
+// Scatter-add with float atomics: the order of the additions into a pixel several points touch is whatever the hardware makes it
+// (results agree to fp32 rounding, not bit for bit).  Only for maps of 2^17 pixels or more (the sorted form's key has 17 pixel bits).
+__global__ __launch_bounds__(256) void bev_gather_bwd_atomic_kernel(GatherBwdArgs a, int total_points) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= total_points) return;
+    const int pt = wave % a.num_point, n = (wave / a.num_point) % a.N, b = wave / (a.num_point * a.N);
+    int pix[4];
+    float wgt[4];
+    gather_bwd_corners(a, b, n, pt, pix, wgt);
+    float* im = a.dbev + (size_t)b * a.H * a.W * a.C;
+    const float* g = a.dfeat + (size_t)b * a.batch_stride + (size_t)n * a.row_stride + (size_t)pt * a.C;
+    for (int ch = lane; ch < a.C; ch += 64) {
         const float v = g[ch];
-        atomicAdd(im + ((size_t)y0 * W + x0) * C + ch, v * wa);
-        atomicAdd(im + ((size_t)y1 * W + x0) * C + ch, v * wb);
-        atomicAdd(im + ((size_t)y0 * W + x1) * C + ch, v * wc);
-        atomicAdd(im + ((size_t)y1 * W + x1) * C + ch, v * wd);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(im + (size_t)pix[k] * a.C + ch, __fmul_rn(v, wgt[k]));
+    }
+}
+
+// The same sums in a FIXED order (bit-reproducible).  G workgroups per batch item (G a power of two); workgroup q takes the pixels with
+// pixel mod G == q: it walks the item's N * num_point * 4 contributions (contribution i = corner i & 3 of point i >> 2), keeps the
+// ones that fall on its pixels - key (pixel << 15 | i) and bilinear weight in LDS -, a bitonic sort puts the contributions of a pixel
+// next to each other in ascending i, and the first of every run - a quarter wavefront per run, lanes over the channels - adds the run's
+// terms w * dfeat in that order and adds the sum to the pixel (nobody else writes that pixel).  Items with more than 16384
+// contributions are taken in chunks of 16384, one after the other; a pixel keeps its workgroup over the chunks.
+// (One workgroup per item sorting all 8000 keys of N = 500 and walking the runs a wavefront each: 1.1 ms; the runs by quarter
+// wavefronts, 16 workgroups per item each sorting everything: 0.122 ms = 8 us keys + 51 us sort + 63 us runs; this form: see DESIGN.md.)
+constexpr int GB_CHUNK = 16384, GB_THREADS = 1024;
+// the compare-exchange steps with partner distance j <= 64 of the merge widths k_lo .. k_hi, on blocks of 128 keys held two per lane
+// (positions base + lane and base + 64 + lane): j = 64 compares the lane's own two keys, smaller j exchange across lanes
+__device__ __forceinline__ void gb_wave_steps(uint32_t* keys, int npad, int k_lo, int k_hi, int wave, int lane) {
+    for (int base = wave * 128; base < npad; base += (GB_THREADS / 64) * 128) {
+        const int p0 = base + lane, p1 = p0 + 64;
+        uint32_t x0 = keys[p0], x1 = keys[p1];
+        for (int k = k_lo; k <= k_hi; k <<= 1) {
+            const bool up0 = (p0 & k) == 0, up1 = (p1 & k) == 0;
+            for (int j = min(k >> 1, 64); j > 0; j >>= 1) {
+                if (j == 64) {
+                    if ((x0 > x1) == up0) {  // (p0 and p1 differ in bit 6 only: same direction for k > 64)
+                        const uint32_t t = x0;
+                        x0 = x1;
+                        x1 = t;
+                    }
+                } else {
+                    const uint32_t y0 = (uint32_t)__shfl_xor((int)x0, j, 64), y1 = (uint32_t)__shfl_xor((int)x1, j, 64);
+                    const bool lower = (lane & j) == 0;
+                    x0 = (lower == up0) ? min(x0, y0) : max(x0, y0);
+                    x1 = (lower == up1) ? min(x1, y1) : max(x1, y1);
+                }
+            }
+        }
+        keys[p0] = x0;
+        keys[p1] = x1;
+    }
+}
+__global__ __launch_bounds__(GB_THREADS) void bev_gather_bwd_sorted_kernel(GatherBwdArgs a, int G) {
+    extern __shared__ uint32_t gb_keys[];  // [npad] keys, then [chunk] weights
+    const int b = blockIdx.x / G, q = blockIdx.x % G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = a.N * a.num_point * 4;
+    float* im = a.dbev + (size_t)b * a.H * a.W * a.C;
+    int npad_max = 128;
+    while (npad_max < per && npad_max < GB_CHUNK) npad_max <<= 1;
+    float* gb_w = reinterpret_cast<float*>(gb_keys + npad_max);
+    __shared__ int gb_cnt;
+    const uint32_t gmask = (uint32_t)G - 1u;
+    const bool vec4 = a.C % 4 == 0 && (a.row_stride | a.batch_stride) % 4 == 0 && (((uintptr_t)a.dfeat | (uintptr_t)a.dbev) & 15) == 0;
+    for (int c0 = 0; c0 < per; c0 += GB_CHUNK) {
+        const int n = min(GB_CHUNK, per - c0);
+        if (tid == 0) gb_cnt = 0;
+        __syncthreads();
+        for (int p = tid; p < (n + 3) / 4; p += GB_THREADS) {  // a point: its (up to) four contributions
+            const int pg = (c0 >> 2) + p;
+            int pix[4];
+            float wgt[4];
+            gather_bwd_corners(a, b, pg / a.num_point, pg % a.num_point, pix, wgt);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (4 * p + k < n && ((uint32_t)pix[k] & gmask) == (uint32_t)q) {
+                    gb_keys[atomicAdd(&gb_cnt, 1)] = ((uint32_t)pix[k] << 15) | (uint32_t)(4 * p + k);  // (any order: sorted below)
+                    gb_w[4 * p + k] = wgt[k];
+                }
+        }
+        __syncthreads();
+        const int m = gb_cnt;  // this workgroup's contributions of the chunk
+        int npad = 128;
+        while (npad < m) npad <<= 1;
+        for (int i = m + tid; i < npad; i += GB_THREADS) gb_keys[i] = 0xffffffffu;
+        __syncthreads();
+#ifndef SHASTA_GB_SKIP_SORT  // timing diagnostic only (tools/time_gather_bwd.py): wrong results without the sort
+        gb_wave_steps(gb_keys, npad, 2, 128, wave, lane);
+        __syncthreads();
+        for (int k = 256; k <= npad; k <<= 1) {
+            for (int j = k >> 1; j >= 128; j >>= 1) {
+                for (int t = tid; t < (npad >> 1); t += GB_THREADS) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                    const uint32_t x = gb_keys[i], y = gb_keys[l];
+                    if ((x > y) == ((i & k) == 0)) {
+                        gb_keys[i] = y;
+                        gb_keys[l] = x;
+                    }
+                }
+                __syncthreads();
+            }
+            gb_wave_steps(gb_keys, npad, k, k, wave, lane);
+            __syncthreads();
+        }
+#endif
+        // runs -> pixels.  A quarter wavefront (16 lanes x 4 channels) per run, so that a wavefront has four runs' loads in flight;
+        // quarter qw walks the sorted positions [m qw / 64, m (qw + 1) / 64) and takes the runs that START there.
+#ifndef SHASTA_GB_SKIP_RUNS  // timing diagnostic only
+        {
+            const int qw = tid >> 4, ql = tid & 15;
+            const int r1 = (int)((long)m * (qw + 1) / 64);
+            int s = (int)((long)m * qw / 64);
+            for (;;) {
+                while (s < r1 && s > 0 && (gb_keys[s - 1] >> 15) == (gb_keys[s] >> 15)) ++s;  // the next start of a run
+                if (!__any(s < r1)) break;  // the whole wavefront is through
+                if (s < r1) {
+                    const uint32_t pixel = gb_keys[s] >> 15;
+                    float* o = im + (size_t)pixel * a.C;
+                    if (vec4) {
+                        for (int ch = 4 * ql; ch < a.C; ch += 64) {
+                            const f32x4 cur = *reinterpret_cast<const f32x4*>(o + ch);
+                            f32x4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
+                            for (int t = s; t < m && (gb_keys[t] >> 15) == pixel; ++t) {
+                                const int li = (int)(gb_keys[t] & 0x7fffu), pg = (c0 + li) >> 2;
+                                const float* g = a.dfeat + (size_t)b * a.batch_stride + (size_t)(pg / a.num_point) * a.row_stride + (size_t)(pg % a.num_point) * a.C;
+                                const f32x4 v = *reinterpret_cast<const f32x4*>(g + ch);
+                                const float w = gb_w[li];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) sum[e] = __fadd_rn(sum[e], __fmul_rn(v[e], w));
+                            }
+                            f32x4 r;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) r[e] = __fadd_rn(cur[e], sum[e]);
+                            *reinterpret_cast<f32x4*>(o + ch) = r;
+                        }
+                    } else {
+                        for (int ch = ql; ch < a.C; ch += 16) {
+                            float sum = 0.0f;
+                            for (int t = s; t < m && (gb_keys[t] >> 15) == pixel; ++t) {
+                                const int li = (int)(gb_keys[t] & 0x7fffu), pg = (c0 + li) >> 2;
+                                const float* g = a.dfeat + (size_t)b * a.batch_stride + (size_t)(pg / a.num_point) * a.row_stride + (size_t)(pg % a.num_point) * a.C;
+                                sum = __fadd_rn(sum, __fmul_rn(g[ch], gb_w[li]));
+                            }
+                            o[ch] = __fadd_rn(o[ch], sum);
+                        }
+                    }
+                    ++s;
+                }
+            }
+        }
+#endif
+        __syncthreads();  // the next chunk reuses the LDS arrays - and may add to the same pixels: its reads come behind these stores
+                          // (__syncthreads = release fence, barrier, acquire fence at workgroup scope; the wavefronts share the CU's L1)
     }
 }
 
@@ -787,9 +938,27 @@ extern "C" int shasta_bev_gather_bwd_f32(const float* dfeat, int B, int H, int W
     SHASTA_REQUIRE(num_point == 1 || num_point == 4 || num_point == 5, "bev_gather_bwd: num_point must be 1, 4 or 5");
     const long total = (long)B * N * num_point;
     if (total == 0) return SHASTA_OK;
-    hipLaunchKernelGGL(bev_gather_bwd_kernel, dim3(cdiv((int)total, 4)), dim3(256), 0, as_stream(stream), dfeat, H, W, C, boxes, N,
-                       box_stride, box_batch_stride, num_point, pc_x0, pc_y0, vs_x, vs_y, out_stride, row_stride, batch_stride,
-                       (int)total, dbev);
+    SHASTA_REQUIRE(total < (1L << 29) && H > 0 && W > 0 && C > 0, "bev_gather_bwd: bad size");
+    GatherBwdArgs a;
+    a.dfeat = dfeat; a.boxes = boxes; a.dbev = dbev;
+    a.H = H; a.W = W; a.C = C; a.N = N; a.box_stride = box_stride; a.box_batch_stride = box_batch_stride; a.num_point = num_point;
+    a.row_stride = row_stride; a.batch_stride = batch_stride;
+    a.pc_x0 = pc_x0; a.pc_y0 = pc_y0; a.vs_x = vs_x; a.vs_y = vs_y; a.out_stride_px = out_stride;
+    if ((long)H * W < (1L << 17)) {  // strictly: the largest key must stay below the padding word
+        const int per = N * num_point * 4;
+        int npad = 128;
+        while (npad < per && npad < GB_CHUNK) npad <<= 1;
+        const size_t lds = (size_t)(npad + (per < GB_CHUNK ? per : GB_CHUNK)) * sizeof(uint32_t);
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)bev_gather_bwd_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error_msg("bev_gather_bwd: the device refuses 128 KB of LDS per workgroup");
+            return SHASTA_E_UNSUPPORTED;
+        }
+        int G = 1;  // workgroups per batch item: two per CU as long as the items are few
+        while (G < 64 && (long)B * G < 512) G <<= 1;
+        hipLaunchKernelGGL(bev_gather_bwd_sorted_kernel, dim3((unsigned)(B * G)), dim3(GB_THREADS), lds, as_stream(stream), a, G);
+    } else {
+        hipLaunchKernelGGL(bev_gather_bwd_atomic_kernel, dim3(cdiv((int)total, 4)), dim3(256), 0, as_stream(stream), a, (int)total);
+    }
     return check_launch("bev_gather_bwd");
 }
 

@@ -750,7 +750,7 @@ def test_adam_lowrank_with_the_product_in_the_same_pass(R, Rdx, H, K):
 def test_backward_at_the_headline_size_twice_the_same_bits():
     """N = M = 500, F = 256, nf = 7 (the configuration the metric is quoted on), two frame-pairs: every parameter gradient of rows 6-16 is
     a sum in a fixed order (per-pair kernels, split-K slices, partial-sum passes) - two backward passes over the same inputs give the same
-    bits - finite, and not all zero; only the scatter-add into the BEV maps' gradient uses float atomics (agreement to fp32 rounding)."""
+    bits - finite, and not all zero; so do the gradients of the two BEV maps (the gather's backward sums a pixel's terms in a fixed order)."""
     import shasta_amd
     from shasta_amd import training
     dev = torch.device("cuda:0")
@@ -778,8 +778,48 @@ def test_backward_at_the_headline_size_twice_the_same_bits():
         assert torch.isfinite(v).all(), k
         assert torch.equal(v, runs[1][0][k]), k
     assert sum(float(v.abs().max()) > 0 for v in runs[0][0].values()) >= 60
-    for x, y in ((runs[0][1], runs[1][1]), (runs[0][2], runs[1][2])):
-        assert float((x - y).abs().max()) <= 1e-5 * max(float(x.abs().max()), 1e-12)
+    for x, y in ((runs[0][1], runs[1][1]), (runs[0][2], runs[1][2])):  # the BEV maps' gradients: sorted by pixel since round 6, no atomics
+        assert torch.equal(x, y) and float(x.abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,npnt,C,H,W,spread", [(3, 90, 5, 64, 180, 180, 2.0), (2, 500, 4, 64, 180, 180, 40.0), (1, 1700, 5, 32, 180, 180, 10.0),
+                                                  (2, 40, 4, 96, 31, 57, 8.0), (2, 25, 1, 64, 8, 8, 0.2), (2, 60, 5, 16, 400, 400, 5.0), (5, 30, 4, 30, 64, 64, 4.0),
+                                                  (300, 12, 5, 16, 48, 48, 3.0)])
+def test_gather_backward_is_a_fixed_order_sum(B, N, npnt, C, H, W, spread):
+    """shasta_bev_gather_bwd_f32 (autograd of bilinear_interpolate_torch, center_utils.py:92-121): boxes crowded into a few metres so that
+    many points share pixels; against autograd of the oracle's gather in float64, and - maps below 2^17 pixels: the contributions of a
+    batch item sorted by pixel in LDS, a pixel's terms added in ascending order - twice the same bits; 1700 x 5 points = 34 000
+    contributions go through the kernel in three chunks, boxes off the map through the clamped indices, a 400 x 400 map (2^17 pixels or
+    more) through the atomic form (equal to fp32 rounding only), 30 channels (no 16-byte accesses), 300 items (one workgroup each)."""
+    from shasta_amd import hip
+    lib = hip.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    boxes = O.synth_boxes(g, B, N, None)[:, :, :7].contiguous()
+    boxes[:, :, :2] = (torch.rand(B, N, 2, generator=g) - 0.5) * spread - 20.0
+    boxes[:, ::7, 0] = -60.0 - torch.rand(B, len(range(0, N, 7)), generator=g) * 5  # off the map
+    F = npnt * C
+    dfeat = torch.randn(B, N, F, generator=g)
+    stride = 108.0 / (0.075 * W)  # the map covers the 108 m range
+    bev = torch.zeros(B, H, W, C, dtype=torch.float64, requires_grad=True)
+    out = O.bev_gather(bev, boxes.double(), npnt, out_stride=stride)
+    out.backward(dfeat.double())
+    want = bev.grad
+    runs = []
+    dfeat_d, boxes_d = dfeat.to(dev), boxes.to(dev)  # (named: a temporary would be freed - and its block reused - before the launch)
+    for _ in range(2):
+        dbev = torch.zeros(B, H, W, C, device=dev)
+        hip.check(lib.shasta_bev_gather_bwd_f32(hip.ptr(dfeat_d), B, H, W, C, hip.ptr(boxes_d), N, 7, N * 7, npnt, -54.0, -54.0, 0.075, 0.075,
+                                                stride, F, N * F, hip.ptr(dbev), hip.stream_ptr()), "shasta_bev_gather_bwd_f32")
+        runs.append(dbev.cpu())
+    touched = int((want.abs().sum(-1) > 0).sum())
+    assert touched < B * N * npnt * 4 * 0.9 or spread > 20  # pixels ARE shared
+    _close("d bev (gather backward)", runs[0], want, rtol=2e-5)
+    if H * W < (1 << 17):
+        assert torch.equal(runs[0], runs[1])
+    else:
+        assert float((runs[0] - runs[1]).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
 @pytest.mark.gpu
