@@ -206,3 +206,55 @@ def test_training_from_the_neck_follows_the_sequential_path_step_by_step():
         assert float((p - q).abs().max()) <= 2e-4 * max(1.0, float(q.abs().max())), k
     for k in ("running_mean", "running_var"):
         assert torch.allclose(getattr(a.shared_conv[1], k), getattr(b.shared_conv[1], k), rtol=1e-3, atol=1e-5)
+
+
+def test_training_from_the_neck_is_bit_reproducible():
+    """Six training steps from the neck outputs (K0 hand-written, boxes crowded so that the gather's backward adds several terms into
+    the same pixels), twice from the same start: the same losses and the same weights bit for bit - every sum of the step, the
+    scatter-add into the BEV maps' gradient included, has a fixed order."""
+    import shasta_amd
+    from shasta_amd import training
+    dev = _dev()
+    torch.manual_seed(9)
+    cfg = dict(type="Shasta", reader=None, backbone=None, neck=None,
+               bev_extractor=dict(type="BEVFeatureExtractor", pc_start=[-54, -54], voxel_size=[0.075, 0.075], out_stride=8),
+               max_obj=40, num_feats=3, num_point=5, in_channels=32)
+    base = shasta_amd.build_simp_track(cfg).to(dev).train()
+    g = torch.Generator().manual_seed(10)
+    B, N, HW = 2, 40, 180
+    x = torch.relu(torch.randn(B, 32, HW, HW, generator=g)).to(dev)
+    xp = torch.relu(torch.randn(B, 32, HW, HW, generator=g)).to(dev)
+
+    def boxes():
+        t = torch.zeros(B, N, 11)
+        t[:, :, :2] = (torch.rand(B, N, 2, generator=g) - 0.5) * 6 + 10  # 40 boxes within 6 m: shared pixels
+        t[:, :, 2] = torch.randn(B, N, generator=g)
+        t[:, :, 3:6] = torch.rand(B, N, 3, generator=g) * 3 + 0.5
+        t[:, :, 6] = (torch.rand(B, N, generator=g) - 0.5) * 6.28
+        t[:, :, 7:9] = torch.randn(B, N, 2, generator=g)
+        t[:, :, 9] = 0.5
+        return t.to(dev)
+    det, prev = boxes(), boxes()
+    gt = torch.zeros(B, N + 2, N + 2)
+    perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B)])
+    gt[torch.arange(B)[:, None], torch.arange(N)[None, :], perm] = 1.0
+    gt = gt.to(dev)
+    runs = []
+    for _ in range(2):
+        m = copy.deepcopy(base)
+        opt = training.FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+        ls = []
+        for _ in range(6):
+            opt.zero_grad(set_to_none=True)
+            m1, m2, _ = m(dict(det_boxes=det.clone(), prev_det_boxes=prev.clone(), bev_map=x, prev_bev_map=xp), train_mode=True)
+            loss = training.affinity_loss(m1, m2, gt)
+            loss.backward()
+            opt.step()
+            ls.append(loss.detach().clone())
+        assert getattr(m, "_conv_raw", None) is not None
+        runs.append((torch.stack(ls), {k: p.detach().clone() for k, p in m.named_parameters()}))
+    assert torch.equal(runs[0][0], runs[1][0]), (runs[0][0], runs[1][0])
+    assert float(runs[0][0][-1]) < float(runs[0][0][0])
+    for k, p in runs[0][1].items():
+        assert torch.equal(p, runs[1][1][k]), k
+    assert not torch.equal(runs[0][1]["shared_conv.0.weight"], dict(base.named_parameters())["shared_conv.0.weight"])  # it moved
