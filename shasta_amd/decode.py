@@ -64,7 +64,8 @@ def decode_flags_launch(matched1, matched2, n_prev, n_cur):
     counts = torch.tensor([list(n_prev), list(n_cur)], dtype=torch.int32)
     counts = (counts.pin_memory() if dev.type == "cuda" else counts).to(dev, non_blocking=True)
     buf = torch.empty(4, B, N, dtype=torch.int32, device=dev)
-    hip.check(lib.shasta_decode_flags_f32(hip.ptr(matched1.contiguous()), hip.ptr(matched2.contiguous()), hip.ptr(counts[0]), hip.ptr(counts[1]),
+    m1c, m2c = matched1.contiguous(), matched2.contiguous()  # named: a copy made inside the call would be freed - and its block reused by the next one - before the launch
+    hip.check(lib.shasta_decode_flags_f32(hip.ptr(m1c), hip.ptr(m2c), hip.ptr(counts[0]), hip.ptr(counts[1]),
                                           B, N, hip.ptr(buf[0]), hip.ptr(buf[1].view(torch.float32)), hip.ptr(buf[2]),
                                           hip.ptr(buf[3].view(torch.float32)), hip.stream_ptr()), "shasta_decode_flags_f32")
     return buf

@@ -67,7 +67,8 @@ class SharedConvBank:
                 wp = torch.zeros(64, self.cin_padded, 3, 3, device=dev)
                 wp[:, :self.in_channels] = w
                 w = wp
-            hip.check(lib.shasta_shared_conv_pack_f16x2(hip.ptr(w), *[hip.ptr(t.contiguous()) for t in ts[1:]], float(m.shared_conv[1].eps),
+            rest = [t.contiguous() for t in ts[1:]]  # kept alive until the launch (a copy freed inside the call would lend its block to the next one)
+            hip.check(lib.shasta_shared_conv_pack_f16x2(hip.ptr(w), *[hip.ptr(t) for t in rest], float(m.shared_conv[1].eps),
                                                         self.cin_padded, C.c_void_p(self._packed.data_ptr() + i * self._stride), stride,
                                                         hip.stream_ptr()), "shasta_shared_conv_pack_f16x2")
         self._key = key

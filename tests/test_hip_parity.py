@@ -1243,7 +1243,8 @@ def test_fp16_weight_stream_with_outliers_inside_a_row(kind):
         det = O.synth_boxes(torch.Generator().manual_seed(1), B, N).to(dev)
         tabs = torch.empty(B, N + 2, 8, device=dev), torch.empty(B, N + 2, 8, device=dev)
         m1, m2 = torch.empty(B, N, N + 2, device=dev), torch.empty(B, N + 2, N, device=dev)
-        hip.check(lib.shasta_affinity_forward_train_f32(C.byref(w), hip.ptr(m._packed), B, hip.ptr(f1), hip.ptr(f2), hip.ptr(det), hip.ptr(det.clone()),
+        det2 = det.clone()
+        hip.check(lib.shasta_affinity_forward_train_f32(C.byref(w), hip.ptr(m._packed), B, hip.ptr(f1), hip.ptr(f2), hip.ptr(det), hip.ptr(det2),
                                                         11, hip.ptr(tabs[0]), hip.ptr(tabs[1]), hip.ptr(m1), hip.ptr(m2), hip.ptr(keep_res),
                                                         hip.ptr(keep_hid), hip.ptr(ws), wsb, hip.stream_ptr()), "forward_train")
         torch.cuda.synchronize()
