@@ -56,6 +56,7 @@ bash $R/tools/gpu_pmc_convtrain.sh ${1:-final} 8 > $O/convtrain_pmc.log 2>&1
 (cd $R && python3 tools/time_conv_train.py --batch 8 > $O/conv_train.jsonl 2>/dev/null; python3 tools/time_conv_train.py --batch 2 >> $O/conv_train.jsonl 2>/dev/null; python3 tools/time_conv_train.py --batch 64 --iters 4 >> $O/conv_train.jsonl 2>/dev/null)
 VOX_ITERS=5 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_voxelize -o d -- python3 $R/tools/time_voxelize.py > $O/voxelize_prof.log 2>&1
 (cd $R && python3 tools/time_voxelize.py > $O/voxelize.log 2>&1)
+(cd $R && python3 tools/time_gather_bwd.py 2>&1 | grep us > $O/gather_bwd.log; python3 tools/probes/train_determinism.py 2>&1 | tail -3 > $O/train_determinism.log; python3 tools/train_soak_conv.py 2>&1 | tail -3 > $O/train_soak_conv.log)
 grep -h '^{' $O/bench_default.json $O/bench_b1.json $O/bench_b64.json $O/bench_b128.json $O/bench_b512.json $O/bench_pieces.json $O/bench_f32.json $O/bench_torchrun.json | cut -c1-230
 grep time $O/conv_check.jsonl | cut -c1-200; tail -1 $O/pipeline.log | cut -c1-400; grep -h "^{" $O/pair320_car.log $O/pair320_n500.log
 ls $O

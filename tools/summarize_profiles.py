@@ -95,6 +95,8 @@ if __name__ == "__main__":
             json.dump(json.load(open(os.path.join(G, SRC, f))), open(os.path.join(P, TAG + "_bench_extra.json"), "w"), indent=1)
         if f == "voxelize.log":
             shutil.copy(os.path.join(G, SRC, f), os.path.join(P, TAG + "_voxelize.txt"))
+        if f in ("gather_bwd.log", "train_determinism.log", "train_soak_conv.log"):
+            shutil.copy(os.path.join(G, SRC, f), os.path.join(P, TAG + "_" + f.replace(".log", ".txt")))
         if f in ("conv_check.jsonl", "pipeline.log", "pipeline_sync.log", "pair320_car.log", "pair320_n500.log", "conv_train.jsonl"):
             rows = [json.loads(l) for l in open(os.path.join(G, SRC, f)) if l.startswith("{")]
             json.dump(rows, open(os.path.join(P, TAG + "_" + f.split(".")[0] + ".json"), "w"), indent=1)
