@@ -441,6 +441,16 @@ int shasta_gemm_strided_f32(const float* A, long sa_m, long sa_k, const float* W
                             int N, int K, int act, void* splitk_ws, size_t splitk_ws_bytes,
                             shasta_stream_t stream);
 
+/* `count` (<= 8) such products of ONE shape in one launch (two with a split reduction): the four aug_shape / aug_dets MLPs of the anchor
+ * backward (det3d/models/tracker/shasta.py:49-57, 69-76 have four of each, equal in shape), the two sides of a pair MLP's first layer.
+ * A, W, bias, relu_mask, C: HOST arrays of `count` device pointers (bias / relu_mask: NULL or an array whose entries may be NULL alike
+ * for all members); strides, sizes and `act` are shared.  Member i is computed exactly as shasta_gemm_strided_f32 would compute it
+ * alone with splitk_ws_bytes / count bytes of scratch (same tiles, same reduction slices, same bits).  Members must not overlap in C. */
+int shasta_gemm_strided_group_f32(int count, const float* const* A, const float* const* W, const float* const* bias,
+                                  const float* const* relu_mask, float* const* C, long sa_m, long sa_k, long sw_n, long sw_k,
+                                  int ldmask, int ldc, int M, int N, int K, int act, void* splitk_ws, size_t splitk_ws_bytes,
+                                  shasta_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Rotated BEV NMS
  * replaces det3d/ops/iou3d_nms: `nms_gpu` (src/iou3d_nms.cpp:100-143 with nms_kernel, src/iou3d_nms_kernel.cu:267-311 and

@@ -419,12 +419,36 @@ __device__ __forceinline__ void strided_epilogue(const GemmS& g, const f32x16& a
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_strided_f32_kernel(GemmS g) {
+// A GROUP of up to 8 products of one shape (the four aug_shape / aug_dets MLPs of the anchor backward, the two sides of a pair MLP's
+// first layer): operands, bias, mask and result per member, everything else shared; grid.y = members x row tiles.  Each member is
+// computed exactly as a launch of its own would (same tiles, same reduction slices): the group saves launches, not arithmetic.
+constexpr int GEMM_GROUP_MAX = 8;
+struct GemmGroup {
+    const float* A[GEMM_GROUP_MAX];
+    const float* W[GEMM_GROUP_MAX];
+    const float* bias[GEMM_GROUP_MAX];
+    const float* mask[GEMM_GROUP_MAX];
+    float* C[GEMM_GROUP_MAX];
+    int mtiles;  // row tiles per member
+};
+__device__ __forceinline__ GemmS group_member(const GemmS& g0, const GemmGroup& gg, int& by) {
+    GemmS g = g0;
+    const int m = blockIdx.y / gg.mtiles;
+    by = blockIdx.y - m * gg.mtiles;
+    g.A = gg.A[m];
+    g.W = gg.W[m];
+    g.bias = gg.bias[m];
+    g.mask = gg.mask[m];
+    g.C = gg.C[m];
+    return g;
+}
+
+__device__ __forceinline__ void gemm_strided_f32_body(const GemmS& g, int by) {
     __shared__ float As[BM * LDS_LD];
     __shared__ float Ws[BN * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * g.kslice, kend = min(g.K, kbeg + g.kslice);
     float ra[2][4], rw[2][4];
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -449,6 +473,12 @@ __global__ __launch_bounds__(256) void gemm_strided_f32_kernel(GemmS g) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2 * s], wf[2 * s], acc, 0, 0, 0);
     }
     strided_epilogue(g, acc, m0, n0, wm, wn, lane);
+}
+__global__ __launch_bounds__(256) void gemm_strided_f32_kernel(GemmS g) { gemm_strided_f32_body(g, blockIdx.y); }
+__global__ __launch_bounds__(256) void gemm_strided_group_f32_kernel(GemmS g0, GemmGroup gg) {
+    int by;
+    const GemmS g = group_member(g0, gg, by);
+    gemm_strided_f32_body(g, by);
 }
 
 // bf16 operands (act & 8; BASELINE config 5's reduced-precision option for the training GEMMs): the fp32 operands in HBM are
@@ -482,12 +512,12 @@ __device__ __forceinline__ void store_slice_strided_bf16(uint16_t* S, long s_r, 
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_strided_bf16_kernel(GemmS g) {
+__device__ __forceinline__ void gemm_strided_bf16_body(const GemmS& g, int by) {
     __shared__ __attribute__((aligned(16))) uint16_t As[BM * LDH];
     __shared__ __attribute__((aligned(16))) uint16_t Ws[BN * LDH];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * g.kslice, kend = min(g.K, kbeg + g.kslice);
     float ra[2][4], rw[2][4];
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -515,11 +545,17 @@ __global__ __launch_bounds__(256) void gemm_strided_bf16_kernel(GemmS g) {
     }
     strided_epilogue(g, acc, m0, n0, wm, wn, lane);
 }
+__global__ __launch_bounds__(256) void gemm_strided_bf16_kernel(GemmS g) { gemm_strided_bf16_body(g, blockIdx.y); }
+__global__ __launch_bounds__(256) void gemm_strided_group_bf16_kernel(GemmS g0, GemmGroup gg) {
+    int by;
+    const GemmS g = group_member(g0, gg, by);
+    gemm_strided_bf16_body(g, by);
+}
 
 // C[row][col] = sum_z part[z*stride + i], i = row*N + col: 16 elements x 16 z-groups per block, each group sums its
 // slices in order and the groups are combined in order (fixed association -> deterministic)
-__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, long stride, int nz, float* __restrict__ C,
-                                                          long n, int N, int ldc, const float* __restrict__ bias, int act) {
+__device__ __forceinline__ void gemm_reduce_body(const float* __restrict__ part, long stride, int nz, float* __restrict__ C, long n, int N,
+                                                 int ldc, const float* __restrict__ bias, int act) {
     __shared__ float red[16][17];
     const int e = threadIdx.x & 15, q = threadIdx.x >> 4;
     const long i = (long)blockIdx.x * 16 + e;
@@ -537,6 +573,15 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restric
         else if ((act & 3) == 2) t = fabsf(t);
         C[(i / N) * ldc + (i % N)] = t;
     }
+}
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, long stride, int nz, float* __restrict__ C,
+                                                          long n, int N, int ldc, const float* __restrict__ bias, int act) {
+    gemm_reduce_body(part, stride, nz, C, n, N, ldc, bias, act);
+}
+// grid.y = member: its slices lie nz * stride apart in `part`
+__global__ __launch_bounds__(256) void gemm_reduce_group_kernel(const float* __restrict__ part, long stride, int nz, GemmGroup gg, long n, int N,
+                                                                int ldc, int act) {
+    gemm_reduce_body(part + (size_t)blockIdx.y * nz * stride, stride, nz, gg.C[blockIdx.y], n, N, ldc, gg.bias[blockIdx.y], act);
 }
 
 int launch_gemm_strided(const float* A, long sa_m, long sa_k, const float* W, long sw_n, long sw_k, const float* bias,
@@ -582,7 +627,82 @@ int launch_gemm_strided(const float* A, long sa_m, long sa_k, const float* W, lo
     return check_launch("gemm_reduce");
 }
 
+// `count` products of one shape in one launch (two with a split reduction); every member as launch_gemm_strided would compute it alone
+// when given count-th of the scratch
+int launch_gemm_strided_group(int count, const float* const* A, const float* const* W, const float* const* bias, const float* const* mask,
+                              float* const* C, long sa_m, long sa_k, long sw_n, long sw_k, int ldmask, int ldc, int M, int N, int K, int act,
+                              float* splitk_ws, size_t splitk_ws_bytes, hipStream_t st) {
+    if (M == 0 || N == 0 || count == 0) return SHASTA_OK;
+    GemmS g;
+    GemmGroup gg;
+    bool va = sa_k == 1 && sa_m % 4 == 0, vw = sw_k == 1 && sw_n % 4 == 0, any_mask = false;
+    for (int i = 0; i < GEMM_GROUP_MAX; ++i) {
+        const int j = i < count ? i : 0;
+        gg.A[i] = A[j];
+        gg.W[i] = W[j];
+        gg.bias[i] = bias ? bias[j] : nullptr;
+        gg.mask[i] = mask ? mask[j] : nullptr;
+        gg.C[i] = C[j];
+        va = va && ((uintptr_t)A[j] & 15) == 0;
+        vw = vw && ((uintptr_t)W[j] & 15) == 0;
+        any_mask = any_mask || gg.mask[i] != nullptr;
+    }
+    g.A = gg.A[0]; g.W = gg.W[0]; g.bias = gg.bias[0]; g.mask = gg.mask[0]; g.C = gg.C[0];
+    g.sa_m = sa_m; g.sa_k = sa_k; g.sw_n = sw_n; g.sw_k = sw_k;
+    g.ldc = ldc; g.ldmask = ldmask; g.M = M; g.N = N; g.K = K; g.act = act;
+    g.vec_a = va ? 1 : 0;
+    g.vec_w = vw ? 1 : 0;
+    gg.mtiles = cdiv(M, BM);
+    const int tiles = cdiv(M, BM) * cdiv(N, BN);
+    int nz = 1;
+    if (splitk_ws && K >= 256 && tiles < 128 && !any_mask && (act & 4) == 0) {
+        nz = min(min(512, cdiv(1024, tiles)), cdiv(K, 128));
+        while (nz > 1 && (size_t)nz * M * N * sizeof(float) > splitk_ws_bytes / count) --nz;
+    }
+    const dim3 grid(cdiv(N, BN), gg.mtiles * count, 1);
+    if (nz <= 1) {
+        g.kslice = cdiv(max(K, 1), BK) * BK;
+        g.slice_stride = 0;
+        if (act & 8) hipLaunchKernelGGL(gemm_strided_group_bf16_kernel, grid, dim3(256), 0, st, g, gg);
+        else hipLaunchKernelGGL(gemm_strided_group_f32_kernel, grid, dim3(256), 0, st, g, gg);
+        return check_launch("gemm_strided_group");
+    }
+    g.kslice = cdiv(cdiv(K, nz), BK) * BK;
+    nz = cdiv(K, g.kslice);
+    GemmGroup gs = gg;  // the slices of member i: splitk_ws + i * nz * M * N
+    for (int i = 0; i < GEMM_GROUP_MAX; ++i) {
+        gs.C[i] = splitk_ws + (size_t)(i < count ? i : 0) * nz * M * N;
+        gs.bias[i] = nullptr;
+    }
+    g.act = act & 8;
+    g.ldc = N;
+    g.slice_stride = (long)M * N;
+    const dim3 gridz(cdiv(N, BN), gg.mtiles * count, nz);
+    if (act & 8) hipLaunchKernelGGL(gemm_strided_group_bf16_kernel, gridz, dim3(256), 0, st, g, gs);
+    else hipLaunchKernelGGL(gemm_strided_group_f32_kernel, gridz, dim3(256), 0, st, g, gs);
+    int rc = check_launch("gemm_strided_group(split-K)");
+    if (rc) return rc;
+    const long n = (long)M * N;
+    hipLaunchKernelGGL(gemm_reduce_group_kernel, dim3((unsigned)((n + 15) / 16), count), dim3(256), 0, st, splitk_ws, g.slice_stride, nz, gg, n, N, ldc, act);
+    return check_launch("gemm_reduce_group");
+}
+
 }  // namespace shasta
+
+extern "C" int shasta_gemm_strided_group_f32(int count, const float* const* A, const float* const* W, const float* const* bias,
+                                             const float* const* relu_mask, float* const* C, long sa_m, long sa_k, long sw_n, long sw_k,
+                                             int ldmask, int ldc, int M, int N, int K, int act, void* splitk_ws, size_t splitk_ws_bytes,
+                                             shasta_stream_t stream) {
+    using namespace shasta;
+    SHASTA_REQUIRE(count >= 0 && count <= GEMM_GROUP_MAX, "gemm_strided_group: 0 to 8 members");
+    SHASTA_REQUIRE(count == 0 || (A && W && C), "gemm_strided_group: null pointer");
+    for (int i = 0; i < count; ++i) SHASTA_REQUIRE(A[i] && W[i] && C[i], "gemm_strided_group: null member pointer");
+    SHASTA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && ldc >= N, "gemm_strided_group: bad size");
+    SHASTA_REQUIRE(act >= 0 && act <= 14 && (act & 3) != 3,
+                   "gemm_strided_group: bad activation (0 none, 1 relu, 2 abs, +4 accumulate into C, +8 bf16 operands)");
+    return launch_gemm_strided_group(count, A, W, bias, relu_mask, C, sa_m, sa_k, sw_n, sw_k, ldmask, ldc, M, N, K, act,
+                                     static_cast<float*>(splitk_ws), splitk_ws_bytes, as_stream(stream));
+}
 
 extern "C" int shasta_gemm_strided_f32(const float* A, long sa_m, long sa_k, const float* W, long sw_n, long sw_k, const float* bias,
                                        const float* relu_mask, int ldmask, float* C, int ldc, int M, int N, int K, int act,

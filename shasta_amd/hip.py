@@ -9,7 +9,7 @@ import os
 
 import torch
 
-ABI_VERSION = 14  # must equal shasta_abi_version() of the loaded library
+ABI_VERSION = 15  # must equal shasta_abi_version() of the loaded library
 # SHASTA_HIP_LIB: load another build of the same ABI (A/B timing of kernel variants on one box)
 _LIB_PATH = os.environ.get("SHASTA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libshasta_hip.so")
 _lib = None
@@ -135,6 +135,7 @@ SYMBOLS = {
     "shasta_track_merged_f64": (_I, [_P] * 9 + [_I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "shasta_decode_flags_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "shasta_gemm_strided_f32": (_I, [_P, C.c_long, C.c_long, _P, C.c_long, C.c_long, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "shasta_gemm_strided_group_f32": (_I, [_I, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_long, C.c_long, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "shasta_gemm_nt_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "shasta_gemm_nt_pieces_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
 }

@@ -22,11 +22,26 @@ from . import hip
 
 def _gemm(lib, A, sa, W, sw, M, N, K, out, ldc=None, bias=None, act=0, mask=None, ldmask=0, accum=False, ws=None, bf16=False):
     """bf16: operands rounded to bf16 on chip, bf16 matrix path, fp32 accumulation and output (`Shasta.train_precision = "bf16"`)"""
-    hip.check(lib.shasta_gemm_strided_f32(hip.ptr_view(A), sa[0], sa[1], hip.ptr_view(W), sw[0], sw[1], hip.ptr(bias), hip.ptr(mask), ldmask,
+    hip.check(lib.shasta_gemm_strided_f32(hip.ptr_view(A), sa[0], sa[1], hip.ptr_view(W), sw[0], sw[1], hip.ptr(bias), hip.ptr_view(mask), ldmask,
                                           hip.ptr_view(out), ldc if ldc is not None else N, M, N, K, act + (4 if accum else 0) + (8 if bf16 else 0),
                                           hip.ptr(ws), ws.numel() * 4 if ws is not None else 0, hip.stream_ptr()),
               "shasta_gemm_strided_f32")
     return out
+
+
+def _gemm_group(lib, As, sa, Ws, sw, M, N, K, outs, ldc=None, biases=None, act=0, masks=None, ldmask=0, accum=False, ws=None, bf16=False):
+    """len(As) <= 8 products of one shape in one launch (shasta_gemm_strided_group_f32): As / Ws / outs (/ biases / masks) are lists of
+    tensors or views, strides and sizes are shared; each member exactly as _gemm would compute it."""
+    n = len(As)
+    if n == 1:
+        return [_gemm(lib, As[0], sa, Ws[0], sw, M, N, K, outs[0], ldc=ldc, bias=biases[0] if biases else None, act=act,
+                      mask=masks[0] if masks else None, ldmask=ldmask, accum=accum, ws=ws, bf16=bf16)]
+    arr = lambda ts: (C.c_void_p * n)(*[hip.ptr_view(t).value if t is not None else None for t in ts])
+    hip.check(lib.shasta_gemm_strided_group_f32(n, arr(As), arr(Ws), arr(biases) if biases else None, arr(masks) if masks else None, arr(outs),
+                                                sa[0], sa[1], sw[0], sw[1], ldmask, ldc if ldc is not None else N, M, N, K,
+                                                act + (4 if accum else 0) + (8 if bf16 else 0), hip.ptr(ws),
+                                                ws.numel() * 4 if ws is not None else 0, hip.stream_ptr()), "shasta_gemm_strided_group_f32")
+    return outs
 
 
 def _outer(lib, G, ldg, X, ldx, R, H, K, dW):

@@ -21,7 +21,7 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "library does not export " + n
         assert n in hip.SYMBOLS, "ctypes binding missing for " + n
-    assert lib.shasta_abi_version() == hip.ABI_VERSION == 14
+    assert lib.shasta_abi_version() == hip.ABI_VERSION == 15
     assert b"gfx950" in lib.shasta_build_info()
 
 

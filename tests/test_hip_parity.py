@@ -1521,6 +1521,61 @@ def test_gemm_strided_backward_forms(M, N, K):
     assert torch.equal(dw, dw2)                                    # split-K partials are summed in a fixed order
 
 
+@pytest.mark.parametrize("n,M,N,K,bf16", [(4, 64, 320, 450, False), (4, 16, 7, 19, False), (2, 9200, 40, 325, False), (8, 3, 450, 28800, False),
+                                          (3, 70, 33, 5000, True), (4, 8, 2000, 128, False)])
+def test_gemm_strided_group_equals_the_single_launches(n, M, N, K, bf16):
+    """shasta_gemm_strided_group_f32: n products of one shape in one launch - the three forms of an nn.Linear with bias / ReLU mask /
+    accumulate / split reduction, members reading column blocks of shared matrices and writing column blocks of a shared result (the
+    anchor backward's layout) - every member bit for bit what shasta_gemm_strided_f32 gives for it alone."""
+    from shasta_amd import hip, training
+    dev = _dev()
+    lib = hip.load()
+    g = torch.Generator().manual_seed(n * 1000 + M + N)
+    X = [torch.randn(M, K, generator=g).to(dev) for _ in range(n)]
+    W = [(torch.randn(N, K, generator=g) / K ** 0.5).to(dev) for _ in range(n)]
+    b = [torch.randn(N, generator=g).to(dev) for _ in range(n)]
+    dY = torch.randn(M, n * N, generator=g).to(dev)          # column block i belongs to member i
+    mask = torch.randn(M, n * K, generator=g).to(dev)
+    ws = torch.empty(64 * 1024 * 1024 // 4, device=dev)
+    ws1 = ws[: ws.numel() // n]                              # what a member of the group gets
+
+    def both(As, sa, Ws_, sw, m, nn, k, ldc, biases=None, act=0, masks=None, ldmask=0, accum=False, use_ws=True):
+        outs = []
+        for grouped in (False, True):
+            if ldc == nn:
+                res = [torch.full((m, nn), 0.5, device=dev) for _ in range(n)]
+            else:  # column blocks of one matrix
+                base = torch.full((m, ldc), 0.5, device=dev)
+                res = [base[:, i * nn:(i + 1) * nn] for i in range(n)]
+            if grouped:
+                training._gemm_group(lib, As, sa, Ws_, sw, m, nn, k, res, ldc=ldc, biases=biases, act=act, masks=masks, ldmask=ldmask,
+                                     accum=accum, ws=ws if use_ws else None, bf16=bf16)
+            else:
+                for i in range(n):
+                    training._gemm(lib, As[i], sa, Ws_[i], sw, m, nn, k, res[i], ldc=ldc, bias=biases[i] if biases else None, act=act,
+                                   mask=masks[i] if masks else None, ldmask=ldmask, accum=accum, ws=ws1 if use_ws else None, bf16=bf16)
+            outs.append([r.clone() for r in res])
+        for i, (a_, b_) in enumerate(zip(*outs)):
+            assert torch.equal(a_, b_), i
+        return outs[1]
+
+    y = both(X, (K, 1), W, (K, 1), M, N, K, N, biases=b, act=1)                                   # Y = relu(X W^T + b)
+    np.testing.assert_allclose(y[1].cpu().numpy(), torch.relu(X[1].double() @ W[1].double().t() + b[1].double()).float().cpu().numpy(),
+                               rtol=2e-2 if bf16 else 1e-4, atol=2e-2 if bf16 else 1e-4)
+    both(X, (K, 1), W, (K, 1), M, N, K, n * N, biases=b)                                          # ... into column blocks of one matrix
+    dYi = [dY[:, i * N:(i + 1) * N] for i in range(n)]
+    mi = [mask[:, i * K:(i + 1) * K] for i in range(n)]
+    both(dYi, (n * N, 1), W, (1, K), M, K, N, n * K, masks=mi, ldmask=n * K, use_ws=False)        # dX = (dY W) * (mask > 0), blocks
+    both(dYi, (n * N, 1), W, (1, K), M, K, N, K, accum=True, use_ws=False)                        # C += dY W
+    dw = both(dYi, (1, n * N), X, (1, K), N, K, M, K)                                             # dW = dY^T X (reduction over M)
+    ref = dYi[n - 1].double().t() @ X[n - 1].double()
+    np.testing.assert_allclose(dw[n - 1].cpu().numpy(), ref.float().cpu().numpy(), rtol=3e-2 if bf16 else 1e-4,
+                               atol=(3e-2 if bf16 else 2e-4) * max(1.0, float(ref.abs().max())))
+    # errors, not writes
+    nine = (C.c_void_p * 9)(*[hip.ptr(X[0]).value] * 9)
+    assert lib.shasta_gemm_strided_group_f32(9, nine, nine, None, None, nine, K, 1, K, 1, 0, N, M, N, K, 0, None, 0, hip.stream_ptr()) != 0
+
+
 def test_device_decode_flags_match_host_decode():
     """f-4: batched decode decisions on the GPU vs the restated host loop (eval.py:127-173), incl. ties, empty frames and
     every threshold branch; the resulting anno lists must be identical."""
