@@ -172,11 +172,15 @@ class _AffinityTrainFn(torch.autograd.Function):
             E, kin = w0.shape
             UP, UC = torch.empty(R, E, device=dev), torch.empty(R, E, device=dev)
             col, offs = 0, []
-            for side, U in ((0, UP), (1, UC)):
-                for k, (tab, ld, wd, _) in enumerate(parts[name][side]):
-                    _gemm(lib, tab, (ld, 1), w0[:, col:], (kin, 1), R, E, wd, U, bias=b0 if (side == 1 and k == 0) else None, accum=k > 0, bf16=bf)
+            for side in (0, 1):
+                for _, _, wd, _ in parts[name][side]:
                     offs.append(col)
                     col += wd
+            npart = len(parts[name][0])
+            for k in range(npart):  # the two sides have the same shapes: one launch for both (the parts of a side accumulate in turn)
+                (tp, ld, wd, _), (tc, _, _, _) = parts[name][0][k], parts[name][1][k]
+                _gemm_group(lib, [tp, tc], (ld, 1), [w0[:, offs[k]:], w0[:, offs[npart + k]:]], (kin, 1), R, E, wd, [UP, UC],
+                            biases=[None, b0] if k == 0 else None, accum=k > 0, bf16=bf)
             return UP, UC, offs
 
         def first_layer(name):
@@ -200,13 +204,12 @@ class _AffinityTrainFn(torch.autograd.Function):
             E, kin = w0.shape
             gW0, gb0 = torch.empty_like(w0), torch.empty_like(b0)
             _colsum(lib, gUC, E, R, E, gb0, ws)
-            k = 0
-            for side, gU in ((0, gUP), (1, gUC)):
-                for tab, ld, wd, gtab in parts[name][side]:
-                    col = offs[k]
-                    k += 1
-                    _gemm(lib, gU, (1, E), tab, (1, ld), E, wd, R, gW0[:, col:], ldc=kin, ws=ws, bf16=bf)          # dW0 block = gU^T X
-                    _gemm(lib, gU, (E, 1), w0[:, col:], (1, kin), R, wd, E, gtab, ldc=ld, accum=True, bf16=bf)      # dX += gU W0 block
+            npart = len(parts[name][0])
+            for k in range(npart):  # both sides per launch (distinct column blocks of gW0, distinct gradient tables)
+                (tp, ld, wd, gtp), (tc, _, _, gtc) = parts[name][0][k], parts[name][1][k]
+                cp, cc = offs[k], offs[npart + k]
+                _gemm_group(lib, [gUP, gUC], (1, E), [tp, tc], (1, ld), E, wd, R, [gW0[:, cp:], gW0[:, cc:]], ldc=kin, ws=ws, bf16=bf)   # dW0 block = gU^T X
+                _gemm_group(lib, [gUP, gUC], (E, 1), [w0[:, cp:], w0[:, cc:]], (1, kin), R, wd, E, [gtp, gtc], ldc=ld, accum=True, bf16=bf)  # dX += gU W0 block
             return gW0, gb0
 
         # The later layers of a pair MLP.  Default (F = 64 | 256 | 320): recomputed and back-propagated per pair on chip in fp32
@@ -312,35 +315,84 @@ class _AffinityTrainFn(torch.autograd.Function):
         # weights as they are before the update): the 1 GB matrix is read once for both (shasta_adam_lowrank_dx_f32)
         in_bwd = lowrank and stepper is not None and stepper.in_backward and world * B <= 64 and B <= 16 and N * F >= 4
         shape_grads, box_grads, ghids = [None] * 4, [None] * 4, [None] * 4
-        for i in range(4):
-            # aug_shape[i]: input = rows < N of feat (i<2) / prev_feat (i>=2); output row N + (i&1) of prev_feat (i<2) / feat (i>=2)
-            x = S["feat"] if i < 2 else S["prev_feat"]
-            gtab = dprev_feat if i < 2 else dfeat
-            g_out = gtab[:, N + (i & 1), :].contiguous()
-            Hs_ = N * F // 64
-            hid = S["shape_hidden"][:, i * Hs_:(i + 1) * Hs_].contiguous() if Hs_ > 0 else None
-            grads, ghid, w1 = anchor_bwd(model.aug_shape[i], x, T * F, N * F, g_out, 0, F, hid=hid, defer_w1=exchange or lowrank)
-            shape_grads[i] = grads
-            ghids[i] = ghid
-            if ghid is not None and not in_bwd:  # dx = ghid W1 accumulated into the rows < N of the INPUT table's gradient
-                gin = dfeat if i < 2 else dprev_feat
-                if B <= 16 and (N * F) % 4 == 0:  # small batch: stream the 1 GB matrix once (csrc/train.hip)
-                    nb = lib.shasta_smallm_nn_workspace_bytes(B, ghid.shape[1], N * F)
-                    sws = torch.empty((nb + 3) // 4, device=dev)
-                    hip.check(lib.shasta_smallm_nn_f32(hip.ptr(ghid), ghid.shape[1], hip.ptr(w1), B, ghid.shape[1], N * F, hip.ptr(gin), T * F, 1,
-                                                       hip.ptr(sws), nb, st()), "shasta_smallm_nn_f32")
+
+        def anchor_bwd_group(seqs, xs, sx_m, K, g_list, c0, c1, hid_cat=None, defer_w1=False):
+            """The four MLPs of an anchor kind at once (they are equal in shape): every nn.Linear product of the four in ONE launch
+            (shasta_gemm_strided_group_f32), hidden activations / their gradients / the pre-|.| outputs side by side in (B, 4 H) and
+            (B, 4 out) matrices so that one abs and one column-sum launch serve all four.  Returns (grads per MLP, ghid blocks, ghid)."""
+            n = len(seqs)
+            w1s, b1s = [q[0].weight.detach() for q in seqs], [q[0].bias.detach() for q in seqs]
+            w2s, b2s = [q[2].weight.detach() for q in seqs], [q[2].bias.detach() for q in seqs]
+            H, nout = w1s[0].shape[0], w2s[0].shape[0]
+            blocks = lambda t, w: [t[:, i * w:(i + 1) * w] for i in range(n)]  # noqa: E731
+            if hid_cat is None:
+                hid_cat = torch.empty(B, n * H, device=dev)
+                _gemm_group(lib, xs, (sx_m, 1), w1s, (K, 1), B, H, K, blocks(hid_cat, H), ldc=n * H, biases=b1s, act=1, ws=ws)
+            hids = blocks(hid_cat, H)
+            pre = torch.empty(B, n * nout, device=dev)
+            _gemm_group(lib, hids, (n * H, 1), w2s, (H, 1), B, nout, H, blocks(pre, nout), ldc=n * nout, biases=b2s, ws=ws)
+            g_cat = torch.cat(g_list, dim=1)
+            gpre = torch.empty_like(pre)
+            hip.check(lib.shasta_abs_f32(hip.ptr(pre), hip.ptr(g_cat), hip.ptr(gpre), B * n * nout, nout, c0, c1, 1, st()), "shasta_abs_f32")
+            gb2 = torch.empty(n * nout, device=dev)
+            _colsum(lib, gpre, n * nout, B, n * nout, gb2, ws)
+            gpres = blocks(gpre, nout)
+            gW2 = torch.empty(n, nout, H, device=dev)
+            _gemm_group(lib, gpres, (1, n * nout), hids, (1, n * H), nout, H, B, [gW2[i] for i in range(n)])
+            ghid = torch.empty(B, n * H, device=dev)
+            gh = blocks(ghid, H)
+            _gemm_group(lib, gpres, (n * nout, 1), w2s, (1, H), B, H, nout, gh, ldc=n * H, masks=hids, ldmask=n * H)
+            gb1 = torch.empty(n * H, device=dev)
+            _colsum(lib, ghid, n * H, B, n * H, gb1, ws)
+            gW1s = [None] * n
+            if not defer_w1:
+                gW1s = [torch.empty_like(w) for w in w1s]
+                if B <= 16 and K % 4 == 0 and sx_m % 4 == 0:  # rank-B updates: the streaming kernel, one pass over each output
+                    for i in range(n):
+                        _outer(lib, gh[i], n * H, xs[i], sx_m, B, H, K, gW1s[i])
                 else:
-                    _gemm(lib, ghid, (ghid.shape[1], 1), w1, (1, N * F), B, N * F, ghid.shape[1], gin, ldc=T * F, accum=True)
-            # aug_dets[i]: input = boxes[:, :, :7] before back-projection (det for i<2, prev for i>=2), output anchor box row
-            xb = (S["det_pre"] if i < 2 else S["prev"])[:, :, :7].contiguous()
-            gbt = dprev_tab if i < 2 else ddet_tab
-            g_box = gbt[:, N + (i & 1), :7].contiguous()
-            grads, _, _ = anchor_bwd(model.aug_dets[i], xb, 7 * N, 7 * N, g_box, 3, 6)
-            box_grads[i] = grads
+                    _gemm_group(lib, gh, (1, n * H), xs, (1, sx_m), H, K, B, gW1s)
+            return [(gW1s[i], gb1[i * H:(i + 1) * H], gW2[i], gb2[i * nout:(i + 1) * nout]) for i in range(n)], gh, ghid
+
+        # aug_shape[i]: input = rows < N of feat (i<2) / prev_feat (i>=2); output row N + (i&1) of prev_feat (i<2) / feat (i>=2)
+        Hs_ = N * F // 64
+        ghid_cat = None
+        shape_x = [S["feat"], S["feat"], S["prev_feat"], S["prev_feat"]]
+        shape_gout = [(dprev_feat if i < 2 else dfeat)[:, N + (i & 1), :] for i in range(4)]
+        if Hs_ > 0:
+            grads, ghids, ghid_cat = anchor_bwd_group([model.aug_shape[i] for i in range(4)], shape_x, T * F, N * F, shape_gout, 0, F,
+                                                      hid_cat=S["shape_hidden"], defer_w1=exchange or lowrank)
+            shape_grads = list(grads)
+        else:
+            for i in range(4):
+                shape_grads[i], ghids[i], _ = anchor_bwd(model.aug_shape[i], shape_x[i], T * F, N * F, shape_gout[i].contiguous(), 0, F, hid=None,
+                                                         defer_w1=exchange or lowrank)
+        if ghids[0] is not None and not in_bwd:  # dx = ghid W1 accumulated into the rows < N of the INPUT table's gradient
+            w1s = [model.aug_shape[i][0].weight.detach() for i in range(4)]
+            gins = [dfeat, dfeat, dprev_feat, dprev_feat]
+            if B <= 16 and (N * F) % 4 == 0:  # small batch: stream the 1 GB matrix once (csrc/train.hip)
+                for i in range(4):
+                    nb = lib.shasta_smallm_nn_workspace_bytes(B, Hs_, N * F)
+                    sws = torch.empty((nb + 3) // 4, device=dev)
+                    hip.check(lib.shasta_smallm_nn_f32(hip.ptr_view(ghids[i]), ghids[i].stride(0), hip.ptr(w1s[i]), B, Hs_, N * F, hip.ptr(gins[i]),
+                                                       T * F, 1, hip.ptr(sws), nb, st()), "shasta_smallm_nn_f32")
+            else:  # two MLPs add into each table: one launch for the first of each pair, one for the second
+                for pair in ((0, 2), (1, 3)):
+                    _gemm_group(lib, [ghids[i] for i in pair], (ghids[0].stride(0), 1), [w1s[i] for i in pair], (1, N * F), B, N * F, Hs_,
+                                [gins[i] for i in pair], ldc=T * F, accum=True)
+        # aug_dets[i]: input = boxes[:, :, :7] before back-projection (det for i<2, prev for i>=2), output anchor box row
+        xb_det, xb_prev = S["det_pre"][:, :, :7].contiguous(), S["prev"][:, :, :7].contiguous()
+        box_x = [xb_det, xb_det, xb_prev, xb_prev]
+        box_gout = [(dprev_tab if i < 2 else ddet_tab)[:, N + (i & 1), :7] for i in range(4)]
+        if 7 * N // 32 > 0:
+            box_grads, _, _ = anchor_bwd_group([model.aug_dets[i] for i in range(4)], box_x, 7 * N, 7 * N, box_gout, 3, 6)
+        else:
+            for i in range(4):
+                box_grads[i], _, _ = anchor_bwd(model.aug_dets[i], box_x[i], 7 * N, 7 * N, box_gout[i].contiguous(), 3, 6)
 
         if exchange and ghids[0] is not None:
             Hs_, K = N * F // 64, N * F
-            gh_all = _all_gather_rows(torch.cat(ghids, dim=1), world, group)             # (world*B, 4H)
+            gh_all = _all_gather_rows(ghid_cat if ghid_cat is not None else torch.cat(ghids, dim=1), world, group)             # (world*B, 4H)
             xs = [_all_gather_rows(S[k][:, :N, :].reshape(B, K), world, group) for k in ("feat", "prev_feat")]  # (world*B, K)
             hip.check(lib.shasta_scale_f32(hip.ptr(gh_all), gh_all.numel(), 1.0 / world, st()), "shasta_scale_f32")
             for i in range(4):
@@ -355,13 +407,13 @@ class _AffinityTrainFn(torch.autograd.Function):
                 w1p._shasta_grad_is_global = True  # allreduce_gradients must not reduce it again
         elif lowrank and ghids[0] is not None:
             for i in range(4):  # one rank: the local factors as they are (the input rows lie T * F apart in the feature table)
-                model.aug_shape[i][0].weight._shasta_grad_factors = (ghids[i], ghids[i].shape[1], S["feat"] if i < 2 else S["prev_feat"], T * F, B)
+                model.aug_shape[i][0].weight._shasta_grad_factors = (ghids[i], ghids[i].stride(0), S["feat"] if i < 2 else S["prev_feat"], T * F, B)
 
         if in_bwd and ghids[0] is not None:
             for i in range(4):
                 w1p = model.aug_shape[i][0].weight
                 gin = dfeat if i < 2 else dprev_feat
-                stepper.step_in_backward(w1p, w1p.__dict__.pop("_shasta_grad_factors"), ghids[i], ghids[i].shape[1], B, gin, T * F)
+                stepper.step_in_backward(w1p, w1p.__dict__.pop("_shasta_grad_factors"), ghids[i], ghids[i].stride(0), B, gin, T * F)
 
         # ---- gather (shasta.py:231-238) -> gradient of the two NHWC maps ----
         def gather_bwd(gtab, boxes):
