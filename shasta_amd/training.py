@@ -367,19 +367,24 @@ class _AffinityTrainFn(torch.autograd.Function):
             for i in range(4):
                 shape_grads[i], ghids[i], _ = anchor_bwd(model.aug_shape[i], shape_x[i], T * F, N * F, shape_gout[i].contiguous(), 0, F, hid=None,
                                                          defer_w1=exchange or lowrank)
-        if ghids[0] is not None and not in_bwd:  # dx = ghid W1 accumulated into the rows < N of the INPUT table's gradient
+        # dx = ghid W1 into the rows < N of the input table's gradient feeds the gather's backward only: skipped for a map whose gradient
+        # nobody asked for (features from a frozen pipeline; autograd's needs_input_grad), with the gather's backward itself
+        need_dx = [bool(ctx.needs_input_grad[1])] * 2 + [bool(ctx.needs_input_grad[2])] * 2
+        if ghids[0] is not None and not in_bwd and any(need_dx):  # dx = ghid W1 accumulated into the rows < N of the INPUT table's gradient
             w1s = [model.aug_shape[i][0].weight.detach() for i in range(4)]
             gins = [dfeat, dfeat, dprev_feat, dprev_feat]
             if B <= 16 and (N * F) % 4 == 0:  # small batch: stream the 1 GB matrix once (csrc/train.hip)
-                for i in range(4):
+                for i in (j for j in range(4) if need_dx[j]):
                     nb = lib.shasta_smallm_nn_workspace_bytes(B, Hs_, N * F)
                     sws = torch.empty((nb + 3) // 4, device=dev)
                     hip.check(lib.shasta_smallm_nn_f32(hip.ptr_view(ghids[i]), ghids[i].stride(0), hip.ptr(w1s[i]), B, Hs_, N * F, hip.ptr(gins[i]),
                                                        T * F, 1, hip.ptr(sws), nb, st()), "shasta_smallm_nn_f32")
             else:  # two MLPs add into each table: one launch for the first of each pair, one for the second
                 for pair in ((0, 2), (1, 3)):
-                    _gemm_group(lib, [ghids[i] for i in pair], (ghids[0].stride(0), 1), [w1s[i] for i in pair], (1, N * F), B, N * F, Hs_,
-                                [gins[i] for i in pair], ldc=T * F, accum=True)
+                    pair = [i for i in pair if need_dx[i]]
+                    if pair:
+                        _gemm_group(lib, [ghids[i] for i in pair], (ghids[0].stride(0), 1), [w1s[i] for i in pair], (1, N * F), B, N * F, Hs_,
+                                    [gins[i] for i in pair], ldc=T * F, accum=True)
         # aug_dets[i]: input = boxes[:, :, :7] before back-projection (det for i<2, prev for i>=2), output anchor box row
         xb_det, xb_prev = S["det_pre"][:, :, :7].contiguous(), S["prev"][:, :, :7].contiguous()
         box_x = [xb_det, xb_det, xb_prev, xb_prev]
@@ -410,7 +415,7 @@ class _AffinityTrainFn(torch.autograd.Function):
                 model.aug_shape[i][0].weight._shasta_grad_factors = (ghids[i], ghids[i].stride(0), S["feat"] if i < 2 else S["prev_feat"], T * F, B)
 
         if in_bwd and ghids[0] is not None:
-            for i in range(4):
+            for i in (j for j in range(4) if need_dx[j]):  # (a matrix whose dx nobody needs keeps its factors for step())
                 w1p = model.aug_shape[i][0].weight
                 gin = dfeat if i < 2 else dprev_feat
                 stepper.step_in_backward(w1p, w1p.__dict__.pop("_shasta_grad_factors"), ghids[i], ghids[i].stride(0), B, gin, T * F)
@@ -425,8 +430,8 @@ class _AffinityTrainFn(torch.autograd.Function):
                       "shasta_bev_gather_bwd_f32")
             return dbev
 
-        dbev = gather_bwd(dfeat, S["det_pre"])
-        dprev_bev = gather_bwd(dprev_feat, S["prev"])
+        dbev = gather_bwd(dfeat, S["det_pre"]) if ctx.needs_input_grad[1] else None
+        dprev_bev = gather_bwd(dprev_feat, S["prev"]) if ctx.needs_input_grad[2] else None
 
         # ---- gradients in the order of affinity_params(model) ----
         out = []

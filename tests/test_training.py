@@ -718,6 +718,55 @@ def test_adam_stepped_inside_the_backward_equals_the_step_after_it(exchange, siz
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["plain", "lowrank", "in_backward"])
+@pytest.mark.parametrize("which", ["neither", "current only"])
+def test_feature_maps_without_grad_skip_their_gradient_and_change_nothing_else(mode, which):
+    """Features from a frozen pipeline (requires_grad False on a BEV map): autograd asks for no gradient of that map, and the backward then
+    skips its scatter-add AND the dx = ghid W1 products that feed only it (needs_input_grad) - every parameter gradient, and three Adam steps
+    in each first-layer mode, bit for bit what the run with both maps' gradients gives; a matrix whose dx is not needed is stepped in
+    step() even under in_backward=True."""
+    import copy
+    from shasta_amd import training
+    c, model, w, a, b, det, prev, gt = _case(20, 7, 5, 3, seed=11)
+    dev = torch.device("cuda:0")
+    base = model.to(dev).train()
+    gtd = gt.to(dev)
+    detd, prevd = det.to(dev).contiguous(), prev.to(dev).contiguous()
+    runs = []
+    for full in (True, False):
+        m = copy.deepcopy(base)
+        kw = {} if mode == "plain" else dict(lowrank_first_layers=m, in_backward=mode == "in_backward")
+        opt = training.FusedAdam(m.parameters(), lr=1e-3, weight_decay=0.01, **kw)
+        grads = None
+        for it in range(3):
+            opt.zero_grad(set_to_none=True)
+            ad = a.to(dev).requires_grad_(full or which == "current only")
+            bd = b.to(dev).requires_grad_(full)
+            before = [m.aug_shape[i][0].weight.detach().clone() for i in range(4)]
+            m1, m2 = training.affinity_train(m, ad, bd, detd.clone(), prevd)
+            training.affinity_loss(m1, m2, gtd).backward()
+            if it == 0:
+                grads = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+                moved = [not torch.equal(before[i], m.aug_shape[i][0].weight.detach()) for i in range(4)]
+                if mode == "in_backward":  # aug_shape 0, 1 read the current map's table, 2, 3 the previous map's
+                    assert moved == ([True] * 4 if full else [which == "current only"] * 2 + [False] * 2), moved
+                else:
+                    assert moved == [False] * 4
+                assert (ad.grad is not None) == (full or which == "current only") and (bd.grad is not None) == full
+                dcur = None if ad.grad is None else ad.grad.clone()
+            opt.step()
+        runs.append((grads, {k: p.detach().clone() for k, p in m.named_parameters()}, dcur))
+    (g0, p0, d0), (g1, p1, d1) = runs
+    assert set(g0) == set(g1) and len(g0) >= 60
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    if which == "current only":
+        assert torch.equal(d0, d1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("R,Rdx,H,K", [(1, 1, 5, 8), (8, 8, 70, 1032), (3, 16, 129, 260), (16, 5, 33, 4096), (24, 8, 70, 516), (64, 8, 131, 1032), (33, 12, 64, 260)])
 def test_adam_lowrank_with_the_product_in_the_same_pass(R, Rdx, H, K):
     """shasta_adam_lowrank_dx_f32 against shasta_adam_lowrank_f32 (the same update, bit for bit) and Gdx W in float64 (W before the update)."""
