@@ -26,7 +26,11 @@ namespace shasta {
 typedef __bf16 ebf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t eu32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int ER_ROWS = 256, ER_WAVES = 8;
+// Workgroup shapes (rows = 32 x waves).  <256 rows, 8 waves>: one workgroup per CU, three ring slots.  <128, 4, two slots> at F = 256:
+// 72 KB of LDS, TWO workgroups per CU - the epilogue of one (staging, box columns, row maxima, 64 KB of stores: about as long as its
+// main loop) runs under the MFMAs of the other: 0.496 -> 0.459 ms per 1024 frame-pairs in an alternating A/B on one box
+// (tools/gpu_kernel_ab.sh; <64, 2>: 0.77, <128, 4, three slots> = one workgroup per CU again: 0.67).  Results are the same bits - a
+// wavefront's arithmetic does not depend on the shape.
 
 __device__ __forceinline__ void er_cut3(float a, float& h, float& m, float& l) {
     h = __uint_as_float(__float_as_uint(a) & 0xffff0000u);
@@ -102,19 +106,20 @@ struct EmbedArgs {
     int M, F, nf, N;
 };
 
-template <int NFB>
+template <int NFB, int ER_ROWS, int ER_WAVES, int ER_NS>
 struct ErShape {
-    static constexpr int XB = ER_ROWS * 128;              // x chunk: 256 rows x 32 floats
+    static_assert(ER_ROWS == 32 * ER_WAVES, "a wave owns 32 rows");
+    static constexpr int XB = ER_ROWS * 128;              // x chunk: ER_ROWS rows x 32 floats
     static constexpr int SLOT = XB + NFB * 6 * 1024;      // + NFB x 2 k steps x 3 pieces fragments
-    static constexpr int NS = 3 * SLOT <= 152 * 1024 ? 3 : 2;
+    static constexpr int NS = ER_NS ? ER_NS : (3 * SLOT <= 152 * 1024 ? 3 : 2);
     static constexpr int NW = NFB * 6;                    // weight fragments per chunk
     static constexpr int PW = (NW + ER_WAVES - 1) / ER_WAVES, PER = 4 + PW;  // LDS-DMA instructions per chunk and wave
     static_assert(PER * (NS - 1) <= 63, "vmcnt is 6 bits");
 };
 
-template <int NFB>
+template <int NFB, int ER_ROWS, int ER_WAVES, int ER_NS>
 __global__ __launch_bounds__(64 * ER_WAVES) void embed_rows_kernel(EmbedArgs a) {
-    using S = ErShape<NFB>;
+    using S = ErShape<NFB, ER_ROWS, ER_WAVES, ER_NS>;
     constexpr int NS = S::NS, PW = S::PW, PER = S::PER;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -335,13 +340,13 @@ __global__ __launch_bounds__(64 * ER_WAVES) void embed_rows_kernel(EmbedArgs a) 
 
 bool embed_rows_serves(int F) { return F == 64 || F == 256 || F == 320; }
 
-template <int NFB>
+template <int NFB, int ER_ROWS, int ER_WAVES, int ER_NS>
 static int launch_embed_shape(const EmbedArgs& a, hipStream_t st) {
-    using S = ErShape<NFB>;
+    using S = ErShape<NFB, ER_ROWS, ER_WAVES, ER_NS>;
     const PairDims d(a.F);
     const size_t lds = (size_t)std::max(S::NS * S::SLOT, ER_ROWS * (d.ET + 8) * 4) + 7 * 104 * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)embed_rows_kernel<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((embed_rows_kernel<NFB>), dim3(cdiv(a.M, ER_ROWS), 2), dim3(64 * ER_WAVES), lds, st, a);
+    (void)hipFuncSetAttribute((const void*)embed_rows_kernel<NFB, ER_ROWS, ER_WAVES, ER_NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((embed_rows_kernel<NFB, ER_ROWS, ER_WAVES, ER_NS>), dim3(cdiv(a.M, ER_ROWS), 2), dim3(64 * ER_WAVES), lds, st, a);
     return check_launch("embed_rows");
 }
 
@@ -364,9 +369,9 @@ int launch_embed_rows(const shasta_weights* w, const float* packed, const float*
     a.nf = w->num_feats;
     a.N = w->max_obj;
     switch ((P.E12 + 31) / 32) {
-        case 2: return launch_embed_shape<2>(a, st);
-        case 3: return launch_embed_shape<3>(a, st);
-        case 4: return launch_embed_shape<4>(a, st);
+        case 2: return launch_embed_shape<2, 256, 8, 0>(a, st);
+        case 3: return launch_embed_shape<3, 128, 4, 2>(a, st);  // F = 256: two workgroups per CU
+        case 4: return launch_embed_shape<4, 256, 8, 0>(a, st);
     }
     set_error_msg("embed_rows: unsupported feat_dim");
     return SHASTA_E_ARG;
