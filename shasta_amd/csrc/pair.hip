@@ -143,6 +143,11 @@ __device__ __forceinline__ void col_norm_block(const RowPrepArgs& a, int cb, int
         const f32x4* h = reinterpret_cast<const f32x4*>(a.tab[1] + ((size_t)b * D + min(d0 + 16 * j, D - 1)) * 8);
         const f32x4 x = h[0], c = h[1];
         db[j][0] = x[0]; db[j][1] = x[1]; db[j][2] = x[2]; db[j][3] = x[3]; db[j][4] = c[0]; db[j][5] = c[1]; db[j][6] = c[2];
+        // columns >= nf take no part: zero on both sides (here and in the staged previous boxes), so that their difference is +0 and
+        // the loop below runs over all seven without a mask - a select per column and detection was 40 % of its instructions
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (k >= nf) db[j][k] = 0.0f;
     }
     // the frame's previous boxes pass through LDS in chunks of 512 rows (one coalesced copy per chunk, then broadcast reads)
     __shared__ __attribute__((aligned(16))) f32x4 sp[2 * 512];
@@ -157,7 +162,14 @@ __device__ __forceinline__ void col_norm_block(const RowPrepArgs& a, int cb, int
     for (int t0 = 0; t0 < T; t0 += 512) {
         const int nt = min(512, T - t0);
         if (t0) __syncthreads();
-        for (int e = tid; e < 2 * nt; e += 256) sp[e] = hp[(size_t)t0 * 2 + e];
+        for (int e = tid; e < 2 * nt; e += 256) {
+            f32x4 v = hp[(size_t)t0 * 2 + e];
+            const int k0 = (e & 1) * 4;  // box columns k0 .. k0 + 3 of the row
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (k0 + q >= nf) v[q] = 0.0f;
+            sp[e] = v;
+        }
         __syncthreads();
         for (int t = tg; t < nt; t += 32) {
             const int tb = t + 16;
@@ -170,11 +182,9 @@ __device__ __forceinline__ void col_norm_block(const RowPrepArgs& a, int cb, int
             for (int j = 0; j < ND; ++j) {
                 f2 d2 = {0.0f, 0.0f};
 #pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    if (k < nf) {  // (columns >= nf take no part; the former multiplication by a 1.0 / 0.0 mask gave the same bits)
-                        const f2 df = p[k] - f2{db[j][k], db[j][k]};
-                        d2 += df * df;
-                    }
+                for (int k = 0; k < (NF ? NF : 7); ++k) {
+                    const f2 df = p[k] - f2{db[j][k], db[j][k]};
+                    d2 += df * df;
                 }
                 f2 sq = d2 * d2;
                 if (!two) sq[1] = 0.0f;
@@ -582,8 +592,17 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     rp.nhand_blocks = cdiv(2 * B * T, 256);
     rp.dper = cdiv(D, 16) * B >= 2048 ? 4 : 1;
     rp.dblocks = cdiv(D, 16 * rp.dper);
+    // (the column norms as a kernel of their own - 118 registers and 21 KB of LDS instead of the fused kernel's 130 / 41 KB, four
+    // wavefronts per SIMD instead of three - took the same 0.166 ms per 1024 frame-pairs: the role is bound by its VALU instructions)
     hipLaunchKernelGGL(row_prep_kernel, dim3(rp.nrow_blocks + rp.nhand_blocks + rp.dblocks * B), dim3(256), 0, st, rp);
     rc = check_launch("row_prep");
+    if (rc) return rc;
+        hipLaunchKernelGGL(col_norm_kernel, dim3(rp.dblocks * B), dim3(256), 0, st, rp);
+        rc = check_launch("col_norm");
+    } else {
+        hipLaunchKernelGGL(row_prep_kernel, dim3(rp.nrow_blocks + rp.nhand_blocks + rp.dblocks * B), dim3(256), 0, st, rp);
+        rc = check_launch("row_prep");
+    }
     if (rc) return rc;
     if ((w->options & SHASTA_OPT_F16X2_PAIR) && F == 256) {
         // second layers of the three pair MLPs on the f16 matrix path (pair_f16.hip), everything else as below
