@@ -207,6 +207,12 @@ __device__ __forceinline__ void col_norm_block(const RowPrepArgs& a, int cb, int
     }
 }
 
+// the column-norm role alone (large batches: 4 detections per thread): its own register budget and LDS (118 registers, 21 KB: four
+// wavefronts per SIMD) - inside row_prep_kernel the three roles share one allocation (130 registers, 41 KB, three wavefronts per SIMD).
+// Measured equal to the fused form (0.031 hand rows + 0.135 against 0.166 ms per 1024 frame-pairs): the role is bound by its VALU
+// instructions - 124 per 8 pairs, of which the packed subtract / multiply / add of 7 columns need 92 - not by occupancy.
+__global__ __launch_bounds__(256) void col_norm_kernel(RowPrepArgs a) { col_norm_block<4, 0>(a, blockIdx.x, threadIdx.x); }
+
 __global__ __launch_bounds__(256) void row_prep_kernel(RowPrepArgs a) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < a.nrow_blocks) {
@@ -592,11 +598,10 @@ int pair_residual(const shasta_weights* w, const float* packed, int B, const flo
     rp.nhand_blocks = cdiv(2 * B * T, 256);
     rp.dper = cdiv(D, 16) * B >= 2048 ? 4 : 1;
     rp.dblocks = cdiv(D, 16 * rp.dper);
-    // (the column norms as a kernel of their own - 118 registers and 21 KB of LDS instead of the fused kernel's 130 / 41 KB, four
-    // wavefronts per SIMD instead of three - took the same 0.166 ms per 1024 frame-pairs: the role is bound by its VALU instructions)
-    hipLaunchKernelGGL(row_prep_kernel, dim3(rp.nrow_blocks + rp.nhand_blocks + rp.dblocks * B), dim3(256), 0, st, rp);
-    rc = check_launch("row_prep");
-    if (rc) return rc;
+    if (rp.dper == 4) {  // large batches: the column norms as a kernel of their own
+        hipLaunchKernelGGL(row_prep_kernel, dim3(rp.nrow_blocks + rp.nhand_blocks), dim3(256), 0, st, rp);
+        rc = check_launch("row_prep");
+        if (rc) return rc;
         hipLaunchKernelGGL(col_norm_kernel, dim3(rp.dblocks * B), dim3(256), 0, st, rp);
         rc = check_launch("col_norm");
     } else {
