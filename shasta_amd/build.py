@@ -5,6 +5,7 @@
 
 hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the repo snapshot.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -34,13 +35,28 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def _dep_files():
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h", ".map"))]
+    deps.append(os.path.normpath(os.path.join(os.path.dirname(CSRC), "..", "include", "shasta_hip.h")))
+    return [d for d in deps if os.path.exists(d)]
+
+
+def source_hash():
+    """16 hex digits over the names and contents of everything the library is built from; compiled into the library
+    (shasta_build_info) so that a stale libshasta_hip.so - sources edited, build failed or forgotten - is refused at load."""
+    h = hashlib.sha256()
+    for d in _dep_files():
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h", ".map"))]
-    deps.append(os.path.join(os.path.dirname(CSRC), "..", "include", "shasta_hip.h"))
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return any(os.path.getmtime(d) > t for d in _dep_files())
 
 
 def build(force=False, verbose=True):
@@ -49,10 +65,12 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
+    srchash = source_hash()
 
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        extra = ['-DSHASTA_SOURCE_HASH="%s"' % srchash] if src == "abi.hip" else []
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))

@@ -161,6 +161,12 @@ def load():
     if lib.shasta_abi_version() != ABI_VERSION:
         raise ShastaHipError("%s has ABI version %d, this binding needs %d: rebuild with `python -m shasta_amd.build`"
                              % (_LIB_PATH, lib.shasta_abi_version(), ABI_VERSION))
+    if not os.environ.get("SHASTA_HIP_LIB"):  # (a variant library for an A/B is built from other sources on purpose)
+        from . import build as _build
+        info, want = lib.shasta_build_info().decode(), _build.source_hash()
+        if not info.endswith("src " + want):
+            raise ShastaHipError("%s was built from other sources than the ones next to it (%s, sources now %s): the last build failed or "
+                                 "was forgotten - run `python -m shasta_amd.build`" % (_LIB_PATH, info.rsplit(" ", 1)[-1], want))
     _lib = lib
     return lib
 

@@ -23,6 +23,9 @@ def test_header_symbols_are_exported_and_bound():
         assert n in hip.SYMBOLS, "ctypes binding missing for " + n
     assert lib.shasta_abi_version() == hip.ABI_VERSION == 15
     assert b"gfx950" in lib.shasta_build_info()
+    # the library carries the hash of the sources it was built from; hip.load() refuses a stale one
+    from shasta_amd import build
+    assert lib.shasta_build_info().decode().endswith("src " + build.source_hash())
 
 
 def test_library_exports_exactly_the_declared_abi_and_reads_no_environment():
