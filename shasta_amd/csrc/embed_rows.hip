@@ -371,7 +371,11 @@ int launch_embed_rows(const shasta_weights* w, const float* packed, const float*
     switch ((P.E12 + 31) / 32) {
         case 2: return launch_embed_shape<2, 256, 8, 0>(a, st);
         case 3: return launch_embed_shape<3, 128, 4, 2>(a, st);  // F = 256: two workgroups per CU
+#ifdef SHASTA_ER_F320_128  // experiment (tools/build_variant.py): 128-row workgroups at F = 320 too - 83 KB each, still one per CU: 81 - 82 us against 75 - 77 at the car tables x 512
+        case 4: return launch_embed_shape<4, 128, 4, 2>(a, st);
+#else
         case 4: return launch_embed_shape<4, 256, 8, 0>(a, st);
+#endif
     }
     set_error_msg("embed_rows: unsupported feat_dim");
     return SHASTA_E_ARG;
