@@ -55,10 +55,19 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long per = (M + gridDim.x - 1) / gridDim.x, beg = blockIdx.x * per, end = min(M, beg + per);
     double s = 0.0, ss = 0.0;
-    for (long p = beg + g; p < end; p += 4) {
-        const double v = (double)y[p * BN_C + c];
-        s += v;
-        ss += v * v;
+    // eight rows' loads in flight, then the adds in the rows' order (the same sums as a row at a time)
+    for (long p0 = beg + g; p0 < end; p0 += 32) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = y[min(p0 + 4 * u, end - 1) * BN_C + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (p0 + 4 * u < end) {
+                const double v = (double)t[u];
+                s += v;
+                ss += v * v;
+            }
+        }
     }
     red[0][g][c] = s;
     red[1][g][c] = ss;
@@ -167,14 +176,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const float mean = stat[c], inv = stat[BN_C + c], ga = gamma[c], be = beta[c];
     double s1 = 0.0, s2 = 0.0;
     float mg = 0.0f, mx = 0.0f;
-    for (long p = beg + g; p < end; p += 4) {
-        const float xh = (y[p * BN_C + c] - mean) * inv;
-        const float pre = xh * ga + be;
-        const float gp = pre > 0.0f ? gout[p * BN_C + c] : 0.0f;
-        s1 += (double)gp;
-        s2 += (double)gp * (double)xh;
-        mg = absmax_keep_nan(mg, fabsf(gp));
-        mx = absmax_keep_nan(mx, fabsf(xh));
+    // four rows' loads of both tensors in flight (the incoming gradient is read whether the ReLU passed or not: a load behind the
+    // comparison would wait for y first), then the sums in the rows' order
+    for (long p0 = beg + g; p0 < end; p0 += 16) {
+        float ty[4], tg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long p = min(p0 + 4 * u, end - 1);
+            ty[u] = y[p * BN_C + c];
+            tg[u] = gout[p * BN_C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p0 + 4 * u < end) {
+                const float xh = (ty[u] - mean) * inv;
+                const float pre = xh * ga + be;
+                const float gp = pre > 0.0f ? tg[u] : 0.0f;
+                s1 += (double)gp;
+                s2 += (double)gp * (double)xh;
+                mg = absmax_keep_nan(mg, fabsf(gp));
+                mx = absmax_keep_nan(mx, fabsf(xh));
+            }
+        }
     }
     red[0][g][c] = s1;
     red[1][g][c] = s2;
@@ -232,16 +255,29 @@ __global__ __launch_bounds__(256) void bn_bwd_dy_kernel(const float* __restrict_
     const float* yr = y + row * W * BN_C;
     const float* gr = gout + row * W * BN_C;
     double sdy = 0.0;
-    for (int px = g; px < PW; px += 4) {
-        float dy = 0.0f;
-        if (px < W) {
-            const float xh = (yr[(size_t)px * BN_C + c] - mean) * inv;
-            const float pre = xh * ga + be;
-            const float gp = pre > 0.0f ? gr[(size_t)px * BN_C + c] : 0.0f;
-            dy = ((gp - mg) - xh * mgx) * a;
-            sdy += (double)dy;
+    for (int px0 = g; px0 < PW; px0 += 16) {  // four pixels' loads of both tensors in flight (see bn_bwd_reduce_kernel)
+        float ty[4], tg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int px = min(px0 + 4 * u, W - 1);
+            ty[u] = yr[(size_t)px * BN_C + c];
+            tg[u] = gr[(size_t)px * BN_C + c];
         }
-        tile[px * 65 + c] = dy * sc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int px = px0 + 4 * u;
+            if (px < PW) {
+                float dy = 0.0f;
+                if (px < W) {
+                    const float xh = (ty[u] - mean) * inv;
+                    const float pre = xh * ga + be;
+                    const float gp = pre > 0.0f ? tg[u] : 0.0f;
+                    dy = ((gp - mg) - xh * mgx) * a;
+                    sdy += (double)dy;
+                }
+                tile[px * 65 + c] = dy * sc;
+            }
+        }
     }
     red[g][c] = sdy;
     __syncthreads();
