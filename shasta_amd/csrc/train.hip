@@ -302,12 +302,37 @@ __global__ __launch_bounds__(256) void softmax_bwd_cols_kernel(const float* __re
     const float* m = m2 + (size_t)b * T * N + dc;
     const float* g = g2 + (size_t)b * T * N + dc;
     float s = 0.0f;
-    for (int t = tq; t < T; t += 4) s += g[(size_t)t * N] * m[(size_t)t * N];
+    // eight rows' loads in flight, the products added in the rows' order (the same sum as a row at a time: a loop of one dependent
+    // load pair per step was latency bound - 77 us at N = 500 x 8 frame pairs on 64 workgroups)
+    for (int t0 = tq; t0 < T; t0 += 32) {
+        float tg[8], tm[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t t = (size_t)min(t0 + 4 * u, T - 1);
+            tg[u] = g[t * N];
+            tm[u] = m[t * N];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (t0 + 4 * u < T) s += tg[u] * tm[u];
+    }
     red[tq][dl] = s;
     __syncthreads();
     s = (red[0][dl] + red[1][dl]) + (red[2][dl] + red[3][dl]);
     if (d >= N) return;
-    for (int t = tq; t < T; t += 4) gm[((size_t)b * T + t) * ld + d] += m[(size_t)t * N] * (g[(size_t)t * N] - s);
+    for (int t0 = tq; t0 < T; t0 += 16) {
+        float tg[4], tm[4], to[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t t = (size_t)min(t0 + 4 * u, T - 1);
+            tg[u] = g[t * N];
+            tm[u] = m[t * N];
+            to[u] = gm[((size_t)b * T + t) * ld + d];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t0 + 4 * u < T) gm[((size_t)b * T + t0 + 4 * u) * ld + d] = to[u] + tm[u] * (tg[u] - s);
+    }
 }
 
 // ---- small helpers ------------------------------------------------------------------------------------------------------
