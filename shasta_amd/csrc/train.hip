@@ -1106,10 +1106,15 @@ extern "C" int shasta_adam_lowrank_f32(float* param, float* exp_avg, float* exp_
         hipLaunchKernelGGL(kern, dim3(kblocks, cdiv(H, rpb)), dim3(256), 0, as_stream(stream), param, exp_avg, exp_avg_sq, G, ldg, X, ldx, R, H, K,
                            rpb, a, (const float*)nullptr, 0, 0, (float*)nullptr);
     };
-    if (R <= 8) launch(adam_lowrank_kernel<8, 4>, 4);
+    // Columns per thread.  Large matrices (the 2000 x 128000 first layers at N = 500): 4 up to rank 16, 2 above (1.10 ms per matrix at
+    // R = 8; one column at R = 64: 1.31 -> 1.37 ms).  Small ones (the car configuration's 450 x 28800): fewer columns = more workgroups
+    // and, above rank 32, half the registers for the X rows - 0.072 -> 0.063 ms at R = 8, 0.069 -> 0.063 at R = 32, 0.113 -> 0.092 at
+    // R = 64 (two columns at R = 16: 0.056 -> 0.21, the scalar loads of G then bound it: kept at 4).  Same arithmetic per element.
+    const bool small = (long)H * K <= (1L << 26);
+    if (R <= 8) small ? launch(adam_lowrank_kernel<8, 2>, 2) : launch(adam_lowrank_kernel<8, 4>, 4);
     else if (R <= 16) launch(adam_lowrank_kernel<16, 4>, 4);
-    else if (R <= 32) launch(adam_lowrank_kernel<32, 2>, 2);
-    else launch(adam_lowrank_kernel<64, 2>, 2);
+    else if (R <= 32) small ? launch(adam_lowrank_kernel<32, 1>, 1) : launch(adam_lowrank_kernel<32, 2>, 2);
+    else small ? launch(adam_lowrank_kernel<64, 1>, 1) : launch(adam_lowrank_kernel<64, 2>, 2);
     return check_launch("adam_lowrank");
 }
 

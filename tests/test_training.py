@@ -589,6 +589,43 @@ def test_fused_adam_from_gradient_factors_matches_torch_adam(R, wd):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R", [5, 16, 24, 64])
+def test_adam_from_gradient_factors_small_and_large_matrices_agree(R):
+    """shasta_adam_lowrank_f32 picks the columns per thread by the size of the matrix (more workgroups for the car configuration's
+    450 x 28800, wider threads for the 2000 x 128000 of N = 500): the arithmetic per element is the same - a (1100, 65536) matrix
+    (the wide form) and its first rows stepped as a matrix of their own (the narrow form) end up with the same bits, and with those of
+    torch.optim.Adam's update rule on the materialised gradient to rounding."""
+    from shasta_amd import hip
+    lib = hip.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(R)
+    H, K, Hs = 1100, 65536, 200
+    assert H * K > (1 << 26) >= Hs * K
+    G = (torch.randn(R, H, generator=g) * 0.3).to(dev)
+    X = torch.randn(R, K, generator=g).to(dev)
+    big = [torch.randn(H, K, generator=g).to(dev), torch.zeros(H, K, device=dev), torch.zeros(H, K, device=dev)]
+    small = [t[:Hs].clone() for t in big]
+    p0 = big[0][:Hs].clone()
+    for step in (1, 2):
+        for p, m, v, h in (big + [H], small + [Hs]):
+            hip.check(lib.shasta_adam_lowrank_f32(hip.ptr(p), hip.ptr(m), hip.ptr(v), h, K, hip.ptr(G), H, hip.ptr(X), K, R, 1e-3, 0.9, 0.999, 1e-8,
+                                                  0.01, step, None, hip.stream_ptr()), "shasta_adam_lowrank_f32")
+    for a_, b_ in zip(big, small):
+        assert torch.equal(a_[:Hs], b_)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, weight_decay=0.01)
+    grad = (G[:, :Hs].double().t() @ X.double()).float()
+    for _ in range(2):
+        ref.grad = grad.clone()
+        opt.step()
+    diff = (small[0] - ref.detach()).abs()
+    # (where the gradient - with its weight-decay term - is within rounding of zero, m / sqrt(v) is its sign: an update of +-lr either way)
+    clear = (grad + 0.01 * p0).abs() > 1e-3
+    assert float(diff[clear].max()) <= 5e-6 * max(1.0, float(ref.abs().max())) and float(clear.float().mean()) > 0.99
+    assert float(diff.max()) <= 2.5e-3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("exchange", [False, True])
 def test_train_steps_with_adam_from_the_factors_equal_the_dense_steps(exchange):
     """FusedAdam(..., lowrank_first_layers=model): the backward hands the factors of the four aug_shape first-layer gradients to the
